@@ -1,0 +1,116 @@
+/* vargeno_hip.h -- C-ABI of the MI355X (gfx950) `vargeno geno` read-processing path.
+ *
+ * The reference has no plugin/FFI seam: the whole path is inlined in `static void genotype()`
+ * (src/qv.cc:475-1787 of medvedevgroup/vargeno).  This header is the seam a maintainer would cut:
+ * each entry point names the span of genotype() it replaces.  Plain pointers and sizes only; every
+ * function returns 0 on success or a negative VG_E* code and never aborts (the reference asserts /
+ * exit(EXIT_FAILURE)s instead: src/util.c:31-50, src/qv.cc:526-529).  One handle per GPU; a handle
+ * is thread-compatible (one caller at a time).
+ *
+ * There is NO CPU fallback behind these calls: without a HIP device they fail with VG_ENODEV.
+ */
+#ifndef VARGENO_HIP_H
+#define VARGENO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VG_OK        0
+#define VG_EINVAL   -1   /* bad argument                                                     */
+#define VG_EIO      -2   /* index file missing / short (reference: assert in util.c:31-50)   */
+#define VG_ENOMEM   -3   /* host or device allocation failed                                 */
+#define VG_ENODEV   -4   /* no HIP device / HIP runtime error (message via vg_last_error)    */
+#define VG_ETOOBIG  -5   /* dictionary > 2^32 entries (reference: exit, qv.cc:526, 612)      */
+#define VG_EBADREAD -6   /* a read longer than 1022 bases (reference BUF_SIZE, qv.cc:700)    */
+
+typedef struct vg_index vg_index;        /* device-resident index + pile-up counters         */
+
+/* The dictionaries and bit vectors exactly as the reference's files hold them, field by field
+ * (dictgen.c:63-154 ref dict, :156-275 SNP dict; sdsl int_vector<1> payload words for the .bf
+ * files).  Host pointers; copied, never retained. */
+typedef struct {
+	uint64_t n_ref;            const uint64_t *ref_kmer;  const uint32_t *ref_pos;  const uint8_t *ref_amb;
+	uint64_t n_ref_aux;        const uint32_t *ref_aux;        /* [n_ref_aux][10]            */
+	uint64_t n_snp;            const uint64_t *snp_kmer;  const uint32_t *snp_pos;
+	const uint8_t *snp_info;   const uint8_t *snp_amb;    const uint8_t *snp_rf;    const uint8_t *snp_af;
+	uint64_t n_snp_aux;        const uint32_t *snp_aux_pos;    /* [n_snp_aux][10]            */
+	                           const uint8_t  *snp_aux_info;   /* [n_snp_aux][10]            */
+	uint64_t ref_bf_bits;      const uint64_t *ref_bf_words;   /* >= ceil(min(bits,2^32)/64) */
+	uint64_t snp_bf_bits;      const uint64_t *snp_bf_words;   /* >= ceil(bits/64)           */
+} vg_index_arrays;
+
+/* Counters mirroring the reference's `#if DEBUG` set (qv.cc:737-751) plus the event counts that
+ * price algorithmic bytes.  All accumulate since open / vg_counts_reset. */
+typedef struct {
+	uint64_t reads, reads_n, reads_invalid, passes, passes_ok, chunks, gate_open,
+	         refbf_pos, snpbf_pos, large_block, ref_query, snp_query, ref_probe, snp_probe,
+	         scan_ref, scan_snp, scan_oob, aux_ref, aux_snp, site_test, ctx, walks, incr,
+	         ingest_bytes;
+	uint64_t overflow_reads;     /* reads re-run by the large-scratch kernel                  */
+	uint64_t alg_bytes;          /* sum of unit cost x event count                            */
+} vg_stats;
+
+/* Timing of the kernels of the last vg_reads_process_device / vg_sync, from HIP events recorded on
+ * the handle's own stream. */
+typedef struct {
+	float    ms_total;           /* first kernel start -> last kernel end                      */
+	float    ms_main;            /* the dominant kernel (vg_pass_kernel, both passes summed)   */
+	uint32_t launches_main;
+} vg_timing;
+
+const char *vg_last_error(void);
+int  vg_device_count(void);
+
+/* Replaces the loader half of genotype(): qv.cc:519-695 (dict files -> jump tables, dict arrays,
+ * aux tables, pile-up seeding) and main()'s BloomFilter::load (qv.cc:2140-2144).
+ * vg_index_open reads <prefix>.ref.dict/.snp.dict/.ref.bf/.snp.bf; vg_index_create takes the same
+ * content from memory. */
+int  vg_index_open(const char *prefix, int device, vg_index **out);
+int  vg_index_create(const vg_index_arrays *a, int device, vg_index **out);
+void vg_index_close(vg_index *ix);               /* qv.cc:1775-1786 */
+
+/* Device bytes held by the index (tables + pile-up + scratch). */
+uint64_t vg_index_device_bytes(const vg_index *ix);
+
+/* Replaces the FASTQ loop body, qv.cc:760-1558, for a batch of reads: flat ASCII bases and quality
+ * characters (same offsets; offsets[n_reads] = total length) in HOST memory.  Copies to the
+ * device and enqueues the kernels on the handle's stream; returns before they finish. */
+int  vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals,
+                     const uint64_t *offsets, uint64_t n_reads);
+
+/* Same, for a batch already resident in device memory (hipMalloc'd by the caller on ix's device):
+ * what bench.py times. */
+int  vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals,
+                             const uint64_t *d_offsets, uint64_t n_reads);
+
+int  vg_sync(vg_index *ix);                       /* drain the stream                          */
+int  vg_stats_get(vg_index *ix, vg_stats *out);   /* implies vg_sync                           */
+int  vg_set_stats(vg_index *ix, int enable);      /* event counting on (default) / off: the
+                                                     counting build of the kernel carries ~50 extra
+                                                     registers per lane, so timed runs switch it off */
+int  vg_timing_get(vg_index *ix, vg_timing *out);
+
+/* SNP sites = positions seeded with ref != alt (qv.cc:637-659, 1580), ascending.
+ * Counters are exact sums; the reference's 6-bit saturation (vartype.h:27, qv.cc:1411, 1419) is
+ * min(63, sum) and is applied by vg_counts_fetch. */
+uint64_t vg_num_sites(const vg_index *ix);
+int  vg_sites_fetch(vg_index *ix, uint32_t *pos, uint8_t *ref_base, uint8_t *alt_base,
+                    uint8_t *ref_freq, uint8_t *alt_freq);
+int  vg_counts_fetch(vg_index *ix, uint8_t *ref_cnt, uint8_t *alt_cnt);    /* clamped at 63     */
+int  vg_counts_reset(vg_index *ix);
+
+/* Device pointer to the raw u32 counter array, length 2 * vg_num_sites: [2*s] = ref, [2*s+1] = alt.
+ * This is the ONE buffer that crosses GPUs: sum it over ranks (RCCL all-reduce over xGMI) before
+ * vg_counts_fetch.  Reads shard with no other exchange. */
+int  vg_counts_device_ptr(vg_index *ix, void **d_counts, uint64_t *n_u32);
+
+/* All-reduce (sum) the counters over the ranks of an RCCL communicator (ncclComm_t passed as
+ * void*), on the handle's stream. */
+int  vg_counts_allreduce(vg_index *ix, void *nccl_comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,601 @@
+/* vg_oracle.c -- CPU restatement of the `vargeno geno` per-read loop.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Follows the reference (paths relative to /root/reference) function by function; every block
+ * cites the lines it restates.  It is written from the behaviour, not from the text: one generic
+ * hit handler replaces the reference's six copies, the 16 GiB jump table is replaced by a 2^24
+ * coarse table + binary search with identical results, and the per-read unordered_map/IndexTable
+ * pair is one small key list.  Accidental behaviours that change output are kept on purpose:
+ *   B1  strided bucket scan              src/qv.cc:359, 448
+ *   qual[chunk_index] gate               src/qv.cc:836, 943
+ *   contexts pushed even when the vote is refused   src/qv.cc:132-139
+ *   u8 vote frequency, u32 wrap of pos - offset
+ *
+ * Parity status: PINNED against oracle/_ref/vargeno on F-small (tests/test_oracle_golden.py).
+ * Nothing under vargeno_amd/ may include, link or dlopen this file.
+ */
+#define _GNU_SOURCE
+#include "vg_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define POS_AMBIGUOUS 0xFFFFFFFFu   /* src/vartype.h:38 */
+#define NOMOD 10086u                 /* src/qv.cc:711 NO_MODIFICATION */
+#define AUX_COLS 10                  /* src/vartype.h:93 */
+#define BLOCK_THRESHOLD 100          /* src/vartype.h:103 */
+#define MAX_COV 63                   /* src/vartype.h:27 */
+#define QUALITY_SCORE '8'            /* src/vartype.h:17 */
+
+struct vgo_index {
+	uint64_t n_ref, n_ref_aux, n_snp, n_snp_aux;
+	uint64_t *ref_kmer; uint32_t *ref_pos; uint8_t *ref_amb; uint32_t *ref_aux;
+	uint64_t *snp_kmer; uint32_t *snp_pos; uint8_t *snp_info; uint8_t *snp_amb;
+	uint32_t *snp_aux_pos; uint8_t *snp_aux_info;
+	uint32_t *ref_cj;            /* coarse jump table over HI32 >> 8, 2^24 + 1 entries            */
+	uint32_t *snp_jg;            /* full jump table over HI24, 2^24 + 1 entries (qv.cc:622-678)   */
+	uint64_t ref_bf_bits, snp_bf_bits; uint64_t *ref_bf, *snp_bf; uint64_t ref_bf_nwords, snp_bf_nwords;
+	/* dense pileup, one u32 per genome position, the reference's packed_pileup_entry bit for bit
+	 * (src/vartype.h:81-90): bits 0-1 ref, 2-3 alt, 4-9 ref_cnt, 10-15 alt_cnt, 16-23 ref_freq, 24-31 alt_freq */
+	uint32_t *pile; uint64_t pile_len;
+	int ref_stride, snp_stride;  /* 9 and 11 = sizeof(struct kmer_entry / snp_kmer_entry): bug B1 */
+};
+
+#define P_REF(w) ((w) & 3u)
+#define P_ALT(w) (((w) >> 2) & 3u)
+#define P_RCNT(w) (((w) >> 4) & 63u)
+#define P_ACNT(w) (((w) >> 10) & 63u)
+
+static void *xmalloc(size_t n) { void *p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "vg_oracle: out of memory (%zu)\n", n); abort(); } return p; }
+static void *xdup(const void *src, size_t n) { void *p = xmalloc(n); if (n) memcpy(p, src, n); return p; }
+
+/* ---- bit vectors: BloomFilter::hash32 / hash40 / check_value, src/generate_bf.h:112-142 ---- */
+static inline uint32_t hash32(uint32_t x) { x = ((x >> 16) ^ x) * 0x45d9f3bu; x = ((x >> 16) ^ x) * 0x45d9f3bu; x = (x >> 16) ^ x; return x; }
+static inline uint64_t hash40(uint64_t x) { x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL; x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL; x = x ^ (x >> 31); return x; }
+static inline int bf_bit(const uint64_t *w, uint64_t p) { return (int)((w[p >> 6] >> (p & 63)) & 1u); }
+
+/* ---- bucket bounds.  The reference's jumpgate[h] = index of the first entry with HI >= h and
+ *      = n past the last used HI (qv.cc:539-584); lower_bound gives the same numbers. ---- */
+static uint64_t lower_bound_u64(const uint64_t *a, uint64_t lo, uint64_t hi, uint64_t key)
+{
+	while (lo < hi) { uint64_t mid = lo + ((hi - lo) >> 1); if (a[mid] < key) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+static inline void ref_bounds(const vgo_index *ix, uint32_t h, uint64_t *lo, uint64_t *hi)
+{
+	uint32_t c = h >> 8;
+	uint64_t a = ix->ref_cj[c], b = ix->ref_cj[c + 1];
+	*lo = lower_bound_u64(ix->ref_kmer, a, b, (uint64_t)h << 32);
+	*hi = (h == 0xFFFFFFFFu) ? ix->n_ref : lower_bound_u64(ix->ref_kmer, *lo, b, ((uint64_t)h + 1) << 32);
+}
+static inline void snp_bounds(const vgo_index *ix, uint32_t h24, uint64_t *lo, uint64_t *hi)
+{
+	*lo = ix->snp_jg[h24]; *hi = ix->snp_jg[h24 + 1];
+}
+static inline unsigned ceil_log2_p1(uint64_t b) { unsigned k = 0; while ((1ull << k) < b + 1) ++k; return k; }
+
+/* query_ref_dict, src/qv.cc:206-240: returns entry index or -1 */
+static int64_t query_ref(const vgo_index *ix, uint64_t kmer, vgo_stats *st)
+{
+	uint64_t lo, hi; ref_bounds(ix, (uint32_t)(kmer >> 32), &lo, &hi);
+	st->ref_query++;
+	if (lo == ix->n_ref || lo == hi) return -1;
+	st->ref_probe += ceil_log2_p1(hi - lo);
+	uint64_t i = lower_bound_u64(ix->ref_kmer, lo, hi, kmer);
+	return (i < hi && ix->ref_kmer[i] == kmer) ? (int64_t)i : -1;
+}
+/* query_snp_dict, src/qv.cc:385-411 */
+static int64_t query_snp(const vgo_index *ix, uint64_t kmer, vgo_stats *st)
+{
+	uint64_t lo, hi; snp_bounds(ix, (uint32_t)(kmer >> 40), &lo, &hi);
+	st->snp_query++;
+	if (lo == ix->n_snp || lo == hi) return -1;
+	st->snp_probe += ceil_log2_p1(hi - lo);
+	uint64_t i = lower_bound_u64(ix->snp_kmer, lo, hi, kmer);
+	return (i < hi && ix->snp_kmer[i] == kmer) ? (int64_t)i : -1;
+}
+
+/* one_hamming_distance_32/64, src/qv.cc:267-312: x != 0 and confined to one bit pair -> pair index */
+static inline int onebase(uint64_t x)
+{
+	if (x == 0) return -1;
+	int d = __builtin_ctzll(x) >> 1;
+	return (x & ~(3ull << (2 * d))) ? -1 : d;
+}
+
+/* ---- per-pass state: contexts (qv.cc:718-729) and the vote (qv.cc:57-178) ---- */
+typedef struct { uint64_t kmer; uint32_t position, kmer_pos, mod; } ctx_t;
+typedef struct { ctx_t *v; size_t n, cap; } ctxvec;
+typedef struct { uint32_t index, first_kpos; uint8_t freq, multi; } vkey;
+typedef struct {
+	ctxvec ref, snp;
+	vkey *keys; size_t nkeys, kcap;
+	int64_t best; int amb;
+} pass_state;
+
+static void ctx_push(ctxvec *c, uint64_t kmer, uint32_t position, uint32_t kpos, uint32_t mod)
+{
+	if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 64; c->v = realloc(c->v, c->cap * sizeof(ctx_t)); if (!c->v) abort(); }
+	c->v[c->n++] = (ctx_t){kmer, position, kpos, mod};
+}
+
+/* improved_index_table_add, src/qv.cc:132-178.  The IndexTable slot lists and the
+ * unordered_map<index, set<kmer_pos>> always hold the same key set, so one list serves both;
+ * |set| >= 2 is "a kmer_pos different from the first one was inserted". */
+static void vote(pass_state *ps, uint32_t index, uint32_t kpos, int neigh)
+{
+	int64_t e = -1;
+	for (size_t i = 0; i < ps->nkeys; i++) if (ps->keys[i].index == index) { e = (int64_t)i; break; }
+	if (e < 0) {
+		if (neigh) return;                                                   /* :134-139 */
+		if (ps->nkeys == ps->kcap) { ps->kcap = ps->kcap ? ps->kcap * 2 : 32; ps->keys = realloc(ps->keys, ps->kcap * sizeof(vkey)); if (!ps->keys) abort(); }
+		e = (int64_t)ps->nkeys++;
+		ps->keys[e] = (vkey){index, kpos, 0, 0};
+	}
+	vkey *k = &ps->keys[e];
+	k->freq++;                                                               /* uint8_t, :146/:158 */
+	if (kpos != k->first_kpos) k->multi = 1;                                 /* :163 */
+	if (!k->multi) return;                                                   /* :165 */
+	if (ps->best < 0) { ps->best = e; ps->amb = 0; }
+	else if (e == ps->best) ps->amb = 0;
+	else if (k->freq == ps->keys[ps->best].freq) ps->amb = 1;
+	else if (k->freq > ps->keys[ps->best].freq) { ps->best = e; ps->amb = 0; }
+}
+
+static inline int is_site_loose(const vgo_index *ix, uint32_t p)   /* !(ref==0 && alt==0), qv.cc:990-991 */
+{
+	return p < ix->pile_len && (ix->pile[p] & 15u) != 0;
+}
+
+/* A ref-dict hit (entry idx supplies pos/ambig_flag).  Exact: qv.cc:850-890; neighbour: :979-1047,
+ * :1131-1171, :1228-1296.  kk = k-mer recorded in the context, mod = mutated base or NOMOD. */
+static void ref_hit(const vgo_index *ix, pass_state *ps, int64_t idx, uint64_t kk, uint32_t off, uint32_t mod, int neigh, vgo_stats *st)
+{
+	if (idx < 0) return;
+	uint32_t pos = ix->ref_pos[idx];
+	if (pos == POS_AMBIGUOUS) return;
+	if (ix->ref_amb[idx] == 0) {
+		if (neigh) { st->site_test++; if (is_site_loose(ix, pos + mod)) return; }
+		ctx_push(&ps->ref, kk, pos - off, pos, mod); st->ctx++;
+		vote(ps, pos - off, pos, neigh);
+	} else {
+		const uint32_t *row = &ix->ref_aux[(uint64_t)pos * AUX_COLS];
+		st->aux_ref++;
+		for (int j = 0; j < AUX_COLS; j++) {
+			uint32_t p = row[j];
+			if (p == 0) break;
+			if (neigh) { st->site_test++; if (is_site_loose(ix, p + mod)) continue; }
+			ctx_push(&ps->ref, kk, p - off, p, mod); st->ctx++;
+			vote(ps, p - off, p, neigh);
+		}
+	}
+}
+/* A SNP-dict hit.  Exact: qv.cc:897-937; neighbour: :1055-1101, :1176-1207, :1308-1352. */
+static void snp_hit(const vgo_index *ix, pass_state *ps, int64_t idx, uint64_t kk, uint32_t off, uint32_t mod, int neigh, vgo_stats *st)
+{
+	if (idx < 0) return;
+	uint32_t pos = ix->snp_pos[idx];
+	if (pos == POS_AMBIGUOUS) return;
+	if (ix->snp_amb[idx] == 0) {
+		if (neigh && (uint32_t)(ix->snp_info[idx] >> 3) == mod) return;
+		ctx_push(&ps->snp, kk, pos - off, pos, mod); st->ctx++;
+		vote(ps, pos - off, pos, neigh);
+	} else {
+		const uint32_t *prow = &ix->snp_aux_pos[(uint64_t)pos * AUX_COLS];
+		const uint8_t *irow = &ix->snp_aux_info[(uint64_t)pos * AUX_COLS];
+		st->aux_snp++;
+		for (int j = 0; j < AUX_COLS; j++) {
+			uint32_t p = prow[j];
+			if (p == 0) break;
+			if (neigh && (uint32_t)(irow[j] >> 3) == mod) continue;
+			ctx_push(&ps->snp, kk, p - off, p, mod); st->ctx++;
+			vote(ps, p - off, p, neigh);
+		}
+	}
+}
+
+/* saturating +1 on a 6-bit field of the packed pileup word; atomic so OpenMP runs give the same sums */
+static inline void sat_inc(uint32_t *w, int shift)
+{
+	uint32_t old = __atomic_load_n(w, __ATOMIC_RELAXED);
+	for (;;) {
+		if (((old >> shift) & 63u) == MAX_COV) return;
+		if (__atomic_compare_exchange_n(w, &old, old + (1u << shift), 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return;
+	}
+}
+
+/* pileup walk of one supporting context, src/qv.cc:1386-1436 (ref) = :1444-1494 (snp) */
+static void walk(vgo_index *ix, const ctx_t *c, vgo_stats *st)
+{
+	st->walks++;
+	for (uint32_t b = 0; b < 32; b++) {
+		if (b == c->mod) continue;
+		uint32_t p = c->kmer_pos + b;
+		if (p >= ix->pile_len) continue;
+		uint32_t w = ix->pile[p];
+		if (P_REF(w) == P_ALT(w)) continue;
+		uint32_t base = (uint32_t)(c->kmer >> (2 * b)) & 3u;
+		if (base == P_REF(w)) { sat_inc(&ix->pile[p], 4); st->incr++; }
+		else if (base == P_ALT(w)) { sat_inc(&ix->pile[p], 10); st->incr++; }
+	}
+}
+
+/* One pass over the chunk k-mers K[0..n) (src/qv.cc:834-1502).  Returns 1 if the read was processed. */
+static int run_pass(vgo_index *ix, pass_state *ps, const uint64_t *K, size_t n, const uint8_t *qual, vgo_stats *st, uint32_t *target_out)
+{
+	ps->ref.n = ps->snp.n = 0; ps->nkeys = 0; ps->best = -1; ps->amb = 0;
+	st->passes++;
+	for (size_t c = 0; c < n; c++) {
+		const uint64_t k = K[c];
+		const uint32_t off = (uint32_t)(32 * c);
+		st->chunks++;
+		uint64_t lo, hi; ref_bounds(ix, (uint32_t)(k >> 32), &lo, &hi);
+		const uint64_t bs = (lo == ix->n_ref) ? 0 : hi - lo;                 /* check_block_size :242-264 */
+		ref_hit(ix, ps, query_ref(ix, k, st), k, off, NOMOD, 0, st);        /* :840, :850-890 */
+		snp_hit(ix, ps, query_snp(ix, k, st), k, off, NOMOD, 0, st);        /* :841, :897-937 */
+		if ((int)qual[c] - QUALITY_SCORE >= 0) continue;                     /* :836, :943 -- c = chunk number */
+		st->gate_open++;
+		uint32_t rsb = 64, ssb = 64;                                         /* :946-956 */
+		{
+			uint64_t rp = (uint64_t)hash32((uint32_t)k) % ix->ref_bf_bits;
+			uint64_t sp = hash40(k & 0xFFFFFFFFFFull) % ix->snp_bf_bits;
+			if (bf_bit(ix->ref_bf, rp)) st->refbf_pos++; else rsb = 32;
+			if (bf_bit(ix->snp_bf, sp)) st->snpbf_pos++; else ssb = 40;
+		}
+		if (bs >= BLOCK_THRESHOLD) {                                         /* :962-1109 */
+			st->large_block++;
+			for (uint32_t i = 0; i < 32; i += 2) {
+				uint64_t base = (k >> i) & 3u;
+				for (uint64_t j = 0; j < 4; j++) {
+					if (j == base) continue;
+					uint64_t nb = (k & ~(3ull << i)) | (j << i);
+					int64_t r = query_ref(ix, nb, st), s = query_snp(ix, nb, st);
+					ref_hit(ix, ps, r, nb, off, i / 2, 1, st);
+					snp_hit(ix, ps, s, nb, off, i / 2, 1, st);
+				}
+			}
+		} else {                                                             /* :1110-1209 */
+			/* iterate_ref_dict :316-376 -- tests entry lo + 9*(i-lo), records entry i (B1) */
+			if (!(lo == ix->n_ref || lo == hi)) {
+				for (uint64_t i = lo; i < hi; i++) {
+					uint64_t t = lo + (i - lo) * (uint64_t)ix->ref_stride;
+					uint32_t tlo = 0;
+					st->scan_ref++;
+					if (t < ix->n_ref) tlo = (uint32_t)ix->ref_kmer[t]; else st->scan_oob++;
+					int d = onebase((uint64_t)((uint32_t)k ^ tlo));
+					if (d >= 0) ref_hit(ix, ps, (int64_t)i, (k & 0xFFFFFFFF00000000ull) | tlo, off, (uint32_t)d, 1, st);
+				}
+			}
+			/* iterate_snp_dict :413-464 */
+			uint64_t slo, shi; snp_bounds(ix, (uint32_t)(k >> 40), &slo, &shi);
+			if (!(slo == ix->n_snp || slo == shi)) {
+				for (uint64_t i = slo; i < shi; i++) {
+					uint64_t t = slo + (i - slo) * (uint64_t)ix->snp_stride;
+					uint64_t tlo = 0;
+					st->scan_snp++;
+					if (t < ix->n_snp) tlo = ix->snp_kmer[t] & 0xFFFFFFFFFFull; else st->scan_oob++;
+					int d = onebase((k & 0xFFFFFFFFFFull) ^ tlo);
+					if (d >= 0) snp_hit(ix, ps, (int64_t)i, (k & 0xFFFFFF0000000000ull) | tlo, off, (uint32_t)d, 1, st);
+				}
+			}
+		}
+		for (uint32_t i = 32; i < 64; i += 2) {                              /* :1213-1365 */
+			uint64_t base = (k >> i) & 3u;
+			for (uint64_t j = 0; j < 4; j++) {
+				if (j == base) continue;
+				uint64_t nb = (k & ~(3ull << i)) | (j << i);
+				if (i < rsb) ref_hit(ix, ps, query_ref(ix, nb, st), nb, off, i / 2, 1, st);
+				if (bs >= BLOCK_THRESHOLD || i >= 40) {
+					if (i >= ssb) continue;
+					snp_hit(ix, ps, query_snp(ix, nb, st), nb, off, i / 2, 1, st);
+				}
+			}
+		}
+	}
+	const int processed = ps->best >= 0 && ps->keys[ps->best].freq > 1 && !ps->amb;   /* :1375 */
+	const uint32_t target = ps->best >= 0 ? ps->keys[ps->best].index : 0;           /* :1376 */
+	if (target_out) *target_out = target;
+	if (processed) {
+		st->passes_ok++;
+		for (size_t i = 0; i < ps->ref.n; i++) if (ps->ref.v[i].position == target) walk(ix, &ps->ref.v[i], st);
+		for (size_t i = 0; i < ps->snp.n; i++) if (ps->snp.v[i].position == target) walk(ix, &ps->snp.v[i], st);
+	}
+	return processed;
+}
+
+/* encode the floor(len/32) chunks (util.c:89-111 scans each chunk from base 31 down to 0).
+ * returns 0 ok, 1 = N found first (skip read), 2 = invalid base found first (reference: assert(0)) */
+static int encode_chunks(const uint8_t *s, size_t n, uint64_t *K)
+{
+	for (size_t c = 0; c < n; c++) {
+		uint64_t k = 0;
+		for (int j = 31; j >= 0; j--) {
+			uint64_t code;
+			switch (s[32 * c + j]) {
+			case 'A': case 'a': code = 0; break;
+			case 'C': case 'c': code = 1; break;
+			case 'G': case 'g': code = 2; break;
+			case 'T': case 't': code = 3; break;
+			case 'N': case 'n': return 1;
+			default: return 2;
+			}
+			k = (k << 2) | code;
+		}
+		K[c] = k;
+	}
+	return 0;
+}
+
+/* reverse complement of the trimmed read in 2-bit space (qv.cc:786-806 does it on characters):
+ * chunk c' = reverse of chunk n-1-c', bases complemented (3 - x). */
+static inline uint64_t revcomp64(uint64_t k)
+{
+	k = ((k >> 2) & 0x3333333333333333ull) | ((k & 0x3333333333333333ull) << 2);
+	k = ((k >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((k & 0x0F0F0F0F0F0F0F0Full) << 4);
+	k = __builtin_bswap64(k);
+	return ~k;
+}
+
+typedef struct { pass_state ps; uint64_t *K, *R; size_t kcap; } worker;
+
+static int do_read(vgo_index *ix, worker *w, const uint8_t *bases, const uint8_t *quals, uint64_t rlen, vgo_stats *st, uint32_t *trace)
+{
+	/* qv.cc:778-779: read_len_true = strlen(read) - 1 = rlen; len = (rlen/32)*32 */
+	const size_t n = (size_t)(rlen / 32);
+	st->reads++;
+	st->ingest_bytes += n * 8 + n;
+	if (n > w->kcap) { w->kcap = n + 8; w->K = realloc(w->K, w->kcap * 8); w->R = realloc(w->R, w->kcap * 8); if (!w->K || !w->R) abort(); }
+	int e = encode_chunks(bases, n, w->K);
+	if (e == 1) { st->reads_n++; return 0; }
+	if (e == 2) { st->reads_invalid++; return 1; }
+	uint32_t target = 0;
+	int ok = run_pass(ix, &w->ps, w->K, n, quals, st, &target);
+	int passes = 1;
+	if (!ok) {                                                               /* :1504-1510 */
+		for (size_t c = 0; c < n; c++) w->R[c] = revcomp64(w->K[n - 1 - c]);
+		ok = run_pass(ix, &w->ps, w->R, n, quals, st, &target);             /* quality string NOT reversed */
+		passes = 2;
+	}
+	if (trace) { trace[0] = (uint32_t)passes; trace[1] = (uint32_t)ok; trace[2] = target; trace[3] = (uint32_t)w->ps.ref.n; trace[4] = (uint32_t)w->ps.snp.n; }
+	return 0;
+}
+
+static void worker_free(worker *w) { free(w->ps.ref.v); free(w->ps.snp.v); free(w->ps.keys); free(w->K); free(w->R); }
+
+static void stats_add(vgo_stats *a, const vgo_stats *b)
+{
+	uint64_t *x = (uint64_t *)a; const uint64_t *y = (const uint64_t *)b;
+	for (size_t i = 0; i < sizeof(vgo_stats) / 8; i++) x[i] += y[i];
+}
+
+int64_t vgo_process(vgo_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets,
+                    uint64_t n_reads, int nthreads, vgo_stats *stats)
+{
+	int64_t invalid = 0;
+	if (nthreads <= 1) {
+		worker w; memset(&w, 0, sizeof w);
+		vgo_stats st; memset(&st, 0, sizeof st);
+		for (uint64_t r = 0; r < n_reads; r++)
+			invalid += do_read(ix, &w, bases + offsets[r], quals + offsets[r], offsets[r + 1] - offsets[r], &st, NULL);
+		worker_free(&w);
+		if (stats) stats_add(stats, &st);
+		return invalid;
+	}
+#ifdef _OPENMP
+	#pragma omp parallel num_threads(nthreads) reduction(+:invalid)
+	{
+		worker w; memset(&w, 0, sizeof w);
+		vgo_stats st; memset(&st, 0, sizeof st);
+		#pragma omp for schedule(dynamic, 1024)
+		for (uint64_t r = 0; r < n_reads; r++)
+			invalid += do_read(ix, &w, bases + offsets[r], quals + offsets[r], offsets[r + 1] - offsets[r], &st, NULL);
+		worker_free(&w);
+		#pragma omp critical
+		{ if (stats) stats_add(stats, &st); }
+	}
+#endif
+	return invalid;
+}
+
+void vgo_trace_read(vgo_index *ix, const uint8_t *bases, const uint8_t *quals, uint64_t len, uint32_t out[5])
+{
+	worker w; memset(&w, 0, sizeof w);
+	vgo_stats st; memset(&st, 0, sizeof st);
+	memset(out, 0, 5 * sizeof(uint32_t));
+	do_read(ix, &w, bases, quals, len, &st, out);
+	worker_free(&w);
+}
+
+/* ---------------------------------------------------------------- index construction (qv.cc:519-695) */
+
+vgo_index *vgo_index_from_arrays(
+	uint64_t n_ref, const uint64_t *ref_kmer, const uint32_t *ref_pos, const uint8_t *ref_amb,
+	uint64_t n_ref_aux, const uint32_t *ref_aux,
+	uint64_t n_snp, const uint64_t *snp_kmer, const uint32_t *snp_pos, const uint8_t *snp_info,
+	const uint8_t *snp_amb, const uint8_t *snp_rf, const uint8_t *snp_af,
+	uint64_t n_snp_aux, const uint32_t *snp_aux_pos, const uint8_t *snp_aux_info,
+	uint64_t ref_bf_bits, const uint64_t *ref_bf_words, uint64_t snp_bf_bits, const uint64_t *snp_bf_words)
+{
+	vgo_index *ix = calloc(1, sizeof *ix);
+	if (!ix) return NULL;
+	ix->n_ref = n_ref; ix->n_ref_aux = n_ref_aux; ix->n_snp = n_snp; ix->n_snp_aux = n_snp_aux;
+	ix->ref_stride = 9; ix->snp_stride = 11;
+	ix->ref_kmer = xdup(ref_kmer, n_ref * 8); ix->ref_pos = xdup(ref_pos, n_ref * 4); ix->ref_amb = xdup(ref_amb, n_ref);
+	ix->ref_aux = xdup(ref_aux, n_ref_aux * AUX_COLS * 4);
+	ix->snp_kmer = xdup(snp_kmer, n_snp * 8); ix->snp_pos = xdup(snp_pos, n_snp * 4); ix->snp_info = xdup(snp_info, n_snp); ix->snp_amb = xdup(snp_amb, n_snp);
+	ix->snp_aux_pos = xdup(snp_aux_pos, n_snp_aux * AUX_COLS * 4); ix->snp_aux_info = xdup(snp_aux_info, n_snp_aux * AUX_COLS);
+	/* the reference addresses bit (hash % bv_size); only words below that are ever read.  hash32 is 32-bit. */
+	ix->ref_bf_bits = ref_bf_bits; ix->snp_bf_bits = snp_bf_bits;
+	uint64_t rbits = ref_bf_bits < (1ull << 32) ? ref_bf_bits : (1ull << 32);
+	ix->ref_bf_nwords = (rbits + 63) / 64; ix->snp_bf_nwords = (snp_bf_bits + 63) / 64;
+	ix->ref_bf = xdup(ref_bf_words, ix->ref_bf_nwords * 8); ix->snp_bf = xdup(snp_bf_words, ix->snp_bf_nwords * 8);
+
+	/* coarse ref jump table: cj[c] = first entry with (HI32 >> 8) >= c */
+	ix->ref_cj = xmalloc(((1u << 24) + 1) * sizeof(uint32_t));
+	{
+		uint64_t i = 0;
+		for (uint64_t c = 0; c <= (1u << 24); c++) {
+			while (i < n_ref && (ref_kmer[i] >> 40) < c) i++;
+			ix->ref_cj[c] = (uint32_t)i;
+		}
+	}
+	ix->snp_jg = xmalloc(((1u << 24) + 1) * sizeof(uint32_t));
+	{
+		uint64_t i = 0;
+		for (uint64_t c = 0; c <= (1u << 24); c++) {
+			while (i < n_snp && (snp_kmer[i] >> 40) < c) i++;
+			ix->snp_jg[c] = (uint32_t)i;
+		}
+	}
+	/* pileup table.  The reference sizes it max(raw pos field)+33 (qv.cc:554-555, 602-603), which is
+	 * 2^32+32 as soon as one k-mer is POS_AMBIGUOUS; only real positions are ever indexed, so size by those. */
+	uint64_t maxp = 0;
+	for (uint64_t i = 0; i < n_ref; i++) if (ref_amb[i] == 0 && ref_pos[i] != POS_AMBIGUOUS && ref_pos[i] > maxp) maxp = ref_pos[i];
+	for (uint64_t i = 0; i < n_ref_aux * AUX_COLS; i++) if (ref_aux[i] > maxp) maxp = ref_aux[i];
+	for (uint64_t i = 0; i < n_snp; i++) if (snp_amb[i] == 0 && snp_pos[i] != POS_AMBIGUOUS && snp_pos[i] > maxp) maxp = snp_pos[i];
+	for (uint64_t i = 0; i < n_snp_aux * AUX_COLS; i++) if (snp_aux_pos[i] > maxp) maxp = snp_aux_pos[i];
+	ix->pile_len = maxp + 64;
+	ix->pile = calloc(ix->pile_len, sizeof(uint32_t));
+	if (!ix->pile) abort();
+	/* seeding, qv.cc:637-659: file order, last writer wins, counters untouched */
+	for (uint64_t i = 0; i < n_snp; i++) {
+		uint32_t info = snp_info[i];
+		if ((info & 4u) == 0 && snp_pos[i] != POS_AMBIGUOUS && snp_amb[i] == 0) {
+			uint32_t sp = snp_pos[i] + (info >> 3);
+			uint32_t alt = (uint32_t)(snp_kmer[i] >> (2 * (info >> 3))) & 3u;
+			uint32_t w = ix->pile[sp];
+			w = (w & 0x0000FFF0u) | (info & 3u) | (alt << 2) | ((uint32_t)snp_rf[i] << 16) | ((uint32_t)snp_af[i] << 24);
+			ix->pile[sp] = w;
+		}
+	}
+	return ix;
+}
+
+static int read_all(const char *path, void **buf, uint64_t *len)
+{
+	FILE *f = fopen(path, "rb");
+	if (!f) return -1;
+	fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+	*buf = xmalloc((size_t)sz);
+	if (fread(*buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(*buf); return -1; }
+	fclose(f); *len = (uint64_t)sz;
+	return 0;
+}
+
+/* sdsl int_vector<1> file: u64 bit count, then ceil(bits/64) LE words (int_vector.hpp:1563-1595).
+ * Only the first `want_bits` bits are kept. */
+static int read_bf(const char *path, uint64_t *bits, uint64_t **words, uint64_t cap_bits)
+{
+	FILE *f = fopen(path, "rb");
+	if (!f) return -1;
+	if (fread(bits, 8, 1, f) != 1) { fclose(f); return -1; }
+	uint64_t keep = *bits < cap_bits ? *bits : cap_bits;
+	uint64_t nw = (keep + 63) / 64;
+	*words = xmalloc(nw * 8);
+	if (fread(*words, 8, nw, f) != nw) { fclose(f); free(*words); return -1; }
+	fclose(f);
+	return 0;
+}
+
+vgo_index *vgo_index_load(const char *prefix)
+{
+	char path[4200];
+	void *rd = NULL, *sd = NULL; uint64_t rlen = 0, slen = 0;
+	snprintf(path, sizeof path, "%s.ref.dict", prefix); if (read_all(path, &rd, &rlen)) return NULL;
+	snprintf(path, sizeof path, "%s.snp.dict", prefix); if (read_all(path, &sd, &slen)) { free(rd); return NULL; }
+	const uint8_t *p = rd;
+	uint64_t n_ref, n_ref_aux; memcpy(&n_ref, p, 8); memcpy(&n_ref_aux, p + 8, 8); p += 16;
+	uint64_t *rk = xmalloc(n_ref * 8); uint32_t *rp = xmalloc(n_ref * 4); uint8_t *ra = xmalloc(n_ref);
+	for (uint64_t i = 0; i < n_ref; i++, p += 13) { memcpy(&rk[i], p, 8); memcpy(&rp[i], p + 8, 4); ra[i] = p[12]; }   /* dictgen.c:63-154 */
+	uint32_t *raux = xmalloc(n_ref_aux * 40); memcpy(raux, p, n_ref_aux * 40);
+	p = sd;
+	uint64_t n_snp, n_snp_aux; memcpy(&n_snp, p, 8); memcpy(&n_snp_aux, p + 8, 8); p += 16;
+	uint64_t *sk = xmalloc(n_snp * 8); uint32_t *sp = xmalloc(n_snp * 4);
+	uint8_t *si = xmalloc(n_snp), *sa = xmalloc(n_snp), *srf = xmalloc(n_snp), *saf = xmalloc(n_snp);
+	for (uint64_t i = 0; i < n_snp; i++, p += 16) { memcpy(&sk[i], p, 8); memcpy(&sp[i], p + 8, 4); si[i] = p[12]; sa[i] = p[13]; srf[i] = p[14]; saf[i] = p[15]; }   /* dictgen.c:156-275 */
+	uint32_t *sap = xmalloc(n_snp_aux * 40); uint8_t *sai = xmalloc(n_snp_aux * 10);
+	for (uint64_t i = 0; i < n_snp_aux; i++) {
+		p += 8;                                                              /* k-mer, unused by geno (qv.cc:682-683) */
+		for (int j = 0; j < AUX_COLS; j++, p += 7) { memcpy(&sap[i * 10 + j], p, 4); sai[i * 10 + j] = p[4]; }
+	}
+	uint64_t rbits = 0, sbits = 0; uint64_t *rw = NULL, *sw = NULL;
+	snprintf(path, sizeof path, "%s.ref.bf", prefix); if (read_bf(path, &rbits, &rw, 1ull << 32)) return NULL;
+	snprintf(path, sizeof path, "%s.snp.bf", prefix); if (read_bf(path, &sbits, &sw, ~0ull)) return NULL;
+	vgo_index *ix = vgo_index_from_arrays(n_ref, rk, rp, ra, n_ref_aux, raux, n_snp, sk, sp, si, sa, srf, saf,
+	                                      n_snp_aux, sap, sai, rbits, rw, sbits, sw);
+	free(rd); free(sd); free(rk); free(rp); free(ra); free(raux); free(sk); free(sp); free(si); free(sa); free(srf); free(saf);
+	free(sap); free(sai); free(rw); free(sw);
+	return ix;
+}
+
+void vgo_index_free(vgo_index *ix)
+{
+	if (!ix) return;
+	free(ix->ref_kmer); free(ix->ref_pos); free(ix->ref_amb); free(ix->ref_aux);
+	free(ix->snp_kmer); free(ix->snp_pos); free(ix->snp_info); free(ix->snp_amb); free(ix->snp_aux_pos); free(ix->snp_aux_info);
+	free(ix->ref_cj); free(ix->snp_jg); free(ix->ref_bf); free(ix->snp_bf); free(ix->pile);
+	free(ix);
+}
+
+void vgo_set_scan_stride(vgo_index *ix, int r, int s) { ix->ref_stride = r; ix->snp_stride = s; }
+
+void vgo_reset_counts(vgo_index *ix) { for (uint64_t i = 0; i < ix->pile_len; i++) ix->pile[i] &= 0xFFFF000Fu; }
+
+uint64_t vgo_num_sites(const vgo_index *ix)
+{
+	uint64_t n = 0;
+	for (uint64_t i = 0; i < ix->pile_len; i++) n += P_REF(ix->pile[i]) != P_ALT(ix->pile[i]);    /* qv.cc:1580 */
+	return n;
+}
+
+void vgo_get_sites(const vgo_index *ix, uint32_t *pos, uint8_t *rb, uint8_t *ab, uint8_t *rf, uint8_t *af, uint8_t *rc, uint8_t *ac)
+{
+	uint64_t n = 0;
+	for (uint64_t i = 0; i < ix->pile_len; i++) {
+		uint32_t w = ix->pile[i];
+		if (P_REF(w) == P_ALT(w)) continue;
+		if (pos) pos[n] = (uint32_t)i;
+		if (rb) rb[n] = (uint8_t)P_REF(w);
+		if (ab) ab[n] = (uint8_t)P_ALT(w);
+		if (rf) rf[n] = (uint8_t)(w >> 16);
+		if (af) af[n] = (uint8_t)(w >> 24);
+		if (rc) rc[n] = (uint8_t)P_RCNT(w);
+		if (ac) ac[n] = (uint8_t)P_ACNT(w);
+		n++;
+	}
+}
+
+/* choose_best_genotype, src/qv.cc:1789-1848 (ERR_RATE 0.01, AVG_COV 7.1, vartype.h:13-14) */
+int vgo_call(int r, int a, uint8_t rf, uint8_t af, double *conf, int *gq)
+{
+	if ((r == 0 && a == 0) || (r == MAX_COV && a == MAX_COV)) { if (conf) *conf = 0.0; if (gq) *gq = 0; return 0; }
+	const double g0 = pow(1.0 - 0.01, r) * pow(0.01, a);
+	const double g1 = pow(0.5, r + a);
+	const double g2 = pow(0.01, r) * pow(1.0 - 0.01, a);
+	const double p = rf / 255.0, q = af / 255.0, p2 = p * p, q2 = q * q;
+	const double pg0 = p2 * g0, pg1 = (1.0 - p2 - q2) * g1, pg2 = q2 * g2, total = pg0 + pg1 + pg2;
+	const int n = r + a;
+	const double poisson = (exp(-7.1) * pow(7.1, n)) / exp(lgamma(n + 1.0));
+	int g; double c;
+	if (pg0 > pg1 && pg0 > pg2) { g = 1; c = (pg0 / total) * poisson; }
+	else if (pg1 > pg0 && pg1 > pg2) { g = 3; c = (pg1 / total) * poisson; }
+	else { g = 2; c = (pg2 / total) * poisson; }
+	if (conf) *conf = c;
+	if (gq) *gq = (int)(-1 * 10 * log(c));                                   /* qv.cc:1683 */
+	return g;
+}
+
+uint64_t vgo_alg_bytes(const vgo_stats *s)
+{
+	/* SURVEY.md §8(d) unit costs */
+	uint64_t scans = s->gate_open - s->large_block;
+	return s->ingest_bytes
+	     + 8 * (s->ref_query + s->snp_query) + 9 * s->ref_probe + 11 * s->snp_probe
+	     + 8 * 2 * s->gate_open
+	     + 8 * 2 * scans + 9 * s->scan_ref + 11 * s->scan_snp
+	     + 40 * s->aux_ref + 50 * s->aux_snp + 4 * s->site_test
+	     + 128 * s->walks + 4 * s->incr;
+}

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ from the REAL reference (oracle/_ref/vargeno, built by oracle/Makefile
+from /root/reference).  Runs only in the build container; the GPU box and the tests use the
+committed outputs.  Usage:  python tests/golden/make_golden.py [workdir]
+
+Produces
+  ftiny.*      60 kbp / 2 951 SNPs / 4 000 reads -- committed whole: inputs, the reference-written
+               dict files, the set bits of its bit-vector files, its output VCF.
+  fsmall.*     F-small of SURVEY.md §8c (300 kbp / 29 868 SNPs / 40 000 reads): inputs are a pure
+               function of the seed (vargeno_amd/synth.py), so only the sha256 list and the
+               reference's output VCF are committed.
+Fixtures are data (inputs and reference outputs); no reference source text is stored here.
+"""
+import gzip
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from vargeno_amd import synth  # noqa: E402
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "vargeno")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def gz(src, dst):
+    with open(src, "rb") as f, gzip.GzipFile(dst, "wb", compresslevel=9, mtime=0) as g:
+        shutil.copyfileobj(f, g)
+
+
+def bf_setbits(path):
+    w = np.fromfile(path, dtype=np.uint64)
+    bits, words = int(w[0]), w[1:]
+    nz = np.nonzero(words)[0]
+    pos = []
+    for i in nz:
+        v = int(words[i])
+        while v:
+            b = (v & -v).bit_length() - 1
+            pos.append(int(i) * 64 + b)
+            v &= v - 1
+    return bits, np.array(pos, dtype=np.uint64)
+
+
+def run(name, gen, work, commit_all):
+    d = os.path.join(work, name)
+    os.makedirs(d, exist_ok=True)
+    g, s, r = gen()
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    synth.write_fastq(os.path.join(d, "reads.fq"), r)
+    subprocess.check_call([REF_BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, stdout=subprocess.DEVNULL)
+    subprocess.check_call([REF_BIN, "geno", "idx", "reads.fq", "snps.vcf", "out.vcf"], cwd=d, stdout=subprocess.DEVNULL)
+    files = ["ref.fa", "snps.vcf", "reads.fq", "idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf",
+             "idx.snp.bf", "out.vcf"]
+    with open(os.path.join(OUT, name + ".sha256"), "w") as f:
+        for fn in files:
+            f.write("%s  %s\n" % (sha(os.path.join(d, fn)), fn))
+    gz(os.path.join(d, "out.vcf"), os.path.join(OUT, name + ".out.vcf.gz"))
+    if commit_all:
+        for fn in ("ref.fa", "snps.vcf", "reads.fq", "idx.ref.dict", "idx.snp.dict"):
+            gz(os.path.join(d, fn), os.path.join(OUT, "%s.%s.gz" % (name, fn)))
+        shutil.copy(os.path.join(d, "idx.chrlens"), os.path.join(OUT, name + ".idx.chrlens"))
+        rb, rp = bf_setbits(os.path.join(d, "idx.ref.bf"))
+        sb, sp = bf_setbits(os.path.join(d, "idx.snp.bf"))
+        np.savez_compressed(os.path.join(OUT, name + ".bf.npz"), ref_bits=np.uint64(rb), ref_set=rp,
+                            snp_bits=np.uint64(sb), snp_set=sp)
+
+
+if __name__ == "__main__":
+    work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/vg_golden"
+    if not os.path.exists(REF_BIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall"]
+    if "ftiny" in which:
+        run("ftiny", synth.f_tiny, work, True)
+    if "fsmall" in which:
+        run("fsmall", synth.f_small, work, False)
+    # the reference's own test data (test/snp.vcf, test/expected_output): data files, copied verbatim
+    if os.path.isdir("/root/reference/test"):
+        shutil.copy("/root/reference/test/snp.vcf", os.path.join(OUT, "reftest.snp.vcf"))
+        shutil.copy("/root/reference/test/expected_output", os.path.join(OUT, "reftest.expected_output"))

@@ -1,0 +1,137 @@
+"""Parity of the HIP path (through the C-ABI) against the oracle and the reference's golden output.
+Bit-exact: this is integer / index work, there is no tolerance anywhere."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as O
+from vargeno_amd import index_io
+from vargeno_amd.api import GenoIndex
+
+pytestmark = pytest.mark.gpu
+
+CMP_STATS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chunks", "gate_open", "refbf_pos", "snpbf_pos",
+             "large_block", "ref_query", "snp_query", "ref_probe", "snp_probe", "scan_ref", "scan_snp", "scan_oob",
+             "aux_ref", "aux_snp", "site_test", "ctx", "walks", "incr", "ingest_bytes"]
+
+
+def _oracle_counts(prefix, r):
+    ox = O.OracleIndex.load(prefix)
+    bad = ox.process(r.bases, r.quals, r.offsets)
+    return ox, bad, ox.sites()
+
+
+def test_ftiny_counts_sites_stats_equal_oracle(ftiny_dir, ftiny_reads):
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    ox, bad, so = _oracle_counts(prefix, r)
+    with GenoIndex.open(prefix) as gx:
+        sg = gx.sites()
+        for k in ("pos", "ref_base", "alt_base", "ref_freq", "alt_freq"):
+            assert np.array_equal(sg[k], so[k]), k
+        gx.submit(r.bases, r.quals, r.offsets)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        st = gx.stats()
+        want = ox.stats.as_dict()
+        for k in CMP_STATS:
+            assert st[k] == want[k], k
+        assert st["alg_bytes"] == ox.alg_bytes()
+        # and straight against the reference's own VCF
+        sg.update(ref_cnt=rc, alt_cnt=ac)
+        mine = O.calls_by_key(sg, index_io.read_chrlens(prefix + ".chrlens"))
+        assert mine == O.parse_vcf_calls(os.path.join(GOLDEN, "ftiny.out.vcf.gz"))
+
+
+def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    _, _, so = _oracle_counts(prefix, r)
+    with GenoIndex.open(prefix) as gx:
+        gx.set_stats(False)
+        gx.submit(r.bases, r.quals, r.offsets)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        assert gx.timing()["ms_main"] > 0
+
+
+def test_batching_and_reset_invariance(ftiny_dir, ftiny_reads):
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    _, _, so = _oracle_counts(prefix, r)
+    with GenoIndex.open(prefix) as gx:
+        cuts = [0, 1, 2, 700, 701, 2500, r.n]
+        for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
+            s = r.slice(lo, hi)
+            gx.submit(s.bases, s.quals, s.offsets)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        gx.reset()
+        rc, ac = gx.counts()
+        assert not rc.any() and not ac.any()
+        gx.submit(r.bases, r.quals, r.offsets)
+        gx.submit(r.bases, r.quals, r.offsets)          # twice: sums double, the clamp holds at 63
+        rc2, ac2 = gx.counts()
+        ox2 = O.OracleIndex.load(prefix)
+        ox2.process(r.bases, r.quals, r.offsets)
+        ox2.process(r.bases, r.quals, r.offsets)
+        s2 = ox2.sites()
+        assert np.array_equal(rc2, s2["ref_cnt"]) and np.array_equal(ac2, s2["alt_cnt"])
+        assert rc2.max() == 63
+
+
+def test_scratch_overflow_path_is_exact(ftiny_dir, ftiny_reads, monkeypatch):
+    """Lanes that run out of per-lane scratch hand the read to the deep-scratch launch."""
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    ox, _, so = _oracle_counts(prefix, r)
+    monkeypatch.setenv("VG_SCRATCH_CAP", "3")
+    monkeypatch.setenv("VG_SCRATCH_KCAP", "2")
+    with GenoIndex.open(prefix) as gx:
+        gx.submit(r.bases, r.quals, r.offsets)
+        rc, ac = gx.counts()
+        st = gx.stats()
+        assert st["overflow_reads"] > 0
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        want = ox.stats.as_dict()
+        for k in CMP_STATS:
+            assert st[k] == want[k], k
+
+
+def test_edge_reads(ftiny_dir):
+    prefix = os.path.join(ftiny_dir, "idx")
+    reads = [b"", b"ACGT", b"A" * 31, b"ACGTN" * 10, b"ACGT" * 8 + b"N", b"ACGX" * 8, b"acgt" * 16,
+             b"ACGTACGTACGTACGTACGTACGTACGTACGN" + b"X" * 32, b"T" * 1022]
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offs = np.cumsum([0] + [len(x) for x in reads]).astype(np.uint64)
+    quals = np.full(len(bases), ord("#"), np.uint8)
+    ox = O.OracleIndex.load(prefix)
+    ox.process(bases, quals, offs)
+    with GenoIndex.open(prefix) as gx:
+        gx.submit(bases, quals, offs)
+        st = gx.stats()
+        want = ox.stats.as_dict()
+        for k in CMP_STATS:
+            assert st[k] == want[k], k
+        assert st["reads_invalid"] == 1 and st["reads_n"] == 2
+        so = ox.sites()
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        # zero reads is a no-op, not an error
+        gx.submit(bases[:0], quals[:0], np.zeros(1, np.uint64))
+
+
+def test_errors_are_codes_not_aborts(ftiny_dir, tmp_path):
+    from vargeno_amd._lib import VgError
+
+    with pytest.raises(VgError) as e:
+        GenoIndex.open(str(tmp_path / "nope"))
+    assert e.value.code == -2
+    prefix = os.path.join(ftiny_dir, "idx")
+    with GenoIndex.open(prefix) as gx:
+        long = np.full(1023, ord("A"), np.uint8)
+        with pytest.raises(VgError) as e:
+            gx.submit(long, long, np.array([0, 1023], np.uint64))
+        assert e.value.code == -6

@@ -1,0 +1,94 @@
+"""ctypes binding of libvargeno_hip.so (include/vargeno_hip.h).  No fallback of any kind: if the
+library is missing or the machine has no HIP device, the calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libvargeno_hip.so")
+
+VG_ERRORS = {-1: "VG_EINVAL", -2: "VG_EIO", -3: "VG_ENOMEM", -4: "VG_ENODEV", -5: "VG_ETOOBIG", -6: "VG_EBADREAD"}
+
+STAT_FIELDS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chunks", "gate_open",
+               "refbf_pos", "snpbf_pos", "large_block", "ref_query", "snp_query", "ref_probe", "snp_probe",
+               "scan_ref", "scan_snp", "scan_oob", "aux_ref", "aux_snp", "site_test", "ctx", "walks", "incr",
+               "ingest_bytes", "overflow_reads", "alg_bytes"]
+
+# every symbol include/vargeno_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
+SYMBOLS = ["vg_last_error", "vg_device_count", "vg_index_open", "vg_index_create", "vg_index_close",
+           "vg_index_device_bytes", "vg_reads_submit", "vg_reads_process_device", "vg_sync", "vg_stats_get",
+           "vg_set_stats", "vg_timing_get", "vg_num_sites", "vg_sites_fetch", "vg_counts_fetch", "vg_counts_reset",
+           "vg_counts_device_ptr", "vg_counts_allreduce"]
+
+
+class VgStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in STAT_FIELDS]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in STAT_FIELDS}
+
+
+class VgTiming(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_main", C.c_float), ("launches_main", C.c_uint32)]
+
+
+u64p, u32p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+
+
+class VgIndexArrays(C.Structure):
+    _fields_ = [("n_ref", C.c_uint64), ("ref_kmer", u64p), ("ref_pos", u32p), ("ref_amb", u8p),
+                ("n_ref_aux", C.c_uint64), ("ref_aux", u32p),
+                ("n_snp", C.c_uint64), ("snp_kmer", u64p), ("snp_pos", u32p),
+                ("snp_info", u8p), ("snp_amb", u8p), ("snp_rf", u8p), ("snp_af", u8p),
+                ("n_snp_aux", C.c_uint64), ("snp_aux_pos", u32p), ("snp_aux_info", u8p),
+                ("ref_bf_bits", C.c_uint64), ("ref_bf_words", u64p),
+                ("snp_bf_bits", C.c_uint64), ("snp_bf_words", u64p)]
+
+
+class VgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (VG_ERRORS.get(code, "VG_E?"), code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.vg_last_error.restype = C.c_char_p
+        L.vg_device_count.restype = C.c_int
+        L.vg_index_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.vg_index_create.argtypes = [C.POINTER(VgIndexArrays), C.c_int, C.POINTER(vp)]
+        L.vg_index_close.argtypes = [vp]
+        L.vg_index_close.restype = None
+        L.vg_index_device_bytes.argtypes = [vp]
+        L.vg_index_device_bytes.restype = C.c_uint64
+        L.vg_reads_submit.argtypes = [vp, vp, vp, vp, C.c_uint64]
+        L.vg_reads_process_device.argtypes = [vp, vp, vp, vp, C.c_uint64]
+        L.vg_sync.argtypes = [vp]
+        L.vg_stats_get.argtypes = [vp, C.POINTER(VgStats)]
+        L.vg_set_stats.argtypes = [vp, C.c_int]
+        L.vg_timing_get.argtypes = [vp, C.POINTER(VgTiming)]
+        L.vg_num_sites.argtypes = [vp]
+        L.vg_num_sites.restype = C.c_uint64
+        L.vg_sites_fetch.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.vg_counts_fetch.argtypes = [vp, vp, vp]
+        L.vg_counts_reset.argtypes = [vp]
+        L.vg_counts_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
+        L.vg_counts_allreduce.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise VgError(rc, lib().vg_last_error().decode(errors="replace"))

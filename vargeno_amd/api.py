@@ -1,0 +1,185 @@
+"""Python host mirror of the `vargeno geno` read path over the C-ABI (include/vargeno_hip.h).
+
+The reference is one C++ function (`genotype()`, src/qv.cc:475); its stages map to:
+    loader              qv.cc:519-695    -> GenoIndex.open / GenoIndex.create
+    FASTQ loop body     qv.cc:760-1558   -> GenoIndex.submit / GenoIndex.process_device
+    counters to caller  qv.cc:1573-1626  -> GenoIndex.counts() (+ all_reduce_counts across ranks)
+PyTorch appears only as plumbing (device buffers, torch.distributed); the computation is the HIP
+library.  Nothing here can run without it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import VgIndexArrays, VgStats, VgTiming, check, lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class GenoIndex:
+    """One device-resident index replica + its pile-up counters (one per GPU / rank)."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self.device = device
+
+    # ---- construction -------------------------------------------------------------------
+    @classmethod
+    def open(cls, prefix, device=0):
+        h = C.c_void_p()
+        check(lib().vg_index_open(os.fsencode(prefix), device, C.byref(h)))
+        return cls(h, device)
+
+    @classmethod
+    def create(cls, arrays, device=0):
+        """arrays: dict as returned by vargeno_amd.index_io.read_index."""
+        keep = {}
+
+        def c(k, dt):
+            keep[k] = np.ascontiguousarray(arrays[k], dtype=dt)
+            return keep[k]
+
+        a = VgIndexArrays()
+        rk = c("ref_kmer", np.uint64)
+        a.n_ref = len(rk)
+        a.ref_kmer = rk.ctypes.data_as(_lib.u64p)
+        a.ref_pos = c("ref_pos", np.uint32).ctypes.data_as(_lib.u32p)
+        a.ref_amb = c("ref_amb", np.uint8).ctypes.data_as(_lib.u8p)
+        rx = c("ref_aux", np.uint32)
+        a.n_ref_aux = rx.size // 10
+        a.ref_aux = rx.ctypes.data_as(_lib.u32p)
+        sk = c("snp_kmer", np.uint64)
+        a.n_snp = len(sk)
+        a.snp_kmer = sk.ctypes.data_as(_lib.u64p)
+        a.snp_pos = c("snp_pos", np.uint32).ctypes.data_as(_lib.u32p)
+        a.snp_info = c("snp_info", np.uint8).ctypes.data_as(_lib.u8p)
+        a.snp_amb = c("snp_amb", np.uint8).ctypes.data_as(_lib.u8p)
+        a.snp_rf = c("snp_rf", np.uint8).ctypes.data_as(_lib.u8p)
+        a.snp_af = c("snp_af", np.uint8).ctypes.data_as(_lib.u8p)
+        sxp = c("snp_aux_pos", np.uint32)
+        a.n_snp_aux = sxp.size // 10
+        a.snp_aux_pos = sxp.ctypes.data_as(_lib.u32p)
+        a.snp_aux_info = c("snp_aux_info", np.uint8).ctypes.data_as(_lib.u8p)
+        a.ref_bf_bits = int(arrays["ref_bf_bits"])
+        a.ref_bf_words = c("ref_bf_words", np.uint64).ctypes.data_as(_lib.u64p)
+        a.snp_bf_bits = int(arrays["snp_bf_bits"])
+        a.snp_bf_words = c("snp_bf_words", np.uint64).ctypes.data_as(_lib.u64p)
+        h = C.c_void_p()
+        check(lib().vg_index_create(C.byref(a), device, C.byref(h)))
+        return cls(h, device)
+
+    def close(self):
+        if self._h:
+            lib().vg_index_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the read loop -------------------------------------------------------------------
+    def submit(self, bases, quals, offsets):
+        """Host batch: flat uint8 ASCII bases / quality chars, uint64 offsets[n+1]."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        check(lib().vg_reads_submit(self._h, _ptr(bases), _ptr(quals), _ptr(offsets), len(offsets) - 1))
+
+    def process_device(self, d_bases, d_quals, d_offsets, n_reads):
+        """Device-resident batch: torch CUDA tensors (uint8, uint8, int64/uint64 offsets[n+1])."""
+        check(lib().vg_reads_process_device(self._h, C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_quals.data_ptr()),
+                                            C.c_void_p(d_offsets.data_ptr()), int(n_reads)))
+
+    def sync(self):
+        check(lib().vg_sync(self._h))
+
+    def set_stats(self, enable):
+        check(lib().vg_set_stats(self._h, 1 if enable else 0))
+
+    def stats(self):
+        s = VgStats()
+        check(lib().vg_stats_get(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def timing(self):
+        t = VgTiming()
+        check(lib().vg_timing_get(self._h, C.byref(t)))
+        return dict(ms_total=float(t.ms_total), ms_main=float(t.ms_main), launches_main=int(t.launches_main))
+
+    # ---- results -------------------------------------------------------------------------
+    @property
+    def num_sites(self):
+        return int(lib().vg_num_sites(self._h))
+
+    @property
+    def device_bytes(self):
+        return int(lib().vg_index_device_bytes(self._h))
+
+    def sites(self):
+        n = self.num_sites
+        pos = np.empty(n, np.uint32)
+        u8 = [np.empty(n, np.uint8) for _ in range(4)]
+        check(lib().vg_sites_fetch(self._h, _ptr(pos), *[_ptr(x) for x in u8]))
+        return dict(pos=pos, ref_base=u8[0], alt_base=u8[1], ref_freq=u8[2], alt_freq=u8[3])
+
+    def counts(self):
+        n = self.num_sites
+        r, a = np.empty(n, np.uint8), np.empty(n, np.uint8)
+        check(lib().vg_counts_fetch(self._h, _ptr(r), _ptr(a)))
+        return r, a
+
+    def reset(self):
+        check(lib().vg_counts_reset(self._h))
+
+    def counts_device(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib().vg_counts_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return int(p.value or 0), int(n.value)
+
+    def counts_tensor(self):
+        """The device counter array as a torch int32 tensor aliasing the library's memory (a u32 sum
+        and an i32 sum are the same bits), for torch.distributed.all_reduce over RCCL."""
+        import torch
+
+        ptr, n = self.counts_device()
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2, "strides": None}
+
+        return torch.as_tensor(_Alias(), device="cuda:%d" % self.device)
+
+
+def all_reduce_counts(index, group=None):
+    """The path's one exchange step: sum the per-site counters over the ranks that
+    each processed a shard of the reads.  RCCL (backend 'nccl') on GPUs; any backend works."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    index.sync()
+    t = index.counts_tensor()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    import torch
+
+    torch.cuda.synchronize(index.device)
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for `rank` of `world` (reads shard by index, no exchange)."""
+    base, rem = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

@@ -1,0 +1,727 @@
+// vargeno_hip.hip -- HIP kernels (gfx950) and the C-ABI of include/vargeno_hip.h.
+//
+// Path: the per-read loop of `vargeno geno` (reference src/qv.cc:760-1558): 2-bit encode of the
+// 32-base chunks, exact ref/SNP dictionary lookups, quality-gated Hamming-1 neighbour search bounded
+// by two bit vectors, order-dependent position vote, pile-up counter updates.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see Makefile).  No CPU fallback exists:
+// every entry point fails with VG_ENODEV when no HIP device is usable.
+#include "../../include/vargeno_hip.h"
+#include "vg_device.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+using namespace vg;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, const char *a = "", const char *b = "")
+{
+	snprintf(g_err, sizeof g_err, fmt, a, b);
+	return code;
+}
+#define HIP_TRY(expr)                                                                              \
+	do {                                                                                           \
+		hipError_t e_ = (expr);                                                                    \
+		if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? VG_ENOMEM : VG_ENODEV, "%s: %s", #expr, hipGetErrorString(e_)); \
+	} while (0)
+
+extern "C" const char *vg_last_error(void) { return g_err; }
+extern "C" int vg_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: index construction
+// ------------------------------------------------------------------------------------------------
+constexpr int JG_SPAN = 16384;                       // bucket ids per workgroup
+constexpr int JG_LDS = JG_SPAN + JG_SPAN / 32;       // padded: one spare word per 32 keeps the per-thread runs off one bank
+
+__device__ inline uint64_t lower_bound_dev(const uint64_t *a, uint64_t n, uint64_t key)
+{
+	uint64_t lo = 0, hi = n;
+	while (lo < hi) { uint64_t m = lo + ((hi - lo) >> 1); if (a[m] < key) lo = m + 1; else hi = m; }
+	return lo;
+}
+
+// jump table: jg[h] = number of entries whose (kmer >> SHIFT) < h  (= index of the first entry with
+// HI >= h, = n past the last used HI: exactly what src/qv.cc:539-584 / :622-678 build).  One
+// workgroup owns JG_SPAN consecutive h: LDS histogram of its slice of the sorted array, LDS scan,
+// coalesced write.  jg has n_buckets + 1 entries; the last one is the sentinel n.
+template <int SHIFT>
+__global__ __launch_bounds__(256) void vg_build_jumpgate(const uint64_t *__restrict__ kmer, uint64_t n, uint32_t *__restrict__ jg, uint64_t n_buckets)
+{
+	__shared__ uint32_t hist[JG_LDS];
+	__shared__ uint64_t range[2];
+	__shared__ uint32_t wave_tot[4];
+	const uint64_t h0 = (uint64_t)blockIdx.x * JG_SPAN;
+	const uint32_t t = threadIdx.x;
+	if (t < 2) {
+		const uint64_t h = h0 + (t ? JG_SPAN : 0);
+		range[t] = (h >= n_buckets) ? n : lower_bound_dev(kmer, n, h << SHIFT);
+	}
+	for (uint32_t i = t; i < JG_LDS; i += 256) hist[i] = 0;
+	__syncthreads();
+	const uint64_t e0 = range[0], e1 = range[1];
+	for (uint64_t e = e0 + t; e < e1; e += 256) {
+		const uint32_t b = (uint32_t)((kmer[e] >> SHIFT) - h0);
+		atomicAdd(&hist[b + (b >> 5)], 1u);
+	}
+	__syncthreads();
+	// thread t owns buckets [64t, 64t+64): serial exclusive scan in place, then a block scan of the 256 run totals
+	uint32_t run = 0;
+	for (uint32_t j = 0; j < 64; j++) {
+		const uint32_t b = t * 64 + j, at = b + (b >> 5);
+		const uint32_t v = hist[at];
+		hist[at] = run;
+		run += v;
+	}
+	uint32_t incl = run;
+	const uint32_t lane = t & 63, wv = t >> 6;
+	for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(incl, o); if ((int)lane >= o) incl += y; }
+	if (lane == 63) wave_tot[wv] = incl;
+	__syncthreads();
+	uint32_t base = incl - run;
+	for (uint32_t w = 0; w < wv; w++) base += wave_tot[w];
+	__syncthreads();
+	for (uint32_t j = 0; j < 64; j++) { const uint32_t b = t * 64 + j, at = b + (b >> 5); hist[at] += base; }
+	__syncthreads();
+	for (uint32_t i = t; i < JG_SPAN; i += 256) {
+		const uint64_t h = h0 + i;
+		if (h < n_buckets) jg[h] = (uint32_t)(e0 + hist[i + (i >> 5)]);
+	}
+	if (blockIdx.x == gridDim.x - 1 && t == 0) jg[n_buckets] = (uint32_t)n;
+}
+
+__global__ void vg_split_lo32(const uint64_t *__restrict__ kmer, uint64_t n, uint32_t *__restrict__ lo)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) lo[i] = (uint32_t)kmer[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: the read loop
+// ------------------------------------------------------------------------------------------------
+
+// 8 ASCII bases (little-endian in v) -> 16 bits, base 0 in bits 0-1 (encode_kmer, src/util.c:89-111:
+// A0 C1 G2 T3, case-insensitive).  `bad` gets a non-zero value if any byte is not one of ACGTacgt.
+__device__ inline uint32_t pack8(uint64_t v, uint64_t &bad)
+{
+	const uint64_t K01 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full;
+	const uint64_t u = v & 0xDFDFDFDFDFDFDFDFull;
+	auto eq = [&](uint64_t c) { const uint64_t z = u ^ (c * K01); return ~(((z & K7F) + K7F) | z | K7F); };   // 0x80 in each byte equal to c
+	const uint64_t ok = eq(0x41) | eq(0x43) | eq(0x47) | eq(0x54);
+	bad |= ok ^ 0x8080808080808080ull;
+	uint64_t x = (v >> 1) & 0x0303030303030303ull;     // A0 C1 G3 T2
+	x ^= (x >> 1) & K01;                               // A0 C1 G2 T3
+	x = (x | (x >> 6)) & 0x000F000F000F000Full;
+	x = (x | (x >> 12)) & 0x000000FF000000FFull;
+	x = (x | (x >> 24)) & 0xFFFFull;
+	return (uint32_t)x;
+}
+
+__device__ inline uint64_t load8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+__device__ inline uint64_t encode32(const uint8_t *p, uint64_t &bad)
+{
+	return (uint64_t)pack8(load8(p), bad) | ((uint64_t)pack8(load8(p + 8), bad) << 16) |
+	       ((uint64_t)pack8(load8(p + 16), bad) << 32) | ((uint64_t)pack8(load8(p + 24), bad) << 48);
+}
+
+// Exact classification when some byte is not ACGT: the reference encodes chunk 0..n-1, each from base
+// 31 down to 0, and the FIRST offending character decides: N/n -> skip the read (src/qv.cc:815-828),
+// anything else -> assert(0) (src/util.c:103).  1 = N, 2 = invalid.
+__device__ inline int classify_bad(const uint8_t *p, uint32_t n)
+{
+	for (uint32_t c = 0; c < n; c++)
+		for (int j = 31; j >= 0; j--) {
+			const uint8_t ch = p[32 * c + j] & 0xDF;
+			if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') continue;
+			return ch == 'N' ? 1 : 2;
+		}
+	return 0;
+}
+
+// One lane = one read: forward pass, then the reverse-complement retry (src/qv.cc:1504-1510).
+// A read touches the counters only at the end of its last pass, so a lane that runs out of scratch
+// simply drops the read onto the overflow list and the same kernel re-runs it with a deep scratch.
+template <bool STATS>
+__global__ __launch_bounds__(256) void vg_pass_kernel(DevIndex d, Scratch s, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
+                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads, const uint32_t *__restrict__ read_ids,
+                                                      uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats)
+{
+	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t stride = gridDim.x * blockDim.x;
+	Lane<STATS> L(d, s, gtid);
+	LaneStats<STATS> tot;
+	if constexpr (STATS) for (int i = 0; i < S_COUNT; i++) tot.v[i] = 0;
+
+	for (uint64_t r = gtid; r < n_reads; r += stride) {
+		const uint64_t rid = read_ids ? read_ids[r] : r;
+		const uint64_t off = offsets[rid];
+		const uint32_t n = (uint32_t)((offsets[rid + 1] - off) >> 5);            // src/qv.cc:778-779: len = (read_len/32)*32
+		const uint8_t *p = bases + off;
+		const uint8_t *q = quals + off;
+		if constexpr (STATS) { for (int i = 0; i < S_COUNT; i++) L.st.v[i] = 0; }
+		L.st.add(S_READS, 1);
+		L.st.add(S_INGEST, 9 * n);
+		L.overflow = false;
+
+		uint64_t bad = 0;
+		for (uint32_t c = 0; c < n; c++) (void)encode32(p + 32 * c, bad);
+		int cls = 0;
+		if (bad) cls = classify_bad(p, n);
+		if (cls == 1) L.st.add(S_READS_N, 1);
+		if (cls == 2) L.st.add(S_READS_INVALID, 1);
+		if (cls == 0) {
+			bool ok = false;
+			L.reset_pass();
+			for (uint32_t c = 0; c < n && !L.overflow; c++) {
+				uint64_t b2 = 0;
+				const uint64_t k = encode32(p + 32 * c, b2);
+				L.do_chunk(k, c, (int)(int8_t)q[c] - '8' < 0);                    // src/qv.cc:836, 943: chunk NUMBER indexes the quality string
+			}
+			if (!L.overflow) ok = L.finish_pass();
+			if (!L.overflow && !ok) {
+				L.reset_pass();
+				for (uint32_t c = 0; c < n && !L.overflow; c++) {
+					uint64_t b2 = 0;
+					const uint64_t k = revcomp64(encode32(p + 32 * (n - 1 - c), b2));
+					L.do_chunk(k, c, (int)(int8_t)q[c] - '8' < 0);                // quality string is NOT reversed (qv.cc:786-806)
+				}
+				if (!L.overflow) (void)L.finish_pass();
+			}
+		}
+		if (L.overflow) {
+			const uint32_t at = atomicAdd(overflow_count, 1u);
+			overflow_list[at] = (uint32_t)rid;
+		} else if constexpr (STATS) {
+			for (int i = 0; i < S_COUNT; i++) tot.v[i] += L.st.v[i];
+		}
+	}
+	if constexpr (STATS) {
+		for (int i = 0; i < S_COUNT; i++) if (tot.v[i]) atomicAdd(&stats[i], (unsigned long long)tot.v[i]);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the handle
+// ------------------------------------------------------------------------------------------------
+struct ScratchBuf {
+	Scratch s{};
+	size_t bytes = 0;
+};
+
+struct vg_index {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	DevIndex d{};
+	std::vector<void *> owned;            // every device allocation of the index
+	uint64_t dev_bytes = 0;
+	uint64_t n_sites = 0;
+	std::vector<uint32_t> site_pos;
+	std::vector<uint8_t> site_ref, site_alt, site_rf, site_af;
+	ScratchBuf small, big;
+	uint32_t *d_overflow_list = nullptr;  uint64_t overflow_cap = 0;
+	uint32_t *d_overflow_count = nullptr;
+	unsigned long long *d_stats = nullptr;
+	uint64_t overflow_total = 0, lost_total = 0;
+	bool stats_enabled = true;
+	// staging for vg_reads_submit
+	uint8_t *d_bases = nullptr, *d_quals = nullptr; uint64_t *d_offsets = nullptr;
+	uint64_t stage_bytes = 0, stage_reads = 0;
+	// timing
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+	bool timing_valid = false; bool had_overflow_launch = false;
+	uint32_t launches = 0;
+	int grid_blocks = 0;
+};
+
+template <class T>
+static int dev_alloc(vg_index *ix, T **p, uint64_t count, bool zero = false)
+{
+	void *q = nullptr;
+	const size_t bytes = (size_t)(count ? count : 1) * sizeof(T);
+	hipError_t e = hipMalloc(&q, bytes);
+	if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(%s bytes): %s", std::to_string(bytes).c_str(), hipGetErrorString(e));
+	if (zero) { e = hipMemsetAsync(q, 0, bytes, ix->stream); if (e != hipSuccess) return fail(VG_ENODEV, "hipMemset: %s", hipGetErrorString(e)); }
+	ix->owned.push_back(q);
+	ix->dev_bytes += bytes;
+	*p = (T *)q;
+	return VG_OK;
+}
+template <class T>
+static int dev_upload(vg_index *ix, T **p, const T *src, uint64_t count)
+{
+	int rc = dev_alloc(ix, p, count);
+	if (rc) return rc;
+	if (count) HIP_TRY(hipMemcpy(*p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
+	return VG_OK;
+}
+
+static int alloc_scratch(vg_index *ix, ScratchBuf &b, uint32_t nlanes, uint32_t cap, uint32_t kcap)
+{
+	b.s.nlanes = nlanes; b.s.cap = cap; b.s.kcap = kcap;
+	const uint64_t before = ix->dev_bytes;
+	int rc;
+	if ((rc = dev_alloc(ix, &b.s.ctx_kmer, (uint64_t)cap * nlanes))) return rc;
+	if ((rc = dev_alloc(ix, &b.s.ctx_kpos, (uint64_t)cap * nlanes))) return rc;
+	if ((rc = dev_alloc(ix, &b.s.ctx_meta, (uint64_t)cap * nlanes))) return rc;
+	if ((rc = dev_alloc(ix, &b.s.key_index, (uint64_t)kcap * nlanes))) return rc;
+	if ((rc = dev_alloc(ix, &b.s.key_first, (uint64_t)kcap * nlanes))) return rc;
+	if ((rc = dev_alloc(ix, &b.s.key_fm, (uint64_t)kcap * nlanes))) return rc;
+	b.bytes = ix->dev_bytes - before;
+	return VG_OK;
+}
+
+extern "C" void vg_index_close(vg_index *ix)
+{
+	if (!ix) return;
+	(void)hipSetDevice(ix->device);
+	if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+	for (void *p : ix->owned) (void)hipFree(p);
+	if (ix->d_overflow_list) (void)hipFree(ix->d_overflow_list);
+	if (ix->d_bases) (void)hipFree(ix->d_bases);
+	if (ix->d_quals) (void)hipFree(ix->d_quals);
+	if (ix->d_offsets) (void)hipFree(ix->d_offsets);
+	if (ix->ev0) (void)hipEventDestroy(ix->ev0);
+	if (ix->ev1) (void)hipEventDestroy(ix->ev1);
+	if (ix->ev2) (void)hipEventDestroy(ix->ev2);
+	if (ix->stream) (void)hipStreamDestroy(ix->stream);
+	delete ix;
+}
+
+static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
+{
+	if (a->n_ref >= (1ull << 32) || a->n_snp >= (1ull << 32)) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
+	if (a->ref_bf_bits == 0 || a->snp_bf_bits == 0) return fail(VG_EINVAL, "empty bit vector");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VG_ENODEV, "no HIP device available (this library has no CPU fallback)");
+	if (device < 0 || device >= ndev) return fail(VG_EINVAL, "device index out of range");
+	ix->device = device;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreate(&ix->ev0)); HIP_TRY(hipEventCreate(&ix->ev1)); HIP_TRY(hipEventCreate(&ix->ev2));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	ix->grid_blocks = cus * 8;                                   // 2048 lanes per CU = every wave slot
+	int rc;
+	DevIndex &d = ix->d;
+	d.n_ref = a->n_ref; d.n_snp = a->n_snp;
+
+	// ---- reference dictionary: jump table + LO32 on the device from the sorted k-mers
+	{
+		uint64_t *d_kmer = nullptr;
+		const size_t kb = (size_t)(a->n_ref ? a->n_ref : 1) * 8;
+		hipError_t e = hipMalloc((void **)&d_kmer, kb);
+		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(ref k-mers): %s", hipGetErrorString(e));
+		struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{d_kmer};
+		if (a->n_ref) HIP_TRY(hipMemcpy(d_kmer, a->ref_kmer, (size_t)a->n_ref * 8, hipMemcpyHostToDevice));
+		uint32_t *jg = nullptr, *lo = nullptr;
+		if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
+		if ((rc = dev_alloc(ix, &lo, a->n_ref))) return rc;
+		vg_build_jumpgate<32><<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, ix->stream>>>(d_kmer, a->n_ref, jg, 1ull << 32);
+		vg_split_lo32<<<2048, 256, 0, ix->stream>>>(d_kmer, a->n_ref, lo);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+		d.ref_jg = jg; d.ref_lo = lo;
+	}
+	{
+		uint32_t *p = nullptr; uint8_t *q = nullptr; uint32_t *x = nullptr;
+		if ((rc = dev_upload(ix, &p, a->ref_pos, a->n_ref))) return rc;
+		if ((rc = dev_upload(ix, &q, a->ref_amb, a->n_ref))) return rc;
+		if ((rc = dev_upload(ix, &x, a->ref_aux, a->n_ref_aux * AUX_COLS))) return rc;
+		d.ref_pos = p; d.ref_amb = q; d.ref_aux = x;
+	}
+	// ---- SNP dictionary
+	{
+		uint64_t *d_kmer = nullptr;
+		const size_t kb = (size_t)(a->n_snp ? a->n_snp : 1) * 8;
+		hipError_t e = hipMalloc((void **)&d_kmer, kb);
+		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(snp k-mers): %s", hipGetErrorString(e));
+		struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{d_kmer};
+		if (a->n_snp) HIP_TRY(hipMemcpy(d_kmer, a->snp_kmer, (size_t)a->n_snp * 8, hipMemcpyHostToDevice));
+		uint32_t *jg = nullptr;
+		if ((rc = dev_alloc(ix, &jg, (1ull << 24) + 1))) return rc;
+		vg_build_jumpgate<40><<<(unsigned)((1ull << 24) / JG_SPAN), 256, 0, ix->stream>>>(d_kmer, a->n_snp, jg, 1ull << 24);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+		d.snp_jg = jg;
+		std::vector<uint64_t> key(a->n_snp);
+		for (uint64_t i = 0; i < a->n_snp; i++)
+			key[i] = (a->snp_kmer[i] & LO40_MASK) | ((uint64_t)a->snp_info[i] << 40) | ((uint64_t)a->snp_amb[i] << 48);
+		uint64_t *k = nullptr; uint32_t *p = nullptr, *xp = nullptr; uint8_t *xi = nullptr;
+		if ((rc = dev_upload(ix, &k, key.data(), a->n_snp))) return rc;
+		if ((rc = dev_upload(ix, &p, a->snp_pos, a->n_snp))) return rc;
+		if ((rc = dev_upload(ix, &xp, a->snp_aux_pos, a->n_snp_aux * AUX_COLS))) return rc;
+		if ((rc = dev_upload(ix, &xi, a->snp_aux_info, a->n_snp_aux * AUX_COLS))) return rc;
+		d.snp_key = k; d.snp_pos = p; d.snp_aux_pos = xp; d.snp_aux_info = xi;
+	}
+	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first
+	//      2^32 bits of the 9.6 Gbit reference vector can ever be read (src/generate_bf.h:112-128)
+	{
+		const uint64_t rbits = std::min<uint64_t>(a->ref_bf_bits, 1ull << 32);
+		uint64_t *r = nullptr, *s2 = nullptr;
+		if ((rc = dev_upload(ix, &r, a->ref_bf_words, (rbits + 63) / 64))) return rc;
+		if ((rc = dev_upload(ix, &s2, a->snp_bf_words, (a->snp_bf_bits + 63) / 64))) return rc;
+		d.ref_bf = r; d.ref_bf_bits = a->ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = a->snp_bf_bits;
+	}
+	// ---- pile-up sites (src/qv.cc:602-603, 637-659).  The reference sizes its table max(raw pos field)+33,
+	//      i.e. 2^32+32 entries as soon as one k-mer is POS_AMBIGUOUS; only real positions are ever indexed.
+	{
+		uint64_t maxp = 0;
+		for (uint64_t i = 0; i < a->n_ref; i++) if (a->ref_amb[i] == 0 && a->ref_pos[i] != POS_AMBIGUOUS && a->ref_pos[i] > maxp) maxp = a->ref_pos[i];
+		for (uint64_t i = 0; i < a->n_ref_aux * AUX_COLS; i++) if (a->ref_aux[i] > maxp) maxp = a->ref_aux[i];
+		for (uint64_t i = 0; i < a->n_snp; i++) if (a->snp_amb[i] == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_pos[i] > maxp) maxp = a->snp_pos[i];
+		for (uint64_t i = 0; i < a->n_snp_aux * AUX_COLS; i++) if (a->snp_aux_pos[i] > maxp) maxp = a->snp_aux_pos[i];
+		const uint64_t plen = maxp + 64;
+		std::vector<uint32_t> pile(plen, 0);        // low nibble ref|alt<<2, bit 4 = seeded, bits 16.. freqs (host only)
+		for (uint64_t i = 0; i < a->n_snp; i++) {   // file order, last writer wins
+			const uint32_t info = a->snp_info[i];
+			if ((info & 4u) == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_amb[i] == 0) {
+				const uint32_t sp = a->snp_pos[i] + (info >> 3);
+				const uint32_t alt = (uint32_t)(a->snp_kmer[i] >> (2 * (info >> 3))) & 3u;
+				pile[sp] = (info & 3u) | (alt << 2) | ((uint32_t)a->snp_rf[i] << 16) | ((uint32_t)a->snp_af[i] << 24);
+			}
+		}
+		for (uint64_t p = 0; p < plen; p++) {
+			const uint32_t w = pile[p];
+			const uint32_t r = w & 3u, al = (w >> 2) & 3u;
+			if (r != al) {
+				ix->site_pos.push_back((uint32_t)p); ix->site_ref.push_back((uint8_t)r); ix->site_alt.push_back((uint8_t)al);
+				ix->site_rf.push_back((uint8_t)(w >> 16)); ix->site_af.push_back((uint8_t)(w >> 24));
+				pile[p] = (w & 15u) | ((uint32_t)ix->site_pos.size() << 4);      // site id + 1
+			} else {
+				pile[p] = w & 15u;
+			}
+		}
+		ix->n_sites = ix->site_pos.size();
+		if (ix->n_sites >= (1ull << 28)) return fail(VG_ETOOBIG, "more than 2^28 SNP sites");
+		uint32_t *dp = nullptr, *dc = nullptr;
+		if ((rc = dev_upload(ix, &dp, pile.data(), plen))) return rc;
+		if ((rc = dev_alloc(ix, &dc, 2 * ix->n_sites + 2, true))) return rc;
+		d.pile = dp; d.pile_len = plen; d.cnt = dc;
+	}
+	// ---- scratch, overflow list, stats
+	// VG_SCRATCH_CAP / VG_SCRATCH_KCAP shrink the per-lane scratch so tests can drive the overflow path
+	uint32_t cap = 64, kcap = 32;
+	if (const char *e = getenv("VG_SCRATCH_CAP")) cap = (uint32_t)std::max(1, atoi(e));
+	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
+	if ((rc = alloc_scratch(ix, ix->small, (uint32_t)ix->grid_blocks * 256u, cap, kcap))) return rc;
+	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_overflow_count, 4, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+	return VG_OK;
+}
+
+extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **out)
+{
+	if (!a || !out) return fail(VG_EINVAL, "null argument");
+	*out = nullptr;
+	vg_index *ix = new (std::nothrow) vg_index();
+	if (!ix) return fail(VG_ENOMEM, "host allocation failed");
+	int rc = create_impl(a, device, ix);
+	if (rc) { vg_index_close(ix); return rc; }
+	*out = ix;
+	return VG_OK;
+}
+
+// ---- index files (formats: SURVEY.md §8f-1; writers src/dictgen.c:63-275, sdsl int_vector.hpp:1563-1595)
+static int read_file(const std::string &path, std::vector<uint8_t> &buf)
+{
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) return fail(VG_EIO, "cannot open %s", path.c_str());
+	fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
+	buf.resize((size_t)sz);
+	const size_t got = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+	fclose(f);
+	if (got != (size_t)sz) return fail(VG_EIO, "short read on %s", path.c_str());
+	return VG_OK;
+}
+static int read_bf(const std::string &path, uint64_t cap_bits, uint64_t &bits, std::vector<uint64_t> &words)
+{
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) return fail(VG_EIO, "cannot open %s", path.c_str());
+	if (fread(&bits, 8, 1, f) != 1) { fclose(f); return fail(VG_EIO, "short read on %s", path.c_str()); }
+	const uint64_t nw = (std::min(bits, cap_bits) + 63) / 64;
+	words.resize(nw);
+	const size_t got = nw ? fread(words.data(), 8, nw, f) : 0;
+	fclose(f);
+	if (got != nw) return fail(VG_EIO, "short read on %s", path.c_str());
+	return VG_OK;
+}
+
+extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
+{
+	if (!prefix || !out) return fail(VG_EINVAL, "null argument");
+	*out = nullptr;
+	const std::string pre(prefix);
+	std::vector<uint8_t> rd, sd;
+	int rc;
+	if ((rc = read_file(pre + ".ref.dict", rd))) return rc;
+	if ((rc = read_file(pre + ".snp.dict", sd))) return rc;
+	if (rd.size() < 16 || sd.size() < 16) return fail(VG_EIO, "dictionary file too short: %s", prefix);
+	uint64_t n_ref, n_ref_aux, n_snp, n_snp_aux;
+	memcpy(&n_ref, rd.data(), 8); memcpy(&n_ref_aux, rd.data() + 8, 8);
+	memcpy(&n_snp, sd.data(), 8); memcpy(&n_snp_aux, sd.data() + 8, 8);
+	if (n_ref > (1ull << 32) || n_snp > (1ull << 32)) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
+	if (rd.size() != 16 + 13 * n_ref + 40 * n_ref_aux) return fail(VG_EIO, "%s.ref.dict: size does not match its header", prefix);
+	if (sd.size() != 16 + 16 * n_snp + 78 * n_snp_aux) return fail(VG_EIO, "%s.snp.dict: size does not match its header", prefix);
+	std::vector<uint64_t> rk(n_ref), sk(n_snp);
+	std::vector<uint32_t> rp(n_ref), raux(n_ref_aux * 10), sp(n_snp), sxp(n_snp_aux * 10);
+	std::vector<uint8_t> ra(n_ref), si(n_snp), sa(n_snp), srf(n_snp), saf(n_snp), sxi(n_snp_aux * 10);
+	const uint8_t *p = rd.data() + 16;
+	for (uint64_t i = 0; i < n_ref; i++, p += 13) { memcpy(&rk[i], p, 8); memcpy(&rp[i], p + 8, 4); ra[i] = p[12]; }
+	if (n_ref_aux) memcpy(raux.data(), p, n_ref_aux * 40);
+	p = sd.data() + 16;
+	for (uint64_t i = 0; i < n_snp; i++, p += 16) { memcpy(&sk[i], p, 8); memcpy(&sp[i], p + 8, 4); si[i] = p[12]; sa[i] = p[13]; srf[i] = p[14]; saf[i] = p[15]; }
+	for (uint64_t i = 0; i < n_snp_aux; i++) {
+		p += 8;
+		for (int j = 0; j < 10; j++, p += 7) { memcpy(&sxp[i * 10 + j], p, 4); sxi[i * 10 + j] = p[4]; }
+	}
+	rd.clear(); rd.shrink_to_fit(); sd.clear(); sd.shrink_to_fit();
+	uint64_t rbits = 0, sbits = 0;
+	std::vector<uint64_t> rw, sw;
+	if ((rc = read_bf(pre + ".ref.bf", 1ull << 32, rbits, rw))) return rc;
+	if ((rc = read_bf(pre + ".snp.bf", ~0ull, sbits, sw))) return rc;
+	vg_index_arrays a{};
+	a.n_ref = n_ref; a.ref_kmer = rk.data(); a.ref_pos = rp.data(); a.ref_amb = ra.data();
+	a.n_ref_aux = n_ref_aux; a.ref_aux = raux.data();
+	a.n_snp = n_snp; a.snp_kmer = sk.data(); a.snp_pos = sp.data(); a.snp_info = si.data(); a.snp_amb = sa.data(); a.snp_rf = srf.data(); a.snp_af = saf.data();
+	a.n_snp_aux = n_snp_aux; a.snp_aux_pos = sxp.data(); a.snp_aux_info = sxi.data();
+	a.ref_bf_bits = rbits; a.ref_bf_words = rw.data(); a.snp_bf_bits = sbits; a.snp_bf_words = sw.data();
+	return vg_index_create(&a, device, out);
+}
+
+extern "C" uint64_t vg_index_device_bytes(const vg_index *ix) { return ix ? ix->dev_bytes : 0; }
+extern "C" uint64_t vg_num_sites(const vg_index *ix) { return ix ? ix->n_sites : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// read batches
+// ------------------------------------------------------------------------------------------------
+static int launch_batch(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
+{
+	HIP_TRY(hipSetDevice(ix->device));
+	if (n_reads >= (1ull << 32)) return fail(VG_EINVAL, "more than 2^32-1 reads in one batch");
+	if (n_reads > ix->overflow_cap) {
+		if (ix->d_overflow_list) { HIP_TRY(hipStreamSynchronize(ix->stream)); (void)hipFree(ix->d_overflow_list); ix->d_overflow_list = nullptr; }
+		HIP_TRY(hipMalloc((void **)&ix->d_overflow_list, (size_t)n_reads * 4));
+		ix->overflow_cap = n_reads;
+	}
+	HIP_TRY(hipMemsetAsync(ix->d_overflow_count, 0, 4, ix->stream));
+	const unsigned grid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->grid_blocks);
+	ix->launches = 0; ix->had_overflow_launch = false;
+	HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+	if (grid) {
+		if (ix->stats_enabled)
+			vg_pass_kernel<true><<<grid, 256, 0, ix->stream>>>(ix->d, ix->small.s, d_bases, d_quals, d_offsets, n_reads, nullptr, ix->d_overflow_list, ix->d_overflow_count, ix->d_stats);
+		else
+			vg_pass_kernel<false><<<grid, 256, 0, ix->stream>>>(ix->d, ix->small.s, d_bases, d_quals, d_offsets, n_reads, nullptr, ix->d_overflow_list, ix->d_overflow_count, ix->d_stats);
+		ix->launches++;
+	}
+	HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+	HIP_TRY(hipGetLastError());
+	// rare: reads that ran out of per-lane scratch are re-run (whole) with the deep scratch
+	uint32_t n_over = 0;
+	HIP_TRY(hipMemcpyAsync(&n_over, ix->d_overflow_count, 4, hipMemcpyDeviceToHost, ix->stream));
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+	if (n_over) {
+		ix->overflow_total += n_over;
+		std::vector<uint32_t> ids(n_over);
+		HIP_TRY(hipMemcpy(ids.data(), ix->d_overflow_list, (size_t)n_over * 4, hipMemcpyDeviceToHost));
+		std::sort(ids.begin(), ids.end());
+		uint32_t *d_ids = nullptr;
+		HIP_TRY(hipMalloc((void **)&d_ids, (size_t)n_over * 4));
+		HIP_TRY(hipMemcpy(d_ids, ids.data(), (size_t)n_over * 4, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemsetAsync(ix->d_overflow_count, 0, 4, ix->stream));
+		const unsigned g2 = (unsigned)std::min<uint64_t>((n_over + 63) / 64, ix->big.s.nlanes / 64);
+		if (ix->stats_enabled)
+			vg_pass_kernel<true><<<g2, 64, 0, ix->stream>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, n_over, d_ids, ix->d_overflow_list, ix->d_overflow_count, ix->d_stats);
+		else
+			vg_pass_kernel<false><<<g2, 64, 0, ix->stream>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, n_over, d_ids, ix->d_overflow_list, ix->d_overflow_count, ix->d_stats);
+		ix->had_overflow_launch = true;
+		uint32_t lost = 0;
+		HIP_TRY(hipMemcpyAsync(&lost, ix->d_overflow_count, 4, hipMemcpyDeviceToHost, ix->stream));
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+		(void)hipFree(d_ids);
+		ix->lost_total += lost;
+		if (lost) return fail(VG_ENOMEM, "a read produced more hit contexts than the deep scratch holds (the reference overruns MAX_HITS=2000 long before, qv.cc:709)");
+	}
+	HIP_TRY(hipEventRecord(ix->ev2, ix->stream));
+	ix->timing_valid = true;
+	return VG_OK;
+}
+
+extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
+{
+	if (!ix || (!d_offsets && n_reads)) return fail(VG_EINVAL, "null argument");
+	if (n_reads == 0) return VG_OK;
+	return launch_batch(ix, d_bases, d_quals, d_offsets, n_reads);
+}
+
+extern "C" int vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads)
+{
+	if (!ix || !offsets) return fail(VG_EINVAL, "null argument");
+	if (n_reads == 0) return VG_OK;
+	HIP_TRY(hipSetDevice(ix->device));
+	const uint64_t base0 = offsets[0];
+	const uint64_t total = offsets[n_reads] - base0;
+	for (uint64_t i = 0; i < n_reads; i++) {
+		if (offsets[i + 1] < offsets[i]) return fail(VG_EINVAL, "offsets not monotone");
+		if (offsets[i + 1] - offsets[i] > 1022) return fail(VG_EBADREAD, "read longer than 1022 bases (reference BUF_SIZE 1024, qv.cc:700)");
+	}
+	HIP_TRY(hipStreamSynchronize(ix->stream));          // staging buffers are reused
+	if (total + 64 > ix->stage_bytes) {
+		if (ix->d_bases) (void)hipFree(ix->d_bases);
+		if (ix->d_quals) (void)hipFree(ix->d_quals);
+		ix->d_bases = ix->d_quals = nullptr;
+		HIP_TRY(hipMalloc((void **)&ix->d_bases, total + 64));
+		HIP_TRY(hipMalloc((void **)&ix->d_quals, total + 64));
+		ix->stage_bytes = total + 64;
+	}
+	if (n_reads + 1 > ix->stage_reads) {
+		if (ix->d_offsets) (void)hipFree(ix->d_offsets);
+		ix->d_offsets = nullptr;
+		HIP_TRY(hipMalloc((void **)&ix->d_offsets, (n_reads + 1) * 8));
+		ix->stage_reads = n_reads + 1;
+	}
+	std::vector<uint64_t> rel;
+	const uint64_t *off = offsets;
+	if (base0) { rel.resize(n_reads + 1); for (uint64_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - base0; off = rel.data(); }
+	HIP_TRY(hipMemcpyAsync(ix->d_bases, bases + base0, total, hipMemcpyHostToDevice, ix->stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_quals, quals + base0, total, hipMemcpyHostToDevice, ix->stream));
+	HIP_TRY(hipMemcpyAsync(ix->d_offsets, off, (n_reads + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+	HIP_TRY(hipStreamSynchronize(ix->stream));          // `rel` and the caller's buffers may go away
+	return launch_batch(ix, ix->d_bases, ix->d_quals, ix->d_offsets, n_reads);
+}
+
+extern "C" int vg_sync(vg_index *ix)
+{
+	if (!ix) return fail(VG_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(ix->device));
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+	return VG_OK;
+}
+
+extern "C" int vg_set_stats(vg_index *ix, int enable)
+{
+	if (!ix) return fail(VG_EINVAL, "null argument");
+	ix->stats_enabled = enable != 0;
+	return VG_OK;
+}
+
+extern "C" int vg_stats_get(vg_index *ix, vg_stats *out)
+{
+	if (!ix || !out) return fail(VG_EINVAL, "null argument");
+	int rc = vg_sync(ix);
+	if (rc) return rc;
+	unsigned long long h[S_COUNT];
+	HIP_TRY(hipMemcpy(h, ix->d_stats, sizeof h, hipMemcpyDeviceToHost));
+	memset(out, 0, sizeof *out);
+	out->reads = h[S_READS]; out->reads_n = h[S_READS_N]; out->reads_invalid = h[S_READS_INVALID];
+	out->passes = h[S_PASSES]; out->passes_ok = h[S_PASSES_OK]; out->chunks = h[S_CHUNKS]; out->gate_open = h[S_GATE_OPEN];
+	out->refbf_pos = h[S_REFBF_POS]; out->snpbf_pos = h[S_SNPBF_POS]; out->large_block = h[S_LARGE_BLOCK];
+	out->ref_query = h[S_REF_QUERY]; out->snp_query = h[S_SNP_QUERY]; out->ref_probe = h[S_REF_PROBE]; out->snp_probe = h[S_SNP_PROBE];
+	out->scan_ref = h[S_SCAN_REF]; out->scan_snp = h[S_SCAN_SNP]; out->scan_oob = h[S_SCAN_OOB];
+	out->aux_ref = h[S_AUX_REF]; out->aux_snp = h[S_AUX_SNP]; out->site_test = h[S_SITE_TEST]; out->ctx = h[S_CTX];
+	out->walks = h[S_WALKS]; out->incr = h[S_INCR]; out->ingest_bytes = h[S_INGEST];
+	out->overflow_reads = ix->overflow_total;
+	const uint64_t scans = out->gate_open - out->large_block;
+	out->alg_bytes = out->ingest_bytes + 8 * (out->ref_query + out->snp_query) + 9 * out->ref_probe + 11 * out->snp_probe
+	               + 16 * out->gate_open + 16 * scans + 9 * out->scan_ref + 11 * out->scan_snp
+	               + 40 * out->aux_ref + 50 * out->aux_snp + 4 * out->site_test + 128 * out->walks + 4 * out->incr;
+	return VG_OK;
+}
+
+extern "C" int vg_timing_get(vg_index *ix, vg_timing *out)
+{
+	if (!ix || !out) return fail(VG_EINVAL, "null argument");
+	memset(out, 0, sizeof *out);
+	if (!ix->timing_valid) return fail(VG_EINVAL, "no batch has been processed");
+	int rc = vg_sync(ix);
+	if (rc) return rc;
+	HIP_TRY(hipEventElapsedTime(&out->ms_main, ix->ev0, ix->ev1));
+	HIP_TRY(hipEventElapsedTime(&out->ms_total, ix->ev0, ix->ev2));
+	out->launches_main = ix->launches;
+	return VG_OK;
+}
+
+extern "C" int vg_sites_fetch(vg_index *ix, uint32_t *pos, uint8_t *ref_base, uint8_t *alt_base, uint8_t *ref_freq, uint8_t *alt_freq)
+{
+	if (!ix) return fail(VG_EINVAL, "null argument");
+	const size_t n = ix->n_sites;
+	if (pos) memcpy(pos, ix->site_pos.data(), n * 4);
+	if (ref_base) memcpy(ref_base, ix->site_ref.data(), n);
+	if (alt_base) memcpy(alt_base, ix->site_alt.data(), n);
+	if (ref_freq) memcpy(ref_freq, ix->site_rf.data(), n);
+	if (alt_freq) memcpy(alt_freq, ix->site_af.data(), n);
+	return VG_OK;
+}
+
+extern "C" int vg_counts_fetch(vg_index *ix, uint8_t *ref_cnt, uint8_t *alt_cnt)
+{
+	if (!ix || !ref_cnt || !alt_cnt) return fail(VG_EINVAL, "null argument");
+	int rc = vg_sync(ix);
+	if (rc) return rc;
+	std::vector<uint32_t> h(2 * ix->n_sites);
+	if (ix->n_sites) HIP_TRY(hipMemcpy(h.data(), ix->d.cnt, h.size() * 4, hipMemcpyDeviceToHost));
+	for (uint64_t s = 0; s < ix->n_sites; s++) {       // MAX_COV saturation, src/vartype.h:27, qv.cc:1411, 1419
+		ref_cnt[s] = (uint8_t)std::min<uint32_t>(63u, h[2 * s]);
+		alt_cnt[s] = (uint8_t)std::min<uint32_t>(63u, h[2 * s + 1]);
+	}
+	return VG_OK;
+}
+
+extern "C" int vg_counts_reset(vg_index *ix)
+{
+	if (!ix) return fail(VG_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(ix->device));
+	HIP_TRY(hipMemsetAsync(ix->d.cnt, 0, (2 * ix->n_sites + 2) * 4, ix->stream));
+	HIP_TRY(hipMemsetAsync(ix->d_stats, 0, S_COUNT * sizeof(unsigned long long), ix->stream));
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+	ix->overflow_total = 0;
+	return VG_OK;
+}
+
+extern "C" int vg_counts_device_ptr(vg_index *ix, void **d_counts, uint64_t *n_u32)
+{
+	if (!ix || !d_counts || !n_u32) return fail(VG_EINVAL, "null argument");
+	*d_counts = ix->d.cnt; *n_u32 = 2 * ix->n_sites;
+	return VG_OK;
+}
+
+// RCCL is resolved lazily so that the library loads (and the rest of the ABI works) on single-GPU hosts.
+extern "C" int vg_counts_allreduce(vg_index *ix, void *nccl_comm)
+{
+	if (!ix || !nccl_comm) return fail(VG_EINVAL, "null argument");
+	typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+	static allreduce_fn fn = nullptr;
+	if (!fn) {
+		void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) return fail(VG_ENODEV, "cannot load librccl: %s", dlerror());
+		fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+		if (!fn) return fail(VG_ENODEV, "ncclAllReduce not found in librccl");
+	}
+	HIP_TRY(hipSetDevice(ix->device));
+	if (ix->n_sites == 0) return VG_OK;
+	const int ncclUint32 = 3, ncclSum = 0;            // rccl.h: ncclDataType_t / ncclRedOp_t
+	const int rc = fn(ix->d.cnt, ix->d.cnt, (size_t)(2 * ix->n_sites), ncclUint32, ncclSum, nccl_comm, ix->stream);
+	if (rc != 0) return fail(VG_ENODEV, "ncclAllReduce failed");
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+	return VG_OK;
+}

@@ -1,0 +1,323 @@
+// vg_device.h -- device-side data layout and the per-read state machine of the `vargeno geno`
+// hot path (reference: src/qv.cc:760-1558 of medvedevgroup/vargeno), written for gfx950.
+//
+// Everything here is integer / bit work bounded by random HBM gathers; there is no MFMA-shaped
+// computation anywhere on this path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vg {
+
+constexpr uint32_t POS_AMBIGUOUS = 0xFFFFFFFFu;   // src/vartype.h:38
+constexpr uint32_t NOMOD = 10086u;                 // src/qv.cc:711
+constexpr int AUX_COLS = 10;                       // src/vartype.h:93
+constexpr uint32_t BLOCK_THRESHOLD = 100;          // src/vartype.h:103
+constexpr int REF_STRIDE = 9;                      // sizeof(struct kmer_entry), src/vartype.h:64-72      (bug B1)
+constexpr int SNP_STRIDE = 11;                     // sizeof(struct snp_kmer_entry), src/vartype.h:74-79  (bug B1)
+constexpr uint64_t LO40_MASK = 0xFFFFFFFFFFull;
+
+// HBM layout of one index replica (struct-of-arrays; the reference's packed 9/11-byte entries are
+// split so that every gather is naturally aligned).  B1's index arithmetic is evaluated against
+// these arrays in FILE ORDER, which is all the reference's behaviour depends on.
+struct DevIndex {
+	// reference dictionary (src/qv.cc:519-590)
+	const uint32_t *ref_jg;        // [2^32 + 1] jump table over HI32; entry 2^32 = n_ref (sentinel replaces the 0xFFFFFFFF special case)
+	const uint32_t *ref_lo;        // [n_ref] LO32 of each k-mer
+	const uint32_t *ref_pos;       // [n_ref] position | aux row | POS_AMBIGUOUS
+	const uint8_t  *ref_amb;       // [n_ref] ambig_flag
+	const uint32_t *ref_aux;       // [n_ref_aux][10]
+	uint64_t n_ref;
+	// SNP dictionary (src/qv.cc:606-695)
+	const uint32_t *snp_jg;        // [2^24 + 1]
+	const uint64_t *snp_key;       // [n_snp] LO40 | snp_info << 40 | ambig_flag << 48
+	const uint32_t *snp_pos;       // [n_snp]
+	const uint32_t *snp_aux_pos;   // [n_snp_aux][10]
+	const uint8_t  *snp_aux_info;  // [n_snp_aux][10]
+	uint64_t n_snp;
+	// bit vectors (src/generate_bf.h:112-142)
+	const uint64_t *ref_bf; uint64_t ref_bf_bits;
+	const uint64_t *snp_bf; uint64_t snp_bf_bits;
+	// dense per-position site word: bits 0-1 ref, 2-3 alt (src/vartype.h:81-90), bits 4.. = site id + 1
+	// (0 when ref == alt).  Replaces the counters of packed_pileup_entry, which live in `cnt`.
+	const uint32_t *pile; uint64_t pile_len;
+	uint32_t *cnt;                 // [2 * n_sites] exact sums: [2s] ref, [2s+1] alt
+};
+
+// Per-lane scratch in HBM, slot-major so that lanes of a wave touching the same slot coalesce.
+struct Scratch {
+	uint64_t *ctx_kmer;            // [cap][nlanes]
+	uint32_t *ctx_kpos;            // [cap][nlanes]
+	uint32_t *ctx_meta;            // [cap][nlanes]  mod (16 bits) | chunk << 16
+	uint32_t *key_index;           // [kcap][nlanes]
+	uint32_t *key_first;           // [kcap][nlanes]
+	uint32_t *key_fm;              // [kcap][nlanes]  freq (8 bits) | multi << 8
+	uint32_t cap, kcap, nlanes;
+};
+
+enum StatId {
+	S_READS, S_READS_N, S_READS_INVALID, S_PASSES, S_PASSES_OK, S_CHUNKS, S_GATE_OPEN, S_REFBF_POS, S_SNPBF_POS,
+	S_LARGE_BLOCK, S_REF_QUERY, S_SNP_QUERY, S_REF_PROBE, S_SNP_PROBE, S_SCAN_REF, S_SCAN_SNP, S_SCAN_OOB,
+	S_AUX_REF, S_AUX_SNP, S_SITE_TEST, S_CTX, S_WALKS, S_INCR, S_INGEST, S_COUNT
+};
+
+template <bool STATS> struct LaneStats;
+template <> struct LaneStats<false> { __device__ inline void add(int, uint32_t) {} };
+template <> struct LaneStats<true> {
+	uint32_t v[S_COUNT];
+	__device__ inline void add(int id, uint32_t x) { v[id] += x; }
+};
+
+__device__ inline uint32_t hash32(uint32_t x) { x = ((x >> 16) ^ x) * 0x45d9f3bu; x = ((x >> 16) ^ x) * 0x45d9f3bu; return (x >> 16) ^ x; }
+__device__ inline uint64_t hash40(uint64_t x) { x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull; x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; return x ^ (x >> 31); }
+
+__device__ inline uint32_t ceil_log2_p1(uint32_t b) { return 32u - (uint32_t)__clz((int)b); }   // ceil(log2(b+1)) for b >= 1
+
+// one_hamming_distance_32/64 (src/qv.cc:267-312): x != 0 and confined to one base -> base index, else -1
+__device__ inline int onebase(uint64_t x)
+{
+	if (x == 0) return -1;
+	int d = (int)(__ffsll((long long)x) - 1) >> 1;
+	return (x & ~(3ull << (2 * d))) ? -1 : d;
+}
+
+// reverse complement of a 32-mer in 2-bit space (what src/qv.cc:786-806 does on characters)
+__device__ inline uint64_t revcomp64(uint64_t k)
+{
+	k = ((k >> 2) & 0x3333333333333333ull) | ((k & 0x3333333333333333ull) << 2);
+	k = ((k >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((k & 0x0F0F0F0F0F0F0F0Full) << 4);
+	k = __builtin_bswap64(k);
+	return ~k;
+}
+
+// The per-lane machine: one read, one pass at a time.
+template <bool STATS>
+struct Lane {
+	const DevIndex &d;
+	const Scratch &s;
+	uint32_t lane;                 // scratch column
+	uint32_t nctx, nkeys;
+	int best; bool amb; bool overflow;
+	LaneStats<STATS> st;
+
+	__device__ Lane(const DevIndex &d_, const Scratch &s_, uint32_t lane_) : d(d_), s(s_), lane(lane_), nctx(0), nkeys(0), best(-1), amb(false), overflow(false) {}
+
+	__device__ inline void reset_pass() { nctx = 0; nkeys = 0; best = -1; amb = false; }
+
+	// ---- dictionary queries -------------------------------------------------------------
+	// query_ref_dict, src/qv.cc:206-240
+	__device__ inline int64_t ref_query(uint64_t k, uint32_t &lo, uint32_t &hi)
+	{
+		const uint32_t h = (uint32_t)(k >> 32);
+		lo = d.ref_jg[h]; hi = d.ref_jg[(uint64_t)h + 1];
+		st.add(S_REF_QUERY, 1);
+		if (lo == hi) return -1;                      // also covers lo == n_ref (then hi == n_ref)
+		st.add(S_REF_PROBE, ceil_log2_p1(hi - lo));
+		const uint32_t key = (uint32_t)k;
+		uint32_t a = lo, b = hi;
+		while (a < b) { uint32_t m = a + ((b - a) >> 1); if (d.ref_lo[m] < key) a = m + 1; else b = m; }
+		return (a < hi && d.ref_lo[a] == key) ? (int64_t)a : -1;
+	}
+	// query_snp_dict, src/qv.cc:385-411
+	__device__ inline int64_t snp_query(uint64_t k, uint32_t &lo, uint32_t &hi)
+	{
+		const uint32_t h = (uint32_t)(k >> 40);
+		lo = d.snp_jg[h]; hi = d.snp_jg[h + 1];
+		st.add(S_SNP_QUERY, 1);
+		if (lo == hi) return -1;
+		st.add(S_SNP_PROBE, ceil_log2_p1(hi - lo));
+		const uint64_t key = k & LO40_MASK;
+		uint32_t a = lo, b = hi;
+		while (a < b) { uint32_t m = a + ((b - a) >> 1); if ((d.snp_key[m] & LO40_MASK) < key) a = m + 1; else b = m; }
+		return (a < hi && (d.snp_key[a] & LO40_MASK) == key) ? (int64_t)a : -1;
+	}
+
+	// ---- contexts + vote -----------------------------------------------------------------
+	__device__ inline void push_ctx(uint64_t kk, uint32_t kpos, uint32_t mod, uint32_t chunk)
+	{
+		if (nctx >= s.cap) { overflow = true; return; }
+		const uint64_t at = (uint64_t)nctx * s.nlanes + lane;
+		s.ctx_kmer[at] = kk; s.ctx_kpos[at] = kpos; s.ctx_meta[at] = (mod & 0xFFFFu) | (chunk << 16);
+		nctx++;
+		st.add(S_CTX, 1);
+	}
+	// improved_index_table_add, src/qv.cc:132-178
+	__device__ inline void vote(uint32_t index, uint32_t kpos, bool neigh)
+	{
+		int e = -1;
+		for (uint32_t i = 0; i < nkeys; i++) if (s.key_index[(uint64_t)i * s.nlanes + lane] == index) { e = (int)i; break; }
+		uint32_t first, fm;
+		if (e < 0) {
+			if (neigh) return;                                                    // :134-139
+			if (nkeys >= s.kcap) { overflow = true; return; }
+			e = (int)nkeys++;
+			s.key_index[(uint64_t)e * s.nlanes + lane] = index;
+			s.key_first[(uint64_t)e * s.nlanes + lane] = first = kpos;
+			fm = 0;
+		} else {
+			first = s.key_first[(uint64_t)e * s.nlanes + lane];
+			fm = s.key_fm[(uint64_t)e * s.nlanes + lane];
+		}
+		uint32_t freq = (fm + 1) & 0xFFu;                                         // uint8_t freq, :146
+		uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);                   // |set| >= 2, :163-165
+		s.key_fm[(uint64_t)e * s.nlanes + lane] = freq | (multi << 8);
+		if (!multi) return;
+		if (best < 0) { best = e; amb = false; }
+		else if (e == best) amb = false;
+		else {
+			const uint32_t bf = s.key_fm[(uint64_t)best * s.nlanes + lane] & 0xFFu;
+			if (freq == bf) amb = true;
+			else if (freq > bf) { best = e; amb = false; }
+		}
+	}
+	__device__ inline void add(uint64_t kk, uint32_t pos, uint32_t chunk, uint32_t mod, bool neigh)
+	{
+		push_ctx(kk, pos, mod, chunk);
+		vote(pos - 32u * chunk, pos, neigh);
+	}
+	__device__ inline bool site_loose(uint32_t p) { st.add(S_SITE_TEST, 1); return p < d.pile_len && (d.pile[p] & 15u) != 0; }   // qv.cc:990-991
+
+	// a ref-dict hit: exact qv.cc:850-890; neighbour :979-1047, :1131-1171, :1228-1296
+	__device__ inline void ref_hit(int64_t idx, uint64_t kk, uint32_t chunk, uint32_t mod, bool neigh)
+	{
+		if (idx < 0) return;
+		const uint32_t pos = d.ref_pos[idx];
+		if (pos == POS_AMBIGUOUS) return;
+		if (d.ref_amb[idx] == 0) {
+			if (neigh && site_loose(pos + mod)) return;
+			add(kk, pos, chunk, mod, neigh);
+		} else {
+			const uint32_t *row = d.ref_aux + (uint64_t)pos * AUX_COLS;
+			st.add(S_AUX_REF, 1);
+			for (int j = 0; j < AUX_COLS; j++) {
+				const uint32_t p = row[j];
+				if (p == 0) break;
+				if (neigh && site_loose(p + mod)) continue;
+				add(kk, p, chunk, mod, neigh);
+			}
+		}
+	}
+	// a SNP-dict hit: exact qv.cc:897-937; neighbour :1055-1101, :1176-1207, :1308-1352
+	__device__ inline void snp_hit(int64_t idx, uint64_t kk, uint32_t chunk, uint32_t mod, bool neigh)
+	{
+		if (idx < 0) return;
+		const uint32_t pos = d.snp_pos[idx];
+		if (pos == POS_AMBIGUOUS) return;
+		const uint64_t key = d.snp_key[idx];
+		if (((key >> 48) & 0xFFu) == 0) {
+			if (neigh && (uint32_t)((key >> 43) & 0x1Fu) == mod) return;          // SNP_INFO_POS, vartype.h:47
+			add(kk, pos, chunk, mod, neigh);
+		} else {
+			const uint32_t *prow = d.snp_aux_pos + (uint64_t)pos * AUX_COLS;
+			const uint8_t *irow = d.snp_aux_info + (uint64_t)pos * AUX_COLS;
+			st.add(S_AUX_SNP, 1);
+			for (int j = 0; j < AUX_COLS; j++) {
+				const uint32_t p = prow[j];
+				if (p == 0) break;
+				if (neigh && (uint32_t)(irow[j] >> 3) == mod) continue;
+				add(kk, p, chunk, mod, neigh);
+			}
+		}
+	}
+
+	// ---- one chunk: src/qv.cc:834-1365 ---------------------------------------------------
+	__device__ inline void do_chunk(uint64_t k, uint32_t c, bool gate_open)
+	{
+		st.add(S_CHUNKS, 1);
+		uint32_t lo, hi, slo, shi;
+		ref_hit(ref_query(k, lo, hi), k, c, NOMOD, false);                       // :840, :850-890
+		snp_hit(snp_query(k, slo, shi), k, c, NOMOD, false);                     // :841, :897-937
+		if (!gate_open) return;                                                   // :943
+		st.add(S_GATE_OPEN, 1);
+		const uint32_t bs = hi - lo;                                              // check_block_size :242-264
+		uint32_t rsb = 64, ssb = 64;                                              // :946-956
+		{
+			const uint64_t rp = (uint64_t)hash32((uint32_t)k) % d.ref_bf_bits;
+			const uint64_t sp = hash40(k & LO40_MASK) % d.snp_bf_bits;
+			if ((d.ref_bf[rp >> 6] >> (rp & 63)) & 1u) st.add(S_REFBF_POS, 1); else rsb = 32;
+			if ((d.snp_bf[sp >> 6] >> (sp & 63)) & 1u) st.add(S_SNPBF_POS, 1); else ssb = 40;
+		}
+		if (bs >= BLOCK_THRESHOLD) {                                              // :962-1109
+			st.add(S_LARGE_BLOCK, 1);
+			for (uint32_t i = 0; i < 32; i += 2) {
+				const uint64_t base = (k >> i) & 3u;
+				for (uint64_t j = 0; j < 4; j++) {
+					if (j == base) continue;
+					const uint64_t nb = (k & ~(3ull << i)) | (j << i);
+					uint32_t a, b;
+					const int64_t r = ref_query(nb, a, b);
+					const int64_t q = snp_query(nb, a, b);
+					ref_hit(r, nb, c, i >> 1, true);
+					snp_hit(q, nb, c, i >> 1, true);
+					if (overflow) return;
+				}
+			}
+		} else {                                                                  // :1110-1209
+			// iterate_ref_dict :316-376: TEST entry lo + 9*(i-lo), RECORD entry i          (B1)
+			for (uint32_t i = lo; i < hi; i++) {
+				const uint64_t t = (uint64_t)lo + (uint64_t)(i - lo) * REF_STRIDE;
+				uint32_t tlo = 0;
+				st.add(S_SCAN_REF, 1);
+				if (t < d.n_ref) tlo = d.ref_lo[t]; else st.add(S_SCAN_OOB, 1);
+				const int dd = onebase((uint64_t)((uint32_t)k ^ tlo));
+				if (dd >= 0) ref_hit((int64_t)i, (k & 0xFFFFFFFF00000000ull) | tlo, c, (uint32_t)dd, true);
+				if (overflow) return;
+			}
+			// iterate_snp_dict :413-464
+			for (uint32_t i = slo; i < shi; i++) {
+				const uint64_t t = (uint64_t)slo + (uint64_t)(i - slo) * SNP_STRIDE;
+				uint64_t tlo = 0;
+				st.add(S_SCAN_SNP, 1);
+				if (t < d.n_snp) tlo = d.snp_key[t] & LO40_MASK; else st.add(S_SCAN_OOB, 1);
+				const int dd = onebase((k & LO40_MASK) ^ tlo);
+				if (dd >= 0) snp_hit((int64_t)i, (k & 0xFFFFFF0000000000ull) | tlo, c, (uint32_t)dd, true);
+				if (overflow) return;
+			}
+		}
+		for (uint32_t i = 32; i < 64; i += 2) {                                   // :1213-1365
+			const uint64_t base = (k >> i) & 3u;
+			for (uint64_t j = 0; j < 4; j++) {
+				if (j == base) continue;
+				const uint64_t nb = (k & ~(3ull << i)) | (j << i);
+				uint32_t a, b;
+				if (i < rsb) ref_hit(ref_query(nb, a, b), nb, c, i >> 1, true);
+				if ((bs >= BLOCK_THRESHOLD || i >= 40) && i < ssb) snp_hit(snp_query(nb, a, b), nb, c, i >> 1, true);
+				if (overflow) return;
+			}
+		}
+	}
+
+	// ---- decision + pile-up walk: src/qv.cc:1375-1502 -------------------------------------
+	__device__ inline bool finish_pass()
+	{
+		st.add(S_PASSES, 1);
+		if (best < 0 || amb) return false;
+		if ((s.key_fm[(uint64_t)best * s.nlanes + lane] & 0xFFu) <= 1) return false;
+		st.add(S_PASSES_OK, 1);
+		const uint32_t target = s.key_index[(uint64_t)best * s.nlanes + lane];
+		for (uint32_t i = 0; i < nctx; i++) {
+			const uint64_t at = (uint64_t)i * s.nlanes + lane;
+			const uint32_t kpos = s.ctx_kpos[at];
+			const uint32_t meta = s.ctx_meta[at];
+			if (kpos - 32u * (meta >> 16) != target) continue;
+			const uint64_t kk = s.ctx_kmer[at];
+			const uint32_t mod = meta & 0xFFFFu;
+			st.add(S_WALKS, 1);
+			for (uint32_t b = 0; b < 32; b++) {
+				if (b == mod) continue;
+				const uint32_t p = kpos + b;
+				if (p >= d.pile_len) continue;
+				const uint32_t w = d.pile[p];
+				if (w < 16u) continue;                                            // ref == alt: not a site (:1404)
+				const uint32_t base = (uint32_t)(kk >> (2 * b)) & 3u;
+				uint32_t which;
+				if (base == (w & 3u)) which = 0; else if (base == ((w >> 2) & 3u)) which = 1; else continue;
+				atomicAdd(&d.cnt[2ull * ((w >> 4) - 1) + which], 1u);             // saturation applied at fetch: min(63, sum)
+				st.add(S_INCR, 1);
+			}
+		}
+		return true;
+	}
+};
+
+}  // namespace vg

@@ -1,0 +1,313 @@
+"""Seeded synthetic genome / SNP list / donor / read generator.
+
+Host-side data plumbing for tests and bench.py; nothing here is on the hot path.  Everything is a
+function of one integer seed (numpy PCG64), so the GPU box regenerates the same bytes as this
+container and the committed sha256 list in tests/golden/ pins them.
+
+Conventions follow the reference's file formats (README.md:61-72 of the reference): FASTA with
+70-column lines, VCF with 8 columns and ``CAF=ref,alt`` in INFO, 4-line FASTQ, Phred+33.
+"""
+from __future__ import annotations
+
+import io
+from dataclasses import dataclass, field
+
+import numpy as np
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP[_a] = _b
+_CODE = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+    _CODE[_c + 32] = _i
+
+
+@dataclass
+class Genome:
+    names: list            # FASTA header text after '>' (may contain a description)
+    seqs: list             # list of np.uint8 arrays (ASCII, upper-case ACGTN)
+
+    @property
+    def short_names(self):
+        # fasta_parser.c:67-75 of the reference cuts the name at '|' / whitespace / 64 chars
+        out = []
+        for n in self.names:
+            cut = len(n)
+            for i, ch in enumerate(n):
+                if ch == "|" or ch.isspace() or i == 64:
+                    cut = i
+                    break
+            out.append(n[:cut])
+        return out
+
+    @property
+    def total_len(self):
+        return int(sum(len(s) for s in self.seqs))
+
+
+@dataclass
+class SnpSet:
+    chrom: np.ndarray      # int32 index into genome.seqs
+    pos: np.ndarray        # int64, 1-based within chromosome
+    ref: np.ndarray        # uint8 ASCII
+    alt: np.ndarray        # uint8 ASCII
+    caf_ref: np.ndarray    # float64
+    caf_alt: np.ndarray
+    genotype: np.ndarray = field(default=None)   # donor: 0 = 0/0, 1 = 0/1, 2 = 1/1
+
+
+@dataclass
+class Reads:
+    """Flat ASCII read batch, the layout the C-ABI takes: bases/quals concatenated, offsets[n+1]."""
+    bases: np.ndarray      # uint8
+    quals: np.ndarray      # uint8 (same offsets)
+    offsets: np.ndarray    # uint64, n+1
+
+    @property
+    def n(self):
+        return len(self.offsets) - 1
+
+    def slice(self, lo, hi):
+        o = self.offsets
+        b0, b1 = int(o[lo]), int(o[hi])
+        return Reads(self.bases[b0:b1], self.quals[b0:b1], (o[lo:hi + 1] - o[lo]).astype(np.uint64))
+
+
+def random_bases(rng, n):
+    return ACGT[rng.integers(0, 4, size=n, dtype=np.uint8)]
+
+
+def make_genome(rng, lengths, names, *, repeats_per_mbp=50.0, repeat_len=(200, 2000), repeat_div=0.03,
+                microsat_per_mbp=12.5, n_gaps=True, plant_block16=0, plant_hi24=0, plant_copy14=False,
+                plant_ac_run=False, plant_t16=0):
+    """i.i.d. uniform ACGT with planted structure (SURVEY.md §8c F-small / F-mid recipes).
+
+    plant_block16: number of copies of one 16-mer, each preceded by 16 random bases, i.e. that many
+                   distinct 32-mers sharing HI32 -> a ref-dict bucket >= BLOCK_SIZE_THRESHOLD (vartype.h:103).
+    plant_hi24:    number of copies of one 12-mer (dense HI24 buckets in the SNP dict).
+    plant_copy14:  one 100-mer copied 14x (> AUX_TABLE_COLS occurrences -> POS_AMBIGUOUS, dictgen.c:118).
+    plant_ac_run:  an (AC)200 microsatellite.
+    plant_t16:     number of [16 random bases][T x 16] segments: 32-mers in the LAST ref-dict bucket
+                   (HI32 = 0xFFFFFFFF) and SNP k-mers in the last SNP bucket, so the strided scan (B1)
+                   runs past the end of the arrays (SURVEY.md §8a "out-of-range t").
+    """
+    seqs = []
+    for L in lengths:
+        s = random_bases(rng, L)
+        mbp = L / 1e6
+        # diverged repeats: copy a segment elsewhere with `repeat_div` substitutions
+        for _ in range(int(round(repeats_per_mbp * mbp))):
+            rl = int(rng.integers(repeat_len[0], repeat_len[1]))
+            if rl * 2 + 200 >= L:
+                continue
+            src = int(rng.integers(0, L - rl))
+            dst = int(rng.integers(0, L - rl))
+            seg = s[src:src + rl].copy()
+            m = rng.random(rl) < repeat_div
+            seg[m] = random_bases(rng, int(m.sum()))
+            s[dst:dst + rl] = seg
+        # microsatellites
+        for _ in range(int(round(microsat_per_mbp * mbp))):
+            unit = random_bases(rng, int(rng.integers(1, 5)))
+            reps = int(rng.integers(15, 60))
+            run = np.tile(unit, reps)
+            if len(run) + 100 >= L:
+                continue
+            dst = int(rng.integers(0, L - len(run)))
+            s[dst:dst + len(run)] = run
+        seqs.append(s)
+    s0 = seqs[0]
+    L0 = len(s0)
+    if plant_block16:
+        mer = random_bases(rng, 16)
+        for d in rng.choice(np.arange(64, L0 - 64, 48), size=plant_block16, replace=False):
+            s0[d + 16:d + 32] = mer
+    if plant_hi24:
+        mer = random_bases(rng, 12)
+        for d in rng.choice(np.arange(64, L0 - 64, 40), size=plant_hi24, replace=False):
+            s0[d:d + 12] = mer
+    if plant_copy14:
+        mer = random_bases(rng, 100)
+        for d in rng.choice(np.arange(200, L0 - 200, 128), size=14, replace=False):
+            s0[d:d + 100] = mer
+    if plant_ac_run:
+        d = int(rng.integers(1000, L0 - 1000))
+        s0[d:d + 400] = np.tile(np.frombuffer(b"AC", dtype=np.uint8), 200)
+    if plant_t16:
+        for d in rng.choice(np.arange(600, L0 - 600, 64), size=plant_t16, replace=False):
+            s0[d + 16:d + 32] = ord("T")
+    if n_gaps:
+        for s in seqs:
+            g = min(500, len(s) // 100)
+            s[:g] = ord("N")                       # gap at chromosome start
+        g = min(300, L0 // 100)
+        mid = L0 // 2
+        s0[mid:mid + g] = ord("N")                 # one interior gap
+    return Genome(list(names), seqs)
+
+
+def make_snps(rng, genome, n, *, with_caf=True):
+    """Uniform positions (not N, not within 32 of a chromosome end), one alt != ref, CAF ~ Beta(5,1)."""
+    lens = np.array([len(s) for s in genome.seqs], dtype=np.int64)
+    glob = np.sort(rng.choice(int(lens.sum()), size=min(n, int(lens.sum()) // 3), replace=False))
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    chrom = (np.searchsorted(starts, glob, side="right") - 1).astype(np.int32)
+    pos0 = glob - starts[chrom]
+    cat = np.concatenate(genome.seqs)
+    ref = cat[glob]
+    keep = (ref != ord("N")) & (pos0 >= 40) & (pos0 + 40 < lens[chrom])
+    chrom, pos0, ref = chrom[keep], pos0[keep], ref[keep]
+    refc = _CODE[ref]
+    altc = (refc + rng.integers(1, 4, size=len(refc), dtype=np.uint8)) % 4
+    p = 0.01 + 0.98 * rng.beta(5.0, 1.0, size=len(refc))
+    s = SnpSet(chrom, pos0 + 1, ref, ACGT[altc], p, 1.0 - p)
+    s.genotype = rng.integers(0, 3, size=len(refc)).astype(np.uint8)
+    s._with_caf = with_caf
+    return s
+
+
+def haplotypes(genome, snps):
+    """Two donor haplotypes of the concatenated genome (hap0 carries alt only for 1/1)."""
+    cat = np.concatenate(genome.seqs)
+    lens = np.array([len(s) for s in genome.seqs], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)])
+    g = starts[snps.chrom] + snps.pos - 1
+    h0, h1 = cat.copy(), cat.copy()
+    m1 = snps.genotype >= 1
+    m2 = snps.genotype == 2
+    h1[g[m1]] = snps.alt[m1]
+    h0[g[m2]] = snps.alt[m2]
+    return h0, h1, starts
+
+
+def make_reads(rng, genome, snps, n, *, lengths=(150,), err=0.005, lowq=0.08, lower_frac=0.0,
+               rev_frac=0.5):
+    """n reads; uniform start, uniform haplotype, `rev_frac` reverse strand, substitution errors,
+    Phred+33 qualities: with prob `lowq` uniform in '#'..'7' (gate-open for '8' = QUALITY_SCORE,
+    vartype.h:17) else uniform in ':'..'I'."""
+    h0, h1, starts = haplotypes(genome, snps)
+    G = len(h0)
+    lens_choice = np.asarray(lengths, dtype=np.int64)
+    rl = lens_choice[rng.integers(0, len(lens_choice), size=n)]
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(rl)
+    total = int(offsets[-1])
+    bases = np.empty(total, dtype=np.uint8)
+    for L in np.unique(rl):
+        idx = np.nonzero(rl == L)[0]
+        m = len(idx)
+        L = int(L)
+        st = rng.integers(0, G - L, size=m)
+        gi = st[:, None] + np.arange(L)[None, :]
+        hap = rng.integers(0, 2, size=m).astype(bool)
+        b = np.where(hap[:, None], h1[gi], h0[gi])
+        e = rng.random((m, L)) < err
+        ne = int(e.sum())
+        if ne:
+            cur = _CODE[b[e]]
+            sub = (cur + rng.integers(1, 4, size=ne, dtype=np.uint8)) % 4   # N (code 4) -> some base; harmless
+            b[e] = ACGT[sub]
+        rv = rng.random(m) < rev_frac
+        b[rv] = _COMP[b[rv][:, ::-1]]
+        dst = offsets[idx].astype(np.int64)[:, None] + np.arange(L)[None, :]
+        bases[dst] = b
+    q_hi = rng.integers(ord(":"), ord("I") + 1, size=total, dtype=np.uint8)
+    q_lo = rng.integers(ord("#"), ord("7") + 1, size=total, dtype=np.uint8)
+    quals = np.where(rng.random(total) < lowq, q_lo, q_hi).astype(np.uint8)
+    if lower_frac > 0:
+        lc = rng.random(total) < lower_frac
+        bases[lc] |= 0x20
+    return Reads(bases, quals, offsets)
+
+
+# ----------------------------------------------------------------------------- writers
+
+def write_fasta(path, genome, width=70):
+    with open(path, "wb") as f:
+        for name, s in zip(genome.names, genome.seqs):
+            f.write(b">" + name.encode() + b"\n")
+            n = len(s)
+            full = (n // width) * width
+            if full:
+                body = np.empty((full // width, width + 1), dtype=np.uint8)
+                body[:, :width] = s[:full].reshape(-1, width)
+                body[:, width] = 10
+                f.write(body.tobytes())
+            if n > full:
+                f.write(s[full:].tobytes() + b"\n")
+
+
+VCF_HEADER = (
+    "##fileformat=VCFv4.0\n"
+    "##source=vargeno_amd.synth\n"
+    "##INFO=<ID=CAF,Number=.,Type=String,Description=\"ref,alt allele frequencies\">\n"
+    "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+)
+
+
+def write_vcf(path, genome, snps, *, strip_chr=True):
+    names = genome.short_names
+    vnames = [n[3:] if (strip_chr and n.startswith("chr")) else n for n in names]
+    with_caf = getattr(snps, "_with_caf", True)
+    buf = io.StringIO()
+    buf.write(VCF_HEADER)
+    for i in range(len(snps.pos)):
+        info = ("RS=%d;CAF=%.4f,%.4f;COMMON=1" % (i + 1, snps.caf_ref[i], snps.caf_alt[i])) if with_caf else "RS=%d" % (i + 1)
+        buf.write("%s\t%d\trs%d\t%c\t%c\t.\t.\t%s\n" % (vnames[snps.chrom[i]], snps.pos[i], i + 1,
+                                                      snps.ref[i], snps.alt[i], info))
+    with open(path, "w") as f:
+        f.write(buf.getvalue())
+
+
+def write_fastq(path, reads):
+    o = reads.offsets.astype(np.int64)
+    with open(path, "wb") as f:
+        chunk = []
+        for i in range(reads.n):
+            chunk.append(b"@r%d\n" % i)
+            chunk.append(reads.bases[o[i]:o[i + 1]].tobytes())
+            chunk.append(b"\n+\n")
+            chunk.append(reads.quals[o[i]:o[i + 1]].tobytes())
+            chunk.append(b"\n")
+            if len(chunk) >= 50000:
+                f.write(b"".join(chunk))
+                chunk = []
+        f.write(b"".join(chunk))
+
+
+# ----------------------------------------------------------------------------- named data sets
+
+def f_small(seed=20261002):
+    """F-small: 300 kbp, 2 chromosomes, adversarial plants, 30 k SNPs, 40 k reads."""
+    rng = np.random.default_rng(seed)
+    g = make_genome(rng, [220_000, 80_000], ["chr22 synthetic", "chrX"], repeats_per_mbp=200.0,
+                    repeat_len=(200, 1500), repeat_div=0.03, microsat_per_mbp=40.0,
+                    plant_block16=160, plant_hi24=400, plant_copy14=True, plant_ac_run=True)
+    s = make_snps(rng, g, 30_000)
+    r = make_reads(rng, g, s, 40_000, lengths=(150, 150, 150, 101, 250, 64, 31), err=0.01, lowq=0.40,
+                   lower_frac=0.05)
+    return g, s, r
+
+
+def f_tiny(seed=7):
+    """A few-second data set for CPU unit tests: 60 kbp, 3 k SNPs, 4 k reads."""
+    rng = np.random.default_rng(seed)
+    g = make_genome(rng, [40_000, 20_000], ["chr1", "chr2 second"], repeats_per_mbp=300.0,
+                    repeat_len=(100, 600), microsat_per_mbp=100.0, plant_block16=120, plant_hi24=150,
+                    plant_copy14=True, plant_ac_run=True, plant_t16=60)
+    s = make_snps(rng, g, 3_000)
+    r = make_reads(rng, g, s, 4_000, lengths=(150, 150, 101, 64, 31, 250), err=0.01, lowq=0.40,
+                   lower_frac=0.05)
+    return g, s, r
+
+
+def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=1_000_000):
+    """BASELINE.json configs[1]: one 40 Mbp chromosome, ~1 M SNPs, 1 M x 150 bp reads (F-mid recipe)."""
+    rng = np.random.default_rng(seed)
+    g = make_genome(rng, [genome_len], ["chr22"], repeats_per_mbp=50.0, repeat_len=(200, 2000),
+                    repeat_div=0.02, microsat_per_mbp=12.5)
+    s = make_snps(rng, g, n_snps)
+    r = make_reads(rng, g, s, n_reads, lengths=(150,), err=0.005, lowq=0.08)
+    return g, s, r
