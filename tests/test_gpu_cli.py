@@ -1,0 +1,35 @@
+"""End to end through the drop-in command line on a GPU: `vargeno index` + `vargeno geno` must
+write the very bytes the reference wrote (tests/golden/*.out.vcf.gz, captured from oracle/_ref)."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+from vargeno_amd import synth
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno")
+
+
+@pytest.mark.parametrize("name,gen", [("ftiny", synth.f_tiny), ("fsmall", synth.f_small)])
+def test_cli_vcf_is_byte_identical_to_the_reference(name, gen, tmp_path):
+    g, s, r = gen()
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    synth.write_fastq(os.path.join(d, "reads.fq"), r)
+    env = dict(os.environ, VARGENO_NO_LITE="1", VARGENO_BATCH="7000")     # several batches
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=env, stdout=subprocess.DEVNULL)
+    p = subprocess.run([BIN, "geno", "idx", "reads.fq", "snps.vcf", "out.vcf"], cwd=d, env=env, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert p.stderr.startswith("Initializing...\nProcessing...\n") and p.stdout.startswith("Time: ")
+    want = gzip.open(os.path.join(GOLDEN, name + ".out.vcf.gz"), "rb").read()
+    got = open(os.path.join(d, "out.vcf"), "rb").read()
+    assert got == want
+
+
+def test_cli_without_index_fails_cleanly(tmp_path):
+    p = subprocess.run([BIN, "geno", "nope", "reads.fq", "snps.vcf", "out.vcf"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert p.returncode == 1

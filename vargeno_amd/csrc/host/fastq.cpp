@@ -1,0 +1,77 @@
+// fastq.cpp -- FASTQ framing with the reference's semantics (src/qv.cc:699-784): four fgets() calls
+// of at most 1023 characters per record (id, read, separator, quality); the read length is
+// strlen(read) - 1 whatever the last character is; chunk c is gated by the c-th character of the
+// quality LINE.  Records are packed into the flat batch layout the C-ABI takes.
+#include <stdio.h>
+#include <string.h>
+
+#include "vg_host.h"
+
+namespace vgh {
+
+struct FastqReader::Impl {
+	FILE *f = nullptr;
+	std::vector<char> buf;
+	size_t pos = 0, end = 0;
+	bool eof = false;
+	char line[4][1024];
+	// fgets(dst, 1024, f): up to 1023 chars, stops after '\n'; false at end of file with nothing read
+	bool gets(char *dst)
+	{
+		size_t n = 0;
+		for (;;) {
+			if (pos == end) {
+				if (eof) break;
+				end = fread(buf.data(), 1, buf.size(), f);
+				pos = 0;
+				if (end == 0) { eof = true; break; }
+			}
+			const char *s = buf.data() + pos;
+			const size_t avail = end - pos, room = 1023 - n;
+			const size_t take = avail < room ? avail : room;
+			const char *nl = (const char *)memchr(s, '\n', take);
+			const size_t m = nl ? (size_t)(nl - s) + 1 : take;
+			memcpy(dst + n, s, m);
+			n += m; pos += m;
+			if (nl || n == 1023) break;
+		}
+		dst[n] = '\0';
+		return n > 0;
+	}
+};
+
+FastqReader::FastqReader(const std::string &path) : p(new Impl)
+{
+	p->f = fopen(path.c_str(), "r");
+	if (!p->f) { delete p; throw Error{"cannot open " + path}; }
+	p->buf.resize(1 << 24);
+	for (auto &l : p->line) l[0] = '\0';
+}
+FastqReader::~FastqReader() { if (p->f) fclose(p->f); delete p; }
+
+uint64_t FastqReader::next(ReadBatch &out, uint64_t max_reads)
+{
+	if (out.offsets.empty()) out.offsets.assign(1, 0);
+	uint64_t got = 0;
+	while (got < max_reads) {
+		if (!p->gets(p->line[0])) break;                        // while (fgets(id, ...)), qv.cc:760
+		// a NULL return leaves the previous record's buffer in place in the reference (qv.cc:761-763);
+		// a truncated final record is therefore processed with stale lines.  Reproduced as is.
+		(void)p->gets(p->line[1]);
+		(void)p->gets(p->line[2]);
+		(void)p->gets(p->line[3]);
+		const size_t sl = strlen(p->line[1]);
+		const size_t rlen = sl ? sl - 1 : 0;                    // strlen(read) - 1, qv.cc:778 (size_t wrap on an empty buffer is not reproduced)
+		const size_t ql = strlen(p->line[3]);
+		const size_t at = out.bases.size();
+		out.bases.insert(out.bases.end(), p->line[1], p->line[1] + rlen);
+		out.quals.resize(at + rlen, 0);
+		// qual[c] for c < rlen/32 is all the path reads; copy what the quality line has (its newline included, as in the buffer)
+		memcpy(out.quals.data() + at, p->line[3], ql < rlen ? ql : rlen);
+		out.offsets.push_back(out.bases.size());
+		got++;
+	}
+	return got;
+}
+
+}  // namespace vgh

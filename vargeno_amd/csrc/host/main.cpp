@@ -1,0 +1,165 @@
+// main.cpp -- the `vargeno` command line of the drop-in (reference front-end: src/qv.cc:1853-2395).
+//   vargeno index <ref.fa> <snps.vcf> <prefix>
+//   vargeno geno  <prefix> <reads.fq> <snps.vcf> <out.vcf>
+// Same positional arguments, file names, messages and exit codes as upstream.  `geno` drives the
+// HIP library through the C-ABI of include/vargeno_hip.h only.  Extra knobs come from the
+// environment so that the argument list stays the reference's:
+//   VARGENO_GPUS=n        shard read batches over n GPUs of this node (default 1), counters summed with RCCL
+//   VARGENO_BATCH=n       reads per submitted batch (default 4194304)
+//   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/vargeno_hip.h"
+#include "vg_host.h"
+
+static void print_help()
+{
+	fprintf(stderr, "Usage: vargeno <option> [option parameters ...]\n");
+	fprintf(stderr, "Option  Description                   Parameters\n");
+	fprintf(stderr, "------  -----------                   ----------\n");
+	fprintf(stderr, "index   Generate index            <input FASTA> <input SNPs in VCF> <index_prefix>\n");
+	fprintf(stderr, "geno    Perform genotyping        <index_prefix> <input FASTQ> <input SNPs in VCF> <output file in VCF>\n");
+}
+static void arg_check(int argc, int expected)
+{
+	if (argc - 2 != expected) { print_help(); exit(EXIT_FAILURE); }
+}
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+
+#define VG_CHECK(call)                                                                           \
+	do {                                                                                         \
+		int rc_ = (call);                                                                        \
+		if (rc_ != VG_OK) { fprintf(stderr, "vargeno: %s failed (%d): %s\n", #call, rc_, vg_last_error()); exit(EXIT_FAILURE); } \
+	} while (0)
+
+static int run_geno(const std::string &prefix, const std::string &fastq, const std::string &vcf_in, const std::string &vcf_out)
+{
+	const clock_t begin = clock();
+	struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+	std::vector<vgh::ChrLen> chrlens = vgh::read_chrlens(prefix + ".chrlens");
+	int ngpu = env_int("VARGENO_GPUS", 1);
+	const int have = vg_device_count();
+	if (have <= 0) { fprintf(stderr, "vargeno: no HIP device found (this build has no CPU path)\n"); return EXIT_FAILURE; }
+	if (ngpu > have) ngpu = have;
+	if (ngpu < 1) ngpu = 1;
+	const uint64_t batch = (uint64_t)env_int("VARGENO_BATCH", 1 << 22);
+
+	fprintf(stderr, "Initializing...\n");
+	std::vector<vg_index *> ix((size_t)ngpu, nullptr);
+	{
+		std::vector<std::thread> th;
+		std::vector<int> rcs((size_t)ngpu, 0);
+		std::vector<std::string> errs((size_t)ngpu);
+		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_index_open(prefix.c_str(), g, &ix[(size_t)g]); if (rcs[(size_t)g]) errs[(size_t)g] = vg_last_error(); });
+		for (auto &t : th) t.join();
+		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) { fprintf(stderr, "vargeno: cannot load index %s on GPU %d (%d): %s\n", prefix.c_str(), g, rcs[(size_t)g], errs[(size_t)g].c_str()); return EXIT_FAILURE; }
+	}
+	for (auto *h : ix) VG_CHECK(vg_set_stats(h, env_int("VARGENO_STATS", 0)));
+
+	fprintf(stderr, "Processing...\n");
+	vgh::FastqReader rd(fastq);
+	vgh::ReadBatch rb;
+	uint64_t total = 0; int next_gpu = 0;
+	for (;;) {
+		rb.clear();
+		const uint64_t n = rd.next(rb, batch);
+		if (!n) break;
+		total += n;
+		VG_CHECK(vg_reads_submit(ix[(size_t)next_gpu], rb.bases.data(), rb.quals.data(), rb.offsets.data(), n));
+		next_gpu = (next_gpu + 1) % ngpu;
+	}
+	for (auto *h : ix) VG_CHECK(vg_sync(h));
+	{
+		vg_stats st;
+		uint64_t invalid = 0;
+		if (env_int("VARGENO_STATS", 0)) for (auto *h : ix) { VG_CHECK(vg_stats_get(h, &st)); invalid += st.reads_invalid; }
+		if (invalid) { fprintf(stderr, "vargeno: %lu reads contain a character other than ACGTN (the reference aborts on these)\n", (unsigned long)invalid); return EXIT_FAILURE; }
+	}
+	if (ngpu > 1) {
+		// one process, n devices: ncclCommInitAll + one all-reduce of the per-site counters over xGMI
+		void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!lib) { fprintf(stderr, "vargeno: cannot load librccl: %s\n", dlerror()); return EXIT_FAILURE; }
+		typedef int (*init_all_fn)(void **, int, const int *);
+		typedef int (*group_fn)();
+		typedef int (*destroy_fn)(void *);
+		init_all_fn init_all = (init_all_fn)dlsym(lib, "ncclCommInitAll");
+		group_fn gstart = (group_fn)dlsym(lib, "ncclGroupStart"), gend = (group_fn)dlsym(lib, "ncclGroupEnd");
+		destroy_fn destroy = (destroy_fn)dlsym(lib, "ncclCommDestroy");
+		if (!init_all || !gstart || !gend) { fprintf(stderr, "vargeno: RCCL symbols missing\n"); return EXIT_FAILURE; }
+		std::vector<void *> comms((size_t)ngpu, nullptr);
+		std::vector<int> devs;
+		for (int g = 0; g < ngpu; g++) devs.push_back(g);
+		if (init_all(comms.data(), ngpu, devs.data()) != 0) { fprintf(stderr, "vargeno: ncclCommInitAll failed\n"); return EXIT_FAILURE; }
+		std::vector<std::thread> th;
+		std::vector<int> rcs((size_t)ngpu, 0);
+		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_counts_allreduce(ix[(size_t)g], comms[(size_t)g]); });
+		for (auto &t : th) t.join();
+		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) { fprintf(stderr, "vargeno: counter all-reduce failed on GPU %d\n", g); return EXIT_FAILURE; }
+		if (destroy) for (void *c : comms) destroy(c);
+	}
+	vgh::SiteCounts sc;
+	const uint64_t ns = vg_num_sites(ix[0]);
+	sc.pos.resize(ns); sc.ref_freq.resize(ns); sc.alt_freq.resize(ns); sc.ref_cnt.resize(ns); sc.alt_cnt.resize(ns);
+	VG_CHECK(vg_sites_fetch(ix[0], sc.pos.data(), nullptr, nullptr, sc.ref_freq.data(), sc.alt_freq.data()));
+	VG_CHECK(vg_counts_fetch(ix[0], sc.ref_cnt.data(), sc.alt_cnt.data()));
+	vgh::write_genotyped_vcf(sc, chrlens, vcf_in, vcf_out);
+	for (auto *h : ix) vg_index_close(h);
+	const double cpu = (double)(clock() - begin) / CLOCKS_PER_SEC;
+	printf("Time: %f sec\n", cpu);                                       // qv.cc:1749-1751 prints CPU seconds
+	if (env_int("VARGENO_VERBOSE", 0)) {
+		struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+		fprintf(stderr, "reads: %lu  wall: %.3f s  gpus: %d\n", (unsigned long)total, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), ngpu);
+	}
+	return EXIT_SUCCESS;
+}
+
+int main(int argc, const char *argv[])
+{
+	if (argc < 2) { print_help(); return 0; }
+	const std::string opt = argv[1];
+	try {
+		if (opt == "index") {
+			arg_check(argc, 3);
+			vgh::IndexOptions io;
+			io.write_lite = !env_int("VARGENO_NO_LITE", 0);
+			io.threads = env_int("VARGENO_THREADS", 0);
+			vgh::build_index(argv[2], argv[3], argv[4], io);
+			return EXIT_SUCCESS;
+		} else if (opt == "geno") {
+			arg_check(argc, 4);
+			return run_geno(argv[2], argv[3], argv[4], argv[5]);
+		} else if (opt == "callvcf") {
+			// hidden (like the reference's vcfd/ucscd/filt): caller + VCF writer alone, from a counts table
+			// "pos ref_freq alt_freq ref_cnt alt_cnt" per line: <chrlens> <counts.txt> <snps.vcf> <out.vcf>
+			arg_check(argc, 4);
+			vgh::SiteCounts sc;
+			FILE *f = fopen(argv[3], "r");
+			if (!f) throw vgh::Error{std::string("cannot open ") + argv[3]};
+			unsigned long p; unsigned rf, af, rc, ac;
+			while (fscanf(f, "%lu %u %u %u %u", &p, &rf, &af, &rc, &ac) == 5) {
+				sc.pos.push_back((uint32_t)p); sc.ref_freq.push_back((uint8_t)rf); sc.alt_freq.push_back((uint8_t)af);
+				sc.ref_cnt.push_back((uint8_t)rc); sc.alt_cnt.push_back((uint8_t)ac);
+			}
+			fclose(f);
+			vgh::write_genotyped_vcf(sc, vgh::read_chrlens(argv[2]), argv[4], argv[5]);
+			return EXIT_SUCCESS;
+		} else if (opt == "help") {
+			print_help();
+			return EXIT_SUCCESS;
+		}
+	} catch (const vgh::Error &e) {
+		fprintf(stderr, "vargeno: %s\n", e.msg.c_str());
+		return EXIT_FAILURE;
+	}
+	print_help();
+	return EXIT_FAILURE;
+}

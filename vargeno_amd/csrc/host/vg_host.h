@@ -1,0 +1,62 @@
+// vg_host.h -- host side of the vargeno drop-in (C++17): `vargeno index` (file producers of the hot
+// path's inputs), FASTQ framing, genotype caller and VCF writer.  None of this is device code; it is
+// what sits on either side of the C-ABI in include/vargeno_hip.h.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace vgh {
+
+// ---- errors: the reference asserts / exit()s; the host library throws, main() turns it into exit(1)
+struct Error {
+	std::string msg;
+};
+
+// ---- `vargeno index` (reference src/qv.cc:2239-2389) ------------------------------------------
+struct IndexOptions {
+	bool write_lite = true;      // <prefix>.ref.bf.lite.bf: written by the reference, read by nothing in `geno`
+	int threads = 0;             // 0 = all
+	bool quiet = false;
+};
+void build_index(const std::string &fasta, const std::string &vcf, const std::string &prefix, const IndexOptions &opt);
+
+// ---- FASTQ framing (reference src/qv.cc:760-784) ----------------------------------------------
+struct ReadBatch {
+	std::vector<uint8_t> bases, quals;     // flat, same offsets
+	std::vector<uint64_t> offsets;         // n + 1
+	uint64_t n() const { return offsets.empty() ? 0 : offsets.size() - 1; }
+	void clear() { bases.clear(); quals.clear(); offsets.assign(1, 0); }
+};
+class FastqReader {
+public:
+	explicit FastqReader(const std::string &path);
+	~FastqReader();
+	// appends up to max_reads records; returns the number appended (0 at end of file)
+	uint64_t next(ReadBatch &out, uint64_t max_reads);
+private:
+	struct Impl;
+	Impl *p;
+};
+
+// ---- caller + VCF writer (reference src/qv.cc:1573-1747, 1789-1848) ---------------------------
+struct Call {
+	int genotype;        // 0 none, 1 = 0/0 (GTYPE_REF), 2 = 1/1 (GTYPE_ALT), 3 = 0/1 (GTYPE_HET)
+	double confidence;
+};
+Call choose_best_genotype(int ref_cnt, int alt_cnt, uint8_t ref_freq_enc, uint8_t alt_freq_enc);
+
+struct ChrLen { std::string name; uint64_t len; };
+std::vector<ChrLen> read_chrlens(const std::string &path);
+
+struct SiteCounts {
+	std::vector<uint32_t> pos;                     // 1-based over the concatenated genome, ascending
+	std::vector<uint8_t> ref_freq, alt_freq, ref_cnt, alt_cnt;
+};
+// returns {ref calls, alt calls, het calls}
+struct CallSummary { uint64_t ref = 0, alt = 0, het = 0; };
+CallSummary write_genotyped_vcf(const SiteCounts &s, const std::vector<ChrLen> &chrlens,
+                                const std::string &vcf_in, const std::string &vcf_out);
+
+}  // namespace vgh
