@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the `vargeno geno` read loop on MI355X (BASELINE.json metric).
+
+One step = one pass of the hot path (encode -> dictionary lookups -> gated neighbour search -> vote
+-> pile-up counter updates) over one batch of synthetic 150 bp reads that is ALREADY RESIDENT in
+HBM as ASCII bases + quality characters, through the C-ABI (vg_reads_process_device); for N > 1
+ranks each step ends with the path's one exchange, an RCCL all-reduce of the per-site counters.
+
+Workload (config.workload): BASELINE.json configs[1] -- chr22-scale: one 40 Mbp synthetic
+chromosome with planted repeats, ~1 M SNPs, 150 bp reads at 0.5 % error, 8 % low-quality characters
+(SURVEY.md §8d), seed 20261002.  The hg38-scale configs[2] needs an index builder that does not go
+through a single host process; see DESIGN.md "what comes next".
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
+        python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--genome", type=int, default=40_000_000)
+    ap.add_argument("--snps", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench"))
+    ap.add_argument("--no-check", action="store_true", help="skip the parity check against the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from vargeno_amd import synth
+    from vargeno_amd.api import GenoIndex, all_reduce_counts
+
+    # ---- data set + index files (rank 0 builds, everyone loads a replica) ------------------------
+    tag = "g%d_s%d" % (args.genome, args.snps)
+    d = os.path.join(args.workdir, tag)
+    prefix = os.path.join(d, "idx")
+    t0 = time.time()
+    g, s, r = synth.chr22_scale(genome_len=args.genome, n_snps=args.snps, n_reads=args.reads)
+    if rank == 0:
+        log("[bench] synthetic data: %.1fs (%d bp, %d SNPs, %d reads)" % (time.time() - t0, g.total_len, len(s.pos), r.n))
+        if not os.path.exists(prefix + ".ref.dict"):
+            os.makedirs(d, exist_ok=True)
+            t0 = time.time()
+            synth.write_fasta(os.path.join(d, "ref.fa"), g)
+            synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+            env = dict(os.environ, VARGENO_NO_LITE="1")
+            subprocess.check_call([os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno"), "index", "ref.fa", "snps.vcf", "idx"],
+                                  cwd=d, env=env, stdout=subprocess.DEVNULL)
+            log("[bench] vargeno index: %.1fs" % (time.time() - t0))
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    gx = GenoIndex.open(prefix, device=local_rank)
+    if rank == 0:
+        log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (time.time() - t0, gx.device_bytes / 1e9, gx.num_sites))
+
+    # ---- reads resident in HBM --------------------------------------------------------------------
+    d_bases = torch.from_numpy(r.bases).to(dev)
+    d_quals = torch.from_numpy(r.quals).to(dev)
+    d_offs = torch.from_numpy(r.offsets.astype(np.int64)).to(dev)
+    torch.cuda.synchronize(dev)
+
+    # ---- one counted pass: event counts -> algorithmic bytes; parity against the oracle -----------
+    gx.set_stats(True)
+    gx.reset()
+    gx.process_device(d_bases, d_quals, d_offs, r.n)
+    st = gx.stats()
+    alg_bytes_per_launch = st["alg_bytes"]
+    cpu = None
+    if rank == 0 and args.cpu_sample > 0:
+        from oracle import oracle as O
+
+        t0 = time.time()
+        ox = O.OracleIndex.load(prefix)
+        log("[bench] oracle index load: %.1fs" % (time.time() - t0))
+        ns = min(args.cpu_sample, r.n)
+        sub = r.slice(0, ns)
+        t0 = time.time()
+        ox.process(sub.bases, sub.quals, sub.offsets, nthreads=1)
+        t_cpu = time.time() - t0
+        cpu = {"value": ns / t_cpu, "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "first %d reads of the same batch, oracle/vg_oracle.c, 1 thread, %.1f s" % (ns, t_cpu)}
+        if not args.no_check:
+            if ns == r.n:
+                so = ox.sites()
+                rc, ac = gx.counts()
+                assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), "HIP counters != oracle"
+                want = ox.stats.as_dict()
+                for k, v in want.items():
+                    assert st[k] == v, "event counter %s: hip %d oracle %d" % (k, st[k], v)
+                log("[bench] parity: %d site counters and %d event counters identical to the oracle" % (2 * len(rc), len(want)))
+        ncores = os.cpu_count() or 1
+        nt = min(ncores, 64)
+        ox.reset()
+        t0 = time.time()
+        ox.process(sub.bases, sub.quals, sub.offsets, nthreads=nt)
+        t_all = time.time() - t0
+        cpu["all_cores"] = {"value": ns / t_all, "threads": nt, "host_cores": ncores}
+        ox.close()
+
+    # ---- timed region -------------------------------------------------------------------------------
+    gx.set_stats(False)
+
+    def step():
+        gx.process_device(d_bases, d_quals, d_offs, r.n)
+        if world > 1:
+            all_reduce_counts(gx)
+
+    for _ in range(args.warmup):
+        step()
+    gx.sync()
+    kern_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kern_ms.append(gx.timing()["ms_main"])        # HIP events on the library's own stream
+    gx.sync()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        k_ms = float(np.mean(kern_ms))
+        achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "reads/sec genotyped (whole node)",
+            "value": world * r.n * args.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "chr22-scale (BASELINE.json configs[1]): %d bp synthetic genome, %d SNPs, %d x 150 bp reads per GPU per step, "
+                                   "0.5%% error, 8%% low-quality chars, seed 20261002" % (g.total_len, len(s.pos), r.n),
+                       "reads_per_step_per_gpu": r.n, "index_bytes_hbm": gx.device_bytes,
+                       "parallelism": "reads sharded over %d GPU(s), index replicated, 1 RCCL all-reduce of site counters per step" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "vg_pass_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "algorithmic_bytes_per_read": alg_bytes_per_launch / r.n},
+            "cpu_baseline": cpu,
+            "events_per_read": {k: st[k] / r.n for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
+        }
+        print(json.dumps(out), flush=True)
+    gx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
