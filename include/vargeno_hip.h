@@ -48,16 +48,17 @@ typedef struct {
 	         refbf_pos, snpbf_pos, large_block, ref_query, snp_query, ref_probe, snp_probe,
 	         scan_ref, scan_snp, scan_oob, aux_ref, aux_snp, site_test, ctx, walks, incr,
 	         ingest_bytes;
-	uint64_t overflow_reads;     /* reads re-run by the large-scratch kernel                  */
+	uint64_t overflow_reads;     /* reads the wave tier handed to the generic lane tier       */
+	uint64_t overflow_deep;      /* of those, reads that needed the deep scratch              */
 	uint64_t alg_bytes;          /* sum of unit cost x event count                            */
 } vg_stats;
 
-/* Timing of the kernels of the last vg_reads_process_device / vg_sync, from HIP events recorded on
- * the handle's own stream. */
+/* Timing of the kernels of the last batch, from HIP events recorded on the handle's own stream. */
 typedef struct {
-	float    ms_total;           /* first kernel start -> last kernel end                      */
-	float    ms_main;            /* the dominant kernel (vg_pass_kernel, both passes summed)   */
-	uint32_t launches_main;
+	float ms_total;              /* first kernel start -> last kernel end of the batch         */
+	float ms_pack;               /* vg_pack_kernel: ASCII -> 2-bit chunk k-mers + gate bits    */
+	float ms_main;               /* vg_wave_kernel, the dominant kernel                        */
+	float ms_tail;               /* generic lane tier for the reads that outgrew the LDS lists */
 } vg_timing;
 
 const char *vg_last_error(void);

@@ -92,11 +92,38 @@ def test_scratch_overflow_path_is_exact(ftiny_dir, ftiny_reads, monkeypatch):
         gx.submit(r.bases, r.quals, r.offsets)
         rc, ac = gx.counts()
         st = gx.stats()
-        assert st["overflow_reads"] > 0
+        assert st["overflow_reads"] > 0 and st["overflow_deep"] > 0
         assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
         want = ox.stats.as_dict()
         for k in CMP_STATS:
             assert st[k] == want[k], k
+
+
+def test_generic_lane_tier_alone_is_exact(ftiny_dir, ftiny_reads, monkeypatch):
+    """VG_FORCE_GENERIC=1 bypasses the wave-cooperative kernel: both tiers must give the same bits."""
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    ox, _, so = _oracle_counts(prefix, r)
+    monkeypatch.setenv("VG_FORCE_GENERIC", "1")
+    with GenoIndex.open(prefix) as gx:
+        gx.submit(r.bases, r.quals, r.offsets)
+        rc, ac = gx.counts()
+        st = gx.stats()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        want = ox.stats.as_dict()
+        for k in CMP_STATS:
+            assert st[k] == want[k], k
+        assert st["overflow_reads"] == 0
+
+
+def test_wave_tier_takes_most_reads(ftiny_dir, ftiny_reads):
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    with GenoIndex.open(prefix) as gx:
+        gx.submit(r.bases, r.quals, r.offsets)
+        st = gx.stats()
+        assert 0 < st["overflow_reads"] < r.n // 2          # the adversarial fixture does spill some reads
+        assert st["overflow_deep"] <= st["overflow_reads"]
 
 
 def test_edge_reads(ftiny_dir):

@@ -8,6 +8,7 @@
 // every entry point fails with VG_ENODEV when no HIP device is usable.
 #include "../../include/vargeno_hip.h"
 #include "vg_device.h"
+#include "vg_wave.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -106,9 +107,16 @@ __global__ __launch_bounds__(256) void vg_build_jumpgate(const uint64_t *__restr
 	if (blockIdx.x == gridDim.x - 1 && t == 0) jg[n_buckets] = (uint32_t)n;
 }
 
-__global__ void vg_split_lo32(const uint64_t *__restrict__ kmer, uint64_t n, uint32_t *__restrict__ lo)
+// SoA as the dictionary file has it -> one 16-byte entry per k-mer (a hit then costs one line)
+__global__ void vg_make_ref_entries(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ pos, const uint8_t *__restrict__ amb, uint64_t n, RefEnt *__restrict__ out)
 {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) lo[i] = (uint32_t)kmer[i];
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		out[i] = RefEnt{(uint32_t)kmer[i], pos[i], (uint32_t)amb[i], 0u};
+}
+__global__ void vg_make_snp_entries(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ pos, const uint8_t *__restrict__ info, const uint8_t *__restrict__ amb, uint64_t n, SnpEnt *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+		out[i] = SnpEnt{(kmer[i] & LO40_MASK) | ((uint64_t)info[i] << 40) | ((uint64_t)amb[i] << 48), pos[i], 0u};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -154,14 +162,42 @@ __device__ inline int classify_bad(const uint8_t *p, uint32_t n)
 	return 0;
 }
 
+// Streaming pre-pass: ASCII -> chunk k-mers + one flag word per read (gate bits: chunk c is gate-open iff
+// qual[c] < '8', src/qv.cc:836, 943 -- the chunk NUMBER indexes the quality string).  Chunk c of read r
+// lands at pk_kmer[(offsets[r] >> 5) + c]; slots of different reads cannot collide.
+__global__ __launch_bounds__(256) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
+                                                      uint64_t n_reads, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta)
+{
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t off = offsets[r];
+		const uint32_t n = (uint32_t)((offsets[r + 1] - off) >> 5);
+		const uint8_t *p = bases + off, *q = quals + off;
+		uint64_t meta = 0, bad = 0;
+		for (uint32_t c = 0; c < n; c++) {
+			pk_kmer[(off >> 5) + c] = encode32(p + 32 * c, bad);
+			if (c < 32 && (int)(int8_t)q[c] - '8' < 0) meta |= 1ull << c;
+		}
+		if (bad) meta |= classify_bad(p, n) == 1 ? PK_SKIP_N : PK_INVALID;
+		if (n > 32) meta |= PK_LONG;
+		pk_meta[r] = meta;
+	}
+}
+
+__global__ void vg_accumulate_counters(uint32_t *ctr)
+{
+	// ctr[0..2]: this batch (wave-tier overflow, lane-tier overflow, lost); ctr[4..6]: since reset
+	ctr[4] += ctr[0]; ctr[5] += ctr[1]; ctr[6] += ctr[2];
+}
+
 // One lane = one read: forward pass, then the reverse-complement retry (src/qv.cc:1504-1510).
 // A read touches the counters only at the end of its last pass, so a lane that runs out of scratch
 // simply drops the read onto the overflow list and the same kernel re-runs it with a deep scratch.
 template <bool STATS>
-__global__ __launch_bounds__(256) void vg_pass_kernel(DevIndex d, Scratch s, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
-                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads, const uint32_t *__restrict__ read_ids,
-                                                      uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats)
+__global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
+                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg, const uint32_t *__restrict__ read_ids,
+                                                      const uint32_t *__restrict__ n_ids, uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats)
 {
+	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;       // a list launch is sized on the device: no host round trip between tiers
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	Lane<STATS> L(d, s, gtid);
@@ -233,20 +269,21 @@ struct vg_index {
 	uint64_t n_sites = 0;
 	std::vector<uint32_t> site_pos;
 	std::vector<uint8_t> site_ref, site_alt, site_rf, site_af;
-	ScratchBuf small, big;
-	uint32_t *d_overflow_list = nullptr;  uint64_t overflow_cap = 0;
-	uint32_t *d_overflow_count = nullptr;
+	ScratchBuf mid, big;                  // lane-tier scratch: every lane x 64 contexts; a few lanes x 16384 contexts
+	uint32_t *d_listA = nullptr, *d_listB = nullptr, *d_listC = nullptr;  uint64_t list_cap = 0;
+	uint32_t *d_ctr = nullptr;            // [0..2] this batch: wave-tier overflow, lane-tier overflow, lost; [4..6] since reset
 	unsigned long long *d_stats = nullptr;
-	uint64_t overflow_total = 0, lost_total = 0;
+	uint64_t *d_pk_kmer = nullptr, *d_pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;
 	bool stats_enabled = true;
+	bool force_generic = false;           // VG_FORCE_GENERIC=1: skip the wave tier (tests compare the tiers)
 	// staging for vg_reads_submit
 	uint8_t *d_bases = nullptr, *d_quals = nullptr; uint64_t *d_offsets = nullptr;
 	uint64_t stage_bytes = 0, stage_reads = 0;
 	// timing
-	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-	bool timing_valid = false; bool had_overflow_launch = false;
-	uint32_t launches = 0;
-	int grid_blocks = 0;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+	bool timing_valid = false;
+	int cus = 256;
+	int lane_grid_blocks = 0, wave_grid = 0;
 };
 
 template <class T>
@@ -270,6 +307,19 @@ static int dev_upload(vg_index *ix, T **p, const T *src, uint64_t count)
 	if (count) HIP_TRY(hipMemcpy(*p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
 	return VG_OK;
 }
+// temporary device copy of a host array, freed when it goes out of scope
+template <class T>
+struct TempDev {
+	T *p = nullptr;
+	~TempDev() { if (p) (void)hipFree(p); }
+	int upload(const T *src, uint64_t count)
+	{
+		hipError_t e = hipMalloc((void **)&p, (size_t)(count ? count : 1) * sizeof(T));
+		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(staging): %s", hipGetErrorString(e));
+		if (count) HIP_TRY(hipMemcpy(p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
+		return VG_OK;
+	}
+};
 
 static int alloc_scratch(vg_index *ix, ScratchBuf &b, uint32_t nlanes, uint32_t cap, uint32_t kcap)
 {
@@ -292,13 +342,10 @@ extern "C" void vg_index_close(vg_index *ix)
 	(void)hipSetDevice(ix->device);
 	if (ix->stream) (void)hipStreamSynchronize(ix->stream);
 	for (void *p : ix->owned) (void)hipFree(p);
-	if (ix->d_overflow_list) (void)hipFree(ix->d_overflow_list);
-	if (ix->d_bases) (void)hipFree(ix->d_bases);
-	if (ix->d_quals) (void)hipFree(ix->d_quals);
-	if (ix->d_offsets) (void)hipFree(ix->d_offsets);
-	if (ix->ev0) (void)hipEventDestroy(ix->ev0);
-	if (ix->ev1) (void)hipEventDestroy(ix->ev1);
-	if (ix->ev2) (void)hipEventDestroy(ix->ev2);
+	void *extra[] = {ix->d_listA, ix->d_listB, ix->d_listC, ix->d_pk_kmer, ix->d_pk_meta, ix->d_bases, ix->d_quals, ix->d_offsets};
+	for (void *p : extra) if (p) (void)hipFree(p);
+	hipEvent_t evs[] = {ix->ev0, ix->ev1, ix->ev2, ix->ev3};
+	for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
 	delete ix;
 }
@@ -313,62 +360,52 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	ix->device = device;
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
-	HIP_TRY(hipEventCreate(&ix->ev0)); HIP_TRY(hipEventCreate(&ix->ev1)); HIP_TRY(hipEventCreate(&ix->ev2));
+	HIP_TRY(hipEventCreate(&ix->ev0)); HIP_TRY(hipEventCreate(&ix->ev1)); HIP_TRY(hipEventCreate(&ix->ev2)); HIP_TRY(hipEventCreate(&ix->ev3));
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
-	const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-	ix->grid_blocks = cus * 8;                                   // 2048 lanes per CU = every wave slot
+	ix->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	ix->lane_grid_blocks = ix->cus * 8;                          // 2048 lanes per CU = every wave slot
+	int wpc = 16;                                                // waves per CU of the wave-tier grid
+	if (const char *e = getenv("VG_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
+	ix->wave_grid = ix->cus * wpc;
+	if (const char *e = getenv("VG_FORCE_GENERIC")) ix->force_generic = atoi(e) != 0;
 	int rc;
 	DevIndex &d = ix->d;
 	d.n_ref = a->n_ref; d.n_snp = a->n_snp;
 
-	// ---- reference dictionary: jump table + LO32 on the device from the sorted k-mers
+	// ---- reference dictionary: jump table + 16-byte entries, built on the device from the file's columns
 	{
-		uint64_t *d_kmer = nullptr;
-		const size_t kb = (size_t)(a->n_ref ? a->n_ref : 1) * 8;
-		hipError_t e = hipMalloc((void **)&d_kmer, kb);
-		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(ref k-mers): %s", hipGetErrorString(e));
-		struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{d_kmer};
-		if (a->n_ref) HIP_TRY(hipMemcpy(d_kmer, a->ref_kmer, (size_t)a->n_ref * 8, hipMemcpyHostToDevice));
-		uint32_t *jg = nullptr, *lo = nullptr;
+		TempDev<uint64_t> tk; TempDev<uint32_t> tp; TempDev<uint8_t> ta;
+		if ((rc = tk.upload(a->ref_kmer, a->n_ref))) return rc;
+		if ((rc = tp.upload(a->ref_pos, a->n_ref))) return rc;
+		if ((rc = ta.upload(a->ref_amb, a->n_ref))) return rc;
+		uint32_t *jg = nullptr; RefEnt *ent = nullptr; uint32_t *x = nullptr;
 		if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
-		if ((rc = dev_alloc(ix, &lo, a->n_ref))) return rc;
-		vg_build_jumpgate<32><<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, ix->stream>>>(d_kmer, a->n_ref, jg, 1ull << 32);
-		vg_split_lo32<<<2048, 256, 0, ix->stream>>>(d_kmer, a->n_ref, lo);
+		if ((rc = dev_alloc(ix, &ent, a->n_ref))) return rc;
+		vg_build_jumpgate<32><<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, ix->stream>>>(tk.p, a->n_ref, jg, 1ull << 32);
+		vg_make_ref_entries<<<2048, 256, 0, ix->stream>>>(tk.p, tp.p, ta.p, a->n_ref, ent);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(ix->stream));
-		d.ref_jg = jg; d.ref_lo = lo;
-	}
-	{
-		uint32_t *p = nullptr; uint8_t *q = nullptr; uint32_t *x = nullptr;
-		if ((rc = dev_upload(ix, &p, a->ref_pos, a->n_ref))) return rc;
-		if ((rc = dev_upload(ix, &q, a->ref_amb, a->n_ref))) return rc;
 		if ((rc = dev_upload(ix, &x, a->ref_aux, a->n_ref_aux * AUX_COLS))) return rc;
-		d.ref_pos = p; d.ref_amb = q; d.ref_aux = x;
+		d.ref_jg = jg; d.ref = ent; d.ref_aux = x;
 	}
 	// ---- SNP dictionary
 	{
-		uint64_t *d_kmer = nullptr;
-		const size_t kb = (size_t)(a->n_snp ? a->n_snp : 1) * 8;
-		hipError_t e = hipMalloc((void **)&d_kmer, kb);
-		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(snp k-mers): %s", hipGetErrorString(e));
-		struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{d_kmer};
-		if (a->n_snp) HIP_TRY(hipMemcpy(d_kmer, a->snp_kmer, (size_t)a->n_snp * 8, hipMemcpyHostToDevice));
-		uint32_t *jg = nullptr;
+		TempDev<uint64_t> tk; TempDev<uint32_t> tp; TempDev<uint8_t> ti, ta;
+		if ((rc = tk.upload(a->snp_kmer, a->n_snp))) return rc;
+		if ((rc = tp.upload(a->snp_pos, a->n_snp))) return rc;
+		if ((rc = ti.upload(a->snp_info, a->n_snp))) return rc;
+		if ((rc = ta.upload(a->snp_amb, a->n_snp))) return rc;
+		uint32_t *jg = nullptr; SnpEnt *ent = nullptr; uint32_t *xp = nullptr; uint8_t *xi = nullptr;
 		if ((rc = dev_alloc(ix, &jg, (1ull << 24) + 1))) return rc;
-		vg_build_jumpgate<40><<<(unsigned)((1ull << 24) / JG_SPAN), 256, 0, ix->stream>>>(d_kmer, a->n_snp, jg, 1ull << 24);
+		if ((rc = dev_alloc(ix, &ent, a->n_snp))) return rc;
+		vg_build_jumpgate<40><<<(unsigned)((1ull << 24) / JG_SPAN), 256, 0, ix->stream>>>(tk.p, a->n_snp, jg, 1ull << 24);
+		vg_make_snp_entries<<<2048, 256, 0, ix->stream>>>(tk.p, tp.p, ti.p, ta.p, a->n_snp, ent);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(ix->stream));
-		d.snp_jg = jg;
-		std::vector<uint64_t> key(a->n_snp);
-		for (uint64_t i = 0; i < a->n_snp; i++)
-			key[i] = (a->snp_kmer[i] & LO40_MASK) | ((uint64_t)a->snp_info[i] << 40) | ((uint64_t)a->snp_amb[i] << 48);
-		uint64_t *k = nullptr; uint32_t *p = nullptr, *xp = nullptr; uint8_t *xi = nullptr;
-		if ((rc = dev_upload(ix, &k, key.data(), a->n_snp))) return rc;
-		if ((rc = dev_upload(ix, &p, a->snp_pos, a->n_snp))) return rc;
 		if ((rc = dev_upload(ix, &xp, a->snp_aux_pos, a->n_snp_aux * AUX_COLS))) return rc;
 		if ((rc = dev_upload(ix, &xi, a->snp_aux_info, a->n_snp_aux * AUX_COLS))) return rc;
-		d.snp_key = k; d.snp_pos = p; d.snp_aux_pos = xp; d.snp_aux_info = xi;
+		d.snp_jg = jg; d.snp = ent; d.snp_aux_pos = xp; d.snp_aux_info = xi;
 	}
 	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first
 	//      2^32 bits of the 9.6 Gbit reference vector can ever be read (src/generate_bf.h:112-128)
@@ -388,7 +425,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		for (uint64_t i = 0; i < a->n_snp; i++) if (a->snp_amb[i] == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_pos[i] > maxp) maxp = a->snp_pos[i];
 		for (uint64_t i = 0; i < a->n_snp_aux * AUX_COLS; i++) if (a->snp_aux_pos[i] > maxp) maxp = a->snp_aux_pos[i];
 		const uint64_t plen = maxp + 64;
-		std::vector<uint32_t> pile(plen, 0);        // low nibble ref|alt<<2, bit 4 = seeded, bits 16.. freqs (host only)
+		std::vector<uint32_t> pile(plen, 0);        // low nibble ref|alt<<2, bits 16.. freqs (host only)
 		for (uint64_t i = 0; i < a->n_snp; i++) {   // file order, last writer wins
 			const uint32_t info = a->snp_info[i];
 			if ((info & 4u) == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_amb[i] == 0) {
@@ -415,14 +452,14 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		if ((rc = dev_alloc(ix, &dc, 2 * ix->n_sites + 2, true))) return rc;
 		d.pile = dp; d.pile_len = plen; d.cnt = dc;
 	}
-	// ---- scratch, overflow list, stats
-	// VG_SCRATCH_CAP / VG_SCRATCH_KCAP shrink the per-lane scratch so tests can drive the overflow path
+	// ---- scratch of the lane tier, overflow counters, stats
+	// VG_SCRATCH_CAP / VG_SCRATCH_KCAP shrink the per-lane scratch so tests can drive every tier
 	uint32_t cap = 64, kcap = 32;
 	if (const char *e = getenv("VG_SCRATCH_CAP")) cap = (uint32_t)std::max(1, atoi(e));
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
-	if ((rc = alloc_scratch(ix, ix->small, (uint32_t)ix->grid_blocks * 256u, cap, kcap))) return rc;
+	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
-	if ((rc = dev_alloc(ix, &ix->d_overflow_count, 4, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_ctr, 8, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	return VG_OK;
@@ -513,55 +550,72 @@ extern "C" uint64_t vg_num_sites(const vg_index *ix) { return ix ? ix->n_sites :
 // ------------------------------------------------------------------------------------------------
 // read batches
 // ------------------------------------------------------------------------------------------------
+// Drain the stream and turn "a read outgrew even the deep scratch" into an error code.
+static int finish_pending(vg_index *ix)
+{
+	HIP_TRY(hipSetDevice(ix->device));
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+	uint32_t c[8];
+	HIP_TRY(hipMemcpy(c, ix->d_ctr, sizeof c, hipMemcpyDeviceToHost));
+	if (c[6]) return fail(VG_ENOMEM, "a read produced more hit contexts than the deep scratch holds (the reference overruns MAX_HITS=2000 long before, qv.cc:709)");
+	return VG_OK;
+}
+
+// One batch = pack -> wave tier -> lane tier (mid scratch) -> lane tier (deep scratch), all enqueued
+// back to back on the handle's stream; the list launches size themselves from device counters.
+template <bool STATS>
+static int enqueue_batch(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
+{
+	uint32_t *ctr = ix->d_ctr;
+	HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
+	HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
+	const uint32_t *listA = nullptr;
+	if (!ix->force_generic) {
+		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->cus * 16);
+		vg_pack_kernel<<<pgrid, 256, 0, ix->stream>>>(d_bases, d_quals, d_offsets, n_reads, ix->d_pk_kmer, ix->d_pk_meta);
+		HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->wave_grid);
+		vg_wave_kernel<STATS><<<wgrid, 64, 0, ix->stream>>>(ix->d, ix->d_pk_kmer, ix->d_pk_meta, d_offsets, n_reads, ix->d_listA, &ctr[0], ix->d_stats);
+		HIP_TRY(hipEventRecord(ix->ev2, ix->stream));
+		listA = ix->d_listA;
+		const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
+		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, 0, listA, &ctr[0], ix->d_listB, &ctr[1], ix->d_stats);
+	} else {
+		HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+		const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
+		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, nullptr, ix->d_listB, &ctr[1], ix->d_stats);
+		HIP_TRY(hipEventRecord(ix->ev2, ix->stream));
+	}
+	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->stream>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, ix->d_listB, &ctr[1], ix->d_listC, &ctr[2], ix->d_stats);
+	vg_accumulate_counters<<<1, 1, 0, ix->stream>>>(ctr);
+	HIP_TRY(hipEventRecord(ix->ev3, ix->stream));
+	HIP_TRY(hipGetLastError());
+	return VG_OK;
+}
+
 static int launch_batch(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
 {
 	HIP_TRY(hipSetDevice(ix->device));
 	if (n_reads >= (1ull << 32)) return fail(VG_EINVAL, "more than 2^32-1 reads in one batch");
-	if (n_reads > ix->overflow_cap) {
-		if (ix->d_overflow_list) { HIP_TRY(hipStreamSynchronize(ix->stream)); (void)hipFree(ix->d_overflow_list); ix->d_overflow_list = nullptr; }
-		HIP_TRY(hipMalloc((void **)&ix->d_overflow_list, (size_t)n_reads * 4));
-		ix->overflow_cap = n_reads;
+	// packed-read buffers are sized from the batch's total length (8 bytes from the device; the handle's stream is
+	// non-blocking, so this copy does not wait for kernels in flight)
+	uint64_t total = 0;
+	HIP_TRY(hipMemcpy(&total, d_offsets + n_reads, 8, hipMemcpyDeviceToHost));
+	const uint64_t need_k = (total >> 5) + 2, need_m = n_reads + 1;
+	if (n_reads > ix->list_cap || need_k > ix->pk_kmer_cap || need_m > ix->pk_meta_cap) {
+		int rc = finish_pending(ix);                      // buffers may be in use by the previous batch
+		if (rc) return rc;
+		if (n_reads > ix->list_cap) {
+			uint32_t **lists[] = {&ix->d_listA, &ix->d_listB, &ix->d_listC};
+			for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4)); }
+			ix->list_cap = n_reads;
+		}
+		if (need_k > ix->pk_kmer_cap) { if (ix->d_pk_kmer) (void)hipFree(ix->d_pk_kmer); ix->d_pk_kmer = nullptr; HIP_TRY(hipMalloc((void **)&ix->d_pk_kmer, need_k * 8)); ix->pk_kmer_cap = need_k; }
+		if (need_m > ix->pk_meta_cap) { if (ix->d_pk_meta) (void)hipFree(ix->d_pk_meta); ix->d_pk_meta = nullptr; HIP_TRY(hipMalloc((void **)&ix->d_pk_meta, need_m * 8)); ix->pk_meta_cap = need_m; }
 	}
-	HIP_TRY(hipMemsetAsync(ix->d_overflow_count, 0, 4, ix->stream));
-	const unsigned grid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->grid_blocks);
-	ix->launches = 0; ix->had_overflow_launch = false;
-	HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
-	if (grid) {
-		if (ix->stats_enabled)
-			vg_pass_kernel<true><<<grid, 256, 0, ix->stream>>>(ix->d, ix->small.s, d_bases, d_quals, d_offsets, n_reads, nullptr, ix->d_overflow_list, ix->d_overflow_count, ix->d_stats);
-		else
-			vg_pass_kernel<false><<<grid, 256, 0, ix->stream>>>(ix->d, ix->small.s, d_bases, d_quals, d_offsets, n_reads, nullptr, ix->d_overflow_list, ix->d_overflow_count, ix->d_stats);
-		ix->launches++;
-	}
-	HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
-	HIP_TRY(hipGetLastError());
-	// rare: reads that ran out of per-lane scratch are re-run (whole) with the deep scratch
-	uint32_t n_over = 0;
-	HIP_TRY(hipMemcpyAsync(&n_over, ix->d_overflow_count, 4, hipMemcpyDeviceToHost, ix->stream));
-	HIP_TRY(hipStreamSynchronize(ix->stream));
-	if (n_over) {
-		ix->overflow_total += n_over;
-		std::vector<uint32_t> ids(n_over);
-		HIP_TRY(hipMemcpy(ids.data(), ix->d_overflow_list, (size_t)n_over * 4, hipMemcpyDeviceToHost));
-		std::sort(ids.begin(), ids.end());
-		uint32_t *d_ids = nullptr;
-		HIP_TRY(hipMalloc((void **)&d_ids, (size_t)n_over * 4));
-		HIP_TRY(hipMemcpy(d_ids, ids.data(), (size_t)n_over * 4, hipMemcpyHostToDevice));
-		HIP_TRY(hipMemsetAsync(ix->d_overflow_count, 0, 4, ix->stream));
-		const unsigned g2 = (unsigned)std::min<uint64_t>((n_over + 63) / 64, ix->big.s.nlanes / 64);
-		if (ix->stats_enabled)
-			vg_pass_kernel<true><<<g2, 64, 0, ix->stream>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, n_over, d_ids, ix->d_overflow_list, ix->d_overflow_count, ix->d_stats);
-		else
-			vg_pass_kernel<false><<<g2, 64, 0, ix->stream>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, n_over, d_ids, ix->d_overflow_list, ix->d_overflow_count, ix->d_stats);
-		ix->had_overflow_launch = true;
-		uint32_t lost = 0;
-		HIP_TRY(hipMemcpyAsync(&lost, ix->d_overflow_count, 4, hipMemcpyDeviceToHost, ix->stream));
-		HIP_TRY(hipStreamSynchronize(ix->stream));
-		(void)hipFree(d_ids);
-		ix->lost_total += lost;
-		if (lost) return fail(VG_ENOMEM, "a read produced more hit contexts than the deep scratch holds (the reference overruns MAX_HITS=2000 long before, qv.cc:709)");
-	}
-	HIP_TRY(hipEventRecord(ix->ev2, ix->stream));
+	int rc = ix->stats_enabled ? enqueue_batch<true>(ix, d_bases, d_quals, d_offsets, n_reads)
+	                           : enqueue_batch<false>(ix, d_bases, d_quals, d_offsets, n_reads);
+	if (rc) return rc;
 	ix->timing_valid = true;
 	return VG_OK;
 }
@@ -612,9 +666,7 @@ extern "C" int vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t
 extern "C" int vg_sync(vg_index *ix)
 {
 	if (!ix) return fail(VG_EINVAL, "null argument");
-	HIP_TRY(hipSetDevice(ix->device));
-	HIP_TRY(hipStreamSynchronize(ix->stream));
-	return VG_OK;
+	return finish_pending(ix);
 }
 
 extern "C" int vg_set_stats(vg_index *ix, int enable)
@@ -639,7 +691,7 @@ extern "C" int vg_stats_get(vg_index *ix, vg_stats *out)
 	out->scan_ref = h[S_SCAN_REF]; out->scan_snp = h[S_SCAN_SNP]; out->scan_oob = h[S_SCAN_OOB];
 	out->aux_ref = h[S_AUX_REF]; out->aux_snp = h[S_AUX_SNP]; out->site_test = h[S_SITE_TEST]; out->ctx = h[S_CTX];
 	out->walks = h[S_WALKS]; out->incr = h[S_INCR]; out->ingest_bytes = h[S_INGEST];
-	out->overflow_reads = ix->overflow_total;
+	{ uint32_t c[8]; HIP_TRY(hipMemcpy(c, ix->d_ctr, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[4]; out->overflow_deep = c[5]; }
 	const uint64_t scans = out->gate_open - out->large_block;
 	out->alg_bytes = out->ingest_bytes + 8 * (out->ref_query + out->snp_query) + 9 * out->ref_probe + 11 * out->snp_probe
 	               + 16 * out->gate_open + 16 * scans + 9 * out->scan_ref + 11 * out->scan_snp
@@ -654,9 +706,10 @@ extern "C" int vg_timing_get(vg_index *ix, vg_timing *out)
 	if (!ix->timing_valid) return fail(VG_EINVAL, "no batch has been processed");
 	int rc = vg_sync(ix);
 	if (rc) return rc;
-	HIP_TRY(hipEventElapsedTime(&out->ms_main, ix->ev0, ix->ev1));
-	HIP_TRY(hipEventElapsedTime(&out->ms_total, ix->ev0, ix->ev2));
-	out->launches_main = ix->launches;
+	HIP_TRY(hipEventElapsedTime(&out->ms_pack, ix->ev0, ix->ev1));
+	HIP_TRY(hipEventElapsedTime(&out->ms_main, ix->ev1, ix->ev2));
+	HIP_TRY(hipEventElapsedTime(&out->ms_tail, ix->ev2, ix->ev3));
+	HIP_TRY(hipEventElapsedTime(&out->ms_total, ix->ev0, ix->ev3));
 	return VG_OK;
 }
 
@@ -692,8 +745,8 @@ extern "C" int vg_counts_reset(vg_index *ix)
 	HIP_TRY(hipSetDevice(ix->device));
 	HIP_TRY(hipMemsetAsync(ix->d.cnt, 0, (2 * ix->n_sites + 2) * 4, ix->stream));
 	HIP_TRY(hipMemsetAsync(ix->d_stats, 0, S_COUNT * sizeof(unsigned long long), ix->stream));
+	HIP_TRY(hipMemsetAsync(ix->d_ctr, 0, 32, ix->stream));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
-	ix->overflow_total = 0;
 	return VG_OK;
 }
 

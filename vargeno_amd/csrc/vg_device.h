@@ -1,8 +1,10 @@
 // vg_device.h -- device-side data layout and the per-read state machine of the `vargeno geno`
 // hot path (reference: src/qv.cc:760-1558 of medvedevgroup/vargeno), written for gfx950.
 //
-// Everything here is integer / bit work bounded by random HBM gathers; there is no MFMA-shaped
-// computation anywhere on this path.
+// Everything here is integer / bit work bounded by random gathers; there is no MFMA-shaped
+// computation anywhere on this path.  Measured on MI355X (tools/gather_probe): the chip sustains
+// ~48.7 G random 8-byte gathers/s whatever the table size, i.e. the bound is L1->L2 line requests,
+// so the layout below is chosen to touch as few distinct 64-byte lines per query as possible.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,21 +19,22 @@ constexpr int REF_STRIDE = 9;                      // sizeof(struct kmer_entry),
 constexpr int SNP_STRIDE = 11;                     // sizeof(struct snp_kmer_entry), src/vartype.h:74-79  (bug B1)
 constexpr uint64_t LO40_MASK = 0xFFFFFFFFFFull;
 
-// HBM layout of one index replica (struct-of-arrays; the reference's packed 9/11-byte entries are
-// split so that every gather is naturally aligned).  B1's index arithmetic is evaluated against
-// these arrays in FILE ORDER, which is all the reference's behaviour depends on.
+// One reference-dictionary entry, 16 bytes so that a hit costs one line (the reference packs 9).
+struct __attribute__((aligned(16))) RefEnt { uint32_t lo, pos, amb, pad; };
+// One SNP-dictionary entry: key = LO40 | snp_info << 40 | ambig_flag << 48.
+struct __attribute__((aligned(16))) SnpEnt { uint64_t key; uint32_t pos, pad; };
+
+// HBM layout of one index replica.  B1's index arithmetic is evaluated against these arrays in
+// FILE ORDER, which is all the reference's behaviour depends on.
 struct DevIndex {
 	// reference dictionary (src/qv.cc:519-590)
 	const uint32_t *ref_jg;        // [2^32 + 1] jump table over HI32; entry 2^32 = n_ref (sentinel replaces the 0xFFFFFFFF special case)
-	const uint32_t *ref_lo;        // [n_ref] LO32 of each k-mer
-	const uint32_t *ref_pos;       // [n_ref] position | aux row | POS_AMBIGUOUS
-	const uint8_t  *ref_amb;       // [n_ref] ambig_flag
+	const RefEnt   *ref;           // [n_ref]
 	const uint32_t *ref_aux;       // [n_ref_aux][10]
 	uint64_t n_ref;
 	// SNP dictionary (src/qv.cc:606-695)
 	const uint32_t *snp_jg;        // [2^24 + 1]
-	const uint64_t *snp_key;       // [n_snp] LO40 | snp_info << 40 | ambig_flag << 48
-	const uint32_t *snp_pos;       // [n_snp]
+	const SnpEnt   *snp;           // [n_snp]
 	const uint32_t *snp_aux_pos;   // [n_snp_aux][10]
 	const uint8_t  *snp_aux_info;  // [n_snp_aux][10]
 	uint64_t n_snp;
@@ -44,17 +47,6 @@ struct DevIndex {
 	uint32_t *cnt;                 // [2 * n_sites] exact sums: [2s] ref, [2s+1] alt
 };
 
-// Per-lane scratch in HBM, slot-major so that lanes of a wave touching the same slot coalesce.
-struct Scratch {
-	uint64_t *ctx_kmer;            // [cap][nlanes]
-	uint32_t *ctx_kpos;            // [cap][nlanes]
-	uint32_t *ctx_meta;            // [cap][nlanes]  mod (16 bits) | chunk << 16
-	uint32_t *key_index;           // [kcap][nlanes]
-	uint32_t *key_first;           // [kcap][nlanes]
-	uint32_t *key_fm;              // [kcap][nlanes]  freq (8 bits) | multi << 8
-	uint32_t cap, kcap, nlanes;
-};
-
 enum StatId {
 	S_READS, S_READS_N, S_READS_INVALID, S_PASSES, S_PASSES_OK, S_CHUNKS, S_GATE_OPEN, S_REFBF_POS, S_SNPBF_POS,
 	S_LARGE_BLOCK, S_REF_QUERY, S_SNP_QUERY, S_REF_PROBE, S_SNP_PROBE, S_SCAN_REF, S_SCAN_SNP, S_SCAN_OOB,
@@ -62,10 +54,14 @@ enum StatId {
 };
 
 template <bool STATS> struct LaneStats;
-template <> struct LaneStats<false> { __device__ inline void add(int, uint32_t) {} };
+template <> struct LaneStats<false> {
+	__device__ inline void add(int, uint32_t) {}
+	__device__ inline void clear() {}
+};
 template <> struct LaneStats<true> {
 	uint32_t v[S_COUNT];
 	__device__ inline void add(int id, uint32_t x) { v[id] += x; }
+	__device__ inline void clear() { for (int i = 0; i < S_COUNT; i++) v[i] = 0; }
 };
 
 __device__ inline uint32_t hash32(uint32_t x) { x = ((x >> 16) ^ x) * 0x45d9f3bu; x = ((x >> 16) ^ x) * 0x45d9f3bu; return (x >> 16) ^ x; }
@@ -90,7 +86,90 @@ __device__ inline uint64_t revcomp64(uint64_t k)
 	return ~k;
 }
 
-// The per-lane machine: one read, one pass at a time.
+// bucket bounds: one 8-byte gather (two adjacent jump-table words)
+__device__ inline void jg_pair(const uint32_t *jg, uint64_t h, uint32_t &lo, uint32_t &hi)
+{
+	uint64_t v;
+	__builtin_memcpy(&v, jg + h, 8);
+	lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+}
+
+// query_ref_dict, src/qv.cc:206-240.  Returns the entry index or -1; lo/hi = bucket of HI32(k).
+template <class ST>
+__device__ inline int64_t ref_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi)
+{
+	jg_pair(d.ref_jg, k >> 32, lo, hi);
+	st.add(S_REF_QUERY, 1);
+	if (lo == hi) return -1;                          // also covers lo == n_ref (then hi == n_ref)
+	st.add(S_REF_PROBE, ceil_log2_p1(hi - lo));
+	const uint32_t key = (uint32_t)k;
+	uint32_t a = lo, b = hi;
+	while (a < b) { const uint32_t m = a + ((b - a) >> 1); if (d.ref[m].lo < key) a = m + 1; else b = m; }
+	return (a < hi && d.ref[a].lo == key) ? (int64_t)a : -1;
+}
+// query_snp_dict, src/qv.cc:385-411
+template <class ST>
+__device__ inline int64_t snp_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi)
+{
+	jg_pair(d.snp_jg, k >> 40, lo, hi);
+	st.add(S_SNP_QUERY, 1);
+	if (lo == hi) return -1;
+	st.add(S_SNP_PROBE, ceil_log2_p1(hi - lo));
+	const uint64_t key = k & LO40_MASK;
+	uint32_t a = lo, b = hi;
+	while (a < b) { const uint32_t m = a + ((b - a) >> 1); if ((d.snp[m].key & LO40_MASK) < key) a = m + 1; else b = m; }
+	return (a < hi && (d.snp[a].key & LO40_MASK) == key) ? (int64_t)a : -1;
+}
+
+template <class ST>
+__device__ inline bool site_loose(const DevIndex &d, ST &st, uint32_t p)     // !(ref == 0 && alt == 0), qv.cc:990-991
+{
+	st.add(S_SITE_TEST, 1);
+	return p < d.pile_len && (d.pile[p] & 15u) != 0;
+}
+
+// pile-up walk of one supporting context (src/qv.cc:1386-1436 = :1444-1494): 32 consecutive site words,
+// fetched as eight 16-byte gathers; saturation is applied at fetch time as min(63, sum).
+template <class ST>
+__device__ inline void walk_ctx(const DevIndex &d, ST &st, uint64_t kk, uint32_t kpos, uint32_t mod)
+{
+	st.add(S_WALKS, 1);
+	if ((uint64_t)kpos + 32 > d.pile_len) return;          // cannot happen: pile_len = max position + 64
+	#pragma unroll 2
+	for (uint32_t g = 0; g < 8; g++) {
+		uint4 w4;
+		__builtin_memcpy(&w4, d.pile + kpos + 4 * g, 16);
+		const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+		#pragma unroll
+		for (uint32_t j = 0; j < 4; j++) {
+			const uint32_t b = 4 * g + j;
+			if (w[j] < 16u || b == mod) continue;               // ref == alt: not a site (:1404)
+			const uint32_t base = (uint32_t)(kk >> (2 * b)) & 3u;
+			uint32_t which;
+			if (base == (w[j] & 3u)) which = 0; else if (base == ((w[j] >> 2) & 3u)) which = 1; else continue;
+			atomicAdd(&d.cnt[2ull * ((w[j] >> 4) - 1) + which], 1u);
+			st.add(S_INCR, 1);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic lane machine: one lane runs one read sequentially with its hit contexts and vote keys in
+// HBM scratch.  It handles every read (any length, any number of hits) and is the tier the
+// wave-cooperative kernel (vg_wave.h) falls back to for the few reads that do not fit its LDS lists.
+// ------------------------------------------------------------------------------------------------
+
+// Per-lane scratch in HBM, slot-major so that lanes of a wave touching the same slot coalesce.
+struct Scratch {
+	uint64_t *ctx_kmer;            // [cap][nlanes]
+	uint32_t *ctx_kpos;            // [cap][nlanes]
+	uint32_t *ctx_meta;            // [cap][nlanes]  mod (16 bits) | chunk << 16
+	uint32_t *key_index;           // [kcap][nlanes]
+	uint32_t *key_first;           // [kcap][nlanes]
+	uint32_t *key_fm;              // [kcap][nlanes]  freq (8 bits) | multi << 8
+	uint32_t cap, kcap, nlanes;
+};
+
 template <bool STATS>
 struct Lane {
 	const DevIndex &d;
@@ -104,35 +183,6 @@ struct Lane {
 
 	__device__ inline void reset_pass() { nctx = 0; nkeys = 0; best = -1; amb = false; }
 
-	// ---- dictionary queries -------------------------------------------------------------
-	// query_ref_dict, src/qv.cc:206-240
-	__device__ inline int64_t ref_query(uint64_t k, uint32_t &lo, uint32_t &hi)
-	{
-		const uint32_t h = (uint32_t)(k >> 32);
-		lo = d.ref_jg[h]; hi = d.ref_jg[(uint64_t)h + 1];
-		st.add(S_REF_QUERY, 1);
-		if (lo == hi) return -1;                      // also covers lo == n_ref (then hi == n_ref)
-		st.add(S_REF_PROBE, ceil_log2_p1(hi - lo));
-		const uint32_t key = (uint32_t)k;
-		uint32_t a = lo, b = hi;
-		while (a < b) { uint32_t m = a + ((b - a) >> 1); if (d.ref_lo[m] < key) a = m + 1; else b = m; }
-		return (a < hi && d.ref_lo[a] == key) ? (int64_t)a : -1;
-	}
-	// query_snp_dict, src/qv.cc:385-411
-	__device__ inline int64_t snp_query(uint64_t k, uint32_t &lo, uint32_t &hi)
-	{
-		const uint32_t h = (uint32_t)(k >> 40);
-		lo = d.snp_jg[h]; hi = d.snp_jg[h + 1];
-		st.add(S_SNP_QUERY, 1);
-		if (lo == hi) return -1;
-		st.add(S_SNP_PROBE, ceil_log2_p1(hi - lo));
-		const uint64_t key = k & LO40_MASK;
-		uint32_t a = lo, b = hi;
-		while (a < b) { uint32_t m = a + ((b - a) >> 1); if ((d.snp_key[m] & LO40_MASK) < key) a = m + 1; else b = m; }
-		return (a < hi && (d.snp_key[a] & LO40_MASK) == key) ? (int64_t)a : -1;
-	}
-
-	// ---- contexts + vote -----------------------------------------------------------------
 	__device__ inline void push_ctx(uint64_t kk, uint32_t kpos, uint32_t mod, uint32_t chunk)
 	{
 		if (nctx >= s.cap) { overflow = true; return; }
@@ -158,8 +208,8 @@ struct Lane {
 			first = s.key_first[(uint64_t)e * s.nlanes + lane];
 			fm = s.key_fm[(uint64_t)e * s.nlanes + lane];
 		}
-		uint32_t freq = (fm + 1) & 0xFFu;                                         // uint8_t freq, :146
-		uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);                   // |set| >= 2, :163-165
+		const uint32_t freq = (fm + 1) & 0xFFu;                                   // uint8_t freq, :146
+		const uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);             // |set| >= 2, :163-165
 		s.key_fm[(uint64_t)e * s.nlanes + lane] = freq | (multi << 8);
 		if (!multi) return;
 		if (best < 0) { best = e; amb = false; }
@@ -175,24 +225,23 @@ struct Lane {
 		push_ctx(kk, pos, mod, chunk);
 		vote(pos - 32u * chunk, pos, neigh);
 	}
-	__device__ inline bool site_loose(uint32_t p) { st.add(S_SITE_TEST, 1); return p < d.pile_len && (d.pile[p] & 15u) != 0; }   // qv.cc:990-991
 
 	// a ref-dict hit: exact qv.cc:850-890; neighbour :979-1047, :1131-1171, :1228-1296
 	__device__ inline void ref_hit(int64_t idx, uint64_t kk, uint32_t chunk, uint32_t mod, bool neigh)
 	{
 		if (idx < 0) return;
-		const uint32_t pos = d.ref_pos[idx];
-		if (pos == POS_AMBIGUOUS) return;
-		if (d.ref_amb[idx] == 0) {
-			if (neigh && site_loose(pos + mod)) return;
-			add(kk, pos, chunk, mod, neigh);
+		const RefEnt e = d.ref[idx];
+		if (e.pos == POS_AMBIGUOUS) return;
+		if (e.amb == 0) {
+			if (neigh && site_loose(d, st, e.pos + mod)) return;
+			add(kk, e.pos, chunk, mod, neigh);
 		} else {
-			const uint32_t *row = d.ref_aux + (uint64_t)pos * AUX_COLS;
+			const uint32_t *row = d.ref_aux + (uint64_t)e.pos * AUX_COLS;
 			st.add(S_AUX_REF, 1);
 			for (int j = 0; j < AUX_COLS; j++) {
 				const uint32_t p = row[j];
 				if (p == 0) break;
-				if (neigh && site_loose(p + mod)) continue;
+				if (neigh && site_loose(d, st, p + mod)) continue;
 				add(kk, p, chunk, mod, neigh);
 			}
 		}
@@ -201,15 +250,14 @@ struct Lane {
 	__device__ inline void snp_hit(int64_t idx, uint64_t kk, uint32_t chunk, uint32_t mod, bool neigh)
 	{
 		if (idx < 0) return;
-		const uint32_t pos = d.snp_pos[idx];
-		if (pos == POS_AMBIGUOUS) return;
-		const uint64_t key = d.snp_key[idx];
-		if (((key >> 48) & 0xFFu) == 0) {
-			if (neigh && (uint32_t)((key >> 43) & 0x1Fu) == mod) return;          // SNP_INFO_POS, vartype.h:47
-			add(kk, pos, chunk, mod, neigh);
+		const SnpEnt e = d.snp[idx];
+		if (e.pos == POS_AMBIGUOUS) return;
+		if (((e.key >> 48) & 0xFFu) == 0) {
+			if (neigh && (uint32_t)((e.key >> 43) & 0x1Fu) == mod) return;        // SNP_INFO_POS, vartype.h:47
+			add(kk, e.pos, chunk, mod, neigh);
 		} else {
-			const uint32_t *prow = d.snp_aux_pos + (uint64_t)pos * AUX_COLS;
-			const uint8_t *irow = d.snp_aux_info + (uint64_t)pos * AUX_COLS;
+			const uint32_t *prow = d.snp_aux_pos + (uint64_t)e.pos * AUX_COLS;
+			const uint8_t *irow = d.snp_aux_info + (uint64_t)e.pos * AUX_COLS;
 			st.add(S_AUX_SNP, 1);
 			for (int j = 0; j < AUX_COLS; j++) {
 				const uint32_t p = prow[j];
@@ -225,8 +273,8 @@ struct Lane {
 	{
 		st.add(S_CHUNKS, 1);
 		uint32_t lo, hi, slo, shi;
-		ref_hit(ref_query(k, lo, hi), k, c, NOMOD, false);                       // :840, :850-890
-		snp_hit(snp_query(k, slo, shi), k, c, NOMOD, false);                     // :841, :897-937
+		ref_hit(ref_query(d, st, k, lo, hi), k, c, NOMOD, false);                // :840, :850-890
+		snp_hit(snp_query(d, st, k, slo, shi), k, c, NOMOD, false);              // :841, :897-937
 		if (!gate_open) return;                                                   // :943
 		st.add(S_GATE_OPEN, 1);
 		const uint32_t bs = hi - lo;                                              // check_block_size :242-264
@@ -245,8 +293,8 @@ struct Lane {
 					if (j == base) continue;
 					const uint64_t nb = (k & ~(3ull << i)) | (j << i);
 					uint32_t a, b;
-					const int64_t r = ref_query(nb, a, b);
-					const int64_t q = snp_query(nb, a, b);
+					const int64_t r = ref_query(d, st, nb, a, b);
+					const int64_t q = snp_query(d, st, nb, a, b);
 					ref_hit(r, nb, c, i >> 1, true);
 					snp_hit(q, nb, c, i >> 1, true);
 					if (overflow) return;
@@ -258,7 +306,7 @@ struct Lane {
 				const uint64_t t = (uint64_t)lo + (uint64_t)(i - lo) * REF_STRIDE;
 				uint32_t tlo = 0;
 				st.add(S_SCAN_REF, 1);
-				if (t < d.n_ref) tlo = d.ref_lo[t]; else st.add(S_SCAN_OOB, 1);
+				if (t < d.n_ref) tlo = d.ref[t].lo; else st.add(S_SCAN_OOB, 1);
 				const int dd = onebase((uint64_t)((uint32_t)k ^ tlo));
 				if (dd >= 0) ref_hit((int64_t)i, (k & 0xFFFFFFFF00000000ull) | tlo, c, (uint32_t)dd, true);
 				if (overflow) return;
@@ -268,7 +316,7 @@ struct Lane {
 				const uint64_t t = (uint64_t)slo + (uint64_t)(i - slo) * SNP_STRIDE;
 				uint64_t tlo = 0;
 				st.add(S_SCAN_SNP, 1);
-				if (t < d.n_snp) tlo = d.snp_key[t] & LO40_MASK; else st.add(S_SCAN_OOB, 1);
+				if (t < d.n_snp) tlo = d.snp[t].key & LO40_MASK; else st.add(S_SCAN_OOB, 1);
 				const int dd = onebase((k & LO40_MASK) ^ tlo);
 				if (dd >= 0) snp_hit((int64_t)i, (k & 0xFFFFFF0000000000ull) | tlo, c, (uint32_t)dd, true);
 				if (overflow) return;
@@ -280,8 +328,8 @@ struct Lane {
 				if (j == base) continue;
 				const uint64_t nb = (k & ~(3ull << i)) | (j << i);
 				uint32_t a, b;
-				if (i < rsb) ref_hit(ref_query(nb, a, b), nb, c, i >> 1, true);
-				if ((bs >= BLOCK_THRESHOLD || i >= 40) && i < ssb) snp_hit(snp_query(nb, a, b), nb, c, i >> 1, true);
+				if (i < rsb) ref_hit(ref_query(d, st, nb, a, b), nb, c, i >> 1, true);
+				if ((bs >= BLOCK_THRESHOLD || i >= 40) && i < ssb) snp_hit(snp_query(d, st, nb, a, b), nb, c, i >> 1, true);
 				if (overflow) return;
 			}
 		}
@@ -300,21 +348,7 @@ struct Lane {
 			const uint32_t kpos = s.ctx_kpos[at];
 			const uint32_t meta = s.ctx_meta[at];
 			if (kpos - 32u * (meta >> 16) != target) continue;
-			const uint64_t kk = s.ctx_kmer[at];
-			const uint32_t mod = meta & 0xFFFFu;
-			st.add(S_WALKS, 1);
-			for (uint32_t b = 0; b < 32; b++) {
-				if (b == mod) continue;
-				const uint32_t p = kpos + b;
-				if (p >= d.pile_len) continue;
-				const uint32_t w = d.pile[p];
-				if (w < 16u) continue;                                            // ref == alt: not a site (:1404)
-				const uint32_t base = (uint32_t)(kk >> (2 * b)) & 3u;
-				uint32_t which;
-				if (base == (w & 3u)) which = 0; else if (base == ((w >> 2) & 3u)) which = 1; else continue;
-				atomicAdd(&d.cnt[2ull * ((w >> 4) - 1) + which], 1u);             // saturation applied at fetch: min(63, sum)
-				st.add(S_INCR, 1);
-			}
+			walk_ctx(d, st, s.ctx_kmer[at], kpos, meta & 0xFFFFu);
 		}
 		return true;
 	}
