@@ -53,12 +53,15 @@ typedef struct {
 	uint64_t alg_bytes;          /* sum of unit cost x event count                            */
 } vg_stats;
 
-/* Timing of the kernels of the last batch, from HIP events recorded on the handle's own stream. */
+/* Kernel timing, averaged over the batches processed since the previous vg_timing_get, from HIP
+ * events recorded on the handle's own streams. */
 typedef struct {
-	float ms_total;              /* first kernel start -> last kernel end of the batch         */
+	float ms_total;              /* first kernel start -> last kernel end of a batch           */
 	float ms_pack;               /* vg_pack_kernel: ASCII -> 2-bit chunk k-mers + gate bits    */
 	float ms_main;               /* vg_wave_kernel, the dominant kernel                        */
-	float ms_tail;               /* generic lane tier for the reads that outgrew the LDS lists */
+	float ms_tail;               /* generic lane tier for the reads that outgrew the LDS lists
+	                                (runs on a second stream, under the next batch's wave tier) */
+	uint32_t batches;
 } vg_timing;
 
 const char *vg_last_error(void);
@@ -82,7 +85,7 @@ int  vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals,
                      const uint64_t *offsets, uint64_t n_reads);
 
 /* Same, for a batch already resident in device memory (hipMalloc'd by the caller on ix's device):
- * what bench.py times. */
+ * what bench.py times.  The buffers must stay valid and unchanged until the next vg_sync. */
 int  vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals,
                              const uint64_t *d_offsets, uint64_t n_reads);
 

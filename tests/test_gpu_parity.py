@@ -54,7 +54,8 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
         gx.submit(r.bases, r.quals, r.offsets)
         rc, ac = gx.counts()
         assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
-        assert gx.timing()["ms_main"] > 0
+        tm = gx.timing()
+        assert tm["ms_main"] > 0 and tm["batches"] == 1
 
 
 def test_batching_and_reset_invariance(ftiny_dir, ftiny_reads):
@@ -82,17 +83,19 @@ def test_batching_and_reset_invariance(ftiny_dir, ftiny_reads):
 
 
 def test_scratch_overflow_path_is_exact(ftiny_dir, ftiny_reads, monkeypatch):
-    """Lanes that run out of per-lane scratch hand the read to the deep-scratch launch."""
+    """Generic lane tier alone, with a tiny first scratch: lanes that run out hand the read to the
+    deep-scratch launch (the path the wave tiers fall back to)."""
     prefix = os.path.join(ftiny_dir, "idx")
     r = ftiny_reads
     ox, _, so = _oracle_counts(prefix, r)
+    monkeypatch.setenv("VG_FORCE_GENERIC", "1")
     monkeypatch.setenv("VG_SCRATCH_CAP", "3")
     monkeypatch.setenv("VG_SCRATCH_KCAP", "2")
     with GenoIndex.open(prefix) as gx:
         gx.submit(r.bases, r.quals, r.offsets)
         rc, ac = gx.counts()
         st = gx.stats()
-        assert st["overflow_reads"] > 0 and st["overflow_deep"] > 0
+        assert st["overflow_reads"] == 0 and st["overflow_deep"] > 0
         assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
         want = ox.stats.as_dict()
         for k in CMP_STATS:
@@ -122,8 +125,34 @@ def test_wave_tier_takes_most_reads(ftiny_dir, ftiny_reads):
     with GenoIndex.open(prefix) as gx:
         gx.submit(r.bases, r.quals, r.offsets)
         st = gx.stats()
-        assert 0 < st["overflow_reads"] < r.n // 2          # the adversarial fixture does spill some reads
+        assert 0 < st["overflow_reads"] < r.n // 2          # the adversarial fixture does spill some reads to the deep-list tier
         assert st["overflow_deep"] <= st["overflow_reads"]
+
+
+def test_fsmall_full_parity_through_all_tiers(tmp_path):
+    """F-small (40 % gate-open chunks, planted repeats, 400-entry SNP buckets, >10-copy k-mers): index built
+    by the product, counters and event counts equal to the oracle, and every tier sees work."""
+    import subprocess
+    from conftest import ROOT
+    from vargeno_amd import synth
+    g, s, r = synth.f_small()
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno"), "index", "ref.fa", "snps.vcf", "idx"], cwd=d,
+                          env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    prefix = os.path.join(d, "idx")
+    ox, _, so = _oracle_counts(prefix, r)
+    with GenoIndex.open(prefix) as gx:
+        gx.submit(r.bases, r.quals, r.offsets)
+        rc, ac = gx.counts()
+        st = gx.stats()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        want = ox.stats.as_dict()
+        for k in CMP_STATS:
+            assert st[k] == want[k], k
+        assert st["overflow_reads"] > 0 and st["large_block"] > 0 and st["scan_oob"] > 0
+        print("fsmall tiers: spilled %d of %d reads, %d to the lane tier" % (st["overflow_reads"], r.n, st["overflow_deep"]))
 
 
 def test_edge_reads(ftiny_dir):

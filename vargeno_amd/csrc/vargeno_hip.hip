@@ -183,10 +183,9 @@ __global__ __launch_bounds__(256) void vg_pack_kernel(const uint8_t *__restrict_
 	}
 }
 
-__global__ void vg_accumulate_counters(uint32_t *ctr)
+__global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 {
-	// ctr[0..2]: this batch (wave-tier overflow, lane-tier overflow, lost); ctr[4..6]: since reset
-	ctr[4] += ctr[0]; ctr[5] += ctr[1]; ctr[6] += ctr[2];
+	cum[0] += ctr[0]; cum[1] += ctr[1]; cum[2] += ctr[2];     // wave-tier overflow, lane-tier overflow, lost
 }
 
 // One lane = one read: forward pass, then the reverse-complement retry (src/qv.cc:1504-1510).
@@ -260,9 +259,21 @@ struct ScratchBuf {
 	size_t bytes = 0;
 };
 
+// Per-batch resources.  A handle keeps NSLOT batches in flight: the wave tier of batch k+1 runs on the
+// main stream while the (rare, latency-bound) lane tiers of batch k finish on the tail stream.
+constexpr int NSLOT = 3;
+struct Slot {
+	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr;  uint64_t list_cap = 0;
+	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
+	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit
+	uint64_t stage_bytes = 0, stage_reads = 0;
+	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr;
+	bool busy = false;
+};
+
 struct vg_index {
 	int device = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr, tail = nullptr;
 	DevIndex d{};
 	std::vector<void *> owned;            // every device allocation of the index
 	uint64_t dev_bytes = 0;
@@ -270,18 +281,14 @@ struct vg_index {
 	std::vector<uint32_t> site_pos;
 	std::vector<uint8_t> site_ref, site_alt, site_rf, site_af;
 	ScratchBuf mid, big;                  // lane-tier scratch: every lane x 64 contexts; a few lanes x 16384 contexts
-	uint32_t *d_listA = nullptr, *d_listB = nullptr, *d_listC = nullptr;  uint64_t list_cap = 0;
-	uint32_t *d_ctr = nullptr;            // [0..2] this batch: wave-tier overflow, lane-tier overflow, lost; [4..6] since reset
+	Slot slot[NSLOT];
+	int next_slot = 0;
+	uint32_t *d_cum = nullptr;            // since reset: [0] wave-tier overflow, [1] lane-tier overflow, [2] lost
 	unsigned long long *d_stats = nullptr;
 	uint64_t *d_pk_kmer = nullptr, *d_pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;
 	bool stats_enabled = true;
 	bool force_generic = false;           // VG_FORCE_GENERIC=1: skip the wave tier (tests compare the tiers)
-	// staging for vg_reads_submit
-	uint8_t *d_bases = nullptr, *d_quals = nullptr; uint64_t *d_offsets = nullptr;
-	uint64_t stage_bytes = 0, stage_reads = 0;
-	// timing
-	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-	bool timing_valid = false;
+	double t_pack = 0, t_main = 0, t_tail = 0, t_total = 0; uint64_t t_batches = 0;   // harvested event times since the last vg_timing_get
 	int cus = 256;
 	int lane_grid_blocks = 0, wave_grid = 0;
 };
@@ -341,12 +348,18 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (!ix) return;
 	(void)hipSetDevice(ix->device);
 	if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+	if (ix->tail) (void)hipStreamSynchronize(ix->tail);
 	for (void *p : ix->owned) (void)hipFree(p);
-	void *extra[] = {ix->d_listA, ix->d_listB, ix->d_listC, ix->d_pk_kmer, ix->d_pk_meta, ix->d_bases, ix->d_quals, ix->d_offsets};
-	for (void *p : extra) if (p) (void)hipFree(p);
-	hipEvent_t evs[] = {ix->ev0, ix->ev1, ix->ev2, ix->ev3};
-	for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+	for (Slot &sl : ix->slot) {
+		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets};
+		for (void *p : extra) if (p) (void)hipFree(p);
+		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4};
+		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+	}
+	if (ix->d_pk_kmer) (void)hipFree(ix->d_pk_kmer);
+	if (ix->d_pk_meta) (void)hipFree(ix->d_pk_meta);
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
+	if (ix->tail) (void)hipStreamDestroy(ix->tail);
 	delete ix;
 }
 
@@ -360,7 +373,8 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	ix->device = device;
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
-	HIP_TRY(hipEventCreate(&ix->ev0)); HIP_TRY(hipEventCreate(&ix->ev1)); HIP_TRY(hipEventCreate(&ix->ev2)); HIP_TRY(hipEventCreate(&ix->ev3));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->tail, hipStreamNonBlocking));
+	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); }
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	ix->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -459,7 +473,8 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
-	if ((rc = dev_alloc(ix, &ix->d_ctr, 8, true))) return rc;
+	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 4, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_cum, 4, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	return VG_OK;
@@ -550,81 +565,109 @@ extern "C" uint64_t vg_num_sites(const vg_index *ix) { return ix ? ix->n_sites :
 // ------------------------------------------------------------------------------------------------
 // read batches
 // ------------------------------------------------------------------------------------------------
-// Drain the stream and turn "a read outgrew even the deep scratch" into an error code.
+static int harvest(vg_index *ix, Slot &sl)
+{
+	if (!sl.busy) return VG_OK;
+	HIP_TRY(hipEventSynchronize(sl.e3));
+	float a = 0, b = 0, c = 0, t = 0;
+	HIP_TRY(hipEventElapsedTime(&a, sl.e0, sl.e1)); HIP_TRY(hipEventElapsedTime(&b, sl.e1, sl.e2));
+	HIP_TRY(hipEventElapsedTime(&c, sl.e2, sl.e3)); HIP_TRY(hipEventElapsedTime(&t, sl.e0, sl.e3));
+	ix->t_pack += a; ix->t_main += b; ix->t_tail += c; ix->t_total += t; ix->t_batches++;
+	sl.busy = false;
+	return VG_OK;
+}
+
+// Drain both streams and turn "a read outgrew even the deep scratch" into an error code.
 static int finish_pending(vg_index *ix)
 {
 	HIP_TRY(hipSetDevice(ix->device));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
-	uint32_t c[8];
-	HIP_TRY(hipMemcpy(c, ix->d_ctr, sizeof c, hipMemcpyDeviceToHost));
-	if (c[6]) return fail(VG_ENOMEM, "a read produced more hit contexts than the deep scratch holds (the reference overruns MAX_HITS=2000 long before, qv.cc:709)");
+	HIP_TRY(hipStreamSynchronize(ix->tail));
+	for (Slot &sl : ix->slot) { int rc = harvest(ix, sl); if (rc) return rc; }
+	uint32_t c[4];
+	HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost));
+	if (c[2]) return fail(VG_ENOMEM, "a read produced more hit contexts than the deep scratch holds (the reference overruns MAX_HITS=2000 long before, qv.cc:709)");
 	return VG_OK;
 }
 
-// One batch = pack -> wave tier -> lane tier (mid scratch) -> lane tier (deep scratch), all enqueued
-// back to back on the handle's stream; the list launches size themselves from device counters.
+// One batch = pack -> wave tier on the main stream, then lane tier (mid scratch) -> lane tier (deep scratch)
+// on the tail stream; the list launches size themselves from device counters, so nothing waits for the host.
 template <bool STATS>
-static int enqueue_batch(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
+static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
 {
-	uint32_t *ctr = ix->d_ctr;
+	uint32_t *ctr = sl.ctr;
 	HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
-	HIP_TRY(hipEventRecord(ix->ev0, ix->stream));
-	const uint32_t *listA = nullptr;
+	HIP_TRY(hipEventRecord(sl.e0, ix->stream));
+	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
 	if (!ix->force_generic) {
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->cus * 16);
 		vg_pack_kernel<<<pgrid, 256, 0, ix->stream>>>(d_bases, d_quals, d_offsets, n_reads, ix->d_pk_kmer, ix->d_pk_meta);
-		HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
+		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->wave_grid);
-		vg_wave_kernel<STATS><<<wgrid, 64, 0, ix->stream>>>(ix->d, ix->d_pk_kmer, ix->d_pk_meta, d_offsets, n_reads, ix->d_listA, &ctr[0], ix->d_stats);
-		HIP_TRY(hipEventRecord(ix->ev2, ix->stream));
-		listA = ix->d_listA;
-		const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
-		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, 0, listA, &ctr[0], ix->d_listB, &ctr[1], ix->d_stats);
+		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP><<<wgrid, 64, 0, ix->stream>>>(ix->d, ix->d_pk_kmer, ix->d_pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], ix->d_stats);
+		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
+		// second tier: the same kernel with deep lists over the spill list (2 waves per CU)
+		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
+		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP><<<w2grid, 64, 0, ix->stream>>>(ix->d, ix->d_pk_kmer, ix->d_pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], ix->d_stats);
+		HIP_TRY(hipEventRecord(sl.e4, ix->stream));
+		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e4, 0));
 	} else {
-		HIP_TRY(hipEventRecord(ix->ev1, ix->stream));
-		const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
-		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, nullptr, ix->d_listB, &ctr[1], ix->d_stats);
-		HIP_TRY(hipEventRecord(ix->ev2, ix->stream));
+		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
+		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, nullptr, sl.listB, &ctr[1], ix->d_stats);
+		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
+		HIP_TRY(hipEventRecord(sl.e4, ix->stream));
+		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e4, 0));
 	}
-	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->stream>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, ix->d_listB, &ctr[1], ix->d_listC, &ctr[2], ix->d_stats);
-	vg_accumulate_counters<<<1, 1, 0, ix->stream>>>(ctr);
-	HIP_TRY(hipEventRecord(ix->ev3, ix->stream));
+	// last tier, on the tail stream: the generic lane machine with the deep HBM scratch for whatever is left
+	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats);
+	vg_accumulate_counters<<<1, 1, 0, ix->tail>>>(ctr, ix->d_cum);
+	HIP_TRY(hipEventRecord(sl.e3, ix->tail));
 	HIP_TRY(hipGetLastError());
+	sl.busy = true;
 	return VG_OK;
 }
 
-static int launch_batch(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
+static int acquire_slot(vg_index *ix, Slot **out)
 {
-	HIP_TRY(hipSetDevice(ix->device));
+	Slot &sl = ix->slot[ix->next_slot];
+	ix->next_slot = (ix->next_slot + 1) % NSLOT;
+	int rc = harvest(ix, sl);                             // blocks only when NSLOT batches are already in flight
+	if (rc) return rc;
+	*out = &sl;
+	return VG_OK;
+}
+
+static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
+{
 	if (n_reads >= (1ull << 32)) return fail(VG_EINVAL, "more than 2^32-1 reads in one batch");
-	// packed-read buffers are sized from the batch's total length (8 bytes from the device; the handle's stream is
+	// packed-read buffers are sized from the batch's total length (8 bytes from the device; the handle's streams are
 	// non-blocking, so this copy does not wait for kernels in flight)
 	uint64_t total = 0;
 	HIP_TRY(hipMemcpy(&total, d_offsets + n_reads, 8, hipMemcpyDeviceToHost));
 	const uint64_t need_k = (total >> 5) + 2, need_m = n_reads + 1;
-	if (n_reads > ix->list_cap || need_k > ix->pk_kmer_cap || need_m > ix->pk_meta_cap) {
-		int rc = finish_pending(ix);                      // buffers may be in use by the previous batch
-		if (rc) return rc;
-		if (n_reads > ix->list_cap) {
-			uint32_t **lists[] = {&ix->d_listA, &ix->d_listB, &ix->d_listC};
-			for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4)); }
-			ix->list_cap = n_reads;
-		}
+	if (need_k > ix->pk_kmer_cap || need_m > ix->pk_meta_cap) {
+		HIP_TRY(hipStreamSynchronize(ix->stream));       // the previous batch's pack/wave kernels read them
 		if (need_k > ix->pk_kmer_cap) { if (ix->d_pk_kmer) (void)hipFree(ix->d_pk_kmer); ix->d_pk_kmer = nullptr; HIP_TRY(hipMalloc((void **)&ix->d_pk_kmer, need_k * 8)); ix->pk_kmer_cap = need_k; }
 		if (need_m > ix->pk_meta_cap) { if (ix->d_pk_meta) (void)hipFree(ix->d_pk_meta); ix->d_pk_meta = nullptr; HIP_TRY(hipMalloc((void **)&ix->d_pk_meta, need_m * 8)); ix->pk_meta_cap = need_m; }
 	}
-	int rc = ix->stats_enabled ? enqueue_batch<true>(ix, d_bases, d_quals, d_offsets, n_reads)
-	                           : enqueue_batch<false>(ix, d_bases, d_quals, d_offsets, n_reads);
-	if (rc) return rc;
-	ix->timing_valid = true;
-	return VG_OK;
+	if (n_reads > sl.list_cap) {                          // the slot is idle (acquire_slot harvested it)
+		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC};
+		for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4)); }
+		sl.list_cap = n_reads;
+	}
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_offsets, n_reads)
+	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_offsets, n_reads);
 }
 
 extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
 {
 	if (!ix || (!d_offsets && n_reads)) return fail(VG_EINVAL, "null argument");
 	if (n_reads == 0) return VG_OK;
-	return launch_batch(ix, d_bases, d_quals, d_offsets, n_reads);
+	HIP_TRY(hipSetDevice(ix->device));
+	Slot *sl = nullptr;
+	int rc = acquire_slot(ix, &sl);
+	if (rc) return rc;
+	return launch_batch(ix, *sl, d_bases, d_quals, d_offsets, n_reads);
 }
 
 extern "C" int vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads)
@@ -638,29 +681,32 @@ extern "C" int vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t
 		if (offsets[i + 1] < offsets[i]) return fail(VG_EINVAL, "offsets not monotone");
 		if (offsets[i + 1] - offsets[i] > 1022) return fail(VG_EBADREAD, "read longer than 1022 bases (reference BUF_SIZE 1024, qv.cc:700)");
 	}
-	HIP_TRY(hipStreamSynchronize(ix->stream));          // staging buffers are reused
-	if (total + 64 > ix->stage_bytes) {
-		if (ix->d_bases) (void)hipFree(ix->d_bases);
-		if (ix->d_quals) (void)hipFree(ix->d_quals);
-		ix->d_bases = ix->d_quals = nullptr;
-		HIP_TRY(hipMalloc((void **)&ix->d_bases, total + 64));
-		HIP_TRY(hipMalloc((void **)&ix->d_quals, total + 64));
-		ix->stage_bytes = total + 64;
+	Slot *slp = nullptr;
+	int rc = acquire_slot(ix, &slp);
+	if (rc) return rc;
+	Slot &sl = *slp;
+	if (total + 64 > sl.stage_bytes) {
+		if (sl.st_bases) (void)hipFree(sl.st_bases);
+		if (sl.st_quals) (void)hipFree(sl.st_quals);
+		sl.st_bases = sl.st_quals = nullptr; sl.stage_bytes = 0;
+		HIP_TRY(hipMalloc((void **)&sl.st_bases, total + 64));
+		HIP_TRY(hipMalloc((void **)&sl.st_quals, total + 64));
+		sl.stage_bytes = total + 64;
 	}
-	if (n_reads + 1 > ix->stage_reads) {
-		if (ix->d_offsets) (void)hipFree(ix->d_offsets);
-		ix->d_offsets = nullptr;
-		HIP_TRY(hipMalloc((void **)&ix->d_offsets, (n_reads + 1) * 8));
-		ix->stage_reads = n_reads + 1;
+	if (n_reads + 1 > sl.stage_reads) {
+		if (sl.st_offsets) (void)hipFree(sl.st_offsets);
+		sl.st_offsets = nullptr; sl.stage_reads = 0;
+		HIP_TRY(hipMalloc((void **)&sl.st_offsets, (n_reads + 1) * 8));
+		sl.stage_reads = n_reads + 1;
 	}
 	std::vector<uint64_t> rel;
 	const uint64_t *off = offsets;
 	if (base0) { rel.resize(n_reads + 1); for (uint64_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - base0; off = rel.data(); }
-	HIP_TRY(hipMemcpyAsync(ix->d_bases, bases + base0, total, hipMemcpyHostToDevice, ix->stream));
-	HIP_TRY(hipMemcpyAsync(ix->d_quals, quals + base0, total, hipMemcpyHostToDevice, ix->stream));
-	HIP_TRY(hipMemcpyAsync(ix->d_offsets, off, (n_reads + 1) * 8, hipMemcpyHostToDevice, ix->stream));
-	HIP_TRY(hipStreamSynchronize(ix->stream));          // `rel` and the caller's buffers may go away
-	return launch_batch(ix, ix->d_bases, ix->d_quals, ix->d_offsets, n_reads);
+	// plain (blocking) copies: when they return the caller's buffers are free again; kernels of earlier batches keep running
+	HIP_TRY(hipMemcpy(sl.st_bases, bases + base0, total, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(sl.st_quals, quals + base0, total, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(sl.st_offsets, off, (n_reads + 1) * 8, hipMemcpyHostToDevice));
+	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, n_reads);
 }
 
 extern "C" int vg_sync(vg_index *ix)
@@ -691,7 +737,7 @@ extern "C" int vg_stats_get(vg_index *ix, vg_stats *out)
 	out->scan_ref = h[S_SCAN_REF]; out->scan_snp = h[S_SCAN_SNP]; out->scan_oob = h[S_SCAN_OOB];
 	out->aux_ref = h[S_AUX_REF]; out->aux_snp = h[S_AUX_SNP]; out->site_test = h[S_SITE_TEST]; out->ctx = h[S_CTX];
 	out->walks = h[S_WALKS]; out->incr = h[S_INCR]; out->ingest_bytes = h[S_INGEST];
-	{ uint32_t c[8]; HIP_TRY(hipMemcpy(c, ix->d_ctr, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[4]; out->overflow_deep = c[5]; }
+	{ uint32_t c[4]; HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[0]; out->overflow_deep = c[1]; }
 	const uint64_t scans = out->gate_open - out->large_block;
 	out->alg_bytes = out->ingest_bytes + 8 * (out->ref_query + out->snp_query) + 9 * out->ref_probe + 11 * out->snp_probe
 	               + 16 * out->gate_open + 16 * scans + 9 * out->scan_ref + 11 * out->scan_snp
@@ -703,13 +749,14 @@ extern "C" int vg_timing_get(vg_index *ix, vg_timing *out)
 {
 	if (!ix || !out) return fail(VG_EINVAL, "null argument");
 	memset(out, 0, sizeof *out);
-	if (!ix->timing_valid) return fail(VG_EINVAL, "no batch has been processed");
-	int rc = vg_sync(ix);
+	int rc = finish_pending(ix);
 	if (rc) return rc;
-	HIP_TRY(hipEventElapsedTime(&out->ms_pack, ix->ev0, ix->ev1));
-	HIP_TRY(hipEventElapsedTime(&out->ms_main, ix->ev1, ix->ev2));
-	HIP_TRY(hipEventElapsedTime(&out->ms_tail, ix->ev2, ix->ev3));
-	HIP_TRY(hipEventElapsedTime(&out->ms_total, ix->ev0, ix->ev3));
+	if (!ix->t_batches) return fail(VG_EINVAL, "no batch has been processed since the last vg_timing_get");
+	const double n = (double)ix->t_batches;
+	out->ms_pack = (float)(ix->t_pack / n); out->ms_main = (float)(ix->t_main / n);
+	out->ms_tail = (float)(ix->t_tail / n); out->ms_total = (float)(ix->t_total / n);
+	out->batches = (uint32_t)ix->t_batches;
+	ix->t_pack = ix->t_main = ix->t_tail = ix->t_total = 0; ix->t_batches = 0;
 	return VG_OK;
 }
 
@@ -742,10 +789,10 @@ extern "C" int vg_counts_fetch(vg_index *ix, uint8_t *ref_cnt, uint8_t *alt_cnt)
 extern "C" int vg_counts_reset(vg_index *ix)
 {
 	if (!ix) return fail(VG_EINVAL, "null argument");
-	HIP_TRY(hipSetDevice(ix->device));
+	{ int rc = finish_pending(ix); if (rc) return rc; }
 	HIP_TRY(hipMemsetAsync(ix->d.cnt, 0, (2 * ix->n_sites + 2) * 4, ix->stream));
 	HIP_TRY(hipMemsetAsync(ix->d_stats, 0, S_COUNT * sizeof(unsigned long long), ix->stream));
-	HIP_TRY(hipMemsetAsync(ix->d_ctr, 0, 32, ix->stream));
+	HIP_TRY(hipMemsetAsync(ix->d_cum, 0, 16, ix->stream));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	return VG_OK;
 }
@@ -770,7 +817,7 @@ extern "C" int vg_counts_allreduce(vg_index *ix, void *nccl_comm)
 		fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
 		if (!fn) return fail(VG_ENODEV, "ncclAllReduce not found in librccl");
 	}
-	HIP_TRY(hipSetDevice(ix->device));
+	{ int rc = finish_pending(ix); if (rc) return rc; }
 	if (ix->n_sites == 0) return VG_OK;
 	const int ncclUint32 = 3, ncclSum = 0;            // rccl.h: ncclDataType_t / ncclRedOp_t
 	const int rc = fn(ix->d.cnt, ix->d.cnt, (size_t)(2 * ix->n_sites), ncclUint32, ncclSum, nccl_comm, ix->stream);

@@ -12,19 +12,22 @@
 //                                                                         (src/qv.cc:943-1365)
 //   C  lane-parallel   the order-dependent vote is replayed per read from the two short lists, then
 //                      the supporting contexts walk the pile-up            (src/qv.cc:132-178, 1375-1502)
-// Lists live in LDS ([slot][lane], conflict-free); vote keys live in registers.  Neighbour contexts
+// Lists and vote keys live in LDS ([slot][lane], conflict-free).  Neighbour contexts
 // whose implied read position is not the position of any exact hit of the same pass can neither
 // vote (qv.cc:134-139) nor support the winner, so stage B drops them -- the lists stay tiny.
-// A job that outgrows its lists touches no counter and is handed, whole, to the generic lane
-// machine of vg_device.h (exactness is never traded).
+// A job that outgrows its lists touches no counter and is handed, whole, to the next tier: the same
+// kernel with deeper lists, then the generic lane machine of vg_device.h (exactness is never traded).
 #pragma once
 #include "vg_device.h"
 
 namespace vg {
 
-constexpr int W_ECAP = 8;        // exact-hit contexts per job-pass held in LDS
-constexpr int W_NCAP = 4;        // kept neighbour contexts per job-pass
-constexpr int W_KCAP = 4;        // vote keys (registers)
+// List capacities per job-pass (LDS, [slot][lane]).  Two instantiations: the main tier keeps 17 waves per CU
+// resident; the second tier takes the reads that spill from it (repeat regions: aux rows, many keys)
+// with lists 6-8x deeper at 2 waves per CU -- still wave-parallel, so a heavy read costs a few dozen
+// dependent gathers instead of the thousands the sequential lane machine needs.
+constexpr int W1_ECAP = 8, W1_NCAP = 4, W1_KCAP = 4;
+constexpr int W2_ECAP = 48, W2_NCAP = 48, W2_KCAP = 32;
 
 // packed reads: chunk k-mers at [offsets[r] >> 5 ...), one flag word per read
 constexpr uint64_t PK_SKIP_N = 1ull << 62;     // an N inside the trimmed read: skipped (qv.cc:815-828)
@@ -41,14 +44,19 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 	return v;
 }
 
-template <bool STATS>
+// read_ids == nullptr: the wave owns a contiguous range of the batch's n_reads_arg reads;
+// otherwise the jobs are read_ids[0 .. *n_ids) (the spill list of the previous tier, sized on the device).
+template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP>
 __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
-                                                     const uint64_t *__restrict__ offsets, uint64_t n_reads,
+                                                     const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
+                                                     const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
                                                      uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats)
 {
 	__shared__ uint32_t E_kpos[W_ECAP][64], E_meta[W_ECAP][64], N_kpos[W_NCAP][64], N_meta[W_NCAP][64];
+	__shared__ uint32_t K_idx[W_KCAP][64], K_first[W_KCAP][64], K_fm[W_KCAP][64];
 	const uint32_t lane = threadIdx.x;
 	const uint64_t lane_bit = 1ull << lane;
+	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;
 	uint64_t cursor = n_reads * (uint64_t)blockIdx.x / gridDim.x;
 	const uint64_t end = n_reads * ((uint64_t)blockIdx.x + 1) / gridDim.x;
 
@@ -74,7 +82,7 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 				if (!active) {
 					const uint32_t rank = (uint32_t)__popcll(freem & (lane_bit - 1));
 					if (rank < take) {
-						rid = (uint32_t)(cursor + rank);
+						rid = read_ids ? read_ids[cursor + rank] : (uint32_t)(cursor + rank);
 						const uint64_t off = offsets[rid];
 						const uint64_t meta = pk_meta[rid];
 						n = (uint32_t)((offsets[rid + 1] - off) >> 5);
@@ -311,35 +319,30 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 		if (active) {
 			bool processed = false;
 			if (!ovf) {
-				uint32_t kidx[W_KCAP], kfirst[W_KCAP], kfm[W_KCAP];
-				#pragma unroll
-				for (int i = 0; i < W_KCAP; i++) { kidx[i] = 0; kfirst[i] = 0; kfm[i] = 0; }
 				uint32_t nkeys = 0;
 				int best = -1; bool amb = false;
-				// improved_index_table_add, qv.cc:132-178
+				// improved_index_table_add, qv.cc:132-178; keys in this lane's LDS column
 				auto vote = [&](uint32_t index, uint32_t kpos, bool neigh) {
 					int e = -1;
-					#pragma unroll
-					for (int i = 0; i < W_KCAP; i++) if (e < 0 && (uint32_t)i < nkeys && kidx[i] == index) e = i;
+					for (uint32_t i = 0; i < nkeys; i++) if (K_idx[i][lane] == index) { e = (int)i; break; }
+					uint32_t first, fm;
 					if (e < 0) {
 						if (neigh) return;
 						if (nkeys >= (uint32_t)W_KCAP) { ovf = true; return; }
 						e = (int)nkeys++;
-						#pragma unroll
-						for (int i = 0; i < W_KCAP; i++) if (i == e) { kidx[i] = index; kfirst[i] = kpos; kfm[i] = 0; }
-					}
-					uint32_t first = 0, fm = 0, bfm = 0;
-					#pragma unroll
-					for (int i = 0; i < W_KCAP; i++) { if (i == e) { first = kfirst[i]; fm = kfm[i]; } if (i == best) bfm = kfm[i]; }
+						K_idx[e][lane] = index; K_first[e][lane] = first = kpos; fm = 0;
+					} else { first = K_first[e][lane]; fm = K_fm[e][lane]; }
 					const uint32_t freq = (fm + 1) & 0xFFu;
 					const uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);
-					#pragma unroll
-					for (int i = 0; i < W_KCAP; i++) if (i == e) kfm[i] = freq | (multi << 8);
+					K_fm[e][lane] = freq | (multi << 8);
 					if (!multi) return;
 					if (best < 0) { best = e; amb = false; }
 					else if (e == best) amb = false;
-					else if (freq == (bfm & 0xFFu)) amb = true;
-					else if (freq > (bfm & 0xFFu)) { best = e; amb = false; }
+					else {
+						const uint32_t bf = K_fm[best][lane] & 0xFFu;
+						if (freq == bf) amb = true;
+						else if (freq > bf) { best = e; amb = false; }
+					}
 				};
 				uint32_t ei = 0, ni = 0;
 				for (uint32_t c = 0; c < n && !ovf; c++) {
@@ -348,9 +351,7 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 				}
 				if (!ovf) {
 					cur.add(S_PASSES, 1);
-					uint32_t bfm = 0, target = 0;
-					#pragma unroll
-					for (int i = 0; i < W_KCAP; i++) if (i == best) { bfm = kfm[i]; target = kidx[i]; }
+					const uint32_t bfm = best >= 0 ? K_fm[best][lane] : 0u, target = best >= 0 ? K_idx[best][lane] : 0u;
 					processed = best >= 0 && !amb && (bfm & 0xFFu) > 1;          // qv.cc:1375
 					if (processed) {
 						cur.add(S_PASSES_OK, 1);
