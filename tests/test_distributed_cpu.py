@@ -1,0 +1,56 @@
+"""world_size-2 gloo test of the N > 1 path (reads shard by index, one all-reduce of the per-site
+counters, clamp at 63) with the CPU oracle standing in for the per-rank worker."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, prefix, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from vargeno_amd import synth
+    from vargeno_amd.api import all_reduce_sum_, clamp_counts, shard_range
+
+    r = synth.f_tiny()[2]
+    lo, hi = shard_range(r.n, rank, world)
+    sub = r.slice(lo, hi)
+    ox = O.OracleIndex.load(prefix)
+    for _ in range(7):                              # 7x coverage so that the clamp matters
+        ox.process(sub.bases, sub.quals, sub.offsets)
+    s = ox.sites()
+    t = torch.from_numpy(np.stack([s["ref_cnt"], s["alt_cnt"]], axis=1).astype(np.int32).reshape(-1).copy())
+    all_reduce_sum_(t)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "reduced.npy"), clamp_counts(t.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_reduce_equals_one_rank(ftiny_dir, tmp_path):
+    from oracle import oracle as O
+    from vargeno_amd import synth
+    from vargeno_amd.api import shard_range
+
+    assert [shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert shard_range(2, 3, 4) == (2, 2)
+    prefix = os.path.join(ftiny_dir, "idx")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, prefix, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "reduced.npy").reshape(-1, 2)
+    r = synth.f_tiny()[2]
+    ox = O.OracleIndex.load(prefix)
+    for _ in range(7):
+        ox.process(r.bases, r.quals, r.offsets)
+    s = ox.sites()
+    assert np.array_equal(got[:, 0], s["ref_cnt"]) and np.array_equal(got[:, 1], s["alt_cnt"])
+    assert got.max() == 63                          # saturation really happened somewhere

@@ -163,18 +163,31 @@ class GenoIndex:
         return torch.as_tensor(_Alias(), device="cuda:%d" % self.device)
 
 
+def all_reduce_sum_(tensor, group=None):
+    """In-place sum over ranks of an integer tensor (device or host); no-op for a single process."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+    return tensor
+
+
+def clamp_counts(summed):
+    """The reference's 6-bit saturation (vartype.h:27) commutes with the sum over shards:
+    min(63, sum_i c_i) == min(63, sum_i min(63, c_i)), so ranks may exchange exact or clamped sums."""
+    return np.minimum(np.asarray(summed, dtype=np.int64), 63).astype(np.uint8)
+
+
 def all_reduce_counts(index, group=None):
     """The path's one exchange step: sum the per-site counters over the ranks that
-    each processed a shard of the reads.  RCCL (backend 'nccl') on GPUs; any backend works."""
+    each processed a shard of the reads.  RCCL (backend 'nccl') over xGMI on GPUs."""
+    import torch
     import torch.distributed as dist
 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     index.sync()
-    t = index.counts_tensor()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    import torch
-
+    all_reduce_sum_(index.counts_tensor(), group)
     torch.cuda.synchronize(index.device)
 
 
