@@ -1,9 +1,16 @@
-mkdir -p gpurun_out/prof
-python bench.py --steps 10 --warmup 2 --reads 8000000 --cpu-sample 0 > gpurun_out/bench_8m.json 2> gpurun_out/bench_8m.err
-cat gpurun_out/bench_8m.json
+#!/bin/bash
+# Round-1 profiling recipe (run on the MI355X box from the repo root: `bash profiles/run_prof_r01.sh`).
+# Kernel-trace/--stats and each --pmc group are separate rocprofv3 runs of the SAME bench.py command.
+# Raw output goes to gpurun_out/prof_r01/ (scratch); profiles/summarize_prof.py turns it into profiles/*_r01.* .
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_r01
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/kt -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-sample 0 > $R/gpurun_out/prof/kt.json 2> $R/gpurun_out/prof/kt.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_fetch -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $R/gpurun_out/prof/pmc_fetch.json 2> $R/gpurun_out/prof/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-sample 0 > $R/gpurun_out/prof/pmc_write.json 2> $R/gpurun_out/prof/pmc_write.err
-cd $R/gpurun_out/prof && find . -type f | head -30 && du -sh .
+CMD="python3 $R/bench.py --steps 10 --warmup 2 --cpu-sample 0"
+python3 $R/bench.py --steps 20 --warmup 3 > $OUT/bench_default.json 2> $OUT/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $CMD > $OUT/kt.json 2> $OUT/kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- $CMD > $OUT/pmc_l2.json 2> $OUT/pmc_l2.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+python3 $R/profiles/summarize_prof.py $OUT r01
