@@ -265,6 +265,7 @@ constexpr int NSLOT = 3;
 struct Slot {
 	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr;  uint64_t list_cap = 0;
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
+	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit
 	uint64_t stage_bytes = 0, stage_reads = 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr;
@@ -273,7 +274,7 @@ struct Slot {
 
 struct vg_index {
 	int device = 0;
-	hipStream_t stream = nullptr, tail = nullptr;
+	hipStream_t stream = nullptr, tail = nullptr;   // pack + wave tier | spill tiers of earlier batches
 	DevIndex d{};
 	std::vector<void *> owned;            // every device allocation of the index
 	uint64_t dev_bytes = 0;
@@ -285,7 +286,6 @@ struct vg_index {
 	int next_slot = 0;
 	uint32_t *d_cum = nullptr;            // since reset: [0] wave-tier overflow, [1] lane-tier overflow, [2] lost
 	unsigned long long *d_stats = nullptr;
-	uint64_t *d_pk_kmer = nullptr, *d_pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;
 	bool stats_enabled = true;
 	bool force_generic = false;           // VG_FORCE_GENERIC=1: skip the wave tier (tests compare the tiers)
 	double t_pack = 0, t_main = 0, t_tail = 0, t_total = 0; uint64_t t_batches = 0;   // harvested event times since the last vg_timing_get
@@ -351,13 +351,11 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (ix->tail) (void)hipStreamSynchronize(ix->tail);
 	for (void *p : ix->owned) (void)hipFree(p);
 	for (Slot &sl : ix->slot) {
-		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets};
+		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta};
 		for (void *p : extra) if (p) (void)hipFree(p);
 		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 	}
-	if (ix->d_pk_kmer) (void)hipFree(ix->d_pk_kmer);
-	if (ix->d_pk_meta) (void)hipFree(ix->d_pk_meta);
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
 	if (ix->tail) (void)hipStreamDestroy(ix->tail);
 	delete ix;
@@ -379,7 +377,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	ix->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ix->lane_grid_blocks = ix->cus * 8;                          // 2048 lanes per CU = every wave slot
-	int wpc = 16;                                                // waves per CU of the wave-tier grid
+	int wpc = 20;                                                // waves per CU of the wave-tier grid: 5 groups of 4 waves fit a CU's LDS
 	if (const char *e = getenv("VG_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
 	ix->wave_grid = ix->cus * wpc;
 	if (const char *e = getenv("VG_FORCE_GENERIC")) ix->force_generic = atoi(e) != 0;
@@ -596,29 +594,33 @@ template <bool STATS>
 static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
 {
 	uint32_t *ctr = sl.ctr;
-	HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
-	HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
 	if (!ix->force_generic) {
+		// main stream: pack, then the wave tier.  (Packing batch k+1 on a third stream under batch k's wave
+		// kernel was measured and lost 12 %: two co-scheduled kernels split the CUs.)
+		HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
+		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->cus * 16);
-		vg_pack_kernel<<<pgrid, 256, 0, ix->stream>>>(d_bases, d_quals, d_offsets, n_reads, ix->d_pk_kmer, ix->d_pk_meta);
+		vg_pack_kernel<<<pgrid, 256, 0, ix->stream>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
-		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->wave_grid);
-		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP><<<wgrid, 64, 0, ix->stream>>>(ix->d, ix->d_pk_kmer, ix->d_pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], ix->d_stats);
+		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->wave_grid / 4);
+		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, 4><<<wgrid, 256, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
-		// second tier: the same kernel with deep lists over the spill list (2 waves per CU)
+		// second tier: the same kernel with deep lists over the spill list (2 waves per CU).  It stays on the main
+		// stream: on the tail stream it ran under the next batch's wave kernel and slowed that by 40 %.
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
-		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP><<<w2grid, 64, 0, ix->stream>>>(ix->d, ix->d_pk_kmer, ix->d_pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], ix->d_stats);
+		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1><<<w2grid, 64, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e4, 0));
 	} else {
+		HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
+		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, nullptr, sl.listB, &ctr[1], ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
-		HIP_TRY(hipEventRecord(sl.e4, ix->stream));
-		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e4, 0));
+		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 	}
-	// last tier, on the tail stream: the generic lane machine with the deep HBM scratch for whatever is left
+	// ... then the generic lane machine with the deep HBM scratch for whatever is left
 	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats);
 	vg_accumulate_counters<<<1, 1, 0, ix->tail>>>(ctr, ix->d_cum);
 	HIP_TRY(hipEventRecord(sl.e3, ix->tail));
@@ -645,12 +647,10 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 	uint64_t total = 0;
 	HIP_TRY(hipMemcpy(&total, d_offsets + n_reads, 8, hipMemcpyDeviceToHost));
 	const uint64_t need_k = (total >> 5) + 2, need_m = n_reads + 1;
-	if (need_k > ix->pk_kmer_cap || need_m > ix->pk_meta_cap) {
-		HIP_TRY(hipStreamSynchronize(ix->stream));       // the previous batch's pack/wave kernels read them
-		if (need_k > ix->pk_kmer_cap) { if (ix->d_pk_kmer) (void)hipFree(ix->d_pk_kmer); ix->d_pk_kmer = nullptr; HIP_TRY(hipMalloc((void **)&ix->d_pk_kmer, need_k * 8)); ix->pk_kmer_cap = need_k; }
-		if (need_m > ix->pk_meta_cap) { if (ix->d_pk_meta) (void)hipFree(ix->d_pk_meta); ix->d_pk_meta = nullptr; HIP_TRY(hipMalloc((void **)&ix->d_pk_meta, need_m * 8)); ix->pk_meta_cap = need_m; }
-	}
-	if (n_reads > sl.list_cap) {                          // the slot is idle (acquire_slot harvested it)
+	// the slot is idle (acquire_slot harvested it), so its buffers may be replaced
+	if (need_k > sl.pk_kmer_cap) { if (sl.pk_kmer) (void)hipFree(sl.pk_kmer); sl.pk_kmer = nullptr; sl.pk_kmer_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_kmer, need_k * 8)); sl.pk_kmer_cap = need_k; }
+	if (need_m > sl.pk_meta_cap) { if (sl.pk_meta) (void)hipFree(sl.pk_meta); sl.pk_meta = nullptr; sl.pk_meta_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_meta, need_m * 8)); sl.pk_meta_cap = need_m; }
+	if (n_reads > sl.list_cap) {
 		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC};
 		for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4)); }
 		sl.list_cap = n_reads;

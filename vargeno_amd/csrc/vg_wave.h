@@ -46,19 +46,31 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 
 // read_ids == nullptr: the wave owns a contiguous range of the batch's n_reads_arg reads;
 // otherwise the jobs are read_ids[0 .. *n_ids) (the spill list of the previous tier, sized on the device).
-template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP>
-__global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
+// Waves of one workgroup never talk to each other: WPB > 1 only exists because a CU takes at most 16
+// workgroups, so single-wave groups cap residency at 16 waves per CU (measured: a 17th wave per CU queues).
+// Cross-lane hand-offs through LDS stay inside a wave, where DS operations issue and complete in order;
+// the wavefront-scope fence pair keeps the compiler from moving LDS accesses across the hand-off.
+#define VG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
                                                      uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats)
 {
-	__shared__ uint32_t E_kpos[W_ECAP][64], E_meta[W_ECAP][64], N_kpos[W_NCAP][64], N_meta[W_NCAP][64];
-	__shared__ uint32_t K_idx[W_KCAP][64], K_first[W_KCAP][64], K_fm[W_KCAP][64];
-	const uint32_t lane = threadIdx.x;
+	// narrow element types keep a wave at 6.5 KB of LDS (24 waves per CU): an exact context only needs its
+	// chunk number next to the position, a neighbour context 13 bits, a vote key 8 + 1 bits of state
+	__shared__ uint32_t E_kpos[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB], K_idx[W_KCAP][64 * WPB], K_first[W_KCAP][64 * WPB];
+	__shared__ uint16_t N_meta[W_NCAP][64 * WPB], K_fm[W_KCAP][64 * WPB];
+	__shared__ uint8_t E_meta[W_ECAP][64 * WPB];
+	const uint32_t lane = threadIdx.x & 63u;             // lane in the wave
+	const uint32_t col = threadIdx.x;                    // this lane's LDS column
+	const uint32_t col0 = threadIdx.x & ~63u;            // first column of this wave
 	const uint64_t lane_bit = 1ull << lane;
 	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;
-	uint64_t cursor = n_reads * (uint64_t)blockIdx.x / gridDim.x;
-	const uint64_t end = n_reads * ((uint64_t)blockIdx.x + 1) / gridDim.x;
+	const uint64_t wave_id = (uint64_t)blockIdx.x * WPB + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * WPB;
+	uint64_t cursor = n_reads * wave_id / n_waves;
+	const uint64_t end = n_reads * (wave_id + 1) / n_waves;
 
 	bool active = false;
 	uint32_t rid = 0, n = 0, gates = 0, pass = 0;
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 					if (e.pos != POS_AMBIGUOUS) {
 						if (e.amb == 0) {
 							cur.add(S_CTX, 1);
-							if (ecnt < W_ECAP) { E_kpos[ecnt][lane] = e.pos; E_meta[ecnt][lane] = mk_meta(c, 0, false, 0); ecnt++; } else ovf = true;
+							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = e.pos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
 						} else {
 							const uint32_t *row = d.ref_aux + (uint64_t)e.pos * AUX_COLS;
 							cur.add(S_AUX_REF, 1);
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 								const uint32_t p = row[j];
 								if (p == 0) break;
 								cur.add(S_CTX, 1);
-								if (ecnt < W_ECAP) { E_kpos[ecnt][lane] = p; E_meta[ecnt][lane] = mk_meta(c, 0, false, 0); ecnt++; } else ovf = true;
+								if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
 							}
 						}
 					}
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 					if (e.pos != POS_AMBIGUOUS) {
 						if (((e.key >> 48) & 0xFFu) == 0) {
 							cur.add(S_CTX, 1);
-							if (ecnt < W_ECAP) { E_kpos[ecnt][lane] = e.pos; E_meta[ecnt][lane] = mk_meta(c, 0, false, 0); ecnt++; } else ovf = true;
+							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = e.pos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
 						} else {
 							const uint32_t *prow = d.snp_aux_pos + (uint64_t)e.pos * AUX_COLS;
 							cur.add(S_AUX_SNP, 1);
@@ -148,14 +160,14 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 								const uint32_t p = prow[j];
 								if (p == 0) break;
 								cur.add(S_CTX, 1);
-								if (ecnt < W_ECAP) { E_kpos[ecnt][lane] = p; E_meta[ecnt][lane] = mk_meta(c, 0, false, 0); ecnt++; } else ovf = true;
+								if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
 							}
 						}
 					}
 				}
 			}
 		}
-		__syncthreads();
+		VG_WAVE_SYNC();
 
 		// ------------------------------------------------------------------ stage B: gate-open chunks, one at a time, 64 lanes wide
 		uint32_t pend = (active && !ovf) ? (n >= 32 ? gates : (gates & ((1u << n) - 1u))) : 0u;
@@ -195,7 +207,7 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 			// is `position` the implied read position of one of the owner's exact hits?
 			auto in_keys = [&](uint32_t position) -> bool {
 				bool f = false;
-				for (uint32_t e = 0; e < o_ecnt; e++) f |= (E_kpos[e][owner] - 32u * (E_meta[e][owner] & 31u)) == position;
+				for (uint32_t e = 0; e < o_ecnt; e++) f |= (E_kpos[e][col0 + owner] - 32u * (E_meta[e][col0 + owner] & 31u)) == position;
 				return f;
 			};
 
@@ -288,17 +300,17 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 				if (wcnt + round_total > (uint32_t)W_NCAP) { wovf = true; break; }
 				uint32_t at = wcnt + incl - keep;
 				if (keepm & 0x3FFu) {
-					if (re.amb == 0) { N_kpos[at][owner] = re.pos; N_meta[at][owner] = mk_meta(c, mod, true, nbase); at++; }
+					if (re.amb == 0) { N_kpos[at][col0 + owner] = re.pos; N_meta[at][col0 + owner] = (uint16_t)mk_meta(c, mod, true, nbase); at++; }
 					else {
 						const uint32_t *row = d.ref_aux + (uint64_t)re.pos * AUX_COLS;
-						for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << j)) { N_kpos[at][owner] = row[j]; N_meta[at][owner] = mk_meta(c, mod, true, nbase); at++; }
+						for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << j)) { N_kpos[at][col0 + owner] = row[j]; N_meta[at][col0 + owner] = (uint16_t)mk_meta(c, mod, true, nbase); at++; }
 					}
 				}
 				if (keepm >> 10) {
-					if (((se.key >> 48) & 0xFFu) == 0) { N_kpos[at][owner] = se.pos; N_meta[at][owner] = mk_meta(c, mod, true, nbase); at++; }
+					if (((se.key >> 48) & 0xFFu) == 0) { N_kpos[at][col0 + owner] = se.pos; N_meta[at][col0 + owner] = (uint16_t)mk_meta(c, mod, true, nbase); at++; }
 					else {
 						const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
-						for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << (10 + j))) { N_kpos[at][owner] = prow[j]; N_meta[at][owner] = mk_meta(c, mod, true, nbase); at++; }
+						for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << (10 + j))) { N_kpos[at][col0 + owner] = prow[j]; N_meta[at][col0 + owner] = (uint16_t)mk_meta(c, mod, true, nbase); at++; }
 					}
 				}
 				wcnt += round_total;
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 				if (wovf) { ovf = true; pend = 0; }
 			}
 		}
-		__syncthreads();
+		VG_WAVE_SYNC();
 
 		// ------------------------------------------------------------------ stage C: replay the vote, walk the pile-up
 		if (active) {
@@ -324,43 +336,43 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 				// improved_index_table_add, qv.cc:132-178; keys in this lane's LDS column
 				auto vote = [&](uint32_t index, uint32_t kpos, bool neigh) {
 					int e = -1;
-					for (uint32_t i = 0; i < nkeys; i++) if (K_idx[i][lane] == index) { e = (int)i; break; }
+					for (uint32_t i = 0; i < nkeys; i++) if (K_idx[i][col] == index) { e = (int)i; break; }
 					uint32_t first, fm;
 					if (e < 0) {
 						if (neigh) return;
 						if (nkeys >= (uint32_t)W_KCAP) { ovf = true; return; }
 						e = (int)nkeys++;
-						K_idx[e][lane] = index; K_first[e][lane] = first = kpos; fm = 0;
-					} else { first = K_first[e][lane]; fm = K_fm[e][lane]; }
+						K_idx[e][col] = index; K_first[e][col] = first = kpos; fm = 0;
+					} else { first = K_first[e][col]; fm = K_fm[e][col]; }
 					const uint32_t freq = (fm + 1) & 0xFFu;
 					const uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);
-					K_fm[e][lane] = freq | (multi << 8);
+					K_fm[e][col] = (uint16_t)(freq | (multi << 8));
 					if (!multi) return;
 					if (best < 0) { best = e; amb = false; }
 					else if (e == best) amb = false;
 					else {
-						const uint32_t bf = K_fm[best][lane] & 0xFFu;
+						const uint32_t bf = K_fm[best][col] & 0xFFu;
 						if (freq == bf) amb = true;
 						else if (freq > bf) { best = e; amb = false; }
 					}
 				};
 				uint32_t ei = 0, ni = 0;
 				for (uint32_t c = 0; c < n && !ovf; c++) {
-					while (ei < ecnt && (E_meta[ei][lane] & 31u) == c) { const uint32_t p = E_kpos[ei][lane]; vote(p - 32u * c, p, false); ei++; }
-					while (ni < ncnt && (N_meta[ni][lane] & 31u) == c) { const uint32_t p = N_kpos[ni][lane]; vote(p - 32u * c, p, true); ni++; }
+					while (ei < ecnt && (E_meta[ei][col] & 31u) == c) { const uint32_t p = E_kpos[ei][col]; vote(p - 32u * c, p, false); ei++; }
+					while (ni < ncnt && (N_meta[ni][col] & 31u) == c) { const uint32_t p = N_kpos[ni][col]; vote(p - 32u * c, p, true); ni++; }
 				}
 				if (!ovf) {
 					cur.add(S_PASSES, 1);
-					const uint32_t bfm = best >= 0 ? K_fm[best][lane] : 0u, target = best >= 0 ? K_idx[best][lane] : 0u;
+					const uint32_t bfm = best >= 0 ? K_fm[best][col] : 0u, target = best >= 0 ? K_idx[best][col] : 0u;
 					processed = best >= 0 && !amb && (bfm & 0xFFu) > 1;          // qv.cc:1375
 					if (processed) {
 						cur.add(S_PASSES_OK, 1);
 						for (uint32_t i = 0; i < ecnt; i++) {
-							const uint32_t p = E_kpos[i][lane], c = E_meta[i][lane] & 31u;
+							const uint32_t p = E_kpos[i][col], c = E_meta[i][col] & 31u;
 							if (p - 32u * c == target) walk_ctx(d, cur, chunk_kmer(c), p, NOMOD);
 						}
 						for (uint32_t i = 0; i < ncnt; i++) {
-							const uint32_t p = N_kpos[i][lane], mt = N_meta[i][lane], c = mt & 31u, mod = (mt >> 5) & 31u;
+							const uint32_t p = N_kpos[i][col], mt = N_meta[i][col], c = mt & 31u, mod = (mt >> 5) & 31u;
 							if (p - 32u * c != target) continue;
 							const uint64_t kk = (chunk_kmer(c) & ~(3ull << (2 * mod))) | ((uint64_t)((mt >> 11) & 3u) << (2 * mod));
 							walk_ctx(d, cur, kk, p, mod);
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(64) void vg_wave_kernel(DevIndex d, const uint64_t 
 				pass = 1;                                                        // reverse-complement retry, qv.cc:1504-1510
 			}
 		}
-		__syncthreads();
+		VG_WAVE_SYNC();
 	}
 	if constexpr (STATS) {
 		for (int i = 0; i < S_COUNT; i++) if (tot.v[i]) atomicAdd(&stats[i], (unsigned long long)tot.v[i]);
