@@ -117,7 +117,14 @@ def main():
                 want = ox.stats.as_dict()
                 for k, v in want.items():
                     assert st[k] == v, "event counter %s: hip %d oracle %d" % (k, st[k], v)
-                log("[bench] parity: %d site counters and %d event counters identical to the oracle" % (2 * len(rc), len(want)))
+                # the timed build (event counting off; it answers the high-half neighbour queries from the
+                # LO32-ordered view) must give the same counters
+                gx.set_stats(False)
+                gx.reset()
+                gx.process_device(d_bases, d_quals, d_offs, r.n)
+                rc2, ac2 = gx.counts()
+                assert np.array_equal(rc2, so["ref_cnt"]) and np.array_equal(ac2, so["alt_cnt"]), "timed build != oracle"
+                log("[bench] parity: %d site counters (both builds) and %d event counters identical to the oracle" % (2 * len(rc), len(want)))
         ncores = os.cpu_count() or 1
         nt = min(ncores, 64)
         ox.reset()

@@ -62,8 +62,7 @@ __device__ inline uint64_t lower_bound_dev(const uint64_t *a, uint64_t n, uint64
 // HI >= h, = n past the last used HI: exactly what src/qv.cc:539-584 / :622-678 build).  One
 // workgroup owns JG_SPAN consecutive h: LDS histogram of its slice of the sorted array, LDS scan,
 // coalesced write.  jg has n_buckets + 1 entries; the last one is the sentinel n.
-template <int SHIFT>
-__global__ __launch_bounds__(256) void vg_build_jumpgate(const uint64_t *__restrict__ kmer, uint64_t n, uint32_t *__restrict__ jg, uint64_t n_buckets)
+__global__ __launch_bounds__(256) void vg_build_jumpgate(const uint64_t *__restrict__ kmer, uint64_t n, uint32_t *__restrict__ jg, uint64_t n_buckets, const int SHIFT)
 {
 	__shared__ uint32_t hist[JG_LDS];
 	__shared__ uint64_t range[2];
@@ -105,6 +104,17 @@ __global__ __launch_bounds__(256) void vg_build_jumpgate(const uint64_t *__restr
 		if (h < n_buckets) jg[h] = (uint32_t)(e0 + hist[i + (i >> 5)]);
 	}
 	if (blockIdx.x == gridDim.x - 1 && t == 0) jg[n_buckets] = (uint32_t)n;
+}
+
+int vg_dev_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, size_t n, hipStream_t stream);   // vg_sort.hip
+
+__global__ void vg_make_sec_keys(const uint64_t *__restrict__ kmer, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t k = kmer[i];
+		key[i] = (k << 32) | (k >> 32);            // LO32 major, HI32 minor
+		val[i] = (uint32_t)i;
+	}
 }
 
 // SoA as the dictionary file has it -> one 16-byte entry per k-mer (a hit then costs one line)
@@ -377,7 +387,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	ix->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ix->lane_grid_blocks = ix->cus * 8;                          // 2048 lanes per CU = every wave slot
-	int wpc = 20;                                                // waves per CU of the wave-tier grid: 5 groups of 4 waves fit a CU's LDS
+	int wpc = 16;                                                // waves per CU of the wave-tier grid: 102 VGPRs -> 4 waves per SIMD
 	if (const char *e = getenv("VG_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
 	ix->wave_grid = ix->cus * wpc;
 	if (const char *e = getenv("VG_FORCE_GENERIC")) ix->force_generic = atoi(e) != 0;
@@ -394,12 +404,35 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		uint32_t *jg = nullptr; RefEnt *ent = nullptr; uint32_t *x = nullptr;
 		if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
 		if ((rc = dev_alloc(ix, &ent, a->n_ref))) return rc;
-		vg_build_jumpgate<32><<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, ix->stream>>>(tk.p, a->n_ref, jg, 1ull << 32);
+		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, ix->stream>>>(tk.p, a->n_ref, jg, 1ull << 32, 32);
 		vg_make_ref_entries<<<2048, 256, 0, ix->stream>>>(tk.p, tp.p, ta.p, a->n_ref, ent);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(ix->stream));
 		if ((rc = dev_upload(ix, &x, a->ref_aux, a->n_ref_aux * AUX_COLS))) return rc;
 		d.ref_jg = jg; d.ref = ent; d.ref_aux = x;
+		// secondary view ordered by (LO32, HI32): device radix sort of the swapped k-mers + a jump table over LO32's top bits
+		if (!getenv("VG_NO_SEC")) {
+			uint32_t bits = 14;
+			while (bits < 28 && (1ull << bits) < a->n_ref / 2) bits++;      // ~2-4 entries per bucket
+			TempDev<uint64_t> kin; TempDev<uint32_t> vin;
+			if ((rc = kin.upload(nullptr, 0))) return rc;
+			(void)hipFree(kin.p); kin.p = nullptr;
+			hipError_t e1 = hipMalloc((void **)&kin.p, (size_t)(a->n_ref ? a->n_ref : 1) * 8);
+			hipError_t e2 = hipMalloc((void **)&vin.p, (size_t)(a->n_ref ? a->n_ref : 1) * 4);
+			if (e1 != hipSuccess || e2 != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(secondary index staging)");
+			uint64_t *skey = nullptr; uint32_t *sidx = nullptr, *sjg = nullptr;
+			if ((rc = dev_alloc(ix, &skey, a->n_ref))) return rc;
+			if ((rc = dev_alloc(ix, &sidx, a->n_ref))) return rc;
+			if ((rc = dev_alloc(ix, &sjg, (1ull << bits) + 1))) return rc;
+			vg_make_sec_keys<<<2048, 256, 0, ix->stream>>>(tk.p, a->n_ref, kin.p, vin.p);
+			HIP_TRY(hipGetLastError());
+			const int se = vg_dev_sort_pairs_u64_u32(kin.p, skey, vin.p, sidx, a->n_ref, ix->stream);
+			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
+			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, ix->stream>>>(skey, a->n_ref, sjg, 1ull << bits, (int)(64 - bits));
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(ix->stream));
+			d.sec_key = skey; d.sec_idx = sidx; d.sec_jg = sjg; d.sec_bits = bits;
+		}
 	}
 	// ---- SNP dictionary
 	{
@@ -411,7 +444,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		uint32_t *jg = nullptr; SnpEnt *ent = nullptr; uint32_t *xp = nullptr; uint8_t *xi = nullptr;
 		if ((rc = dev_alloc(ix, &jg, (1ull << 24) + 1))) return rc;
 		if ((rc = dev_alloc(ix, &ent, a->n_snp))) return rc;
-		vg_build_jumpgate<40><<<(unsigned)((1ull << 24) / JG_SPAN), 256, 0, ix->stream>>>(tk.p, a->n_snp, jg, 1ull << 24);
+		vg_build_jumpgate<<<(unsigned)((1ull << 24) / JG_SPAN), 256, 0, ix->stream>>>(tk.p, a->n_snp, jg, 1ull << 24, 40);
 		vg_make_snp_entries<<<2048, 256, 0, ix->stream>>>(tk.p, tp.p, ti.p, ta.p, a->n_snp, ent);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(ix->stream));

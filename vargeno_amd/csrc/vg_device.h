@@ -32,6 +32,13 @@ struct DevIndex {
 	const RefEnt   *ref;           // [n_ref]
 	const uint32_t *ref_aux;       // [n_ref_aux][10]
 	uint64_t n_ref;
+	// secondary view of the reference dictionary ordered by (LO32, HI32): every k-mer that shares a chunk's first 16
+	// bases is adjacent, so the 48 "last 16 bases differ in one base" neighbour queries of qv.cc:1213-1296 become
+	// one bucket read.  sec_key = LO32 << 32 | HI32, sec_idx = index into `ref`, sec_jg over the top sec_bits of LO32.
+	const uint64_t *sec_key;       // [n_ref]
+	const uint32_t *sec_idx;       // [n_ref]
+	const uint32_t *sec_jg;        // [2^sec_bits + 1]
+	uint32_t sec_bits;
 	// SNP dictionary (src/qv.cc:606-695)
 	const uint32_t *snp_jg;        // [2^24 + 1]
 	const SnpEnt   *snp;           // [n_snp]

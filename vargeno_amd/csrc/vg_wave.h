@@ -28,6 +28,9 @@ namespace vg {
 // dependent gathers instead of the thousands the sequential lane machine needs.
 constexpr int W1_ECAP = 8, W1_NCAP = 4, W1_KCAP = 4;
 constexpr int W2_ECAP = 48, W2_NCAP = 48, W2_KCAP = 32;
+constexpr int PCAP = 32;         // rows of the stage-B pair table (a wave with more gate-open chunks takes several windows)
+constexpr int SEC_RUN = 12;      // longest run of equal-LO32 entries one lane will walk in the LO32-ordered view
+constexpr int HCAP = 4;          // high-half reference hits per pair kept from the LO32-ordered view (more: the 48 queries are issued)
 
 // packed reads: chunk k-mers at [offsets[r] >> 5 ...), one flag word per read
 constexpr uint64_t PK_SKIP_N = 1ull << 62;     // an N inside the trimmed read: skipped (qv.cc:815-828)
@@ -63,6 +66,19 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 	__shared__ uint32_t E_kpos[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB], K_idx[W_KCAP][64 * WPB], K_first[W_KCAP][64 * WPB];
 	__shared__ uint16_t N_meta[W_NCAP][64 * WPB], K_fm[W_KCAP][64 * WPB];
 	__shared__ uint8_t E_meta[W_ECAP][64 * WPB];
+	// stage B pair table: one row per gate-open (owner, chunk) pair of the wave, PCAP rows at a time
+	__shared__ uint32_t P_klo[PCAP][WPB], P_khi[PCAP][WPB], P_lo[PCAP][WPB], P_hi[PCAP][WPB], P_slo[PCAP][WPB], P_shi[PCAP][WPB];
+	__shared__ uint32_t P_meta[PCAP][WPB], P_cnt[PCAP][WPB], P_off[PCAP][WPB], P_hu[PCAP][WPB], P_hidx[HCAP][PCAP][WPB];
+	__shared__ uint8_t P_ecnt[PCAP][WPB];
+	__shared__ uint16_t N_cnt[64 * WPB];
+	__shared__ uint8_t N_ovf[64 * WPB];
+	constexpr int NSH = 11;                               // event counters that helper lanes bump on behalf of an owner
+	constexpr int SH_IDS[NSH] = {S_REF_QUERY, S_SNP_QUERY, S_REF_PROBE, S_SNP_PROBE, S_SCAN_REF, S_SCAN_SNP, S_SCAN_OOB, S_AUX_REF, S_AUX_SNP, S_SITE_TEST, S_CTX};
+	__shared__ uint32_t S_own[STATS ? NSH : 1][STATS ? 64 * WPB : 1];
+	const uint32_t wv = threadIdx.x >> 6;
+	// The secondary (LO32-ordered) view answers the 48 high-half reference queries with one bucket read.  The counting
+	// build keeps the 48 individual queries because the event counters price each of them.
+	const bool use_sec = !STATS && d.sec_key != nullptr;
 	const uint32_t lane = threadIdx.x & 63u;             // lane in the wave
 	const uint32_t col = threadIdx.x;                    // this lane's LDS column
 	const uint32_t col0 = threadIdx.x & ~63u;            // first column of this wave
@@ -169,161 +185,263 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 		}
 		VG_WAVE_SYNC();
 
-		// ------------------------------------------------------------------ stage B: gate-open chunks, one at a time, 64 lanes wide
-		uint32_t pend = (active && !ovf) ? (n >= 32 ? gates : (gates & ((1u << n) - 1u))) : 0u;
-		for (;;) {
-			const uint64_t m = __ballot(pend != 0);
-			if (!m) break;
-			const int owner = __ffsll((long long)m) - 1;
-			uint32_t c = 0, lo = 0, hi = 0, slo = 0, shi = 0, fl = 0, klo = 0, khi = 0;
-			if ((int)lane == owner) {
-				c = (uint32_t)__ffs((int)pend) - 1;
-				const uint64_t k = chunk_kmer(c);
-				klo = (uint32_t)k; khi = (uint32_t)(k >> 32);
-				jg_pair(d.ref_jg, k >> 32, lo, hi);                              // check_block_size, qv.cc:242-264
-				jg_pair(d.snp_jg, k >> 40, slo, shi);
-				const uint64_t rp = (uint64_t)hash32((uint32_t)k) % d.ref_bf_bits;   // qv.cc:946-956
-				const uint64_t sp = hash40(k & LO40_MASK) % d.snp_bf_bits;
-				if ((d.ref_bf[rp >> 6] >> (rp & 63)) & 1u) fl |= 1u;
-				if ((d.snp_bf[sp >> 6] >> (sp & 63)) & 1u) fl |= 2u;
-				cur.add(S_GATE_OPEN, 1);
-				cur.add(S_REFBF_POS, fl & 1u);
-				cur.add(S_SNPBF_POS, (fl >> 1) & 1u);
-				if (hi - lo >= BLOCK_THRESHOLD) cur.add(S_LARGE_BLOCK, 1);
-			}
-			c = __shfl(c, owner); lo = __shfl(lo, owner); hi = __shfl(hi, owner); slo = __shfl(slo, owner); shi = __shfl(shi, owner);
-			fl = __shfl(fl, owner); klo = __shfl(klo, owner); khi = __shfl(khi, owner);
-			const uint64_t k = ((uint64_t)khi << 32) | klo;
-			const uint32_t o_ecnt = __shfl(ecnt, owner);
-			uint32_t wcnt = __shfl(ncnt, owner);
-			bool wovf = false;
-			const bool large = hi - lo >= BLOCK_THRESHOLD;
-			const uint32_t Lr = large ? 48u : hi - lo, Ls = large ? 0u : shi - slo;
-			const uint32_t L = Lr + Ls, total = L + 48u;
-			const uint32_t rsb = (fl & 1u) ? 64u : 32u, ssb = (fl & 2u) ? 64u : 40u;
-			LaneStats<STATS> hs;
-			hs.clear();
-
-			// is `position` the implied read position of one of the owner's exact hits?
-			auto in_keys = [&](uint32_t position) -> bool {
-				bool f = false;
-				for (uint32_t e = 0; e < o_ecnt; e++) f |= (E_kpos[e][col0 + owner] - 32u * (E_meta[e][col0 + owner] & 31u)) == position;
-				return f;
-			};
-
-			for (uint32_t t0 = 0; t0 < total && !wovf; t0 += 64) {
-				const uint32_t t = t0 + lane;
-				int64_t ri = -1, si = -1;
-				uint32_t mod = 0, nbase = 0;
-				if (t < total) {
-					if (t < L) {
-						if (large) {                                             // qv.cc:962-1109
-							const uint32_t pair = t / 3, sel = t % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
+		// ------------------------------------------------------------------ stage B: all gate-open chunks of the wave, flattened
+		// (owner, chunk) pairs in (lane, chunk) order -> one table row each (LDS), their work items laid end to end and dealt
+		// to the lanes 64 at a time, so a round is full whatever the size of each chunk's neighbourhood.
+		{
+			const uint32_t pend = (active && !ovf) ? (n >= 32 ? gates : (gates & ((1u << n) - 1u))) : 0u;
+			const uint32_t my_np = (uint32_t)__popc(pend);
+			uint32_t pincl = my_np;
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pincl, o); if ((int)lane >= o) pincl += y; }
+			const uint32_t my_base = pincl - my_np, P = __shfl(pincl, 63);
+			N_cnt[col] = 0; N_ovf[col] = 0;
+			if constexpr (STATS) for (int i = 0; i < NSH; i++) S_own[i][col] = 0;
+			for (uint32_t w0 = 0; w0 < P; w0 += PCAP) {
+				// ---- B0: each owner lane fills the rows of its own pairs that fall into this window
+				{
+					uint32_t q = my_base, bits = pend;
+					while (bits) {
+						const uint32_t c = (uint32_t)__ffs((int)bits) - 1;
+						bits &= bits - 1;
+						if (q >= w0 && q < w0 + PCAP) {
+							const uint32_t p = q - w0;
+							const uint64_t k = chunk_kmer(c);
+							const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
+							uint32_t lo, hi, slo, shi, b0 = 0, b1 = 0, fl = 0;
+							jg_pair(d.ref_jg, k >> 32, lo, hi);                      // check_block_size, qv.cc:242-264
+							jg_pair(d.snp_jg, k >> 40, slo, shi);
+							if (use_sec) jg_pair(d.sec_jg, klo >> (32 - d.sec_bits), b0, b1);
+							const uint64_t rp = (uint64_t)hash32(klo) % d.ref_bf_bits;   // qv.cc:946-956
+							const uint64_t sp = hash40(k & LO40_MASK) % d.snp_bf_bits;
+							if ((d.ref_bf[rp >> 6] >> (rp & 63)) & 1u) fl |= 1u;
+							if ((d.snp_bf[sp >> 6] >> (sp & 63)) & 1u) fl |= 2u;
+							const bool large = hi - lo >= BLOCK_THRESHOLD;
+							cur.add(S_GATE_OPEN, 1);
+							cur.add(S_REFBF_POS, fl & 1u);
+							cur.add(S_SNPBF_POS, (fl >> 1) & 1u);
+							if (large) cur.add(S_LARGE_BLOCK, 1);
+							// high-half SNP queries are live for a contiguous range of slots u = 3 * (pair - 16) + sel  (qv.cc:1303-1306)
+							uint32_t s_lo = 0, s_hi = 0;
+							if (fl & 2u) { s_lo = large ? 0u : 12u; s_hi = 48u; } else if (large) { s_lo = 0u; s_hi = 12u; }
+							// high-half ref hits from the LO32-ordered view: every dictionary k-mer with the same first 16 bases
+							// whose last 16 differ in exactly one base, kept sorted by slot
+							uint32_t nh = 0, hu = 0;                                   // hu: slot of hit z in byte z (unsorted)
+							bool sec_ok = use_sec;
+							if (use_sec && (fl & 1u)) {
+								// k-mers with this LO32 are adjacent in the view; a popular LO32 (microsatellites, poly-A) would make
+								// one lane walk a long run while its wave waits, so past SEC_RUN entries the pair keeps its 48 queries
+								uint32_t ea = b0, eb = b1;
+								const uint64_t want = (uint64_t)klo << 32;
+								while (ea < eb) { const uint32_t m = ea + ((eb - ea) >> 1); if (d.sec_key[m] < want) ea = m + 1; else eb = m; }
+								for (uint32_t e = ea; e < b1; e++) {
+									const uint64_t key = d.sec_key[e];
+									if ((uint32_t)(key >> 32) != klo) break;
+									if (e - ea >= (uint32_t)SEC_RUN) { sec_ok = false; break; }
+									const int dd = onebase((uint64_t)((uint32_t)key ^ khi));
+									if (dd < 0) continue;
+									if (nh == (uint32_t)HCAP) { sec_ok = false; break; }
+									const uint32_t nbb = ((uint32_t)key >> (2 * dd)) & 3u, base = (khi >> (2 * dd)) & 3u;
+									P_hidx[nh][p][wv] = d.sec_idx[e];
+									hu |= ((uint32_t)dd * 3u + nbb - (nbb > base ? 1u : 0u)) << (8 * nh);
+									nh++;
+								}
+							}
+							uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
+							if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
+							else if (sec_ok && s_hi == s_lo) { mode = 1; nhigh = nh; }
+							else { u_lo = 0; nhigh = 48; }
+							const uint32_t L = large ? 48u : (hi - lo) + (shi - slo);
+							P_klo[p][wv] = klo; P_khi[p][wv] = khi; P_lo[p][wv] = lo; P_hi[p][wv] = hi; P_slo[p][wv] = slo; P_shi[p][wv] = shi;
+							P_meta[p][wv] = lane | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
+							P_cnt[p][wv] = L + nhigh;
+							P_ecnt[p][wv] = (uint8_t)ecnt;
+							P_hu[p][wv] = hu;
+						}
+						q++;
+					}
+				}
+				VG_WAVE_SYNC();
+				const uint32_t np = P - w0 < (uint32_t)PCAP ? P - w0 : (uint32_t)PCAP;
+				uint32_t T;
+				{
+					const uint32_t cntp = lane < np ? P_cnt[lane < (uint32_t)PCAP ? lane : 0][wv] : 0u;
+					uint32_t ci = cntp;
+					for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(ci, o); if ((int)lane >= o) ci += y; }
+					if (lane < np) P_off[lane][wv] = ci - cntp;
+					T = __shfl(ci, 63);
+				}
+				VG_WAVE_SYNC();
+				// ---- B1: rounds of 64 items
+				for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+					const uint32_t g = t0 + lane;
+					const bool valid = g < T;
+					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
+					int32_t ri = -1, si = -1;                                // entry indices (< 2^31 asserted at load) or -1
+					LaneStats<STATS> hs;
+					hs.clear();
+					if (valid) {
+						uint32_t p = 0;                                                  // last row with P_off <= g
+						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g) p += step;
+						const uint32_t t = g - P_off[p][wv];
+						const uint32_t meta = P_meta[p][wv];
+						const uint32_t klo = P_klo[p][wv], khi = P_khi[p][wv], lo = P_lo[p][wv], hi = P_hi[p][wv], slo = P_slo[p][wv], shi = P_shi[p][wv];
+						const uint64_t k = ((uint64_t)khi << 32) | klo;
+						own = meta & 63u; c = (meta >> 6) & 31u;
+						const uint32_t fl = (meta >> 11) & 3u, mode = (meta >> 14) & 1u, nh = (meta >> 16) & 7u, u_lo = (meta >> 19) & 63u;
+						const bool large = (meta >> 13) & 1u, sec_ok = (meta >> 15) & 1u;
+						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (shi - slo);
+						const uint32_t rsb = (fl & 1u) ? 64u : 32u, ssb = (fl & 2u) ? 64u : 40u;
+						o_ecnt = P_ecnt[p][wv];
+						if (t < L) {
+							if (large) {                                         // qv.cc:962-1109
+								const uint32_t pair = t / 3, sel = t % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
+								nbase = sel + (sel >= base ? 1u : 0u);
+								mod = pair;
+								const uint64_t nb = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
+								uint32_t a, b;
+								ri = (int32_t)ref_query(d, hs, nb, a, b);
+								si = (int32_t)snp_query(d, hs, nb, a, b);
+							} else if (t < Lr) {                                 // iterate_ref_dict, qv.cc:316-376   (B1)
+								const uint64_t tt = (uint64_t)lo + (uint64_t)t * REF_STRIDE;
+								uint32_t tlo = 0;
+								hs.add(S_SCAN_REF, 1);
+								if (tt < d.n_ref) tlo = d.ref[tt].lo; else hs.add(S_SCAN_OOB, 1);
+								const int dd = onebase((uint64_t)(klo ^ tlo));
+								if (dd >= 0) { ri = (int32_t)(lo + t); mod = (uint32_t)dd; nbase = (tlo >> (2 * dd)) & 3u; }
+							} else {                                             // iterate_snp_dict, qv.cc:413-464   (B1)
+								const uint32_t u = t - Lr;
+								const uint64_t tt = (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
+								uint64_t tlo = 0;
+								hs.add(S_SCAN_SNP, 1);
+								if (tt < d.n_snp) tlo = d.snp[tt].key & LO40_MASK; else hs.add(S_SCAN_OOB, 1);
+								const int dd = onebase((k & LO40_MASK) ^ tlo);
+								if (dd >= 0) { si = (int32_t)(slo + u); mod = (uint32_t)dd; nbase = (uint32_t)(tlo >> (2 * dd)) & 3u; }
+							}
+						} else {                                                 // qv.cc:1213-1365
+							const uint32_t h = t - L;
+							uint32_t u;
+							bool have_ri = false;
+							if (mode == 1) {                                     // the h-th hit in slot order
+								const uint32_t hu = P_hu[p][wv];
+								uint32_t zsel = 0;
+								for (uint32_t z = 0; z < nh; z++) {
+									const uint32_t uz = (hu >> (8 * z)) & 0xFFu;
+									uint32_t rank = 0;
+									for (uint32_t y = 0; y < nh; y++) rank += ((hu >> (8 * y)) & 0xFFu) < uz ? 1u : 0u;
+									if (rank == h) zsel = z;
+								}
+								u = (hu >> (8 * zsel)) & 0xFFu;
+								ri = (int32_t)P_hidx[zsel][p][wv];
+								have_ri = true;
+							} else u = u_lo + h;
+							const uint32_t pair = 16u + u / 3, sel = u % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
 							nbase = sel + (sel >= base ? 1u : 0u);
 							mod = pair;
 							const uint64_t nb = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
 							uint32_t a, b;
-							ri = ref_query(d, hs, nb, a, b);
-							si = snp_query(d, hs, nb, a, b);
-						} else if (t < Lr) {                                     // iterate_ref_dict, qv.cc:316-376   (B1)
-							const uint64_t tt = (uint64_t)lo + (uint64_t)t * REF_STRIDE;
-							uint32_t tlo = 0;
-							hs.add(S_SCAN_REF, 1);
-							if (tt < d.n_ref) tlo = d.ref[tt].lo; else hs.add(S_SCAN_OOB, 1);
-							const int dd = onebase((uint64_t)(klo ^ tlo));
-							if (dd >= 0) { ri = (int64_t)lo + t; mod = (uint32_t)dd; nbase = (tlo >> (2 * dd)) & 3u; }
-						} else {                                                 // iterate_snp_dict, qv.cc:413-464   (B1)
-							const uint32_t u = t - Lr;
-							const uint64_t tt = (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
-							uint64_t tlo = 0;
-							hs.add(S_SCAN_SNP, 1);
-							if (tt < d.n_snp) tlo = d.snp[tt].key & LO40_MASK; else hs.add(S_SCAN_OOB, 1);
-							const int dd = onebase((k & LO40_MASK) ^ tlo);
-							if (dd >= 0) { si = (int64_t)slo + u; mod = (uint32_t)dd; nbase = (uint32_t)(tlo >> (2 * dd)) & 3u; }
+							if (!have_ri && 2 * pair < rsb) {
+								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) if (((hu >> (8 * z)) & 0xFFu) == u) ri = (int32_t)P_hidx[z < (uint32_t)HCAP ? z : 0][p][wv]; }
+								else ri = (int32_t)ref_query(d, hs, nb, a, b);
+							}
+							if ((large || 2 * pair >= 40u) && 2 * pair < ssb) si = (int32_t)snp_query(d, hs, nb, a, b);
 						}
-					} else {                                                     // qv.cc:1213-1365
-						const uint32_t u = t - L, pair = 16u + u / 3, sel = u % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
-						nbase = sel + (sel >= base ? 1u : 0u);
-						mod = pair;
-						const uint64_t nb = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
-						uint32_t a, b;
-						if (2 * pair < rsb) ri = ref_query(d, hs, nb, a, b);
-						if ((large || 2 * pair >= 40u) && 2 * pair < ssb) si = snp_query(d, hs, nb, a, b);
 					}
-				}
-				// acceptance (site / SNP-base tests) + key filter -> bit j: ref candidate j kept, bit 10+j: snp candidate j kept
-				uint32_t keepm = 0;
-				RefEnt re{}; SnpEnt se{};
-				if (ri >= 0) {
-					re = d.ref[ri];
-					if (re.pos != POS_AMBIGUOUS) {
-						if (re.amb == 0) {
-							if (!site_loose(d, hs, re.pos + mod)) { hs.add(S_CTX, 1); if (in_keys(re.pos - 32u * c)) keepm |= 1u; }
-						} else {
-							const uint32_t *row = d.ref_aux + (uint64_t)re.pos * AUX_COLS;
-							hs.add(S_AUX_REF, 1);
-							for (int j = 0; j < AUX_COLS; j++) {
-								const uint32_t p = row[j];
-								if (p == 0) break;
-								if (site_loose(d, hs, p + mod)) continue;
-								hs.add(S_CTX, 1);
-								if (in_keys(p - 32u * c)) keepm |= 1u << j;
+					// is `position` the implied read position of one of the owner's exact hits?
+					auto in_keys = [&](uint32_t position) -> bool {
+						bool f = false;
+						for (uint32_t e = 0; e < o_ecnt; e++) f |= (E_kpos[e][col0 + own] - 32u * (E_meta[e][col0 + own] & 31u)) == position;
+						return f;
+					};
+					// acceptance (site / SNP-base tests) + key filter -> bit j: ref candidate j kept, bit 10+j: snp candidate j kept
+					uint32_t keepm = 0;
+					if (ri >= 0) {
+						const RefEnt re = d.ref[ri];
+						if (re.pos != POS_AMBIGUOUS) {
+							if (re.amb == 0) {
+								if (!site_loose(d, hs, re.pos + mod)) { hs.add(S_CTX, 1); if (in_keys(re.pos - 32u * c)) keepm |= 1u; }
+							} else {
+								const uint32_t *row = d.ref_aux + (uint64_t)re.pos * AUX_COLS;
+								hs.add(S_AUX_REF, 1);
+								for (int j = 0; j < AUX_COLS; j++) {
+									const uint32_t pp = row[j];
+									if (pp == 0) break;
+									if (site_loose(d, hs, pp + mod)) continue;
+									hs.add(S_CTX, 1);
+									if (in_keys(pp - 32u * c)) keepm |= 1u << j;
+								}
 							}
 						}
 					}
-				}
-				if (si >= 0) {
-					se = d.snp[si];
-					if (se.pos != POS_AMBIGUOUS) {
-						if (((se.key >> 48) & 0xFFu) == 0) {
-							if ((uint32_t)((se.key >> 43) & 0x1Fu) != mod) { hs.add(S_CTX, 1); if (in_keys(se.pos - 32u * c)) keepm |= 1u << 10; }
-						} else {
-							const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
-							const uint8_t *irow = d.snp_aux_info + (uint64_t)se.pos * AUX_COLS;
-							hs.add(S_AUX_SNP, 1);
-							for (int j = 0; j < AUX_COLS; j++) {
-								const uint32_t p = prow[j];
-								if (p == 0) break;
-								if ((uint32_t)(irow[j] >> 3) == mod) continue;
-								hs.add(S_CTX, 1);
-								if (in_keys(p - 32u * c)) keepm |= 1u << (10 + j);
+					if (si >= 0) {
+						const SnpEnt se = d.snp[si];
+						if (se.pos != POS_AMBIGUOUS) {
+							if (((se.key >> 48) & 0xFFu) == 0) {
+								if ((uint32_t)((se.key >> 43) & 0x1Fu) != mod) { hs.add(S_CTX, 1); if (in_keys(se.pos - 32u * c)) keepm |= 1u << 10; }
+							} else {
+								const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
+								const uint8_t *irow = d.snp_aux_info + (uint64_t)se.pos * AUX_COLS;
+								hs.add(S_AUX_SNP, 1);
+								for (int j = 0; j < AUX_COLS; j++) {
+									const uint32_t pp = prow[j];
+									if (pp == 0) break;
+									if ((uint32_t)(irow[j] >> 3) == mod) continue;
+									hs.add(S_CTX, 1);
+									if (in_keys(pp - 32u * c)) keepm |= 1u << (10 + j);
+								}
 							}
 						}
 					}
-				}
-				if (!__any(keepm != 0)) continue;
-				// canonical order inside the round = lane order (item order); ref contexts of an item before its SNP contexts
-				const uint32_t keep = (uint32_t)__popc(keepm);
-				uint32_t incl = keep;
-				for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((int)lane >= o) incl += y; }
-				const uint32_t round_total = __shfl(incl, 63);
-				if (wcnt + round_total > (uint32_t)W_NCAP) { wovf = true; break; }
-				uint32_t at = wcnt + incl - keep;
-				if (keepm & 0x3FFu) {
-					if (re.amb == 0) { N_kpos[at][col0 + owner] = re.pos; N_meta[at][col0 + owner] = (uint16_t)mk_meta(c, mod, true, nbase); at++; }
-					else {
-						const uint32_t *row = d.ref_aux + (uint64_t)re.pos * AUX_COLS;
-						for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << j)) { N_kpos[at][col0 + owner] = row[j]; N_meta[at][col0 + owner] = (uint16_t)mk_meta(c, mod, true, nbase); at++; }
+					if constexpr (STATS) {
+						if (valid) for (int i = 0; i < NSH; i++) { const uint32_t v = hs.v[SH_IDS[i]]; if (v) atomicAdd(&S_own[i][col0 + own], v); }
 					}
-				}
-				if (keepm >> 10) {
-					if (((se.key >> 48) & 0xFFu) == 0) { N_kpos[at][col0 + owner] = se.pos; N_meta[at][col0 + owner] = (uint16_t)mk_meta(c, mod, true, nbase); at++; }
-					else {
-						const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
-						for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << (10 + j))) { N_kpos[at][col0 + owner] = prow[j]; N_meta[at][col0 + owner] = (uint16_t)mk_meta(c, mod, true, nbase); at++; }
+					if (__any(keepm != 0)) {
+						// compaction per owner (a segment of consecutive lanes), canonical order = lane order; ref contexts of an
+						// item before its SNP contexts
+						const uint32_t keep = (uint32_t)__popc(keepm);
+						uint32_t incl = keep;
+						for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((int)lane >= o) incl += y; }
+						const uint32_t prev = __shfl_up(own, 1);
+						const uint64_t smask = __ballot(lane == 0 || own != prev);
+						const uint64_t upto = lane == 63 ? ~0ull : ((lane_bit << 1) - 1);
+						const int ss = 63 - __clzll((long long)(smask & upto));
+						const uint64_t above = smask & ~upto;
+						const int se_l = above ? (__ffsll((long long)above) - 2) : 63;
+						const uint32_t excl_ss = __shfl(incl - keep, ss);
+						const uint32_t seg_total = __shfl(incl, se_l) - excl_ss;
+						const uint32_t curc = valid ? (uint32_t)N_cnt[col0 + own] : 0u;
+						const bool fits = curc + seg_total <= (uint32_t)W_NCAP;
+						if (valid && keep) {
+							if (!fits) N_ovf[col0 + own] = 1;
+							else {
+								uint32_t at = curc + (incl - keep) - excl_ss;
+								const uint16_t mt = (uint16_t)mk_meta(c, mod, true, nbase);
+								if (keepm & 0x3FFu) {                            // kept contexts are rare: re-read the entry instead of carrying it
+									const RefEnt re = d.ref[ri];
+									if (re.amb == 0) { N_kpos[at][col0 + own] = re.pos; N_meta[at][col0 + own] = mt; at++; }
+									else {
+										const uint32_t *row = d.ref_aux + (uint64_t)re.pos * AUX_COLS;
+										for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << j)) { N_kpos[at][col0 + own] = row[j]; N_meta[at][col0 + own] = mt; at++; }
+									}
+								}
+								if (keepm >> 10) {
+									const SnpEnt se = d.snp[si];
+									if (((se.key >> 48) & 0xFFu) == 0) { N_kpos[at][col0 + own] = se.pos; N_meta[at][col0 + own] = mt; at++; }
+									else {
+										const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
+										for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << (10 + j))) { N_kpos[at][col0 + own] = prow[j]; N_meta[at][col0 + own] = mt; at++; }
+									}
+								}
+							}
+						}
+						if (valid && fits && seg_total && (int)lane == se_l) N_cnt[col0 + own] = (uint16_t)(curc + seg_total);
 					}
+					VG_WAVE_SYNC();
 				}
-				wcnt += round_total;
 			}
-			if constexpr (STATS) {
-				const int ids[] = {S_REF_QUERY, S_SNP_QUERY, S_REF_PROBE, S_SNP_PROBE, S_SCAN_REF, S_SCAN_SNP, S_SCAN_OOB, S_AUX_REF, S_AUX_SNP, S_SITE_TEST, S_CTX};
-				for (int id : ids) { const uint32_t sum = wave_sum<STATS>(hs.v[id]); if ((int)lane == owner) cur.v[id] += sum; }
-			}
-			if ((int)lane == owner) {
-				pend &= ~(1u << c);
-				ncnt = wcnt;
-				if (wovf) { ovf = true; pend = 0; }
-			}
+			VG_WAVE_SYNC();
+			ncnt = N_cnt[col];
+			if (N_ovf[col]) ovf = true;
+			if constexpr (STATS) for (int i = 0; i < NSH; i++) cur.v[SH_IDS[i]] += S_own[i][col];
 		}
 		VG_WAVE_SYNC();
 
