@@ -479,22 +479,28 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 				pile[sp] = (info & 3u) | (alt << 2) | ((uint32_t)a->snp_rf[i] << 16) | ((uint32_t)a->snp_af[i] << 24);
 			}
 		}
+		std::vector<uint8_t> pile8(plen, 0);
+		std::vector<ulonglong2> rank(plen / 64 + 1, ulonglong2{0, 0});
 		for (uint64_t p = 0; p < plen; p++) {
 			const uint32_t w = pile[p];
 			const uint32_t r = w & 3u, al = (w >> 2) & 3u;
+			if ((p & 63) == 0) rank[p >> 6].y = ix->site_pos.size();
 			if (r != al) {
 				ix->site_pos.push_back((uint32_t)p); ix->site_ref.push_back((uint8_t)r); ix->site_alt.push_back((uint8_t)al);
 				ix->site_rf.push_back((uint8_t)(w >> 16)); ix->site_af.push_back((uint8_t)(w >> 24));
-				pile[p] = (w & 15u) | ((uint32_t)ix->site_pos.size() << 4);      // site id + 1
+				pile8[p] = (uint8_t)((w & 15u) | 16u);
+				rank[p >> 6].x |= 1ull << (p & 63);
 			} else {
-				pile[p] = w & 15u;
+				pile8[p] = (uint8_t)(w & 15u);
 			}
 		}
 		ix->n_sites = ix->site_pos.size();
-		if (ix->n_sites >= (1ull << 28)) return fail(VG_ETOOBIG, "more than 2^28 SNP sites");
-		uint32_t *dp = nullptr, *dc = nullptr;
-		if ((rc = dev_upload(ix, &dp, pile.data(), plen))) return rc;
+		if (ix->n_sites >= (1ull << 31)) return fail(VG_ETOOBIG, "more than 2^31 SNP sites");
+		uint8_t *dp = nullptr; ulonglong2 *dr = nullptr; uint32_t *dc = nullptr;
+		if ((rc = dev_upload(ix, &dp, pile8.data(), plen))) return rc;
+		if ((rc = dev_upload(ix, &dr, rank.data(), rank.size()))) return rc;
 		if ((rc = dev_alloc(ix, &dc, 2 * ix->n_sites + 2, true))) return rc;
+		d.srank = dr;
 		d.pile = dp; d.pile_len = plen; d.cnt = dc;
 	}
 	// ---- scratch of the lane tier, overflow counters, stats

@@ -48,9 +48,12 @@ struct DevIndex {
 	// bit vectors (src/generate_bf.h:112-142)
 	const uint64_t *ref_bf; uint64_t ref_bf_bits;
 	const uint64_t *snp_bf; uint64_t snp_bf_bits;
-	// dense per-position site word: bits 0-1 ref, 2-3 alt (src/vartype.h:81-90), bits 4.. = site id + 1
-	// (0 when ref == alt).  Replaces the counters of packed_pileup_entry, which live in `cnt`.
-	const uint32_t *pile; uint64_t pile_len;
+	// one byte per genome position: bits 0-1 ref, 2-3 alt as seeded from the SNP dictionary (src/vartype.h:81-90,
+	// qv.cc:637-659), bit 4 = "is a SNP site" (ref != alt).  A 32-base pile-up walk reads 32 contiguous bytes (the
+	// reference's packed_pileup_entry table costs 128).  The site id behind a position comes from a rank block:
+	// per 64 positions {bit mask of sites, number of sites before the block}; counters live in `cnt`.
+	const uint8_t *pile; uint64_t pile_len;
+	const ulonglong2 *srank;       // [pile_len / 64 + 1]  .x = site bits of the block, .y = sites before it
 	uint32_t *cnt;                 // [2 * n_sites] exact sums: [2s] ref, [2s+1] alt
 };
 
@@ -101,9 +104,11 @@ __device__ inline void jg_pair(const uint32_t *jg, uint64_t h, uint32_t &lo, uin
 	lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
 }
 
-// query_ref_dict, src/qv.cc:206-240.  Returns the entry index or -1; lo/hi = bucket of HI32(k).
+// query_ref_dict, src/qv.cc:206-240.  Returns the entry index or -1; lo/hi = bucket of HI32(k); `ent` = the entry
+// found (every probe fetches the whole 16-byte entry, so a hit needs no second gather).  Keys are unique within
+// a bucket, so an equality search returns what bsearch() returns.
 template <class ST>
-__device__ inline int64_t ref_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi)
+__device__ inline int64_t ref_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi, RefEnt &ent)
 {
 	jg_pair(d.ref_jg, k >> 32, lo, hi);
 	st.add(S_REF_QUERY, 1);
@@ -111,12 +116,23 @@ __device__ inline int64_t ref_query(const DevIndex &d, ST &st, uint64_t k, uint3
 	st.add(S_REF_PROBE, ceil_log2_p1(hi - lo));
 	const uint32_t key = (uint32_t)k;
 	uint32_t a = lo, b = hi;
-	while (a < b) { const uint32_t m = a + ((b - a) >> 1); if (d.ref[m].lo < key) a = m + 1; else b = m; }
-	return (a < hi && d.ref[a].lo == key) ? (int64_t)a : -1;
+	while (a < b) {
+		const uint32_t m = a + ((b - a) >> 1);
+		ent = d.ref[m];
+		if (ent.lo == key) return (int64_t)m;
+		if (ent.lo < key) a = m + 1; else b = m;
+	}
+	return -1;
+}
+template <class ST>
+__device__ inline int64_t ref_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi)
+{
+	RefEnt e;
+	return ref_query(d, st, k, lo, hi, e);
 }
 // query_snp_dict, src/qv.cc:385-411
 template <class ST>
-__device__ inline int64_t snp_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi)
+__device__ inline int64_t snp_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi, SnpEnt &ent)
 {
 	jg_pair(d.snp_jg, k >> 40, lo, hi);
 	st.add(S_SNP_QUERY, 1);
@@ -124,8 +140,20 @@ __device__ inline int64_t snp_query(const DevIndex &d, ST &st, uint64_t k, uint3
 	st.add(S_SNP_PROBE, ceil_log2_p1(hi - lo));
 	const uint64_t key = k & LO40_MASK;
 	uint32_t a = lo, b = hi;
-	while (a < b) { const uint32_t m = a + ((b - a) >> 1); if ((d.snp[m].key & LO40_MASK) < key) a = m + 1; else b = m; }
-	return (a < hi && (d.snp[a].key & LO40_MASK) == key) ? (int64_t)a : -1;
+	while (a < b) {
+		const uint32_t m = a + ((b - a) >> 1);
+		ent = d.snp[m];
+		const uint64_t ek = ent.key & LO40_MASK;
+		if (ek == key) return (int64_t)m;
+		if (ek < key) a = m + 1; else b = m;
+	}
+	return -1;
+}
+template <class ST>
+__device__ inline int64_t snp_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi)
+{
+	SnpEnt e;
+	return snp_query(d, st, k, lo, hi, e);
 }
 
 template <class ST>
@@ -135,28 +163,38 @@ __device__ inline bool site_loose(const DevIndex &d, ST &st, uint32_t p)     // 
 	return p < d.pile_len && (d.pile[p] & 15u) != 0;
 }
 
-// pile-up walk of one supporting context (src/qv.cc:1386-1436 = :1444-1494): 32 consecutive site words,
-// fetched as eight 16-byte gathers; saturation is applied at fetch time as min(63, sum).
+// pile-up walk of one supporting context (src/qv.cc:1386-1436 = :1444-1494): 32 consecutive site bytes as two
+// 16-byte gathers; only bases that match ref or alt at a site need the site id (one rank-block gather).
+// Saturation is applied at fetch time as min(63, sum).
 template <class ST>
 __device__ inline void walk_ctx(const DevIndex &d, ST &st, uint64_t kk, uint32_t kpos, uint32_t mod)
 {
 	st.add(S_WALKS, 1);
 	if ((uint64_t)kpos + 32 > d.pile_len) return;          // cannot happen: pile_len = max position + 64
-	#pragma unroll 2
-	for (uint32_t g = 0; g < 8; g++) {
-		uint4 w4;
-		__builtin_memcpy(&w4, d.pile + kpos + 4 * g, 16);
-		const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-		#pragma unroll
-		for (uint32_t j = 0; j < 4; j++) {
-			const uint32_t b = 4 * g + j;
-			if (w[j] < 16u || b == mod) continue;               // ref == alt: not a site (:1404)
-			const uint32_t base = (uint32_t)(kk >> (2 * b)) & 3u;
-			uint32_t which;
-			if (base == (w[j] & 3u)) which = 0; else if (base == ((w[j] >> 2) & 3u)) which = 1; else continue;
-			atomicAdd(&d.cnt[2ull * ((w[j] >> 4) - 1) + which], 1u);
-			st.add(S_INCR, 1);
-		}
+	uint4 w4[2];
+	__builtin_memcpy(&w4[0], d.pile + kpos, 16);
+	__builtin_memcpy(&w4[1], d.pile + kpos + 16, 16);
+	const uint32_t w[8] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w};
+	// site flags of the 32 positions: bit 4 of every byte
+	uint32_t sites = 0;
+	#pragma unroll
+	for (int g = 0; g < 8; g++) {
+		const uint32_t f = (w[g] >> 4) & 0x01010101u;               // one flag per byte
+		sites |= ((f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu) << (4 * g);
+	}
+	if (mod < 32u) sites &= ~(1u << mod);
+	while (sites) {
+		const uint32_t b = (uint32_t)__ffs((int)sites) - 1;
+		sites &= sites - 1;
+		const uint32_t by = (w[b >> 2] >> (8 * (b & 3u))) & 0xFFu;
+		const uint32_t base = (uint32_t)(kk >> (2 * b)) & 3u;
+		uint32_t which;
+		if (base == (by & 3u)) which = 0; else if (base == ((by >> 2) & 3u)) which = 1; else continue;
+		const uint32_t p = kpos + b;
+		const ulonglong2 rb = d.srank[p >> 6];
+		const uint32_t sid = (uint32_t)rb.y + (uint32_t)__popcll(rb.x & ((1ull << (p & 63u)) - 1ull));
+		atomicAdd(&d.cnt[2ull * sid + which], 1u);
+		st.add(S_INCR, 1);
 	}
 }
 

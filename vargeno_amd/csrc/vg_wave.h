@@ -143,9 +143,9 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 				const uint64_t k = chunk_kmer(c);
 				cur.add(S_CHUNKS, 1);
 				uint32_t lo, hi;
-				const int64_t ri = ref_query(d, cur, k, lo, hi);
+				RefEnt e;
+				const int64_t ri = ref_query(d, cur, k, lo, hi, e);
 				if (ri >= 0) {                                                   // qv.cc:850-890
-					const RefEnt e = d.ref[ri];
 					if (e.pos != POS_AMBIGUOUS) {
 						if (e.amb == 0) {
 							cur.add(S_CTX, 1);
@@ -162,15 +162,15 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 						}
 					}
 				}
-				const int64_t si = snp_query(d, cur, k, lo, hi);
+				SnpEnt se;
+				const int64_t si = snp_query(d, cur, k, lo, hi, se);
 				if (si >= 0) {                                                   // qv.cc:897-937
-					const SnpEnt e = d.snp[si];
-					if (e.pos != POS_AMBIGUOUS) {
-						if (((e.key >> 48) & 0xFFu) == 0) {
+					if (se.pos != POS_AMBIGUOUS) {
+						if (((se.key >> 48) & 0xFFu) == 0) {
 							cur.add(S_CTX, 1);
-							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = e.pos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
+							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = se.pos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
 						} else {
-							const uint32_t *prow = d.snp_aux_pos + (uint64_t)e.pos * AUX_COLS;
+							const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
 							cur.add(S_AUX_SNP, 1);
 							for (int j = 0; j < AUX_COLS; j++) {
 								const uint32_t p = prow[j];
