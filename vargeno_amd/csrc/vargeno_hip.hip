@@ -175,21 +175,52 @@ __device__ inline int classify_bad(const uint8_t *p, uint32_t n)
 // Streaming pre-pass: ASCII -> chunk k-mers + one flag word per read (gate bits: chunk c is gate-open iff
 // qual[c] < '8', src/qv.cc:836, 943 -- the chunk NUMBER indexes the quality string).  Chunk c of read r
 // lands at pk_kmer[(offsets[r] >> 5) + c]; slots of different reads cannot collide.
+// A workgroup takes 256 consecutive reads: their bases are one contiguous span, copied to LDS with coalesced
+// 16-byte loads (lane-per-read loads at a 150-byte stride fetched every line ~2.5 times), then each lane packs
+// its own read out of LDS.  Only the first n quality characters of a read are ever looked at.
+constexpr uint32_t PACK_LDS = 40 * 1024;       // 256 reads of up to 160 bases; longer reads take the direct path
 __global__ __launch_bounds__(256) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
                                                       uint64_t n_reads, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta)
 {
-	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
-		const uint64_t off = offsets[r];
-		const uint32_t n = (uint32_t)((offsets[r + 1] - off) >> 5);
-		const uint8_t *p = bases + off, *q = quals + off;
-		uint64_t meta = 0, bad = 0;
-		for (uint32_t c = 0; c < n; c++) {
-			pk_kmer[(off >> 5) + c] = encode32(p + 32 * c, bad);
-			if (c < 32 && (int)(int8_t)q[c] - '8' < 0) meta |= 1ull << c;
+	__shared__ __attribute__((aligned(16))) uint8_t sm[PACK_LDS + 64];
+	for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_reads; r0 += (uint64_t)gridDim.x * 256) {
+		const uint64_t r = r0 + threadIdx.x;
+		const uint64_t rl = r0 + 256 < n_reads ? r0 + 256 : n_reads;
+		const uint64_t base0 = offsets[r0], span = offsets[rl] - base0;
+		const bool staged = span <= PACK_LDS;
+		__syncthreads();                                              // previous tile fully consumed
+		if (staged) {
+			for (uint64_t i = (uint64_t)threadIdx.x * 16; i < span; i += 256 * 16) {
+				if (i + 16 <= span) {
+					uint4 v;
+					__builtin_memcpy(&v, bases + base0 + i, 16);
+					*reinterpret_cast<uint4 *>(sm + i) = v;
+				} else {
+					for (uint64_t j = i; j < span; j++) sm[j] = bases[base0 + j];
+				}
+			}
 		}
-		if (bad) meta |= classify_bad(p, n) == 1 ? PK_SKIP_N : PK_INVALID;
-		if (n > 32) meta |= PK_LONG;
-		pk_meta[r] = meta;
+		__syncthreads();
+		if (r < n_reads) {
+			const uint64_t off = offsets[r];
+			const uint32_t n = (uint32_t)((offsets[r + 1] - off) >> 5);
+			const uint8_t *q = quals + off;
+			uint64_t meta = 0, bad = 0;
+			if (staged) {
+				const uint8_t *p = sm + (off - base0);
+				for (uint32_t c = 0; c < n; c++) {
+					uint64_t w[4];
+					__builtin_memcpy(w, p + 32 * c, 32);
+					pk_kmer[(off >> 5) + c] = (uint64_t)pack8(w[0], bad) | ((uint64_t)pack8(w[1], bad) << 16) | ((uint64_t)pack8(w[2], bad) << 32) | ((uint64_t)pack8(w[3], bad) << 48);
+				}
+			} else {
+				for (uint32_t c = 0; c < n; c++) pk_kmer[(off >> 5) + c] = encode32(bases + off + 32 * c, bad);
+			}
+			for (uint32_t c = 0; c < n && c < 32; c++) if ((int)(int8_t)q[c] - '8' < 0) meta |= 1ull << c;
+			if (bad) meta |= classify_bad(bases + off, n) == 1 ? PK_SKIP_N : PK_INVALID;
+			if (n > 32) meta |= PK_LONG;
+			pk_meta[r] = meta;
+		}
 	}
 }
 
