@@ -117,6 +117,21 @@ __global__ void vg_make_sec_keys(const uint64_t *__restrict__ kmer, uint64_t n, 
 	}
 }
 
+// merged exact-match view: after the stable sort, val = index into the concatenation [ref | snp]
+__global__ void vg_make_mx_entries(const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, uint64_t n_ref,
+                                   const uint32_t *__restrict__ rpos, const uint8_t *__restrict__ ramb, const uint32_t *__restrict__ spos, const uint8_t *__restrict__ samb,
+                                   uint4 *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t v = val[i];
+		const bool is_snp = v >= n_ref;
+		const uint32_t pos = is_snp ? spos[v - n_ref] : rpos[v];
+		const uint32_t amb = is_snp ? samb[v - n_ref] : ramb[v];
+		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1), 0u);
+	}
+}
+__global__ void vg_iota_u32(uint32_t *v, uint64_t n) { for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i; }
+
 // SoA as the dictionary file has it -> one 16-byte entry per k-mer (a hit then costs one line)
 __global__ void vg_make_ref_entries(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ pos, const uint8_t *__restrict__ amb, uint64_t n, RefEnt *__restrict__ out)
 {
@@ -482,6 +497,30 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		if ((rc = dev_upload(ix, &xp, a->snp_aux_pos, a->n_snp_aux * AUX_COLS))) return rc;
 		if ((rc = dev_upload(ix, &xi, a->snp_aux_info, a->n_snp_aux * AUX_COLS))) return rc;
 		d.snp_jg = jg; d.snp = ent; d.snp_aux_pos = xp; d.snp_aux_info = xi;
+		// merged exact-match view (both dictionaries behind one HI32 jump table)
+		const uint64_t nm = a->n_ref + a->n_snp;
+		if (!getenv("VG_NO_MX") && nm < (1ull << 32)) {
+			TempDev<uint64_t> kin, kout; TempDev<uint32_t> vin, vout, rp; TempDev<uint8_t> ra;
+			if ((rc = rp.upload(a->ref_pos, a->n_ref))) return rc;
+			if ((rc = ra.upload(a->ref_amb, a->n_ref))) return rc;
+			hipError_t e1 = hipMalloc((void **)&kin.p, (size_t)(nm ? nm : 1) * 8), e2 = hipMalloc((void **)&kout.p, (size_t)(nm ? nm : 1) * 8);
+			hipError_t e3 = hipMalloc((void **)&vin.p, (size_t)(nm ? nm : 1) * 4), e4 = hipMalloc((void **)&vout.p, (size_t)(nm ? nm : 1) * 4);
+			if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(merged view staging)");
+			if (a->n_ref) HIP_TRY(hipMemcpy(kin.p, a->ref_kmer, (size_t)a->n_ref * 8, hipMemcpyHostToDevice));
+			if (a->n_snp) HIP_TRY(hipMemcpy(kin.p + a->n_ref, tk.p, (size_t)a->n_snp * 8, hipMemcpyDeviceToDevice));
+			vg_iota_u32<<<2048, 256, 0, ix->stream>>>(vin.p, nm);
+			HIP_TRY(hipGetLastError());
+			const int se = vg_dev_sort_pairs_u64_u32(kin.p, kout.p, vin.p, vout.p, nm, ix->stream);     // stable: ref before snp on equal k-mers
+			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
+			uint32_t *mjg = nullptr; uint4 *mx = nullptr;
+			if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
+			if ((rc = dev_alloc(ix, &mx, nm))) return rc;
+			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, ix->stream>>>(kout.p, nm, mjg, 1ull << 32, 32);
+			vg_make_mx_entries<<<2048, 256, 0, ix->stream>>>(kout.p, vout.p, nm, a->n_ref, rp.p, ra.p, tp.p, ta.p, mx);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(ix->stream));
+			d.mx_jg = mjg; d.mx = mx;
+		}
 	}
 	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first
 	//      2^32 bits of the 9.6 Gbit reference vector can ever be read (src/generate_bf.h:112-128)

@@ -39,6 +39,12 @@ struct DevIndex {
 	const uint32_t *sec_idx;       // [n_ref]
 	const uint32_t *sec_jg;        // [2^sec_bits + 1]
 	uint32_t sec_bits;
+	// merged exact-match view: the reference and SNP dictionaries sorted together by k-mer (reference entry first on
+	// ties) behind ONE jump table over HI32, so the two exact look-ups of a chunk (qv.cc:840-841) cost one
+	// jump-table gather + at most one bucket line instead of two of each.  mx entry: {lo32, pos, flags, -} with
+	// flags bit 0 = SNP-dictionary entry, bit 1 = ambig_flag.
+	const uint32_t *mx_jg;         // [2^32 + 1]
+	const uint4 *mx;               // [n_ref + n_snp]
 	// SNP dictionary (src/qv.cc:606-695)
 	const uint32_t *snp_jg;        // [2^24 + 1]
 	const SnpEnt   *snp;           // [n_snp]

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 	// The secondary (LO32-ordered) view answers the 48 high-half reference queries with one bucket read.  The counting
 	// build keeps the 48 individual queries because the event counters price each of them.
 	const bool use_sec = !STATS && d.sec_key != nullptr;
+	const bool use_mx = !STATS && d.mx != nullptr;
 	const uint32_t lane = threadIdx.x & 63u;             // lane in the wave
 	const uint32_t col = threadIdx.x;                    // this lane's LDS column
 	const uint32_t col0 = threadIdx.x & ~63u;            // first column of this wave
@@ -143,41 +144,60 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 				const uint64_t k = chunk_kmer(c);
 				cur.add(S_CHUNKS, 1);
 				uint32_t lo, hi;
-				RefEnt e;
-				const int64_t ri = ref_query(d, cur, k, lo, hi, e);
-				if (ri >= 0) {                                                   // qv.cc:850-890
-					if (e.pos != POS_AMBIGUOUS) {
-						if (e.amb == 0) {
+				// exact hits (qv.cc:850-937).  The timed build reads the merged view (one jump-table gather + one bucket line for
+				// both dictionaries); the counting build does the reference's two separate walks, whose probes the event
+				// counters price.
+				uint32_t rpos = 0, ramb = 0, spos = 0, samb = 0;
+				bool rhit = false, shit = false;
+				if (use_mx) {
+					jg_pair(d.mx_jg, k >> 32, lo, hi);
+					const uint32_t key = (uint32_t)k;
+					uint32_t ea = lo;
+					if (hi - lo > 4) {                                            // rare big bucket (low-complexity HI32): bisect to the first candidate
+						uint32_t eb = hi;
+						while (ea < eb) { const uint32_t m = ea + ((eb - ea) >> 1); if (d.mx[m].x < key) ea = m + 1; else eb = m; }
+					}
+					for (uint32_t e = ea; e < hi; e++) {                          // buckets of the merged view mostly hold 0-2 entries
+						const uint4 v = d.mx[e];
+						if (v.x < key) continue;
+						if (v.x > key) break;
+						if (v.z & 1u) { shit = true; spos = v.y; samb = (v.z >> 1) & 1u; }
+						else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
+					}
+				} else {
+					RefEnt e; SnpEnt se;
+					rhit = ref_query(d, cur, k, lo, hi, e) >= 0;
+					if (rhit) { rpos = e.pos; ramb = e.amb; }
+					shit = snp_query(d, cur, k, lo, hi, se) >= 0;
+					if (shit) { spos = se.pos; samb = (uint32_t)((se.key >> 48) & 0xFFu); }
+				}
+				if (rhit && rpos != POS_AMBIGUOUS) {
+					if (ramb == 0) {
+						cur.add(S_CTX, 1);
+						if (ecnt < W_ECAP) { E_kpos[ecnt][col] = rpos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
+					} else {
+						const uint32_t *row = d.ref_aux + (uint64_t)rpos * AUX_COLS;
+						cur.add(S_AUX_REF, 1);
+						for (int j = 0; j < AUX_COLS; j++) {
+							const uint32_t p = row[j];
+							if (p == 0) break;
 							cur.add(S_CTX, 1);
-							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = e.pos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
-						} else {
-							const uint32_t *row = d.ref_aux + (uint64_t)e.pos * AUX_COLS;
-							cur.add(S_AUX_REF, 1);
-							for (int j = 0; j < AUX_COLS; j++) {
-								const uint32_t p = row[j];
-								if (p == 0) break;
-								cur.add(S_CTX, 1);
-								if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
-							}
+							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
 						}
 					}
 				}
-				SnpEnt se;
-				const int64_t si = snp_query(d, cur, k, lo, hi, se);
-				if (si >= 0) {                                                   // qv.cc:897-937
-					if (se.pos != POS_AMBIGUOUS) {
-						if (((se.key >> 48) & 0xFFu) == 0) {
+				if (shit && spos != POS_AMBIGUOUS) {
+					if (samb == 0) {
+						cur.add(S_CTX, 1);
+						if (ecnt < W_ECAP) { E_kpos[ecnt][col] = spos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
+					} else {
+						const uint32_t *prow = d.snp_aux_pos + (uint64_t)spos * AUX_COLS;
+						cur.add(S_AUX_SNP, 1);
+						for (int j = 0; j < AUX_COLS; j++) {
+							const uint32_t p = prow[j];
+							if (p == 0) break;
 							cur.add(S_CTX, 1);
-							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = se.pos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
-						} else {
-							const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
-							cur.add(S_AUX_SNP, 1);
-							for (int j = 0; j < AUX_COLS; j++) {
-								const uint32_t p = prow[j];
-								if (p == 0) break;
-								cur.add(S_CTX, 1);
-								if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
-							}
+							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
 						}
 					}
 				}
