@@ -166,6 +166,15 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         k_ms = tm["ms_main"]
         achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel cannot be counted inside a timed run: it comes from the separate
+        # rocprofv3 --pmc passes of this same command, committed under profiles/ (null for any other workload)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
+            if tj["workload"] == {"genome": args.genome, "snps": args.snps, "reads": args.reads}:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "reads/sec genotyped (whole node)",
             "value": world * r.n * args.steps / elapsed,
@@ -181,7 +190,7 @@ def main():
                                    "0.5%% error, 8%% low-quality chars, seed 20261002" % (g.total_len, len(s.pos), r.n),
                        "reads_per_step_per_gpu": r.n, "index_bytes_hbm": gx.device_bytes,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K batches" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "vg_wave_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "algorithmic_bytes_per_read": alg_bytes_per_launch / r.n},
             "cpu_baseline": cpu,
