@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
     ap.add_argument("--genome", type=int, default=40_000_000)
     ap.add_argument("--snps", type=int, default=1_000_000)
+    ap.add_argument("--chroms", type=int, default=1, help="number of sequences the genome is split into")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench"))
     ap.add_argument("--no-check", action="store_true", help="skip the parity check against the oracle")
@@ -50,21 +51,27 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)               # one rank per GPU; (VG_BENCH_BACKEND=gloo lets ranks share a GPU for plumbing tests)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        backend = os.environ.get("VG_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
 
     from vargeno_amd import synth
     from vargeno_amd.api import GenoIndex, all_reduce_counts
 
     # ---- data set + index files (rank 0 builds, everyone loads a replica) ------------------------
-    tag = "g%d_s%d" % (args.genome, args.snps)
+    tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms)
     d = os.path.join(args.workdir, tag)
     prefix = os.path.join(d, "idx")
     t0 = time.time()
-    g, s, r = synth.chr22_scale(genome_len=args.genome, n_snps=args.snps, n_reads=args.reads)
+    g, s, r = synth.chr22_scale(genome_len=args.genome, n_snps=args.snps, n_reads=args.reads, n_chroms=args.chroms)
     if rank == 0:
         log("[bench] synthetic data: %.1fs (%d bp, %d SNPs, %d reads)" % (time.time() - t0, g.total_len, len(s.pos), r.n))
         if not os.path.exists(prefix + ".ref.dict"):
@@ -79,7 +86,7 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    gx = GenoIndex.open(prefix, device=local_rank)
+    gx = GenoIndex.open(prefix, device=dev_index)
     if rank == 0:
         log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (time.time() - t0, gx.device_bytes / 1e9, gx.num_sites))
 
@@ -186,8 +193,10 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "chr22-scale (BASELINE.json configs[1]): %d bp synthetic genome, %d SNPs, %d x 150 bp reads per GPU per step, "
-                                   "0.5%% error, 8%% low-quality chars, seed 20261002" % (g.total_len, len(s.pos), r.n),
+            "config": {"workload": "%s: %d bp synthetic genome in %d sequence(s), %d SNPs, %d x 150 bp reads per GPU per step, "
+                                   "0.5%% error, 8%% low-quality chars, seed 20261002" % (
+                                       "chr22-scale (BASELINE.json configs[1])" if g.total_len < 10 ** 9 else "hg38-scale (BASELINE.json configs[2], one batch of its 30x reads)",
+                                       g.total_len, len(g.seqs), len(s.pos), r.n),
                        "reads_per_step_per_gpu": r.n, "index_bytes_hbm": gx.device_bytes,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K batches" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,

@@ -493,31 +493,61 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 		}
 		// stable by k-mer == ascending position within equal k-mers
 		__gnu_parallel::sort(kmers.begin(), kmers.end(), [](const KP &a, const KP &b) { return a.kmer < b.kmer || (a.kmer == b.kmer && a.pos < b.pos); });
-		std::vector<uint8_t> out, aux;
-		out.reserve(16 + total * 13);
-		uint64_t zero = 0; put(out, &zero, 8); put(out, &zero, 8);
-		uint64_t written = 0, aux_count = 0, unamb = 0, amb_unique = 0, amb_total = 0;
-		for (size_t a = 0; a < kmers.size();) {
-			size_t b = a + 1;
-			while (b < kmers.size() && kmers[b].kmer == kmers[a].kmer) b++;
-			put(out, &kmers[a].kmer, 8);
-			const uint8_t z8 = 0, one = 1;
-			if (b - a == 1) { unamb++; put(out, &kmers[a].pos, 4); put(out, &z8, 1); }
-			else {
-				amb_unique++; amb_total += b - a;
-				uint32_t posv;
-				if (b - a > (size_t)AUX_COLS) posv = POS_AMBIGUOUS;
-				else {
-					posv = (uint32_t)aux_count++;
-					for (int j = 0; j < AUX_COLS; j++) { const uint32_t v = a + (size_t)j < b ? kmers[a + (size_t)j].pos : 0u; put(aux, &v, 4); }
-				}
-				put(out, &posv, 4); put(out, &one, 1);
-			}
-			written++;
-			a = b;
+		// write_kmers (dictgen.c:63-154) in parallel: run starts -> unique index, runs of 2..10 -> aux row index
+		const size_t nk = kmers.size();
+		const int T = std::max(1, nthreads);
+		std::vector<size_t> c_runs((size_t)T + 1, 0), c_aux((size_t)T + 1, 0);
+		auto chunk_lo = [&](int t) { return nk * (size_t)t / (size_t)T; };
+		#pragma omp parallel for schedule(static, 1)
+		for (int t = 0; t < T; t++) {
+			size_t runs = 0;
+			for (size_t i = chunk_lo(t); i < chunk_lo(t + 1); i++) runs += (i == 0 || kmers[i].kmer != kmers[i - 1].kmer);
+			c_runs[(size_t)t + 1] = runs;
 		}
+		for (int t = 0; t < T; t++) c_runs[(size_t)t + 1] += c_runs[(size_t)t];
+		const uint64_t written = c_runs[(size_t)T];
+		std::vector<uint32_t> S(written + 1);                           // start of run r (nk < 2^32 is checked by geno's loader anyway)
+		S[written] = (uint32_t)nk;
+		#pragma omp parallel for schedule(static, 1)
+		for (int t = 0; t < T; t++) {
+			size_t r = c_runs[(size_t)t];
+			for (size_t i = chunk_lo(t); i < chunk_lo(t + 1); i++) if (i == 0 || kmers[i].kmer != kmers[i - 1].kmer) S[r++] = (uint32_t)i;
+		}
+		if (nk >= (1ull << 32)) die("more than 2^32 32-mers in the reference");
+		auto run_lo = [&](int t) { return (size_t)written * (size_t)t / (size_t)T; };
+		#pragma omp parallel for schedule(static, 1)
+		for (int t = 0; t < T; t++) {
+			size_t na = 0;
+			for (size_t r = run_lo(t); r < run_lo(t + 1); r++) { const uint32_t L = S[r + 1] - S[r]; na += (L >= 2 && L <= (uint32_t)AUX_COLS); }
+			c_aux[(size_t)t + 1] = na;
+		}
+		for (int t = 0; t < T; t++) c_aux[(size_t)t + 1] += c_aux[(size_t)t];
+		const uint64_t aux_count = c_aux[(size_t)T];
+		std::vector<uint8_t> out(16 + written * 13 + aux_count * 40);
 		memcpy(&out[0], &written, 8); memcpy(&out[8], &aux_count, 8);
-		out.insert(out.end(), aux.begin(), aux.end());
+		uint64_t unamb = 0, amb_unique = 0, amb_total = 0;
+		#pragma omp parallel for schedule(static, 1) reduction(+ : unamb, amb_unique, amb_total)
+		for (int t = 0; t < T; t++) {
+			size_t ax = c_aux[(size_t)t];
+			for (size_t r = run_lo(t); r < run_lo(t + 1); r++) {
+				const size_t a = S[r], bnd = S[r + 1], L = bnd - a;
+				uint8_t *rec = &out[16 + r * 13];
+				memcpy(rec, &kmers[a].kmer, 8);
+				uint32_t posv; uint8_t flag;
+				if (L == 1) { unamb++; posv = kmers[a].pos; flag = 0; }
+				else {
+					amb_unique++; amb_total += L; flag = 1;
+					if (L > (size_t)AUX_COLS) posv = POS_AMBIGUOUS;
+					else {
+						posv = (uint32_t)ax;
+						uint8_t *row = &out[16 + written * 13 + ax * 40];
+						for (int j = 0; j < AUX_COLS; j++) { const uint32_t v = (size_t)j < L ? kmers[a + (size_t)j].pos : 0u; memcpy(row + 4 * j, &v, 4); }
+						ax++;
+					}
+				}
+				memcpy(rec + 8, &posv, 4); rec[12] = flag;
+			}
+		}
 		write_file(prefix + ".ref.dict", out);
 		if (!opt.quiet) {
 			printf("Ref Dictionary\nTotal k-mers:        %lu\nUnambig k-mers:      %lu\nAmbig unique k-mers: %lu\nAmbig total k-mers:  %lu\n",

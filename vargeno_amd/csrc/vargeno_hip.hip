@@ -512,6 +512,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 			HIP_TRY(hipGetLastError());
 			const int se = vg_dev_sort_pairs_u64_u32(kin.p, kout.p, vin.p, vout.p, nm, ix->stream);     // stable: ref before snp on equal k-mers
 			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
+			(void)hipFree(kin.p); kin.p = nullptr; (void)hipFree(vin.p); vin.p = nullptr;      // make room before the 16 GiB table
 			uint32_t *mjg = nullptr; uint4 *mx = nullptr;
 			if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
 			if ((rc = dev_alloc(ix, &mx, nm))) return rc;

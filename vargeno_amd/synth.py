@@ -151,7 +151,14 @@ def make_genome(rng, lengths, names, *, repeats_per_mbp=50.0, repeat_len=(200, 2
 def make_snps(rng, genome, n, *, with_caf=True):
     """Uniform positions (not N, not within 32 of a chromosome end), one alt != ref, CAF ~ Beta(5,1)."""
     lens = np.array([len(s) for s in genome.seqs], dtype=np.int64)
-    glob = np.sort(rng.choice(int(lens.sum()), size=min(n, int(lens.sum()) // 3), replace=False))
+    total = int(lens.sum())
+    n = min(n, total // 3)
+    if total <= 1 << 28:
+        glob = np.sort(rng.choice(total, size=n, replace=False))
+    else:                                        # a permutation of a 3 Gbp population is too slow: draw, de-duplicate, trim
+        glob = np.unique(rng.integers(0, total, size=int(n * 1.02) + 1000, dtype=np.int64))
+        if len(glob) > n:
+            glob = np.sort(rng.choice(glob, size=n, replace=False))
     starts = np.concatenate([[0], np.cumsum(lens)])
     chrom = (np.searchsorted(starts, glob, side="right") - 1).astype(np.int32)
     pos0 = glob - starts[chrom]
@@ -303,10 +310,17 @@ def f_tiny(seed=7):
     return g, s, r
 
 
-def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=1_000_000):
-    """BASELINE.json configs[1]: one 40 Mbp chromosome, ~1 M SNPs, 1 M x 150 bp reads (F-mid recipe)."""
+def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=1_000_000, n_chroms=1):
+    """BASELINE.json configs[1]: one 40 Mbp chromosome, ~1 M SNPs, 1 M x 150 bp reads (F-mid recipe).
+    With genome_len = 3.1e9, n_chroms = 24, n_snps = 1e7 the same recipe gives the hg38-scale configs[2]."""
     rng = np.random.default_rng(seed)
-    g = make_genome(rng, [genome_len], ["chr22"], repeats_per_mbp=50.0, repeat_len=(200, 2000),
+    if n_chroms == 1:
+        lens, names = [genome_len], ["chr22"]
+    else:
+        w = np.linspace(2.0, 0.6, n_chroms)
+        lens = [int(x) for x in np.floor(w / w.sum() * genome_len)]
+        names = ["chr%d" % (i + 1) for i in range(n_chroms)]
+    g = make_genome(rng, lens, names, repeats_per_mbp=50.0, repeat_len=(200, 2000),
                     repeat_div=0.02, microsat_per_mbp=12.5)
     s = make_snps(rng, g, n_snps)
     r = make_reads(rng, g, s, n_reads, lengths=(150,), err=0.005, lowq=0.08)
