@@ -419,7 +419,7 @@ extern "C" void vg_index_close(vg_index *ix)
 
 static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 {
-	if (a->n_ref >= (1ull << 32) || a->n_snp >= (1ull << 32)) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
+	if (a->n_ref >= 0xFFFFFFFFull || a->n_snp >= 0xFFFFFFFFull) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
 	if (a->ref_bf_bits == 0 || a->snp_bf_bits == 0) return fail(VG_EINVAL, "empty bit vector");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VG_ENODEV, "no HIP device available (this library has no CPU fallback)");
@@ -581,7 +581,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
-	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 4, true))) return rc;
+	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 8, true))) return rc;       // [0..2] spill counts, [4],[5] work counters of the two wave tiers
 	if ((rc = dev_alloc(ix, &ix->d_cum, 4, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
 	HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -708,18 +708,18 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 	if (!ix->force_generic) {
 		// main stream: pack, then the wave tier.  (Packing batch k+1 on a third stream under batch k's wave
 		// kernel was measured and lost 12 %: two co-scheduled kernels split the CUs.)
-		HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
+		HIP_TRY(hipMemsetAsync(ctr, 0, 32, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->cus * 16);
 		vg_pack_kernel<<<pgrid, 256, 0, ix->stream>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->wave_grid / 4);
-		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, 4><<<wgrid, 256, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], ix->d_stats);
+		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, 4, 128><<<wgrid, 256, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], &ctr[4], ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		// second tier: the same kernel with deep lists over the spill list (2 waves per CU).  It stays on the main
 		// stream: on the tail stream it ran under the next batch's wave kernel and slowed that by 40 %.
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
-		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1><<<w2grid, 64, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], ix->d_stats);
+		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1, 2><<<w2grid, 64, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e4, 0));
 	} else {

@@ -28,6 +28,7 @@ namespace vg {
 // dependent gathers instead of the thousands the sequential lane machine needs.
 constexpr int W1_ECAP = 8, W1_NCAP = 4, W1_KCAP = 4;
 constexpr int W2_ECAP = 48, W2_NCAP = 48, W2_KCAP = 32;
+constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is also what a failed query's -1 truncates to
 constexpr int PCAP = 32;         // rows of the stage-B pair table (a wave with more gate-open chunks takes several windows)
 constexpr int SEC_RUN = 12;      // longest run of equal-LO32 entries one lane will walk in the LO32-ordered view
 constexpr int HCAP = 4;          // high-half reference hits per pair kept from the LO32-ordered view (more: the 48 queries are issued)
@@ -55,11 +56,13 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 // the wavefront-scope fence pair keeps the compiler from moving LDS accesses across the hand-off.
 #define VG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB>
+// WORK_CHUNK: reads a wave pulls from the launch's work counter at a time (large for the main tier, a handful for the
+// spill tier, whose few hundred heavy reads must spread over all its waves)
+template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB, int WORK_CHUNK>
 __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
-                                                     uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats)
+                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, unsigned long long *stats)
 {
 	// narrow element types keep a wave at 6.5 KB of LDS (24 waves per CU): an exact context only needs its
 	// chunk number next to the position, a neighbour context 13 bits, a vote key 8 + 1 bits of state
@@ -85,9 +88,10 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 	const uint32_t col0 = threadIdx.x & ~63u;            // first column of this wave
 	const uint64_t lane_bit = 1ull << lane;
 	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;
-	const uint64_t wave_id = (uint64_t)blockIdx.x * WPB + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * WPB;
-	uint64_t cursor = n_reads * wave_id / n_waves;
-	const uint64_t end = n_reads * (wave_id + 1) / n_waves;
+	// work distribution: waves pull WORK_CHUNK consecutive reads at a time from one device counter (zeroed per launch), so
+	// the last waves to finish differ by one chunk instead of by the variance of a static 1/n_waves share
+	uint64_t cursor = 0, end = 0;
+	bool drained = false;
 
 	bool active = false;
 	uint32_t rid = 0, n = 0, gates = 0, pass = 0;
@@ -104,6 +108,13 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 		// ------------------------------------------------------------------ refill free lanes
 		{
 			const uint64_t freem = __ballot(!active);
+			if (freem && cursor == end && !drained) {
+				uint32_t c0 = 0;
+				if (lane == 0) c0 = atomicAdd(work_next, (uint32_t)WORK_CHUNK);
+				c0 = __shfl(c0, 0);
+				if ((uint64_t)c0 >= n_reads) drained = true;
+				else { cursor = c0; end = (uint64_t)c0 + WORK_CHUNK < n_reads ? (uint64_t)c0 + WORK_CHUNK : n_reads; }
+			}
 			const uint64_t avail = end - cursor;
 			if (freem && avail) {
 				const uint32_t nfree = (uint32_t)__popcll(freem);
@@ -134,43 +145,14 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 				cursor += take;
 			}
 		}
-		if (!__any(active)) { if (cursor >= end) break; continue; }
+		if (!__any(active)) { if (drained) break; continue; }
 
 		// ------------------------------------------------------------------ stage A: exact look-ups
 		uint32_t ecnt = 0, ncnt = 0;
 		bool ovf = false;
 		if (active) {
-			for (uint32_t c = 0; c < n; c++) {
-				const uint64_t k = chunk_kmer(c);
-				cur.add(S_CHUNKS, 1);
-				uint32_t lo, hi;
-				// exact hits (qv.cc:850-937).  The timed build reads the merged view (one jump-table gather + one bucket line for
-				// both dictionaries); the counting build does the reference's two separate walks, whose probes the event
-				// counters price.
-				uint32_t rpos = 0, ramb = 0, spos = 0, samb = 0;
-				bool rhit = false, shit = false;
-				if (use_mx) {
-					jg_pair(d.mx_jg, k >> 32, lo, hi);
-					const uint32_t key = (uint32_t)k;
-					uint32_t ea = lo;
-					if (hi - lo > 4) {                                            // rare big bucket (low-complexity HI32): bisect to the first candidate
-						uint32_t eb = hi;
-						while (ea < eb) { const uint32_t m = ea + ((eb - ea) >> 1); if (d.mx[m].x < key) ea = m + 1; else eb = m; }
-					}
-					for (uint32_t e = ea; e < hi; e++) {                          // buckets of the merged view mostly hold 0-2 entries
-						const uint4 v = d.mx[e];
-						if (v.x < key) continue;
-						if (v.x > key) break;
-						if (v.z & 1u) { shit = true; spos = v.y; samb = (v.z >> 1) & 1u; }
-						else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
-					}
-				} else {
-					RefEnt e; SnpEnt se;
-					rhit = ref_query(d, cur, k, lo, hi, e) >= 0;
-					if (rhit) { rpos = e.pos; ramb = e.amb; }
-					shit = snp_query(d, cur, k, lo, hi, se) >= 0;
-					if (shit) { spos = se.pos; samb = (uint32_t)((se.key >> 48) & 0xFFu); }
-				}
+			// append the exact contexts of chunk c (qv.cc:850-937): reference hit first, then SNP hit; aux rows expanded
+			auto emit_exact = [&](uint32_t c, bool rhit, uint32_t rpos, uint32_t ramb, bool shit, uint32_t spos, uint32_t samb) {
 				if (rhit && rpos != POS_AMBIGUOUS) {
 					if (ramb == 0) {
 						cur.add(S_CTX, 1);
@@ -200,6 +182,57 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
 						}
 					}
+				}
+			};
+			if (use_mx) {
+				// The timed build reads the merged view: one jump-table gather + one bucket line answers both dictionaries.
+				// Two chunks are in flight at a time (their gathers are issued back to back before either is consumed).
+				auto scan_bucket = [&](uint64_t k, uint32_t lo, uint32_t hi, uint4 first, bool &rhit, uint32_t &rpos, uint32_t &ramb, bool &shit, uint32_t &spos, uint32_t &samb) {
+					const uint32_t key = (uint32_t)k;
+					uint32_t ea = lo;
+					if (hi - lo > 4) {                                            // rare big bucket (low-complexity HI32): bisect to the first candidate
+						uint32_t eb = hi;
+						while (ea < eb) { const uint32_t m = ea + ((eb - ea) >> 1); if (d.mx[m].x < key) ea = m + 1; else eb = m; }
+					}
+					for (uint32_t e = ea; e < hi; e++) {                          // buckets of the merged view mostly hold 0-2 entries
+						const uint4 v = (e == lo) ? first : d.mx[e];
+						if (v.x < key) continue;
+						if (v.x > key) break;
+						if (v.z & 1u) { shit = true; spos = v.y; samb = (v.z >> 1) & 1u; }
+						else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
+					}
+				};
+				for (uint32_t c = 0; c < n; c += 2) {
+					const bool two = c + 1 < n;
+					const uint64_t k0 = chunk_kmer(c), k1 = two ? chunk_kmer(c + 1) : 0;
+					uint32_t lo0, hi0, lo1 = 0, hi1 = 0;
+					jg_pair(d.mx_jg, k0 >> 32, lo0, hi0);
+					if (two) jg_pair(d.mx_jg, k1 >> 32, lo1, hi1);
+					uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0;
+					if (lo0 < hi0) f0 = d.mx[lo0];
+					if (lo1 < hi1) f1 = d.mx[lo1];
+					uint32_t rpos = 0, ramb = 0, spos = 0, samb = 0;
+					bool rhit = false, shit = false;
+					cur.add(S_CHUNKS, 1);
+					scan_bucket(k0, lo0, hi0, f0, rhit, rpos, ramb, shit, spos, samb);
+					emit_exact(c, rhit, rpos, ramb, shit, spos, samb);
+					if (two) {
+						rhit = shit = false;
+						cur.add(S_CHUNKS, 1);
+						scan_bucket(k1, lo1, hi1, f1, rhit, rpos, ramb, shit, spos, samb);
+						emit_exact(c + 1, rhit, rpos, ramb, shit, spos, samb);
+					}
+				}
+			} else {
+				// the counting build does the reference's two separate walks, whose probes the event counters price
+				for (uint32_t c = 0; c < n; c++) {
+					const uint64_t k = chunk_kmer(c);
+					cur.add(S_CHUNKS, 1);
+					uint32_t lo, hi;
+					RefEnt e; SnpEnt se;
+					const bool rhit = ref_query(d, cur, k, lo, hi, e) >= 0;
+					const bool shit = snp_query(d, cur, k, lo, hi, se) >= 0;
+					emit_exact(c, rhit, rhit ? e.pos : 0u, rhit ? e.amb : 0u, shit, shit ? se.pos : 0u, shit ? (uint32_t)((se.key >> 48) & 0xFFu) : 0u);
 				}
 			}
 		}
@@ -296,7 +329,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 					const uint32_t g = t0 + lane;
 					const bool valid = g < T;
 					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
-					int32_t ri = -1, si = -1;                                // entry indices (< 2^31 asserted at load) or -1
+					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
 					LaneStats<STATS> hs;
 					hs.clear();
 					if (valid) {
@@ -319,15 +352,15 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 								mod = pair;
 								const uint64_t nb = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
 								uint32_t a, b;
-								ri = (int32_t)ref_query(d, hs, nb, a, b);
-								si = (int32_t)snp_query(d, hs, nb, a, b);
+								ri = (uint32_t)ref_query(d, hs, nb, a, b);
+								si = (uint32_t)snp_query(d, hs, nb, a, b);
 							} else if (t < Lr) {                                 // iterate_ref_dict, qv.cc:316-376   (B1)
 								const uint64_t tt = (uint64_t)lo + (uint64_t)t * REF_STRIDE;
 								uint32_t tlo = 0;
 								hs.add(S_SCAN_REF, 1);
 								if (tt < d.n_ref) tlo = d.ref[tt].lo; else hs.add(S_SCAN_OOB, 1);
 								const int dd = onebase((uint64_t)(klo ^ tlo));
-								if (dd >= 0) { ri = (int32_t)(lo + t); mod = (uint32_t)dd; nbase = (tlo >> (2 * dd)) & 3u; }
+								if (dd >= 0) { ri = lo + t; mod = (uint32_t)dd; nbase = (tlo >> (2 * dd)) & 3u; }
 							} else {                                             // iterate_snp_dict, qv.cc:413-464   (B1)
 								const uint32_t u = t - Lr;
 								const uint64_t tt = (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 								hs.add(S_SCAN_SNP, 1);
 								if (tt < d.n_snp) tlo = d.snp[tt].key & LO40_MASK; else hs.add(S_SCAN_OOB, 1);
 								const int dd = onebase((k & LO40_MASK) ^ tlo);
-								if (dd >= 0) { si = (int32_t)(slo + u); mod = (uint32_t)dd; nbase = (uint32_t)(tlo >> (2 * dd)) & 3u; }
+								if (dd >= 0) { si = slo + u; mod = (uint32_t)dd; nbase = (uint32_t)(tlo >> (2 * dd)) & 3u; }
 							}
 						} else {                                                 // qv.cc:1213-1365
 							const uint32_t h = t - L;
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 									if (rank == h) zsel = z;
 								}
 								u = (hu >> (8 * zsel)) & 0xFFu;
-								ri = (int32_t)P_hidx[zsel][p][wv];
+								ri = P_hidx[zsel][p][wv];
 								have_ri = true;
 							} else u = u_lo + h;
 							const uint32_t pair = 16u + u / 3, sel = u % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
@@ -360,10 +393,10 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 							const uint64_t nb = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
 							uint32_t a, b;
 							if (!have_ri && 2 * pair < rsb) {
-								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) if (((hu >> (8 * z)) & 0xFFu) == u) ri = (int32_t)P_hidx[z < (uint32_t)HCAP ? z : 0][p][wv]; }
-								else ri = (int32_t)ref_query(d, hs, nb, a, b);
+								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) if (((hu >> (8 * z)) & 0xFFu) == u) ri = P_hidx[z < (uint32_t)HCAP ? z : 0][p][wv]; }
+								else ri = (uint32_t)ref_query(d, hs, nb, a, b);
 							}
-							if ((large || 2 * pair >= 40u) && 2 * pair < ssb) si = (int32_t)snp_query(d, hs, nb, a, b);
+							if ((large || 2 * pair >= 40u) && 2 * pair < ssb) si = (uint32_t)snp_query(d, hs, nb, a, b);
 						}
 					}
 					// is `position` the implied read position of one of the owner's exact hits?
@@ -374,7 +407,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 					};
 					// acceptance (site / SNP-base tests) + key filter -> bit j: ref candidate j kept, bit 10+j: snp candidate j kept
 					uint32_t keepm = 0;
-					if (ri >= 0) {
+					if (ri != NOHIT) {
 						const RefEnt re = d.ref[ri];
 						if (re.pos != POS_AMBIGUOUS) {
 							if (re.amb == 0) {
@@ -392,7 +425,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 							}
 						}
 					}
-					if (si >= 0) {
+					if (si != NOHIT) {
 						const SnpEnt se = d.snp[si];
 						if (se.pos != POS_AMBIGUOUS) {
 							if (((se.key >> 48) & 0xFFu) == 0) {
