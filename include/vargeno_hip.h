@@ -89,6 +89,16 @@ int  vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals,
 int  vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals,
                              const uint64_t *d_offsets, uint64_t n_reads);
 
+/* Same again, starting from raw FASTQ text (host memory): replaces the four fgets() + strlen of
+ * qv.cc:760-784 for a chunk of the file.  The device frames the complete 4-line records of the chunk,
+ * and runs them through the read loop.  *consumed = bytes used (the rest, an incomplete last record,
+ * is the caller's to resubmit with the next chunk); *last_record_start = offset of the last complete
+ * record (a host reader that must reproduce the reference's stale-buffer behaviour on a truncated
+ * final record starts there).  VG_EBADREAD: some line exceeds fgets' 1023 characters -- frame this chunk on
+ * the host (vg_reads_submit); nothing was processed. */
+int  vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbytes,
+                     uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start);
+
 int  vg_sync(vg_index *ix);                       /* drain the stream                          */
 int  vg_stats_get(vg_index *ix, vg_stats *out);   /* implies vg_sync                           */
 int  vg_set_stats(vg_index *ix, int enable);      /* event counting on (default) / off: the

@@ -99,6 +99,14 @@ class GenoIndex:
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         check(lib().vg_reads_submit(self._h, _ptr(bases), _ptr(quals), _ptr(offsets), len(offsets) - 1))
 
+    def submit_fastq(self, text):
+        """Raw FASTQ bytes (numpy uint8 / bytes): framed on the device.  Returns (records, bytes consumed, start of
+        the last complete record)."""
+        text = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+        n, used, last = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib().vg_fastq_submit(self._h, _ptr(text), len(text), C.byref(n), C.byref(used), C.byref(last)))
+        return int(n.value), int(used.value), int(last.value)
+
     def process_device(self, d_bases, d_quals, d_offsets, n_reads):
         """Device-resident batch: torch CUDA tensors (uint8, uint8, int64/uint64 offsets[n+1])."""
         check(lib().vg_reads_process_device(self._h, C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_quals.data_ptr()),

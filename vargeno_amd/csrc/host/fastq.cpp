@@ -49,6 +49,13 @@ FastqReader::FastqReader(const std::string &path) : p(new Impl)
 }
 FastqReader::~FastqReader() { if (p->f) fclose(p->f); delete p; }
 
+void FastqReader::seek(uint64_t off)
+{
+	fseeko(p->f, (off_t)off, SEEK_SET);
+	p->pos = p->end = 0;
+	p->eof = false;
+}
+
 uint64_t FastqReader::next(ReadBatch &out, uint64_t max_reads)
 {
 	if (out.offsets.empty()) out.offsets.assign(1, 0);

@@ -65,16 +65,53 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	for (auto *h : ix) VG_CHECK(vg_set_stats(h, env_int("VARGENO_STATS", 0)));
 
 	fprintf(stderr, "Processing...\n");
-	vgh::FastqReader rd(fastq);
-	vgh::ReadBatch rb;
 	uint64_t total = 0; int next_gpu = 0;
-	for (;;) {
-		rb.clear();
-		const uint64_t n = rd.next(rb, batch);
-		if (!n) break;
-		total += n;
-		VG_CHECK(vg_reads_submit(ix[(size_t)next_gpu], rb.bases.data(), rb.quals.data(), rb.offsets.data(), n));
-		next_gpu = (next_gpu + 1) % ngpu;
+	// Default ingest: the file is read in large chunks and FRAMED ON THE DEVICE (vg_fastq_submit); the host only moves
+	// bytes.  A chunk with a line beyond fgets' 1023 characters, and the (possibly truncated) tail of the file, go
+	// through the host reader, which reproduces the reference's four-fgets framing exactly, stale buffers included.
+	const bool host_framing = env_int("VARGENO_HOST_FASTQ", 0) != 0;
+	uint64_t host_from = 0;                    // file offset the host reader takes over from
+	uint64_t prime_from = UINT64_MAX;          // start of the last record the device framed (to prime the stale buffers)
+	if (!host_framing) {
+		FILE *f = fopen(fastq.c_str(), "rb");
+		if (!f) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
+		const size_t chunk = (size_t)env_int("VARGENO_CHUNK_MB", 256) << 20;
+		std::vector<uint8_t> buf(chunk);
+		size_t have = 0; uint64_t file_off = 0;       // buf[0] is byte file_off of the file
+		for (;;) {
+			const size_t got = fread(buf.data() + have, 1, chunk - have, f);
+			have += got;
+			if (have == 0) break;
+			uint64_t nrec = 0, used = 0, last = 0;
+			const int rc = vg_fastq_submit(ix[(size_t)next_gpu], buf.data(), have, &nrec, &used, &last);
+			if (rc == VG_EBADREAD) break;              // an over-long line: the host reader takes the rest
+			if (rc != VG_OK) { fprintf(stderr, "vargeno: vg_fastq_submit failed (%d): %s\n", rc, vg_last_error()); exit(EXIT_FAILURE); }
+			if (nrec) { total += nrec; prime_from = file_off + last; next_gpu = (next_gpu + 1) % ngpu; }
+			memmove(buf.data(), buf.data() + used, have - used);
+			have -= (size_t)used; file_off += used;
+			if (got == 0 && used == 0) break;          // end of file: what is left is an incomplete record
+			if (have == chunk) break;                  // a single record larger than the chunk: host reader
+		}
+		fclose(f);
+		host_from = file_off;
+	}
+	{
+		vgh::FastqReader rd(fastq);
+		vgh::ReadBatch rb;
+		if (!host_framing && prime_from != UINT64_MAX) {   // re-read the last framed record: it only fills the line buffers
+			rd.seek(prime_from);
+			rb.clear();
+			(void)rd.next(rb, 1);
+		}
+		if (!host_framing) rd.seek(host_from);
+		for (;;) {
+			rb.clear();
+			const uint64_t n = rd.next(rb, batch);
+			if (!n) break;
+			total += n;
+			VG_CHECK(vg_reads_submit(ix[(size_t)next_gpu], rb.bases.data(), rb.quals.data(), rb.offsets.data(), n));
+			next_gpu = (next_gpu + 1) % ngpu;
+		}
 	}
 	for (auto *h : ix) VG_CHECK(vg_sync(h));
 	{

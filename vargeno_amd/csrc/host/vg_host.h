@@ -35,6 +35,8 @@ public:
 	~FastqReader();
 	// appends up to max_reads records; returns the number appended (0 at end of file)
 	uint64_t next(ReadBatch &out, uint64_t max_reads);
+	// continue from byte `off` of the file; the four line buffers keep their content (what a truncated record sees)
+	void seek(uint64_t off);
 private:
 	struct Impl;
 	Impl *p;

@@ -307,6 +307,79 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// kernels: FASTQ framing on the device (reference src/qv.cc:760-784: four fgets() per record)
+// ------------------------------------------------------------------------------------------------
+int vg_dev_exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream);   // vg_sort.hip
+int vg_dev_exclusive_scan_u64(const uint64_t *in, uint64_t *out, size_t n, hipStream_t stream);
+
+constexpr uint32_t FQ_TILE = 4096;                   // bytes per workgroup tile (256 lanes x 16 bytes)
+
+// newlines per 4 KiB tile
+__global__ __launch_bounds__(256) void vg_fq_count_newlines(const uint8_t *__restrict__ text, uint64_t nbytes, uint32_t *__restrict__ tile_cnt)
+{
+	__shared__ uint32_t wsum[4];
+	const uint64_t base = (uint64_t)blockIdx.x * FQ_TILE + (uint64_t)threadIdx.x * 16;
+	uint32_t c = 0;
+	for (uint32_t j = 0; j < 16; j++) if (base + j < nbytes && text[base + j] == '\n') c++;
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// line_start[g + 1] = byte after the g-th newline (line_start[0] = 0 is set by the host side)
+__global__ __launch_bounds__(256) void vg_fq_line_starts(const uint8_t *__restrict__ text, uint64_t nbytes, const uint32_t *__restrict__ tile_off, uint32_t *__restrict__ line_start)
+{
+	__shared__ uint32_t wsum[4];
+	const uint64_t base = (uint64_t)blockIdx.x * FQ_TILE + (uint64_t)threadIdx.x * 16;
+	uint32_t mask = 0;
+	for (uint32_t j = 0; j < 16; j++) if (base + j < nbytes && text[base + j] == '\n') mask |= 1u << j;
+	const uint32_t c = (uint32_t)__popc(mask);
+	uint32_t incl = c;
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((int)lane >= o) incl += y; }
+	if (lane == 63) wsum[wv] = incl;
+	__syncthreads();
+	uint32_t g = tile_off[blockIdx.x] + incl - c;
+	for (uint32_t w = 0; w < wv; w++) g += wsum[w];
+	while (mask) {
+		const uint32_t j = (uint32_t)__ffs((int)mask) - 1;
+		mask &= mask - 1;
+		line_start[++g] = (uint32_t)(base + j + 1);
+	}
+}
+
+// one lane per record: read length = strlen(read line) - 1 (qv.cc:778); flags a line longer than fgets' 1023 characters
+__global__ void vg_fq_record_lengths(const uint32_t *__restrict__ line_start, uint64_t n_rec, uint64_t *__restrict__ rlen, uint32_t *too_long)
+{
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += (uint64_t)gridDim.x * blockDim.x) {
+		bool bad = false;
+		for (int l = 0; l < 4; l++) bad |= (line_start[4 * r + l + 1] - line_start[4 * r + l]) > 1023u;
+		if (bad) atomicOr(too_long, 1u);
+		rlen[r] = line_start[4 * r + 2] - line_start[4 * r + 1] - 1u;       // the line's length minus its newline
+	}
+}
+
+// gather bases and quality characters of every record into the flat batch layout; a quality line shorter than the
+// read keeps what the reference's buffer would hold there: its newline, then NULs (qv.cc:763, 836)
+__global__ __launch_bounds__(256) void vg_fq_gather(const uint8_t *__restrict__ text, const uint32_t *__restrict__ line_start, const uint64_t *__restrict__ offsets,
+                                                    uint64_t n_rec, uint8_t *__restrict__ bases, uint8_t *__restrict__ quals)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+	for (uint64_t r = wave; r < n_rec; r += n_waves) {                          // one wave per record: coalesced copies
+		const uint64_t o = offsets[r], len = offsets[r + 1] - o;
+		const uint32_t s1 = line_start[4 * r + 1], s3 = line_start[4 * r + 3];
+		const uint32_t qlen = line_start[4 * r + 4] - s3;                       // quality line incl. its newline
+		for (uint64_t j = lane; j < len; j += 64) {
+			bases[o + j] = text[s1 + j];
+			quals[o + j] = j < qlen ? text[s3 + j] : (uint8_t)0;
+		}
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side of the handle
 // ------------------------------------------------------------------------------------------------
@@ -322,7 +395,8 @@ struct Slot {
 	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr;  uint64_t list_cap = 0;
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
-	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit
+	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
+	uint8_t *fq_text = nullptr; uint32_t *fq_lines = nullptr, *fq_tiles = nullptr; uint64_t fq_text_cap = 0, fq_lines_cap = 0, fq_tiles_cap = 0;   // FASTQ framing
 	uint64_t stage_bytes = 0, stage_reads = 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr;
 	bool busy = false;
@@ -407,7 +481,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (ix->tail) (void)hipStreamSynchronize(ix->tail);
 	for (void *p : ix->owned) (void)hipFree(p);
 	for (Slot &sl : ix->slot) {
-		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta};
+		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles};
 		for (void *p : extra) if (p) (void)hipFree(p);
 		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -751,7 +825,7 @@ static int acquire_slot(vg_index *ix, Slot **out)
 
 static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
 {
-	if (n_reads >= (1ull << 32)) return fail(VG_EINVAL, "more than 2^32-1 reads in one batch");
+	if (n_reads >= (1ull << 32) - (1ull << 24)) return fail(VG_EINVAL, "more than 2^32 - 2^24 reads in one batch");
 	// packed-read buffers are sized from the batch's total length (8 bytes from the device; the handle's streams are
 	// non-blocking, so this copy does not wait for kernels in flight)
 	uint64_t total = 0;
@@ -817,6 +891,83 @@ extern "C" int vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t
 	HIP_TRY(hipMemcpy(sl.st_quals, quals + base0, total, hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(sl.st_offsets, off, (n_reads + 1) * 8, hipMemcpyHostToDevice));
 	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, n_reads);
+}
+
+// FASTQ text in, framed and processed on the device.  Replaces the four fgets() + strlen of qv.cc:760-784 for a chunk
+// of the file: complete 4-line records are framed (newline scan + prefix sums), gathered into the flat batch layout
+// and run through the read loop; the bytes after the last complete record are the caller's to resubmit.
+extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbytes, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start)
+{
+	if (!ix || (!text && nbytes) || !n_records || !consumed) return fail(VG_EINVAL, "null argument");
+	*n_records = 0; *consumed = 0;
+	if (last_record_start) *last_record_start = 0;
+	if (nbytes == 0) return VG_OK;
+	if (nbytes >= (1ull << 32) - 64) return fail(VG_EINVAL, "FASTQ chunk of 4 GiB or more");
+	HIP_TRY(hipSetDevice(ix->device));
+	Slot *slp = nullptr;
+	int rc = acquire_slot(ix, &slp);
+	if (rc) return rc;
+	Slot &sl = *slp;
+	const uint64_t n_tiles = (nbytes + FQ_TILE - 1) / FQ_TILE;
+	auto grow = [&](void **p, uint64_t &cap, uint64_t need, size_t elem) -> int {
+		if (need <= cap) return VG_OK;
+		if (*p) (void)hipFree(*p);
+		*p = nullptr; cap = 0;
+		hipError_t e = hipMalloc(p, (size_t)need * elem);
+		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(FASTQ staging): %s", hipGetErrorString(e));
+		cap = need;
+		return VG_OK;
+	};
+	if ((rc = grow((void **)&sl.fq_text, sl.fq_text_cap, nbytes + 64, 1))) return rc;
+	if ((rc = grow((void **)&sl.fq_tiles, sl.fq_tiles_cap, n_tiles + 2, 4))) return rc;
+	HIP_TRY(hipMemcpy(sl.fq_text, text, nbytes, hipMemcpyHostToDevice));
+	// newlines per tile -> exclusive scan -> total number of complete lines
+	vg_fq_count_newlines<<<(unsigned)n_tiles, 256, 0, ix->stream>>>(sl.fq_text, nbytes, sl.fq_tiles);
+	HIP_TRY(hipMemsetAsync(sl.fq_tiles + n_tiles, 0, 4, ix->stream));
+	HIP_TRY(hipGetLastError());
+	int se = vg_dev_exclusive_scan_u32(sl.fq_tiles, sl.fq_tiles, n_tiles + 1, ix->stream);
+	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
+	uint32_t n_lines = 0;
+	HIP_TRY(hipMemcpy(&n_lines, sl.fq_tiles + n_tiles, 4, hipMemcpyDeviceToHost));
+	const uint64_t n_rec = n_lines / 4;
+	if (n_rec == 0) return VG_OK;
+	if ((rc = grow((void **)&sl.fq_lines, sl.fq_lines_cap, (uint64_t)n_lines + 2, 4))) return rc;
+	HIP_TRY(hipMemsetAsync(sl.fq_lines, 0, 4, ix->stream));                     // line 0 starts at byte 0
+	vg_fq_line_starts<<<(unsigned)n_tiles, 256, 0, ix->stream>>>(sl.fq_text, nbytes, sl.fq_tiles, sl.fq_lines);
+	HIP_TRY(hipGetLastError());
+	// read lengths -> offsets of the flat batch
+	if (n_rec + 1 > sl.stage_reads) {
+		if (sl.st_offsets) (void)hipFree(sl.st_offsets);
+		sl.st_offsets = nullptr; sl.stage_reads = 0;
+		HIP_TRY(hipMalloc((void **)&sl.st_offsets, (n_rec + 1) * 8));
+		sl.stage_reads = n_rec + 1;
+	}
+	uint32_t *d_flag = sl.ctr + 6;                                              // spare word of the slot's counter block
+	HIP_TRY(hipMemsetAsync(d_flag, 0, 4, ix->stream));
+	vg_fq_record_lengths<<<1024, 256, 0, ix->stream>>>(sl.fq_lines, n_rec, sl.st_offsets, d_flag);
+	HIP_TRY(hipMemsetAsync(sl.st_offsets + n_rec, 0, 8, ix->stream));
+	HIP_TRY(hipGetLastError());
+	se = vg_dev_exclusive_scan_u64(sl.st_offsets, sl.st_offsets, n_rec + 1, ix->stream);
+	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
+	uint32_t too_long = 0; uint64_t total = 0; uint32_t edges[2] = {0, 0};
+	HIP_TRY(hipMemcpy(&too_long, d_flag, 4, hipMemcpyDeviceToHost));
+	if (too_long) return fail(VG_EBADREAD, "a FASTQ line longer than 1023 characters (reference BUF_SIZE 1024, qv.cc:700): frame this chunk on the host");
+	HIP_TRY(hipMemcpy(&total, sl.st_offsets + n_rec, 8, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&edges[0], sl.fq_lines + 4 * (n_rec - 1), 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(&edges[1], sl.fq_lines + 4 * n_rec, 4, hipMemcpyDeviceToHost));
+	if (total + 64 > sl.stage_bytes) {
+		if (sl.st_bases) (void)hipFree(sl.st_bases);
+		if (sl.st_quals) (void)hipFree(sl.st_quals);
+		sl.st_bases = sl.st_quals = nullptr; sl.stage_bytes = 0;
+		HIP_TRY(hipMalloc((void **)&sl.st_bases, total + 64));
+		HIP_TRY(hipMalloc((void **)&sl.st_quals, total + 64));
+		sl.stage_bytes = total + 64;
+	}
+	vg_fq_gather<<<(unsigned)std::min<uint64_t>((n_rec + 3) / 4, (uint64_t)ix->cus * 32), 256, 0, ix->stream>>>(sl.fq_text, sl.fq_lines, sl.st_offsets, n_rec, sl.st_bases, sl.st_quals);
+	HIP_TRY(hipGetLastError());
+	*n_records = n_rec; *consumed = edges[1];
+	if (last_record_start) *last_record_start = edges[0];
+	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, n_rec);
 }
 
 extern "C" int vg_sync(vg_index *ix)
