@@ -67,6 +67,11 @@ typedef struct {
 const char *vg_last_error(void);
 int  vg_device_count(void);
 
+/* Page-locked host buffers for the batches / FASTQ chunks handed to vg_reads_submit / vg_fastq_submit
+ * (optional: any host memory works, pinned memory copies at link speed).  NULL on failure. */
+void *vg_host_alloc_pinned(size_t bytes);
+void  vg_host_free_pinned(void *p);
+
 /* Replaces the loader half of genotype(): qv.cc:519-695 (dict files -> jump tables, dict arrays,
  * aux tables, pile-up seeding) and main()'s BloomFilter::load (qv.cc:2140-2144).
  * vg_index_open reads <prefix>.ref.dict/.snp.dict/.ref.bf/.snp.bf; vg_index_create takes the same

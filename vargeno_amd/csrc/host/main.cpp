@@ -65,6 +65,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	for (auto *h : ix) VG_CHECK(vg_set_stats(h, env_int("VARGENO_STATS", 0)));
 
 	fprintf(stderr, "Processing...\n");
+	struct timespec t_loaded; clock_gettime(CLOCK_MONOTONIC, &t_loaded);
 	uint64_t total = 0; int next_gpu = 0;
 	// Default ingest: the file is read in large chunks and FRAMED ON THE DEVICE (vg_fastq_submit); the host only moves
 	// bytes.  A chunk with a line beyond fgets' 1023 characters, and the (possibly truncated) tail of the file, go
@@ -76,7 +77,10 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		FILE *f = fopen(fastq.c_str(), "rb");
 		if (!f) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
 		const size_t chunk = (size_t)env_int("VARGENO_CHUNK_MB", 256) << 20;
-		std::vector<uint8_t> buf(chunk);
+		uint8_t *pinned = (uint8_t *)vg_host_alloc_pinned(chunk);
+		std::vector<uint8_t> pageable;
+		if (!pinned) pageable.resize(chunk);
+		struct Buf { uint8_t *p; uint8_t *data() const { return p; } } buf{pinned ? pinned : pageable.data()};
 		size_t have = 0; uint64_t file_off = 0;       // buf[0] is byte file_off of the file
 		for (;;) {
 			const size_t got = fread(buf.data() + have, 1, chunk - have, f);
@@ -93,6 +97,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 			if (have == chunk) break;                  // a single record larger than the chunk: host reader
 		}
 		fclose(f);
+		vg_host_free_pinned(pinned);
 		host_from = file_off;
 	}
 	{
@@ -114,6 +119,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		}
 	}
 	for (auto *h : ix) VG_CHECK(vg_sync(h));
+	struct timespec t_reads; clock_gettime(CLOCK_MONOTONIC, &t_reads);
 	{
 		vg_stats st;
 		uint64_t invalid = 0;
@@ -154,7 +160,9 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	printf("Time: %f sec\n", cpu);                                       // qv.cc:1749-1751 prints CPU seconds
 	if (env_int("VARGENO_VERBOSE", 0)) {
 		struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-		fprintf(stderr, "reads: %lu  wall: %.3f s  gpus: %d\n", (unsigned long)total, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec), ngpu);
+		auto secs = [](const struct timespec &a, const struct timespec &b) { return (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec); };
+		fprintf(stderr, "reads: %lu  gpus: %d  wall: %.3f s = index load %.3f + FASTQ->counters %.3f (%.2f M reads/s) + call/VCF %.3f\n", (unsigned long)total, ngpu,
+		        secs(t0, t1), secs(t0, t_loaded), secs(t_loaded, t_reads), total / secs(t_loaded, t_reads) / 1e6, secs(t_reads, t1));
 	}
 	return EXIT_SUCCESS;
 }

@@ -38,6 +38,16 @@ static int fail(int code, const char *fmt, const char *a = "", const char *b = "
 	} while (0)
 
 extern "C" const char *vg_last_error(void) { return g_err; }
+
+// page-locked host memory for callers without HIP headers (the CLI reads FASTQ chunks straight into it: H2D then runs
+// at link speed instead of through the runtime's pageable staging)
+extern "C" void *vg_host_alloc_pinned(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+	return p;
+}
+extern "C" void vg_host_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
 extern "C" int vg_device_count(void)
 {
 	int n = 0;
