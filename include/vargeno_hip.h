@@ -120,7 +120,8 @@ int  vg_sites_fetch(vg_index *ix, uint32_t *pos, uint8_t *ref_base, uint8_t *alt
 int  vg_counts_fetch(vg_index *ix, uint8_t *ref_cnt, uint8_t *alt_cnt);    /* clamped at 63     */
 int  vg_counts_reset(vg_index *ix);
 
-/* Device pointer to the raw u32 counter array, length 2 * vg_num_sites: [2*s] = ref, [2*s+1] = alt.
+/* Device pointer to the raw u32 counter array, length 2 * vg_num_sites: [2*s] = ref, [2*s+1] = alt
+ * (the call first drains the batches in flight).
  * This is the ONE buffer that crosses GPUs: sum it over ranks (RCCL all-reduce over xGMI) before
  * vg_counts_fetch.  Reads shard with no other exchange. */
 int  vg_counts_device_ptr(vg_index *ix, void **d_counts, uint64_t *n_u32);

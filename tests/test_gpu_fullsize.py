@@ -1,0 +1,76 @@
+"""Size-independent properties at the bench's full size (BASELINE.json configs[1]: 40 Mbp, ~1 M SNPs, 1 M x 150 bp
+reads): what the oracle cannot check in seconds is checked through invariants of the path --
+  * linearity: the exact (unclamped) per-site sums of a batch are the sum of the sums of any split of it,
+    in any order, and twice the batch gives twice the sums;
+  * the counting build and the timed build (secondary views) agree;
+  * a 50 000-read sample agrees with the oracle bit for bit.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import oracle as O
+from vargeno_amd import synth
+from vargeno_amd.api import GenoIndex
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def chr22(tmp_path_factory):
+    d = os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench") + "/g40000000_s1000000_c1"
+    g, s, r = synth.chr22_scale()
+    if not os.path.exists(d + "/idx.ref.dict"):
+        os.makedirs(d, exist_ok=True)
+        synth.write_fasta(d + "/ref.fa", g)
+        synth.write_vcf(d + "/snps.vcf", g, s)
+        subprocess.check_call([os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno"), "index", "ref.fa", "snps.vcf", "idx"], cwd=d,
+                              env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    return d + "/idx", r
+
+
+def _raw(gx):
+    return gx.counts_tensor().clone().cpu().numpy().view(np.uint32)
+
+
+def test_linearity_and_build_agreement_at_full_size(chr22):
+    prefix, r = chr22
+    with GenoIndex.open(prefix) as gx:
+        gx.set_stats(False)
+        gx.submit(r.bases, r.quals, r.offsets)
+        whole = _raw(gx)
+        assert whole.sum() > 2_000_000                              # ~2.19 increments per read
+        gx.reset()
+        cuts = [0, 123_457, 500_000, 500_001, 999_999, r.n]
+        for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):      # five uneven shards, last first
+            s = r.slice(lo, hi)
+            gx.submit(s.bases, s.quals, s.offsets)
+        assert np.array_equal(_raw(gx), whole)
+        gx.submit(r.bases, r.quals, r.offsets)                       # on top: exactly twice
+        assert np.array_equal(_raw(gx), 2 * whole)
+        gx.reset()
+        gx.set_stats(True)                                           # the counting build walks the reference's structures
+        gx.submit(r.bases, r.quals, r.offsets)
+        assert np.array_equal(_raw(gx), whole)
+        st = gx.stats()
+        assert st["reads"] == r.n and st["passes"] > r.n
+        # clamp: fetch == min(63, raw)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, np.minimum(whole[0::2], 63)) and np.array_equal(ac, np.minimum(whole[1::2], 63))
+
+
+def test_sample_against_oracle_at_full_index_size(chr22):
+    prefix, r = chr22
+    s = r.slice(200_000, 250_000)
+    ox = O.OracleIndex.load(prefix)
+    ox.process(s.bases, s.quals, s.offsets)
+    so = ox.sites()
+    with GenoIndex.open(prefix) as gx:
+        gx.set_stats(False)
+        gx.submit(s.bases, s.quals, s.offsets)
+        rc, ac = gx.counts()
+    assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])

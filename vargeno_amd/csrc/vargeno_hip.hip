@@ -1071,6 +1071,7 @@ extern "C" int vg_counts_reset(vg_index *ix)
 extern "C" int vg_counts_device_ptr(vg_index *ix, void **d_counts, uint64_t *n_u32)
 {
 	if (!ix || !d_counts || !n_u32) return fail(VG_EINVAL, "null argument");
+	{ int rc = finish_pending(ix); if (rc) return rc; }         // the sums are only meaningful once the batches in flight have landed
 	*d_counts = ix->d.cnt; *n_u32 = 2 * ix->n_sites;
 	return VG_OK;
 }
