@@ -58,6 +58,10 @@ def test_incomplete_tail_is_left_to_the_caller_and_long_lines_are_refused(ftiny_
             gx.submit_fastq(rec + long_rec)
         assert e.value.code == -6
         assert gx.stats()["reads"] == 3                                  # the refused chunk processed nothing
+        short_q = b"@r\n" + b"ACGT" * 16 + b"\n+\nI\n"                  # 2 chunks, 1 quality character: the reference reads its stale buffer
+        with pytest.raises(VgError) as e:
+            gx.submit_fastq(short_q)
+        assert e.value.code == -6
         ok_rec = b"@r\n" + b"A" * 1022 + b"\n+\n" + b"I" * 1022 + b"\n"    # 1023 characters with the newline: fine
         n, used, _ = gx.submit_fastq(ok_rec)
         assert n == 1 and used == len(ok_rec)

@@ -81,3 +81,61 @@ def test_caller_and_vcf_writer_reproduce_reference_expected_output(tmp_path):
     subprocess.check_call([BIN, "callvcf", str(tmp_path / "chrlens"), str(tmp_path / "counts.txt"),
                            os.path.join(GOLDEN, "reftest.snp.vcf"), str(out)])
     assert open(out).read() == exp
+
+
+def _fgets_framing(data):
+    """Independent statement of the reference's framing (qv.cc:699-784): four fgets(buf, 1024) per record, a NULL
+    return leaves the buffer as it was, read length = strlen(read) - 1, chunk c gated by qual[c]."""
+    pos = 0
+
+    def fgets():
+        nonlocal pos
+        if pos >= len(data):
+            return None
+        end = data.find(b"\n", pos, pos + 1023)
+        end = pos + 1023 if end < 0 else end + 1
+        end = min(end, len(data))
+        line = data[pos:end]
+        pos = end
+        return line
+
+    bufs = [bytearray(1024) for _ in range(4)]          # the four char[1024] of qv.cc:699-703: content persists between records
+
+    def store(k, line):
+        bufs[k][:len(line) + 1] = line + b"\0"
+
+    out = []
+    while True:
+        idl = fgets()
+        if idl is None:
+            break
+        store(0, idl)
+        for k in (1, 2, 3):
+            ln = fgets()
+            if ln is not None:
+                store(k, ln)
+        read = bytes(bufs[1][:bufs[1].index(0)])
+        rlen = max(len(read) - 1, 0)
+        out.append((rlen, read[:rlen], bytes(bufs[3][c] for c in range(rlen // 32))))
+    return out
+
+
+def test_host_fastq_framing_matches_fgets_semantics(tmp_path):
+    rec = lambda i, n, q=b"I": b"@r%d\n" % i + (b"ACGT" * 300)[:n] + b"\n+\n" + (q * n)[:n] + b"\n"
+    cases = {
+        "plain": rec(0, 150) + rec(1, 31) + rec(2, 64, b"#") + rec(3, 0),
+        "no_final_newline": rec(0, 150) + rec(1, 101)[:-1],
+        "truncated_record": rec(0, 150, b"#5") + b"@r1\n" + b"ACGT" * 40 + b"\n+",
+        "long_lines": rec(0, 1022) + rec(1, 1023) + rec(2, 1500) + rec(3, 40),     # 1023+ characters: fgets splits the line
+        "short_quality": rec(0, 150, b"#") + b"@r1\n" + b"ACGT" * 64 + b"\n+\nII\n" + rec(2, 64),     # gate chars 2.. come from older lines
+        "empty": b"",
+    }
+    for name, data in cases.items():
+        f = tmp_path / (name + ".fq")
+        f.write_bytes(data)
+        got = subprocess.run([BIN, "fqcheck", str(f)], capture_output=True).stdout.split(b"\n")[:-1]
+        want = _fgets_framing(data)
+        assert len(got) == len(want), name
+        for g, (rlen, read, q) in zip(got, want):
+            parts = g.split(b" ")
+            assert int(parts[0]) == rlen and parts[1] == read and parts[2] == q.hex().encode(), (name, g[:80], rlen)

@@ -35,8 +35,9 @@ struct FastqReader::Impl {
 			n += m; pos += m;
 			if (nl || n == 1023) break;
 		}
+		if (n == 0) return false;                 // fgets() returning NULL leaves the buffer untouched (qv.cc:761-763 rely on it)
 		dst[n] = '\0';
-		return n > 0;
+		return true;
 	}
 };
 
@@ -45,7 +46,7 @@ FastqReader::FastqReader(const std::string &path) : p(new Impl)
 	p->f = fopen(path.c_str(), "r");
 	if (!p->f) { delete p; throw Error{"cannot open " + path}; }
 	p->buf.resize(1 << 24);
-	for (auto &l : p->line) l[0] = '\0';
+	for (auto &l : p->line) memset(l, 0, sizeof l);
 }
 FastqReader::~FastqReader() { if (p->f) fclose(p->f); delete p; }
 
@@ -69,12 +70,12 @@ uint64_t FastqReader::next(ReadBatch &out, uint64_t max_reads)
 		(void)p->gets(p->line[3]);
 		const size_t sl = strlen(p->line[1]);
 		const size_t rlen = sl ? sl - 1 : 0;                    // strlen(read) - 1, qv.cc:778 (size_t wrap on an empty buffer is not reproduced)
-		const size_t ql = strlen(p->line[3]);
 		const size_t at = out.bases.size();
 		out.bases.insert(out.bases.end(), p->line[1], p->line[1] + rlen);
 		out.quals.resize(at + rlen, 0);
-		// qual[c] for c < rlen/32 is all the path reads; copy what the quality line has (its newline included, as in the buffer)
-		memcpy(out.quals.data() + at, p->line[3], ql < rlen ? ql : rlen);
+		// qual[c] for c < rlen/32 is all the path reads, straight out of the 1024-byte buffer: a quality line shorter than that
+		// shows its newline, its NUL, and then whatever earlier lines left there -- exactly what the reference sees (qv.cc:836)
+		memcpy(out.quals.data() + at, p->line[3], rlen);
 		out.offsets.push_back(out.bases.size());
 		got++;
 	}

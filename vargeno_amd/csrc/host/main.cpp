@@ -182,6 +182,25 @@ int main(int argc, const char *argv[])
 		} else if (opt == "geno") {
 			arg_check(argc, 4);
 			return run_geno(argv[2], argv[3], argv[4], argv[5]);
+		} else if (opt == "fqcheck") {
+			// hidden: the host FASTQ framing alone -- one line per record: read length, then the read and the quality
+			// characters the path can see (no device needed; tests/test_host_tools.py)
+			arg_check(argc, 1);
+			vgh::FastqReader rd(argv[2]);
+			vgh::ReadBatch rb;
+			for (;;) {
+				rb.clear();
+				if (!rd.next(rb, 1000)) break;
+				for (uint64_t i = 0; i < rb.n(); i++) {
+					const uint64_t o = rb.offsets[i], len = rb.offsets[i + 1] - o;
+					printf("%lu ", (unsigned long)len);
+					fwrite(rb.bases.data() + o, 1, len, stdout);
+					printf(" ");
+					for (uint64_t j = 0; j < len / 32; j++) printf("%02x", rb.quals[o + j]);
+					printf("\n");
+				}
+			}
+			return EXIT_SUCCESS;
 		} else if (opt == "callvcf") {
 			// hidden (like the reference's vcfd/ucscd/filt): caller + VCF writer alone, from a counts table
 			// "pos ref_freq alt_freq ref_cnt alt_cnt" per line: <chrlens> <counts.txt> <snps.vcf> <out.vcf>

@@ -367,8 +367,11 @@ __global__ void vg_fq_record_lengths(const uint32_t *__restrict__ line_start, ui
 	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += (uint64_t)gridDim.x * blockDim.x) {
 		bool bad = false;
 		for (int l = 0; l < 4; l++) bad |= (line_start[4 * r + l + 1] - line_start[4 * r + l]) > 1023u;
+		const uint32_t len = line_start[4 * r + 2] - line_start[4 * r + 1] - 1u;   // the line's length minus its newline
+		// a quality line without a character for every chunk would expose the reference's stale buffer contents: host framing
+		bad |= (line_start[4 * r + 4] - line_start[4 * r + 3] - 1u) < (len >> 5);
 		if (bad) atomicOr(too_long, 1u);
-		rlen[r] = line_start[4 * r + 2] - line_start[4 * r + 1] - 1u;       // the line's length minus its newline
+		rlen[r] = len;
 	}
 }
 
@@ -459,13 +462,20 @@ template <class T>
 struct TempDev {
 	T *p = nullptr;
 	~TempDev() { if (p) (void)hipFree(p); }
-	int upload(const T *src, uint64_t count)
+	int alloc(uint64_t count)
 	{
 		hipError_t e = hipMalloc((void **)&p, (size_t)(count ? count : 1) * sizeof(T));
 		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(staging): %s", hipGetErrorString(e));
+		return VG_OK;
+	}
+	int upload(const T *src, uint64_t count)
+	{
+		int rc = alloc(count);
+		if (rc) return rc;
 		if (count) HIP_TRY(hipMemcpy(p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
 		return VG_OK;
 	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; }
 };
 
 static int alloc_scratch(vg_index *ix, ScratchBuf &b, uint32_t nlanes, uint32_t cap, uint32_t kcap)
@@ -545,11 +555,8 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 			uint32_t bits = 14;
 			while (bits < 28 && (1ull << bits) < a->n_ref / 2) bits++;      // ~2-4 entries per bucket
 			TempDev<uint64_t> kin; TempDev<uint32_t> vin;
-			if ((rc = kin.upload(nullptr, 0))) return rc;
-			(void)hipFree(kin.p); kin.p = nullptr;
-			hipError_t e1 = hipMalloc((void **)&kin.p, (size_t)(a->n_ref ? a->n_ref : 1) * 8);
-			hipError_t e2 = hipMalloc((void **)&vin.p, (size_t)(a->n_ref ? a->n_ref : 1) * 4);
-			if (e1 != hipSuccess || e2 != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(secondary index staging)");
+			if ((rc = kin.alloc(a->n_ref))) return rc;
+			if ((rc = vin.alloc(a->n_ref))) return rc;
 			uint64_t *skey = nullptr; uint32_t *sidx = nullptr, *sjg = nullptr;
 			if ((rc = dev_alloc(ix, &skey, a->n_ref))) return rc;
 			if ((rc = dev_alloc(ix, &sidx, a->n_ref))) return rc;
@@ -587,16 +594,14 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 			TempDev<uint64_t> kin, kout; TempDev<uint32_t> vin, vout, rp; TempDev<uint8_t> ra;
 			if ((rc = rp.upload(a->ref_pos, a->n_ref))) return rc;
 			if ((rc = ra.upload(a->ref_amb, a->n_ref))) return rc;
-			hipError_t e1 = hipMalloc((void **)&kin.p, (size_t)(nm ? nm : 1) * 8), e2 = hipMalloc((void **)&kout.p, (size_t)(nm ? nm : 1) * 8);
-			hipError_t e3 = hipMalloc((void **)&vin.p, (size_t)(nm ? nm : 1) * 4), e4 = hipMalloc((void **)&vout.p, (size_t)(nm ? nm : 1) * 4);
-			if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(merged view staging)");
+			if ((rc = kin.alloc(nm)) || (rc = kout.alloc(nm)) || (rc = vin.alloc(nm)) || (rc = vout.alloc(nm))) return rc;
 			if (a->n_ref) HIP_TRY(hipMemcpy(kin.p, a->ref_kmer, (size_t)a->n_ref * 8, hipMemcpyHostToDevice));
 			if (a->n_snp) HIP_TRY(hipMemcpy(kin.p + a->n_ref, tk.p, (size_t)a->n_snp * 8, hipMemcpyDeviceToDevice));
 			vg_iota_u32<<<2048, 256, 0, ix->stream>>>(vin.p, nm);
 			HIP_TRY(hipGetLastError());
 			const int se = vg_dev_sort_pairs_u64_u32(kin.p, kout.p, vin.p, vout.p, nm, ix->stream);     // stable: ref before snp on equal k-mers
 			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
-			(void)hipFree(kin.p); kin.p = nullptr; (void)hipFree(vin.p); vin.p = nullptr;      // make room before the 16 GiB table
+			kin.release(); vin.release();                          // make room before the 16 GiB table
 			uint32_t *mjg = nullptr; uint4 *mx = nullptr;
 			if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
 			if ((rc = dev_alloc(ix, &mx, nm))) return rc;
@@ -961,7 +966,7 @@ extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbyte
 	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
 	uint32_t too_long = 0; uint64_t total = 0; uint32_t edges[2] = {0, 0};
 	HIP_TRY(hipMemcpy(&too_long, d_flag, 4, hipMemcpyDeviceToHost));
-	if (too_long) return fail(VG_EBADREAD, "a FASTQ line longer than 1023 characters (reference BUF_SIZE 1024, qv.cc:700): frame this chunk on the host");
+	if (too_long) return fail(VG_EBADREAD, "a FASTQ line longer than 1023 characters (reference BUF_SIZE 1024, qv.cc:700) or a quality line shorter than the read's chunk count: frame this chunk on the host");
 	HIP_TRY(hipMemcpy(&total, sl.st_offsets + n_rec, 8, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(&edges[0], sl.fq_lines + 4 * (n_rec - 1), 4, hipMemcpyDeviceToHost));
 	HIP_TRY(hipMemcpy(&edges[1], sl.fq_lines + 4 * n_rec, 4, hipMemcpyDeviceToHost));
