@@ -195,7 +195,14 @@ def all_reduce_counts(index, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     index.sync()
-    all_reduce_sum_(index.counts_tensor(), group)
+    t = index.counts_tensor()
+    try:
+        all_reduce_sum_(t, group)
+    except RuntimeError:
+        # a backend that refuses memory it did not allocate: reduce a torch-owned copy and write it back
+        tmp = t.clone()
+        all_reduce_sum_(tmp, group)
+        t.copy_(tmp)
     torch.cuda.synchronize(index.device)
 
 

@@ -434,6 +434,7 @@ struct vg_index {
 	double t_pack = 0, t_main = 0, t_tail = 0, t_total = 0; uint64_t t_batches = 0;   // harvested event times since the last vg_timing_get
 	int cus = 256;
 	int lane_grid_blocks = 0, wave_grid = 0;
+	uint32_t work_chunk = 128;            // reads a main-tier wave pulls from the launch's work counter at a time (VG_WORK_CHUNK)
 };
 
 template <class T>
@@ -531,6 +532,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	if (const char *e = getenv("VG_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
 	ix->wave_grid = ix->cus * wpc;
 	if (const char *e = getenv("VG_FORCE_GENERIC")) ix->force_generic = atoi(e) != 0;
+	if (const char *e = getenv("VG_WORK_CHUNK")) ix->work_chunk = (uint32_t)std::max(1, atoi(e));
 	int rc;
 	DevIndex &d = ix->d;
 	d.n_ref = a->n_ref; d.n_snp = a->n_snp;
@@ -803,12 +805,12 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		vg_pack_kernel<<<pgrid, 256, 0, ix->stream>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->wave_grid / 4);
-		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, 4, 128><<<wgrid, 256, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], &ctr[4], ix->d_stats);
+		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, 4><<<wgrid, 256, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		// second tier: the same kernel with deep lists over the spill list (2 waves per CU).  It stays on the main
 		// stream: on the tail stream it ran under the next batch's wave kernel and slowed that by 40 %.
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
-		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1, 2><<<w2grid, 64, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->d_stats);
+		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1><<<w2grid, 64, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], 2u, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e4, 0));
 	} else {

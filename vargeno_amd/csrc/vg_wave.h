@@ -58,11 +58,11 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 
 // WORK_CHUNK: reads a wave pulls from the launch's work counter at a time (large for the main tier, a handful for the
 // spill tier, whose few hundred heavy reads must spread over all its waves)
-template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB, int WORK_CHUNK>
+template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB>
 __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
-                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, unsigned long long *stats)
+                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK, unsigned long long *stats)
 {
 	// narrow element types keep a wave at 6.5 KB of LDS (24 waves per CU): an exact context only needs its
 	// chunk number next to the position, a neighbour context 13 bits, a vote key 8 + 1 bits of state
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 			const uint64_t freem = __ballot(!active);
 			if (freem && cursor == end && !drained) {
 				uint32_t c0 = 0;
-				if (lane == 0) c0 = atomicAdd(work_next, (uint32_t)WORK_CHUNK);
+				if (lane == 0) c0 = atomicAdd(work_next, WORK_CHUNK);
 				c0 = __shfl(c0, 0);
 				if ((uint64_t)c0 >= n_reads) drained = true;
 				else { cursor = c0; end = (uint64_t)c0 + WORK_CHUNK < n_reads ? (uint64_t)c0 + WORK_CHUNK : n_reads; }
