@@ -36,14 +36,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
-    ap.add_argument("--genome", type=int, default=40_000_000)
-    ap.add_argument("--snps", type=int, default=1_000_000)
-    ap.add_argument("--chroms", type=int, default=1, help="number of sequences the genome is split into")
+    ap.add_argument("--workload", choices=["chr22", "hg38"], default="chr22",
+                    help="chr22 = BASELINE.json configs[1] (default, about a minute end to end); hg38 = configs[2] shape: 3.1 Gbp in 24 "
+                         "sequences, 10 M SNPs, 8 M-read batches of its 30x reads (index build + load take ~4 minutes, ~190 GB of HBM)")
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step")
+    ap.add_argument("--genome", type=int, default=None)
+    ap.add_argument("--snps", type=int, default=None)
+    ap.add_argument("--chroms", type=int, default=None, help="number of sequences the genome is split into")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench"))
     ap.add_argument("--no-check", action="store_true", help="skip the parity check against the oracle")
     args = ap.parse_args()
+    preset = {"chr22": dict(genome=40_000_000, snps=1_000_000, chroms=1, reads=1_000_000),
+              "hg38": dict(genome=3_100_000_000, snps=10_000_000, chroms=24, reads=8_000_000)}[args.workload]
+    for k, v in preset.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    args.cpu_sample = min(args.cpu_sample, args.reads) if args.cpu_sample else 0
 
     import torch
     import torch.distributed as dist
@@ -184,7 +193,7 @@ def main():
         except Exception:
             pass
         out = {
-            "metric": "reads/sec genotyped (whole node)",
+            "metric": "reads/sec genotyped (whole node), hg38+dbSNP 30\u00d7; achieved HBM GB/s vs peak",
             "value": world * r.n * args.steps / elapsed,
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
