@@ -16,6 +16,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_context_first():
+    """On a GPU box create torch's HIP context before the library's first big allocations: torch initialised late,
+    after several 35 GB index open/close cycles in the same process, has been seen to report "No HIP GPUs are
+    available" (torch only does plumbing in these tests: device buffers for vg_reads_process_device)."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda:0")
+    except Exception:
+        pass
+    yield
+
+
 def _gunzip(src, dst):
     with gzip.open(src, "rb") as f, open(dst, "wb") as g:
         shutil.copyfileobj(f, g)

@@ -190,3 +190,43 @@ def test_errors_are_codes_not_aborts(ftiny_dir, tmp_path):
         with pytest.raises(VgError) as e:
             gx.submit(long, long, np.array([0, 1023], np.uint64))
         assert e.value.code == -6
+
+
+def test_device_resident_batches_and_very_long_reads(ftiny_dir, ftiny_reads):
+    """vg_reads_process_device (what bench.py times) on torch buffers, including reads far beyond the reference's
+    1022-base line buffer: 32-chunk reads stay in the wave tier, longer ones take the generic lane tier."""
+    import torch
+    from vargeno_amd import synth
+
+    prefix = os.path.join(ftiny_dir, "idx")
+    g = synth.f_tiny()[0]
+    cat = np.concatenate(g.seqs)
+    rng = np.random.default_rng(5)
+    reads = []
+    for L in (1024, 1056, 2000, 5000, 1023, 33):
+        st = int(rng.integers(1000, len(cat) - L - 1000))
+        reads.append(cat[st:st + L])
+    bases = np.concatenate([ftiny_reads.bases] + reads)
+    extra_q = rng.integers(ord("#"), ord("I") + 1, size=sum(len(x) for x in reads), dtype=np.uint8)
+    quals = np.concatenate([ftiny_reads.quals, extra_q])
+    offs = np.concatenate([ftiny_reads.offsets, ftiny_reads.offsets[-1] + np.cumsum([len(x) for x in reads]).astype(np.uint64)])
+    ox = O.OracleIndex.load(prefix)
+    ox.process(bases, quals, offs)
+    so = ox.sites()
+    with GenoIndex.open(prefix) as gx:
+        dev = torch.device("cuda", 0)
+        tb, tq = torch.from_numpy(bases).to(dev), torch.from_numpy(quals).to(dev)
+        to = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        for stats in (True, False):
+            gx.reset()
+            gx.set_stats(stats)
+            gx.process_device(tb, tq, to, len(offs) - 1)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), stats
+        gx.set_stats(True)
+        gx.reset()
+        gx.process_device(tb, tq, to, len(offs) - 1)
+        st = gx.stats()
+        want = ox.stats.as_dict()
+        for k in CMP_STATS:
+            assert st[k] == want[k], k
