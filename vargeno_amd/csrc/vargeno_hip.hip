@@ -411,7 +411,7 @@ struct Slot {
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
 	uint8_t *fq_text = nullptr; uint32_t *fq_lines = nullptr, *fq_tiles = nullptr; uint64_t fq_text_cap = 0, fq_lines_cap = 0, fq_tiles_cap = 0;   // FASTQ framing
 	uint64_t stage_bytes = 0, stage_reads = 0;
-	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
 	bool busy = false;
 };
 
@@ -431,6 +431,7 @@ struct vg_index {
 	unsigned long long *d_stats = nullptr;
 	bool stats_enabled = true;
 	bool force_generic = false;           // VG_FORCE_GENERIC=1: skip the wave tier (tests compare the tiers)
+	hipEvent_t w2_pending = nullptr;      // end of the most recent deep-list tier launch (an event owned by a slot)
 	double t_pack = 0, t_main = 0, t_tail = 0, t_total = 0; uint64_t t_batches = 0;   // harvested event times since the last vg_timing_get
 	int cus = 256;
 	int lane_grid_blocks = 0, wave_grid = 0;
@@ -504,7 +505,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	for (Slot &sl : ix->slot) {
 		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles};
 		for (void *p : extra) if (p) (void)hipFree(p);
-		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4};
+		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 	}
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -523,7 +524,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->tail, hipStreamNonBlocking));
-	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); }
+	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); }
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	ix->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -769,7 +770,7 @@ static int harvest(vg_index *ix, Slot &sl)
 	if (!sl.busy) return VG_OK;
 	HIP_TRY(hipEventSynchronize(sl.e3));
 	float a = 0, b = 0, c = 0, t = 0;
-	HIP_TRY(hipEventElapsedTime(&a, sl.e0, sl.e1)); HIP_TRY(hipEventElapsedTime(&b, sl.e1, sl.e2));
+	HIP_TRY(hipEventElapsedTime(&a, sl.e0, sl.e1)); HIP_TRY(hipEventElapsedTime(&b, sl.e5, sl.e2));
 	HIP_TRY(hipEventElapsedTime(&c, sl.e2, sl.e3)); HIP_TRY(hipEventElapsedTime(&t, sl.e0, sl.e3));
 	ix->t_pack += a; ix->t_main += b; ix->t_tail += c; ix->t_total += t; ix->t_batches++;
 	sl.busy = false;
@@ -804,19 +805,24 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->cus * 16);
 		vg_pack_kernel<<<pgrid, 256, 0, ix->stream>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
+		// the previous batch's deep-list tier (tail stream) may run under this batch's pack kernel, but not under its
+		// wave kernel: its 54 KB-per-wave LDS footprint was measured to slow a co-resident wave kernel by 40 %
+		if (ix->w2_pending) HIP_TRY(hipStreamWaitEvent(ix->stream, ix->w2_pending, 0));
+		HIP_TRY(hipEventRecord(sl.e5, ix->stream));               // the wave kernel's own start (after that wait)
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->wave_grid / 4);
 		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, 4><<<wgrid, 256, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
-		// second tier: the same kernel with deep lists over the spill list (2 waves per CU).  It stays on the main
-		// stream: on the tail stream it ran under the next batch's wave kernel and slowed that by 40 %.
+		// tail stream, second tier: the same kernel with deep lists over the spill list (2 waves per CU)
+		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
-		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1><<<w2grid, 64, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], 2u, ix->d_stats);
-		HIP_TRY(hipEventRecord(sl.e4, ix->stream));
-		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e4, 0));
+		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], 2u, ix->d_stats);
+		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
+		ix->w2_pending = sl.e4;
 	} else {
 		HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
+		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
 		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, nullptr, sl.listB, &ctr[1], ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
