@@ -140,6 +140,20 @@ __global__ void vg_make_mx_entries(const uint64_t *__restrict__ key, const uint3
 		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1), 0u);
 	}
 }
+// direct table: the first entry of every HI32 bucket of the merged view, inline
+__global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ dx)
+{
+	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t lo = jg[h], hi = jg[h + 1];
+		uint4 r = make_uint4(0, 0, 0, 0);
+		if (hi > lo) {
+			const uint4 e = mx[lo];
+			const uint32_t cnt = hi - lo > 0xFFFFFFu ? 0xFFFFFFu : hi - lo;
+			r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (cnt << 8), lo);
+		}
+		dx[h] = r;
+	}
+}
 __global__ void vg_iota_u32(uint32_t *v, uint64_t n) { for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i; }
 
 // SoA as the dictionary file has it -> one 16-byte entry per k-mer (a hit then costs one line)
@@ -613,6 +627,26 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(ix->stream));
 			d.mx_jg = mjg; d.mx = mx;
+			// direct table (64 GiB) in place of the merged jump table (16 GiB) when the device has the room; no bucket may
+			// exceed the 24-bit count field (it would be a >16 M-fold repeated 16-mer)
+			if (!getenv("VG_NO_DIRECT")) {
+				kout.release(); vout.release(); rp.release(); ra.release();
+				size_t free_b = 0, total_b = 0;
+				uint4 *dx = nullptr;
+				if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (80ull << 30) && hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) == hipSuccess) {
+					vg_make_direct<<<ix->cus * 32, 256, 0, ix->stream>>>(mjg, mx, dx);
+					HIP_TRY(hipGetLastError());
+					HIP_TRY(hipStreamSynchronize(ix->stream));
+					ix->owned.push_back(dx); ix->dev_bytes += (uint64_t)(1ull << 32) * 16;
+					d.dx = dx;
+					// the merged jump table is not needed any more
+					for (size_t z = 0; z < ix->owned.size(); z++) if (ix->owned[z] == (void *)mjg) { ix->owned.erase(ix->owned.begin() + (long)z); break; }
+					(void)hipFree(mjg); ix->dev_bytes -= ((1ull << 32) + 1) * 4;
+					d.mx_jg = nullptr;
+				} else {
+					(void)hipGetLastError();                     // not enough memory: keep the jump-table form
+				}
+			}
 		}
 	}
 	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first

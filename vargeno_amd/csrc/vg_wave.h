@@ -202,6 +202,39 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 						else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
 					}
 				};
+				if (d.dx) {
+					// direct table: the bucket's first entry arrives with the bucket itself
+					for (uint32_t c = 0; c < n; c += 2) {
+						const bool two = c + 1 < n;
+						const uint64_t k0 = chunk_kmer(c), k1 = two ? chunk_kmer(c + 1) : 0;
+						const uint4 z = make_uint4(0, 0, 0, 0);
+						const uint4 b0 = d.dx[k0 >> 32], b1 = two ? d.dx[k1 >> 32] : z;
+						auto settle = [&](uint32_t cc, uint64_t k, const uint4 b) {
+							cur.add(S_CHUNKS, 1);
+							uint32_t rpos = 0, ramb = 0, spos = 0, samb = 0;
+							bool rhit = false, shit = false;
+							if (b.z & 1u) {
+								const uint32_t key = (uint32_t)k, cnt = b.z >> 8;
+								if (b.x == key) { if (b.z & 2u) { shit = true; spos = b.y; samb = (b.z >> 2) & 1u; } else { rhit = true; rpos = b.y; ramb = (b.z >> 2) & 1u; } }
+								if (cnt > 1 && b.x <= key) {                              // entries are sorted by lo: nothing below the first
+									const uint32_t lo = b.w, hi = b.w + cnt;
+									uint32_t ea = lo + 1;
+									if (cnt > 5) { uint32_t eb = hi; while (ea < eb) { const uint32_t m = ea + ((eb - ea) >> 1); if (d.mx[m].x < key) ea = m + 1; else eb = m; } }
+									for (uint32_t e = ea; e < hi; e++) {
+										const uint4 v = d.mx[e];
+										if (v.x < key) continue;
+										if (v.x > key) break;
+										if (v.z & 1u) { shit = true; spos = v.y; samb = (v.z >> 1) & 1u; }
+										else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
+									}
+								}
+							}
+							emit_exact(cc, rhit, rpos, ramb, shit, spos, samb);
+						};
+						settle(c, k0, b0);
+						if (two) settle(c + 1, k1, b1);
+					}
+				} else
 				for (uint32_t c = 0; c < n; c += 2) {
 					const bool two = c + 1 < n;
 					const uint64_t k0 = chunk_kmer(c), k1 = two ? chunk_kmer(c + 1) : 0;
