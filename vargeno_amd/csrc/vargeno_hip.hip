@@ -263,6 +263,20 @@ __global__ __launch_bounds__(256) void vg_pack_kernel(const uint8_t *__restrict_
 	}
 }
 
+// base-indexed counters of the wave kernel -> the ref / alt sums (and zero them for the next round)
+__global__ void vg_fold_counters(uint32_t *__restrict__ cnt4, const uint8_t *__restrict__ site_ba, uint32_t *__restrict__ cnt, uint64_t n_sites)
+{
+	for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_sites; s += (uint64_t)gridDim.x * blockDim.x) {
+		uint4 v = ((const uint4 *)cnt4)[s];
+		if ((v.x | v.y | v.z | v.w) == 0) continue;
+		const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+		const uint32_t ba = site_ba[s];
+		cnt[2 * s] += q[ba & 3u];
+		cnt[2 * s + 1] += q[(ba >> 2) & 3u];
+		((uint4 *)cnt4)[s] = make_uint4(0u, 0u, 0u, 0u);
+	}
+}
+
 __global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 {
 	cum[0] += ctr[0]; cum[1] += ctr[1]; cum[2] += ctr[2];     // wave-tier overflow, lane-tier overflow, lost
@@ -436,6 +450,7 @@ struct vg_index {
 	std::vector<void *> owned;            // every device allocation of the index
 	uint64_t dev_bytes = 0;
 	uint64_t n_sites = 0;
+	bool cnt4_dirty = false;                           // base-indexed counters hold increments not yet folded into d.cnt
 	std::vector<uint32_t> site_pos;
 	std::vector<uint8_t> site_ref, site_alt, site_rf, site_af;
 	ScratchBuf mid, big;                  // lane-tier scratch: every lane x 64 contexts; a few lanes x 16384 contexts
@@ -570,7 +585,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		// secondary view ordered by (LO32, HI32): device radix sort of the swapped k-mers + a jump table over LO32's top bits
 		if (!getenv("VG_NO_SEC")) {
 			uint32_t bits = 14;
-			while (bits < 28 && (1ull << bits) < a->n_ref / 2) bits++;      // ~2-4 entries per bucket
+			while (bits < 30 && (1ull << bits) < a->n_ref) bits++;          // ~1-2 entries per bucket
 			TempDev<uint64_t> kin; TempDev<uint32_t> vin;
 			if ((rc = kin.alloc(a->n_ref))) return rc;
 			if ((rc = vin.alloc(a->n_ref))) return rc;
@@ -699,6 +714,12 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		if ((rc = dev_alloc(ix, &dc, 2 * ix->n_sites + 2, true))) return rc;
 		d.srank = dr;
 		d.pile = dp; d.pile_len = plen; d.cnt = dc;
+		std::vector<uint8_t> ba(ix->n_sites + 1, 0);
+		for (uint64_t s2 = 0; s2 < ix->n_sites; s2++) ba[s2] = (uint8_t)(ix->site_ref[s2] | (ix->site_alt[s2] << 2));
+		uint8_t *dba = nullptr; uint32_t *dc4 = nullptr;
+		if ((rc = dev_upload(ix, &dba, ba.data(), ba.size()))) return rc;
+		if ((rc = dev_alloc(ix, &dc4, 4 * ix->n_sites + 4, true))) return rc;
+		d.site_ba = dba; d.cnt4 = dc4;
 	}
 	// ---- scratch of the lane tier, overflow counters, stats
 	// VG_SCRATCH_CAP / VG_SCRATCH_KCAP shrink the per-lane scratch so tests can drive every tier
@@ -818,6 +839,12 @@ static int finish_pending(vg_index *ix)
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	HIP_TRY(hipStreamSynchronize(ix->tail));
 	for (Slot &sl : ix->slot) { int rc = harvest(ix, sl); if (rc) return rc; }
+	if (ix->cnt4_dirty && ix->n_sites) {
+		vg_fold_counters<<<(unsigned)std::min<uint64_t>((ix->n_sites + 255) / 256, 4096), 256, 0, ix->stream>>>(ix->d.cnt4, ix->d.site_ba, ix->d.cnt, ix->n_sites);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+	}
+	ix->cnt4_dirty = false;
 	uint32_t c[4];
 	HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost));
 	if (c[2]) return fail(VG_ENOMEM, "a read produced more hit contexts than the deep scratch holds (the reference overruns MAX_HITS=2000 long before, qv.cc:709)");
@@ -843,6 +870,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		// wave kernel: its 54 KB-per-wave LDS footprint was measured to slow a co-resident wave kernel by 40 %
 		if (ix->w2_pending) HIP_TRY(hipStreamWaitEvent(ix->stream, ix->w2_pending, 0));
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));               // the wave kernel's own start (after that wait)
+		ix->cnt4_dirty = true;
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->wave_grid / 4);
 		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, 4><<<wgrid, 256, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));

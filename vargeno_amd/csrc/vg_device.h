@@ -65,6 +65,11 @@ struct DevIndex {
 	const uint8_t *pile; uint64_t pile_len;
 	const ulonglong2 *srank;       // [pile_len / 64 + 1]  .x = site bits of the block, .y = sites before it
 	uint32_t *cnt;                 // [2 * n_sites] exact sums: [2s] ref, [2s+1] alt
+	// The wave kernel's walks count by the base the read shows -- [4s + base] -- which takes the site's ref/alt bases (and
+	// with them the 32-byte pile window) out of the walk: the rank block alone says where the sites are.  Folded into
+	// `cnt` with site_ba (ref | alt << 2 per site) before anything reads the sums (vg_fold_counters).
+	uint32_t *cnt4;                // [4 * n_sites]
+	const uint8_t *site_ba;        // [n_sites]
 };
 
 enum StatId {
@@ -112,6 +117,17 @@ __device__ inline void jg_pair(const uint32_t *jg, uint64_t h, uint32_t &lo, uin
 	uint64_t v;
 	__builtin_memcpy(&v, jg + h, 8);
 	lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+}
+
+// columns [j0, j0 + 4) of an auxiliary-table row (AUX_COLS = 10 positions, rows 8-byte aligned) as two independent 8-byte
+// gathers; columns past the row read as 0.  Rows end at their first 0, and most hold two or three positions, so one call
+// -- one wait -- usually settles a row that a column-by-column walk would wait on three or four times.
+__device__ inline void load_row4(const uint32_t *row, int j0, uint32_t (&v)[4])
+{
+	uint2 a, b = make_uint2(0u, 0u);
+	__builtin_memcpy(&a, row + j0, 8);
+	if (j0 + 2 < AUX_COLS) __builtin_memcpy(&b, row + j0 + 2, 8);
+	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
 // query_ref_dict, src/qv.cc:206-240.  Returns the entry index or -1; lo/hi = bucket of HI32(k); `ent` = the entry
@@ -166,6 +182,31 @@ __device__ inline int64_t snp_query(const DevIndex &d, ST &st, uint64_t k, uint3
 	return snp_query(d, st, k, lo, hi, e);
 }
 
+// Both dictionary queries of one neighbour k-mer in lock step: the two jump-table gathers go out together and so do the two
+// probes of every bisection step, so the pair costs 1 + max(depth) waits instead of 2 + the sum.  Same results and the same
+// event counts as ref_query + snp_query.  ri / si are left untouched on a miss.
+template <class ST>
+__device__ inline void dual_query(const DevIndex &d, ST &st, uint64_t k, bool want_r, bool want_s, uint32_t &ri, uint32_t &si)
+{
+	uint32_t ra = 0, rb = 0, sa = 0, sb = 0;
+	if (want_r) { jg_pair(d.ref_jg, k >> 32, ra, rb); st.add(S_REF_QUERY, 1); }
+	if (want_s) { jg_pair(d.snp_jg, k >> 40, sa, sb); st.add(S_SNP_QUERY, 1); }
+	if (ra < rb) st.add(S_REF_PROBE, ceil_log2_p1(rb - ra));
+	if (sa < sb) st.add(S_SNP_PROBE, ceil_log2_p1(sb - sa));
+	const uint32_t rkey = (uint32_t)k;
+	const uint64_t skey = k & LO40_MASK;
+	while (ra < rb || sa < sb) {
+		const bool pr = ra < rb, ps = sa < sb;
+		const uint32_t rm = ra + ((rb - ra) >> 1), sm = sa + ((sb - sa) >> 1);
+		uint32_t rlo = 0;
+		uint64_t sk = 0;
+		if (pr) rlo = d.ref[rm].lo;
+		if (ps) sk = d.snp[sm].key & LO40_MASK;
+		if (pr) { if (rlo == rkey) { ri = rm; ra = rb; } else if (rlo < rkey) ra = rm + 1; else rb = rm; }
+		if (ps) { if (sk == skey) { si = sm; sa = sb; } else if (sk < skey) sa = sm + 1; else sb = sm; }
+	}
+}
+
 template <class ST>
 __device__ inline bool site_loose(const DevIndex &d, ST &st, uint32_t p)     // !(ref == 0 && alt == 0), qv.cc:990-991
 {
@@ -176,14 +217,17 @@ __device__ inline bool site_loose(const DevIndex &d, ST &st, uint32_t p)     // 
 // pile-up walk of one supporting context (src/qv.cc:1386-1436 = :1444-1494): 32 consecutive site bytes as two
 // 16-byte gathers; only bases that match ref or alt at a site need the site id (one rank-block gather).
 // Saturation is applied at fetch time as min(63, sum).
-template <class ST>
-__device__ inline void walk_ctx(const DevIndex &d, ST &st, uint64_t kk, uint32_t kpos, uint32_t mod)
+// The walk is split so that a caller can batch it: load_pile_window (two gathers, no dependence on anything
+// else), walk_matches (pure ALU over the window), bump_site (one rank gather + one atomic).
+__device__ inline void load_pile_window(const DevIndex &d, uint32_t kpos, uint4 (&w4)[2])
 {
-	st.add(S_WALKS, 1);
-	if ((uint64_t)kpos + 32 > d.pile_len) return;          // cannot happen: pile_len = max position + 64
-	uint4 w4[2];
 	__builtin_memcpy(&w4[0], d.pile + kpos, 16);
 	__builtin_memcpy(&w4[1], d.pile + kpos + 16, 16);
+}
+
+template <class F>
+__device__ inline void walk_matches(const uint4 (&w4)[2], uint64_t kk, uint32_t kpos, uint32_t mod, F &&hit)
+{
 	const uint32_t w[8] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w};
 	// site flags of the 32 positions: bit 4 of every byte
 	uint32_t sites = 0;
@@ -196,16 +240,34 @@ __device__ inline void walk_ctx(const DevIndex &d, ST &st, uint64_t kk, uint32_t
 	while (sites) {
 		const uint32_t b = (uint32_t)__ffs((int)sites) - 1;
 		sites &= sites - 1;
-		const uint32_t by = (w[b >> 2] >> (8 * (b & 3u))) & 0xFFu;
+		uint32_t by = 0;
+		#pragma unroll
+		for (int g = 0; g < 8; g++) if ((b >> 2) == (uint32_t)g) by = w[g];
+		by = (by >> (8 * (b & 3u))) & 0xFFu;
 		const uint32_t base = (uint32_t)(kk >> (2 * b)) & 3u;
-		uint32_t which;
-		if (base == (by & 3u)) which = 0; else if (base == ((by >> 2) & 3u)) which = 1; else continue;
-		const uint32_t p = kpos + b;
-		const ulonglong2 rb = d.srank[p >> 6];
-		const uint32_t sid = (uint32_t)rb.y + (uint32_t)__popcll(rb.x & ((1ull << (p & 63u)) - 1ull));
-		atomicAdd(&d.cnt[2ull * sid + which], 1u);
-		st.add(S_INCR, 1);
+		if (base == (by & 3u)) hit(kpos + b, 0u);
+		else if (base == ((by >> 2) & 3u)) hit(kpos + b, 1u);
 	}
+}
+
+__device__ inline uint32_t site_id(const ulonglong2 rb, uint32_t p)
+{
+	return (uint32_t)rb.y + (uint32_t)__popcll(rb.x & ((1ull << (p & 63u)) - 1ull));
+}
+
+__device__ inline void bump_site(const DevIndex &d, uint32_t p, uint32_t which)
+{
+	atomicAdd(&d.cnt[2ull * site_id(d.srank[p >> 6], p) + which], 1u);
+}
+
+template <class ST>
+__device__ inline void walk_ctx(const DevIndex &d, ST &st, uint64_t kk, uint32_t kpos, uint32_t mod)
+{
+	st.add(S_WALKS, 1);
+	if ((uint64_t)kpos + 32 > d.pile_len) return;          // cannot happen: pile_len = max position + 64
+	uint4 w4[2];
+	load_pile_window(d, kpos, w4);
+	walk_matches(w4, kk, kpos, mod, [&](uint32_t p, uint32_t which) { bump_site(d, p, which); st.add(S_INCR, 1); });
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,6 +20,22 @@
 #pragma once
 #include "vg_device.h"
 
+#ifndef VG_WPE
+#define VG_WPE 4          // waves per SIMD the main tier is compiled for (128 VGPRs)
+#endif
+#ifndef VG_WALK_BATCH
+#define VG_WALK_BATCH 1
+#endif
+
+// -DVG_STAGE_CLOCKS: development aid, never in the shipped build -- a sample of waves prints the core-clock cycles they spent per stage
+#ifdef VG_STAGE_CLOCKS
+#define VG_CLK(i) do { const long long t_ = clock64(); clk[i] += t_ - tlast; tlast = t_; } while (0)
+#define VG_CLKW(i) do { __builtin_amdgcn_s_waitcnt(0); VG_CLK(i); } while (0)
+#else
+#define VG_CLK(i) do { } while (0)
+#define VG_CLKW(i) do { } while (0)
+#endif
+
 namespace vg {
 
 // List capacities per job-pass (LDS, [slot][lane]).  Two instantiations: the main tier keeps 17 waves per CU
@@ -59,7 +75,7 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 // WORK_CHUNK: reads a wave pulls from the launch's work counter at a time (large for the main tier, a handful for the
 // spill tier, whose few hundred heavy reads must spread over all its waves)
 template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB>
-__global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB == 4 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
                                                      uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK, unsigned long long *stats)
@@ -78,30 +94,42 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 	constexpr int NSH = 11;                               // event counters that helper lanes bump on behalf of an owner
 	constexpr int SH_IDS[NSH] = {S_REF_QUERY, S_SNP_QUERY, S_REF_PROBE, S_SNP_PROBE, S_SCAN_REF, S_SCAN_SNP, S_SCAN_OOB, S_AUX_REF, S_AUX_SNP, S_SITE_TEST, S_CTX};
 	__shared__ uint32_t S_own[STATS ? NSH : 1][STATS ? 64 * WPB : 1];
-	const uint32_t wv = threadIdx.x >> 6;
+	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
 	// The secondary (LO32-ordered) view answers the 48 high-half reference queries with one bucket read.  The counting
 	// build keeps the 48 individual queries because the event counters price each of them.
 	const bool use_sec = !STATS && d.sec_key != nullptr;
 	const bool use_mx = !STATS && d.mx != nullptr;
 	const uint32_t lane = threadIdx.x & 63u;             // lane in the wave
 	const uint32_t col = threadIdx.x;                    // this lane's LDS column
-	const uint32_t col0 = threadIdx.x & ~63u;            // first column of this wave
+	const uint32_t col0 = wv << 6;                       // first column of this wave (scalar)
 	const uint64_t lane_bit = 1ull << lane;
 	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;
 	// work distribution: waves pull WORK_CHUNK consecutive reads at a time from one device counter (zeroed per launch), so
 	// the last waves to finish differ by one chunk instead of by the variance of a static 1/n_waves share
-	uint64_t cursor = 0, end = 0;
+	uint32_t cursor = 0, end = 0;                        // wave-uniform (kept in scalar registers); a launch holds < 2^32 reads
 	bool drained = false;
 
 	bool active = false;
+#ifdef VG_STAGE_CLOCKS
+	long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+	uint32_t iters = 0;
+#endif
 	uint32_t rid = 0, n = 0, gates = 0, pass = 0;
-	uint64_t slot0 = 0;
+	uint32_t slot0 = 0;                                  // first k-mer slot of the read (a batch holds < 2^37 bases: checked on the host)
 	LaneStats<STATS> tot, cur;
 	tot.clear(); cur.clear();
 
 	auto chunk_kmer = [&](uint32_t c) -> uint64_t {
-		const uint64_t kf = pk_kmer[slot0 + (pass ? n - 1 - c : c)];
+		const uint64_t kf = pk_kmer[(uint64_t)slot0 + (pass ? n - 1 - c : c)];
 		return pass ? revcomp64(kf) : kf;
+	};
+
+	// chunks c and c + 1 of the current strand sit side by side in pk_kmer whichever the strand: one 16-byte gather
+	auto chunk_kmer2 = [&](uint32_t c, uint64_t &k0, uint64_t &k1) {
+		ulonglong2 v;
+		__builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + (pass ? n - 2 - c : c)), 16);
+		k0 = pass ? revcomp64(v.y) : v.x;
+		k1 = pass ? revcomp64(v.x) : v.y;
 	};
 
 	for (;;) {
@@ -111,14 +139,14 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 			if (freem && cursor == end && !drained) {
 				uint32_t c0 = 0;
 				if (lane == 0) c0 = atomicAdd(work_next, WORK_CHUNK);
-				c0 = __shfl(c0, 0);
+				c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
 				if ((uint64_t)c0 >= n_reads) drained = true;
-				else { cursor = c0; end = (uint64_t)c0 + WORK_CHUNK < n_reads ? (uint64_t)c0 + WORK_CHUNK : n_reads; }
+				else { cursor = c0; end = (uint64_t)c0 + WORK_CHUNK < n_reads ? c0 + WORK_CHUNK : (uint32_t)n_reads; }
 			}
-			const uint64_t avail = end - cursor;
+			const uint32_t avail = end - cursor;
 			if (freem && avail) {
 				const uint32_t nfree = (uint32_t)__popcll(freem);
-				const uint32_t take = (uint32_t)(avail < nfree ? avail : nfree);
+				const uint32_t take = avail < nfree ? avail : nfree;
 				if (!active) {
 					const uint32_t rank = (uint32_t)__popcll(freem & (lane_bit - 1));
 					if (rank < take) {
@@ -126,7 +154,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 						const uint64_t off = offsets[rid];
 						const uint64_t meta = pk_meta[rid];
 						n = (uint32_t)((offsets[rid + 1] - off) >> 5);
-						slot0 = off >> 5;
+						slot0 = (uint32_t)(off >> 5);
 						gates = (uint32_t)meta;
 						pass = 0;
 						cur.clear();
@@ -146,42 +174,38 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 			}
 		}
 		if (!__any(active)) { if (drained) break; continue; }
+		VG_CLK(0);
+#ifdef VG_STAGE_CLOCKS
+		iters++;
+#endif
 
 		// ------------------------------------------------------------------ stage A: exact look-ups
 		uint32_t ecnt = 0, ncnt = 0;
 		bool ovf = false;
 		if (active) {
 			// append the exact contexts of chunk c (qv.cc:850-937): reference hit first, then SNP hit; aux rows expanded
+			auto push_exact = [&](uint32_t p, uint32_t c) {
+				cur.add(S_CTX, 1);
+				if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
+			};
+			auto push_row = [&](const uint32_t *row, uint32_t c) {               // a row ends at its first 0
+				for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
+					uint32_t v[4];
+					load_row4(row, j0, v);
+					bool live = true;
+					#pragma unroll
+					for (int j = 0; j < 4; j++) { live = live && v[j] != 0; if (live) push_exact(v[j], c); }
+					if (!live) break;
+				}
+			};
 			auto emit_exact = [&](uint32_t c, bool rhit, uint32_t rpos, uint32_t ramb, bool shit, uint32_t spos, uint32_t samb) {
 				if (rhit && rpos != POS_AMBIGUOUS) {
-					if (ramb == 0) {
-						cur.add(S_CTX, 1);
-						if (ecnt < W_ECAP) { E_kpos[ecnt][col] = rpos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
-					} else {
-						const uint32_t *row = d.ref_aux + (uint64_t)rpos * AUX_COLS;
-						cur.add(S_AUX_REF, 1);
-						for (int j = 0; j < AUX_COLS; j++) {
-							const uint32_t p = row[j];
-							if (p == 0) break;
-							cur.add(S_CTX, 1);
-							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
-						}
-					}
+					if (ramb == 0) push_exact(rpos, c);
+					else { cur.add(S_AUX_REF, 1); push_row(d.ref_aux + (uint64_t)rpos * AUX_COLS, c); }
 				}
 				if (shit && spos != POS_AMBIGUOUS) {
-					if (samb == 0) {
-						cur.add(S_CTX, 1);
-						if (ecnt < W_ECAP) { E_kpos[ecnt][col] = spos; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
-					} else {
-						const uint32_t *prow = d.snp_aux_pos + (uint64_t)spos * AUX_COLS;
-						cur.add(S_AUX_SNP, 1);
-						for (int j = 0; j < AUX_COLS; j++) {
-							const uint32_t p = prow[j];
-							if (p == 0) break;
-							cur.add(S_CTX, 1);
-							if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
-						}
-					}
+					if (samb == 0) push_exact(spos, c);
+					else { cur.add(S_AUX_SNP, 1); push_row(d.snp_aux_pos + (uint64_t)spos * AUX_COLS, c); }
 				}
 			};
 			if (use_mx) {
@@ -203,12 +227,16 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 					}
 				};
 				if (d.dx) {
-					// direct table: the bucket's first entry arrives with the bucket itself
-					for (uint32_t c = 0; c < n; c += 2) {
-						const bool two = c + 1 < n;
-						const uint64_t k0 = chunk_kmer(c), k1 = two ? chunk_kmer(c + 1) : 0;
-						const uint4 z = make_uint4(0, 0, 0, 0);
-						const uint4 b0 = d.dx[k0 >> 32], b1 = two ? d.dx[k1 >> 32] : z;
+					// direct table: the bucket's first entry arrives with the bucket itself.  Up to four chunks -- a whole 150 bp
+					// read -- are in flight at a time: their k-mers come as 16-byte pairs, their buckets go out back to back.
+					for (uint32_t c = 0; c < n; c += 4) {
+						const uint32_t m = n - c < 4u ? n - c : 4u;
+						uint64_t kq[4] = {0, 0, 0, 0};
+						if (m >= 2) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
+						if (m >= 4) chunk_kmer2(c + 2, kq[2], kq[3]); else if (m == 3) kq[2] = chunk_kmer(c + 2);
+						uint4 bq[4];
+						#pragma unroll
+						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = d.dx[kq[z] >> 32]; }
 						auto settle = [&](uint32_t cc, uint64_t k, const uint4 b) {
 							cur.add(S_CHUNKS, 1);
 							uint32_t rpos = 0, ramb = 0, spos = 0, samb = 0;
@@ -231,8 +259,8 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 							}
 							emit_exact(cc, rhit, rpos, ramb, shit, spos, samb);
 						};
-						settle(c, k0, b0);
-						if (two) settle(c + 1, k1, b1);
+						#pragma unroll
+						for (uint32_t z = 0; z < 4; z++) if (z < m) settle(c + z, kq[z], bq[z]);
 					}
 				} else
 				for (uint32_t c = 0; c < n; c += 2) {
@@ -270,6 +298,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 			}
 		}
 		VG_WAVE_SYNC();
+		VG_CLK(1);
 
 		// ------------------------------------------------------------------ stage B: all gate-open chunks of the wave, flattened
 		// (owner, chunk) pairs in (lane, chunk) order -> one table row each (LDS), their work items laid end to end and dealt
@@ -279,74 +308,110 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 			const uint32_t my_np = (uint32_t)__popc(pend);
 			uint32_t pincl = my_np;
 			for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pincl, o); if ((int)lane >= o) pincl += y; }
-			const uint32_t my_base = pincl - my_np, P = __shfl(pincl, 63);
+			const uint32_t my_base = pincl - my_np, P = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);    // wave-uniform: scalar
 			N_cnt[col] = 0; N_ovf[col] = 0;
 			if constexpr (STATS) for (int i = 0; i < NSH; i++) S_own[i][col] = 0;
 			for (uint32_t w0 = 0; w0 < P; w0 += PCAP) {
-				// ---- B0: each owner lane fills the rows of its own pairs that fall into this window
+				// ---- B0: owners name their pairs of this window (LDS), then lane p fills row p -- one pair per lane whatever
+				// the owner, so a read with several gate-open chunks does not make its wave walk them one after the other
 				{
 					uint32_t q = my_base, bits = pend;
 					while (bits) {
 						const uint32_t c = (uint32_t)__ffs((int)bits) - 1;
 						bits &= bits - 1;
-						if (q >= w0 && q < w0 + PCAP) {
-							const uint32_t p = q - w0;
-							const uint64_t k = chunk_kmer(c);
-							const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
-							uint32_t lo, hi, slo, shi, b0 = 0, b1 = 0, fl = 0;
-							jg_pair(d.ref_jg, k >> 32, lo, hi);                      // check_block_size, qv.cc:242-264
-							jg_pair(d.snp_jg, k >> 40, slo, shi);
-							if (use_sec) jg_pair(d.sec_jg, klo >> (32 - d.sec_bits), b0, b1);
-							const uint64_t rp = (uint64_t)hash32(klo) % d.ref_bf_bits;   // qv.cc:946-956
-							const uint64_t sp = hash40(k & LO40_MASK) % d.snp_bf_bits;
-							if ((d.ref_bf[rp >> 6] >> (rp & 63)) & 1u) fl |= 1u;
-							if ((d.snp_bf[sp >> 6] >> (sp & 63)) & 1u) fl |= 2u;
-							const bool large = hi - lo >= BLOCK_THRESHOLD;
-							cur.add(S_GATE_OPEN, 1);
-							cur.add(S_REFBF_POS, fl & 1u);
-							cur.add(S_SNPBF_POS, (fl >> 1) & 1u);
-							if (large) cur.add(S_LARGE_BLOCK, 1);
-							// high-half SNP queries are live for a contiguous range of slots u = 3 * (pair - 16) + sel  (qv.cc:1303-1306)
-							uint32_t s_lo = 0, s_hi = 0;
-							if (fl & 2u) { s_lo = large ? 0u : 12u; s_hi = 48u; } else if (large) { s_lo = 0u; s_hi = 12u; }
-							// high-half ref hits from the LO32-ordered view: every dictionary k-mer with the same first 16 bases
-							// whose last 16 differ in exactly one base, kept sorted by slot
-							uint32_t nh = 0, hu = 0;                                   // hu: slot of hit z in byte z (unsorted)
-							bool sec_ok = use_sec;
-							if (use_sec && (fl & 1u)) {
+						if (q >= w0 && q < w0 + PCAP) { P_meta[q - w0][wv] = lane | (c << 6); P_ecnt[q - w0][wv] = (uint8_t)ecnt; }
+						q++;
+					}
+				}
+				VG_WAVE_SYNC();
+				{
+					const uint32_t np0 = P - w0 < (uint32_t)PCAP ? P - w0 : (uint32_t)PCAP;
+					const uint32_t p = lane < (uint32_t)PCAP ? lane : 0u;
+					const bool mine = lane < np0;
+					const uint32_t m0 = mine ? P_meta[p][wv] : 0u;
+					const uint32_t own = m0 & 63u, c = (m0 >> 6) & 31u;
+					// the owner's read: where its k-mers start, how many, which strand
+					const uint32_t o_n = __shfl(n, own), o_pass = __shfl(pass, own);
+					const uint64_t o_slot0 = __shfl(slot0, own);
+					if (mine) {
+						const uint64_t kf = pk_kmer[o_slot0 + (o_pass ? o_n - 1 - c : c)];
+						const uint64_t k = o_pass ? revcomp64(kf) : kf;
+						const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
+						uint32_t lo, hi, slo, shi, b0 = 0, b1 = 0, fl = 0;
+						jg_pair(d.ref_jg, k >> 32, lo, hi);                      // check_block_size, qv.cc:242-264
+						jg_pair(d.snp_jg, k >> 40, slo, shi);
+						if (use_sec) jg_pair(d.sec_jg, klo >> (32 - d.sec_bits), b0, b1);
+						const uint64_t rp = (uint64_t)hash32(klo) % d.ref_bf_bits;   // qv.cc:946-956
+						const uint64_t sp = hash40(k & LO40_MASK) % d.snp_bf_bits;
+						if ((d.ref_bf[rp >> 6] >> (rp & 63)) & 1u) fl |= 1u;
+						if ((d.snp_bf[sp >> 6] >> (sp & 63)) & 1u) fl |= 2u;
+						const bool large = hi - lo >= BLOCK_THRESHOLD;
+						// high-half SNP queries are live for a contiguous range of slots u = 3 * (pair - 16) + sel  (qv.cc:1303-1306)
+						uint32_t s_lo = 0, s_hi = 0;
+						if (fl & 2u) { s_lo = large ? 0u : 12u; s_hi = 48u; } else if (large) { s_lo = 0u; s_hi = 12u; }
+						// high-half ref hits from the LO32-ordered view: every dictionary k-mer with the same first 16 bases
+						// whose last 16 differ in exactly one base, kept sorted by slot
+						uint32_t nh = 0, hu = 0;                                   // hu: slot of hit z in byte z (unsorted)
+						bool sec_ok = use_sec;
+						auto sec_entry = [&](uint64_t key, uint32_t idx) {        // one view entry with this LO32
+							const int dd = onebase((uint64_t)((uint32_t)key ^ khi));
+							if (dd < 0) return;
+							if (nh == (uint32_t)HCAP) { sec_ok = false; return; }
+							const uint32_t nbb = ((uint32_t)key >> (2 * dd)) & 3u, base = (khi >> (2 * dd)) & 3u;
+							P_hidx[nh][p][wv] = idx;
+							hu |= ((uint32_t)dd * 3u + nbb - (nbb > base ? 1u : 0u)) << (8 * nh);
+							nh++;
+						};
+						if (use_sec && (fl & 1u) && b1 > b0) {
+							if (b1 - b0 <= 4u) {
+								// the usual bucket: its (at most four) keys and dictionary indices in one go, no search
+								uint64_t key[4]; uint32_t idx[4];
+								#pragma unroll
+								for (uint32_t z = 0; z < 4; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; key[z] = d.sec_key[e]; idx[z] = d.sec_idx[e]; }
+								#pragma unroll
+								for (uint32_t z = 0; z < 4; z++) if (b0 + z < b1 && (uint32_t)(key[z] >> 32) == klo) sec_entry(key[z], idx[z]);
+							} else {
 								// k-mers with this LO32 are adjacent in the view; a popular LO32 (microsatellites, poly-A) would make
 								// one lane walk a long run while its wave waits, so past SEC_RUN entries the pair keeps its 48 queries
 								uint32_t ea = b0, eb = b1;
 								const uint64_t want = (uint64_t)klo << 32;
 								while (ea < eb) { const uint32_t m = ea + ((eb - ea) >> 1); if (d.sec_key[m] < want) ea = m + 1; else eb = m; }
-								for (uint32_t e = ea; e < b1; e++) {
+								for (uint32_t e = ea; e < b1 && sec_ok; e++) {
 									const uint64_t key = d.sec_key[e];
 									if ((uint32_t)(key >> 32) != klo) break;
 									if (e - ea >= (uint32_t)SEC_RUN) { sec_ok = false; break; }
-									const int dd = onebase((uint64_t)((uint32_t)key ^ khi));
-									if (dd < 0) continue;
-									if (nh == (uint32_t)HCAP) { sec_ok = false; break; }
-									const uint32_t nbb = ((uint32_t)key >> (2 * dd)) & 3u, base = (khi >> (2 * dd)) & 3u;
-									P_hidx[nh][p][wv] = d.sec_idx[e];
-									hu |= ((uint32_t)dd * 3u + nbb - (nbb > base ? 1u : 0u)) << (8 * nh);
-									nh++;
+									if (onebase((uint64_t)((uint32_t)key ^ khi)) >= 0) sec_entry(key, d.sec_idx[e]);
 								}
 							}
-							uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
-							if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
-							else if (sec_ok && s_hi == s_lo) { mode = 1; nhigh = nh; }
-							else { u_lo = 0; nhigh = 48; }
-							const uint32_t L = large ? 48u : (hi - lo) + (shi - slo);
-							P_klo[p][wv] = klo; P_khi[p][wv] = khi; P_lo[p][wv] = lo; P_hi[p][wv] = hi; P_slo[p][wv] = slo; P_shi[p][wv] = shi;
-							P_meta[p][wv] = lane | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
-							P_cnt[p][wv] = L + nhigh;
-							P_ecnt[p][wv] = (uint8_t)ecnt;
-							P_hu[p][wv] = hu;
+						}
+						uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
+						if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
+						else if (sec_ok && s_hi == s_lo) { mode = 1; nhigh = nh; }
+						else { u_lo = 0; nhigh = 48; }
+						const uint32_t L = large ? 48u : (hi - lo) + (shi - slo);
+						P_klo[p][wv] = klo; P_khi[p][wv] = khi; P_lo[p][wv] = lo; P_hi[p][wv] = hi; P_slo[p][wv] = slo; P_shi[p][wv] = shi;
+						P_meta[p][wv] = own | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
+						P_cnt[p][wv] = L + nhigh;
+						P_hu[p][wv] = hu;
+					}
+				}
+				if constexpr (STATS) {
+					VG_WAVE_SYNC();
+					uint32_t q = my_base, bits = pend;                       // the owner books the events of its own pairs
+					while (bits) {
+						bits &= bits - 1;
+						if (q >= w0 && q < w0 + PCAP) {
+							const uint32_t meta = P_meta[q - w0][wv];
+							cur.add(S_GATE_OPEN, 1);
+							cur.add(S_REFBF_POS, (meta >> 11) & 1u);
+							cur.add(S_SNPBF_POS, (meta >> 12) & 1u);
+							cur.add(S_LARGE_BLOCK, (meta >> 13) & 1u);
 						}
 						q++;
 					}
 				}
 				VG_WAVE_SYNC();
+				VG_CLK(2);
 				const uint32_t np = P - w0 < (uint32_t)PCAP ? P - w0 : (uint32_t)PCAP;
 				uint32_t T;
 				{
@@ -354,7 +419,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 					uint32_t ci = cntp;
 					for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(ci, o); if ((int)lane >= o) ci += y; }
 					if (lane < np) P_off[lane][wv] = ci - cntp;
-					T = __shfl(ci, 63);
+					T = (uint32_t)__builtin_amdgcn_readlane((int)ci, 63);
 				}
 				VG_WAVE_SYNC();
 				// ---- B1: rounds of 64 items
@@ -378,30 +443,33 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (shi - slo);
 						const uint32_t rsb = (fl & 1u) ? 64u : 32u, ssb = (fl & 2u) ? 64u : 40u;
 						o_ecnt = P_ecnt[p][wv];
+						bool q_r = false, q_s = false;                          // dictionary queries of the neighbour k-mer qk, issued together below
+						uint64_t qk = 0;
 						if (t < L) {
 							if (large) {                                         // qv.cc:962-1109
 								const uint32_t pair = t / 3, sel = t % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
 								nbase = sel + (sel >= base ? 1u : 0u);
 								mod = pair;
-								const uint64_t nb = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
-								uint32_t a, b;
-								ri = (uint32_t)ref_query(d, hs, nb, a, b);
-								si = (uint32_t)snp_query(d, hs, nb, a, b);
-							} else if (t < Lr) {                                 // iterate_ref_dict, qv.cc:316-376   (B1)
-								const uint64_t tt = (uint64_t)lo + (uint64_t)t * REF_STRIDE;
-								uint32_t tlo = 0;
-								hs.add(S_SCAN_REF, 1);
-								if (tt < d.n_ref) tlo = d.ref[tt].lo; else hs.add(S_SCAN_OOB, 1);
-								const int dd = onebase((uint64_t)(klo ^ tlo));
-								if (dd >= 0) { ri = lo + t; mod = (uint32_t)dd; nbase = (tlo >> (2 * dd)) & 3u; }
-							} else {                                             // iterate_snp_dict, qv.cc:413-464   (B1)
-								const uint32_t u = t - Lr;
-								const uint64_t tt = (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
-								uint64_t tlo = 0;
-								hs.add(S_SCAN_SNP, 1);
-								if (tt < d.n_snp) tlo = d.snp[tt].key & LO40_MASK; else hs.add(S_SCAN_OOB, 1);
-								const int dd = onebase((k & LO40_MASK) ^ tlo);
-								if (dd >= 0) { si = slo + u; mod = (uint32_t)dd; nbase = (uint32_t)(tlo >> (2 * dd)) & 3u; }
+								qk = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
+								q_r = q_s = true;
+							} else {
+								// iterate_ref_dict, qv.cc:316-376 / iterate_snp_dict, qv.cc:413-464   (B1): entry lo + 9u (slo + 11u) is
+								// tested, entry lo + u (slo + u) recorded.  Both dictionaries hold 16-byte entries: one gather site.
+								const bool isr = t < Lr;
+								const uint32_t u = isr ? t : t - Lr;
+								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)u * REF_STRIDE : (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
+								const bool inr = tt < (isr ? d.n_ref : d.n_snp);
+								hs.add(S_SCAN_REF, isr ? 1u : 0u);
+								hs.add(S_SCAN_SNP, isr ? 0u : 1u);
+								hs.add(S_SCAN_OOB, inr ? 0u : 1u);
+								uint4 v = make_uint4(0u, 0u, 0u, 0u);
+								if (inr) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
+								const uint64_t tlo = isr ? (uint64_t)v.x : ((((uint64_t)v.y << 32) | v.x) & LO40_MASK);
+								const int dd = onebase(isr ? (uint64_t)(klo ^ v.x) : ((k & LO40_MASK) ^ tlo));
+								if (dd >= 0) {
+									if (isr) ri = lo + u; else si = slo + u;
+									mod = (uint32_t)dd; nbase = (uint32_t)(tlo >> (2 * dd)) & 3u;
+								}
 							}
 						} else {                                                 // qv.cc:1213-1365
 							const uint32_t h = t - L;
@@ -423,14 +491,14 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 							const uint32_t pair = 16u + u / 3, sel = u % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
 							nbase = sel + (sel >= base ? 1u : 0u);
 							mod = pair;
-							const uint64_t nb = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
-							uint32_t a, b;
+							qk = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
 							if (!have_ri && 2 * pair < rsb) {
 								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) if (((hu >> (8 * z)) & 0xFFu) == u) ri = P_hidx[z < (uint32_t)HCAP ? z : 0][p][wv]; }
-								else ri = (uint32_t)ref_query(d, hs, nb, a, b);
+								else q_r = true;
 							}
-							if ((large || 2 * pair >= 40u) && 2 * pair < ssb) si = (uint32_t)snp_query(d, hs, nb, a, b);
+							q_s = (large || 2 * pair >= 40u) && 2 * pair < ssb;
 						}
+						if (q_r || q_s) dual_query(d, hs, qk, q_r, q_s, ri, si);
 					}
 					// is `position` the implied read position of one of the owner's exact hits?
 					auto in_keys = [&](uint32_t position) -> bool {
@@ -438,42 +506,79 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 						for (uint32_t e = 0; e < o_ecnt; e++) f |= (E_kpos[e][col0 + own] - 32u * (E_meta[e][col0 + own] & 31u)) == position;
 						return f;
 					};
-					// acceptance (site / SNP-base tests) + key filter -> bit j: ref candidate j kept, bit 10+j: snp candidate j kept
-					uint32_t keepm = 0;
-					if (ri != NOHIT) {
-						const RefEnt re = d.ref[ri];
-						if (re.pos != POS_AMBIGUOUS) {
-							if (re.amb == 0) {
-								if (!site_loose(d, hs, re.pos + mod)) { hs.add(S_CTX, 1); if (in_keys(re.pos - 32u * c)) keepm |= 1u; }
-							} else {
-								const uint32_t *row = d.ref_aux + (uint64_t)re.pos * AUX_COLS;
-								hs.add(S_AUX_REF, 1);
-								for (int j = 0; j < AUX_COLS; j++) {
-									const uint32_t pp = row[j];
-									if (pp == 0) break;
-									if (site_loose(d, hs, pp + mod)) continue;
+					// acceptance (site / SNP-base tests) + key filter -> bit j: ref candidate j kept, bit 10+j: snp candidate j kept.
+					// Loads are grouped so the wave waits once per group, not once per load: both entries; then the site byte or
+					// four row columns at a time with their four site bytes.
+					uint32_t keepm = 0, rpos = 0, spos = 0;                   // non-ambiguous kept positions travel to the write phase
+					bool r_aux = false, s_aux = false;
+					{
+						RefEnt re; SnpEnt se;
+						re.pos = POS_AMBIGUOUS; re.amb = 0; se.pos = POS_AMBIGUOUS; se.key = 0;
+						if (ri != NOHIT) re = d.ref[ri];
+						if (si != NOHIT) se = d.snp[si];
+						const bool r_ok = re.pos != POS_AMBIGUOUS, s_ok = se.pos != POS_AMBIGUOUS;
+						r_aux = r_ok && re.amb != 0; s_aux = s_ok && ((se.key >> 48) & 0xFFu) != 0;
+						rpos = re.pos; spos = se.pos;
+						if (r_ok && !r_aux) {
+							if (!site_loose(d, hs, rpos + mod)) { hs.add(S_CTX, 1); if (in_keys(rpos - 32u * c)) keepm |= 1u; }
+						}
+						if (r_aux) {
+							const uint32_t *row = d.ref_aux + (uint64_t)rpos * AUX_COLS;
+							hs.add(S_AUX_REF, 1);
+							for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
+								uint32_t v[4], sb[4];
+								load_row4(row, j0, v);
+								#pragma unroll
+								for (int j = 0; j < 4; j++) { const uint64_t a = (uint64_t)v[j] + mod; sb[j] = d.pile[v[j] && a < d.pile_len ? a : 0]; if (!(v[j] && a < d.pile_len)) sb[j] = 0; }
+								bool live = true;
+								uint32_t cand = 0;
+								#pragma unroll
+								for (int j = 0; j < 4; j++) {
+									live = live && v[j] != 0;
+									if (!live) continue;
+									hs.add(S_SITE_TEST, 1);
+									if (sb[j] & 15u) continue;
 									hs.add(S_CTX, 1);
-									if (in_keys(pp - 32u * c)) keepm |= 1u << j;
+									cand |= 1u << j;
 								}
+								while (cand) {                                       // accepted columns are few: one key-filter loop, not four
+									const uint32_t j = (uint32_t)__ffs((int)cand) - 1;
+									cand &= cand - 1;
+									const uint32_t pp = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3];
+									if (in_keys(pp - 32u * c)) keepm |= 1u << (j0 + j);
+								}
+								if (!live) break;
 							}
 						}
-					}
-					if (si != NOHIT) {
-						const SnpEnt se = d.snp[si];
-						if (se.pos != POS_AMBIGUOUS) {
-							if (((se.key >> 48) & 0xFFu) == 0) {
-								if ((uint32_t)((se.key >> 43) & 0x1Fu) != mod) { hs.add(S_CTX, 1); if (in_keys(se.pos - 32u * c)) keepm |= 1u << 10; }
-							} else {
-								const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
-								const uint8_t *irow = d.snp_aux_info + (uint64_t)se.pos * AUX_COLS;
-								hs.add(S_AUX_SNP, 1);
-								for (int j = 0; j < AUX_COLS; j++) {
-									const uint32_t pp = prow[j];
-									if (pp == 0) break;
-									if ((uint32_t)(irow[j] >> 3) == mod) continue;
+						if (s_ok && !s_aux) {
+							if ((uint32_t)((se.key >> 43) & 0x1Fu) != mod) { hs.add(S_CTX, 1); if (in_keys(spos - 32u * c)) keepm |= 1u << 10; }
+						}
+						if (s_aux) {
+							const uint32_t *prow = d.snp_aux_pos + (uint64_t)spos * AUX_COLS;
+							const uint8_t *irow = d.snp_aux_info + (uint64_t)spos * AUX_COLS;
+							hs.add(S_AUX_SNP, 1);
+							for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
+								uint32_t v[4], inf[4];
+								load_row4(prow, j0, v);
+								#pragma unroll
+								for (int j = 0; j < 4; j++) inf[j] = irow[j0 + j < AUX_COLS ? j0 + j : 0];
+								bool live = true;
+								uint32_t cand = 0;
+								#pragma unroll
+								for (int j = 0; j < 4; j++) {
+									live = live && v[j] != 0;
+									if (!live) continue;
+									if ((inf[j] >> 3) == mod) continue;
 									hs.add(S_CTX, 1);
-									if (in_keys(pp - 32u * c)) keepm |= 1u << (10 + j);
+									cand |= 1u << j;
 								}
+								while (cand) {
+									const uint32_t j = (uint32_t)__ffs((int)cand) - 1;
+									cand &= cand - 1;
+									const uint32_t pp = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3];
+									if (in_keys(pp - 32u * c)) keepm |= 1u << (10 + j0 + j);
+								}
+								if (!live) break;
 							}
 						}
 					}
@@ -501,19 +606,17 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 							else {
 								uint32_t at = curc + (incl - keep) - excl_ss;
 								const uint16_t mt = (uint16_t)mk_meta(c, mod, true, nbase);
-								if (keepm & 0x3FFu) {                            // kept contexts are rare: re-read the entry instead of carrying it
-									const RefEnt re = d.ref[ri];
-									if (re.amb == 0) { N_kpos[at][col0 + own] = re.pos; N_meta[at][col0 + own] = mt; at++; }
-									else {
-										const uint32_t *row = d.ref_aux + (uint64_t)re.pos * AUX_COLS;
+								if (keepm & 0x3FFu) {
+									if (!r_aux) { N_kpos[at][col0 + own] = rpos; N_meta[at][col0 + own] = mt; at++; }
+									else {                                       // kept contexts out of a row are rare: re-read those columns
+										const uint32_t *row = d.ref_aux + (uint64_t)rpos * AUX_COLS;
 										for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << j)) { N_kpos[at][col0 + own] = row[j]; N_meta[at][col0 + own] = mt; at++; }
 									}
 								}
 								if (keepm >> 10) {
-									const SnpEnt se = d.snp[si];
-									if (((se.key >> 48) & 0xFFu) == 0) { N_kpos[at][col0 + own] = se.pos; N_meta[at][col0 + own] = mt; at++; }
+									if (!s_aux) { N_kpos[at][col0 + own] = spos; N_meta[at][col0 + own] = mt; at++; }
 									else {
-										const uint32_t *prow = d.snp_aux_pos + (uint64_t)se.pos * AUX_COLS;
+										const uint32_t *prow = d.snp_aux_pos + (uint64_t)spos * AUX_COLS;
 										for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << (10 + j))) { N_kpos[at][col0 + own] = prow[j]; N_meta[at][col0 + own] = mt; at++; }
 									}
 								}
@@ -523,6 +626,7 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 					}
 					VG_WAVE_SYNC();
 				}
+				VG_CLK(3);
 			}
 			VG_WAVE_SYNC();
 			ncnt = N_cnt[col];
@@ -565,21 +669,116 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 					while (ei < ecnt && (E_meta[ei][col] & 31u) == c) { const uint32_t p = E_kpos[ei][col]; vote(p - 32u * c, p, false); ei++; }
 					while (ni < ncnt && (N_meta[ni][col] & 31u) == c) { const uint32_t p = N_kpos[ni][col]; vote(p - 32u * c, p, true); ni++; }
 				}
+				VG_CLK(4);
 				if (!ovf) {
 					cur.add(S_PASSES, 1);
 					const uint32_t bfm = best >= 0 ? K_fm[best][col] : 0u, target = best >= 0 ? K_idx[best][col] : 0u;
 					processed = best >= 0 && !amb && (bfm & 0xFFu) > 1;          // qv.cc:1375
 					if (processed) {
 						cur.add(S_PASSES_OK, 1);
-						for (uint32_t i = 0; i < ecnt; i++) {
-							const uint32_t p = E_kpos[i][col], c = E_meta[i][col] & 31u;
-							if (p - 32u * c == target) walk_ctx(d, cur, chunk_kmer(c), p, NOMOD);
+						// Timed build, reads of up to four chunks (150 bp): all supporting contexts lie in [target, target + 32 n), which
+						// two or three rank blocks cover.  Those blocks (site bits + rank) and the read's k-mers are all the walk needs
+						// when the counters are indexed by the base the read shows (DevIndex::cnt4): ~2.5 block gathers + one atomic per
+						// site per context, where the byte-per-position walk costs two window gathers per context + a rank gather + an
+						// atomic per counted base.  Same sums: a site's ref and alt differ, and fetch reads cnt4[ref] and cnt4[alt].
+						bool fast = false;
+						if constexpr (!STATS) fast = n <= 4u && (uint64_t)target + 32u * n <= d.pile_len;
+						if (fast) {
+							const uint32_t blk0 = target >> 6, blk_last = (target + 32u * n - 1u) >> 6;
+							// named scalars, not arrays: an array the compiler cannot keep in registers ends up in scratch memory
+							const ulonglong2 zz = make_ulonglong2(0ull, 0ull);
+							const ulonglong2 r0 = d.srank[blk0];
+							const ulonglong2 r1 = blk0 + 1u <= blk_last ? d.srank[blk0 + 1u] : zz;
+							const ulonglong2 r2 = blk0 + 2u <= blk_last ? d.srank[blk0 + 2u] : zz;
+							uint64_t f0, f1, f2 = 0, f3 = 0;                     // the read's k-mers in file order
+							{
+								ulonglong2 v;
+								__builtin_memcpy(&v, pk_kmer + (uint64_t)slot0, 16); f0 = v.x; f1 = v.y;   // n >= 2: one chunk cannot win a vote
+								if (n == 4u) { __builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + 2), 16); f2 = v.x; f3 = v.y; }
+								else if (n == 3u) f2 = pk_kmer[(uint64_t)slot0 + 2];
+							}
+							VG_CLKW(6);
+							// one loop over both lists and no lambda: a select over variables captured by reference becomes a select of
+							// addresses, which parks the whole closure in scratch memory
+							const uint32_t nctx = ecnt + ncnt;
+							for (uint32_t i = 0; i < nctx; i++) {
+								uint32_t p, c, mod = NOMOD;
+								if (i < ecnt) { p = E_kpos[i][col]; c = E_meta[i][col] & 31u; }
+								else { const uint32_t mt = N_meta[i - ecnt][col]; p = N_kpos[i - ecnt][col]; c = mt & 31u; mod = (mt >> 5) & 31u; }
+								if (p - 32u * c != target) continue;
+								const uint32_t fi = pass ? n - 1u - c : c;
+								uint64_t kk = fi == 0 ? f0 : fi == 1 ? f1 : fi == 2 ? f2 : f3;
+								if (pass) kk = revcomp64(kk);
+								const uint32_t o = (target & 63u) + 32u * c;         // bit offset of the window in the blocks
+								const uint32_t z = o >> 6, sh = o & 63u;
+								const uint64_t w0 = z == 0 ? r0.x : z == 1 ? r1.x : r2.x;
+								const uint64_t w1 = z == 0 ? r1.x : r2.x;           // only read when the window crosses into it (then z <= 1)
+								uint32_t sites = (uint32_t)(w0 >> sh);
+								if (sh > 32u) sites |= (uint32_t)(w1 << (64u - sh));
+								if (mod < 32u) sites &= ~(1u << mod);
+								while (sites) {
+									const uint32_t b = (uint32_t)__ffs((int)sites) - 1;
+									sites &= sites - 1;
+									const uint32_t ob = o + b, zb = ob >> 6;
+									const uint64_t mx_ = zb == 0 ? r0.x : zb == 1 ? r1.x : r2.x, my_ = zb == 0 ? r0.y : zb == 1 ? r1.y : r2.y;
+									const uint32_t sid = (uint32_t)my_ + (uint32_t)__popcll(mx_ & ((1ull << (ob & 63u)) - 1ull));
+									atomicAdd(&d.cnt4[4ull * sid + ((uint32_t)(kk >> (2 * b)) & 3u)], 1u);
+								}
+							}
+							VG_CLK(7);
+							VG_CLKW(8);
+						} else {
+						// The walks of a read are batched so that the wave waits for memory three times, not three times per
+						// context: (1) k-mers + pile windows of up to WB supporting contexts in one go, matches parked in the
+						// vote's (now free) LDS key slots; (2) the rank blocks of up to WB matches in one go; (3) atomics, unwaited.
+						constexpr int WB = VG_WALK_BATCH, RB = 4;
+						constexpr uint32_t MCAP = 2u * (uint32_t)W_KCAP;
+						uint32_t it = 0, nm = 0;
+						const uint32_t nctx = ecnt + ncnt;
+						auto park = [&](uint32_t p, uint32_t which) {
+							cur.add(S_INCR, 1);
+							if (nm < MCAP) {
+								const uint32_t v = ((p - target) << 1) | which;      // a site of this read lies < 32 * 33 past its start
+								if (nm < (uint32_t)W_KCAP) K_idx[nm][col] = v; else K_first[nm - W_KCAP][col] = v;
+								nm++;
+							} else bump_site(d, p, which);
+						};
+						while (it < nctx) {
+							bool h[WB]; uint32_t wp[WB], wc[WB], wm[WB], wn[WB];
+							#pragma unroll
+							for (int b = 0; b < WB; b++) {
+								h[b] = false; wp[b] = 0; wc[b] = 0; wm[b] = NOMOD; wn[b] = 0;
+								while (it < nctx && !h[b]) {
+									const uint32_t i = it++;
+									if (i < ecnt) { wp[b] = E_kpos[i][col]; wc[b] = E_meta[i][col] & 31u; wm[b] = NOMOD; }
+									else { const uint32_t mt = N_meta[i - ecnt][col]; wp[b] = N_kpos[i - ecnt][col]; wc[b] = mt & 31u; wm[b] = (mt >> 5) & 31u; wn[b] = (mt >> 11) & 3u; }
+									h[b] = wp[b] - 32u * wc[b] == target;
+								}
+								if (h[b]) { cur.add(S_WALKS, 1); if ((uint64_t)wp[b] + 32 > d.pile_len) h[b] = false; }
+							}
+							uint64_t kf[WB]; uint4 pw[WB][2];
+							#pragma unroll
+							for (int b = 0; b < WB; b++) if (h[b]) { kf[b] = chunk_kmer(wc[b]); load_pile_window(d, wp[b], pw[b]); }
+							#pragma unroll
+							for (int b = 0; b < WB; b++) if (h[b]) {
+								uint64_t kk = kf[b];
+								if (wm[b] < 32u) kk = (kk & ~(3ull << (2 * wm[b]))) | ((uint64_t)wn[b] << (2 * wm[b]));
+								walk_matches(pw[b], kk, wp[b], wm[b], park);
+							}
 						}
-						for (uint32_t i = 0; i < ncnt; i++) {
-							const uint32_t p = N_kpos[i][col], mt = N_meta[i][col], c = mt & 31u, mod = (mt >> 5) & 31u;
-							if (p - 32u * c != target) continue;
-							const uint64_t kk = (chunk_kmer(c) & ~(3ull << (2 * mod))) | ((uint64_t)((mt >> 11) & 3u) << (2 * mod));
-							walk_ctx(d, cur, kk, p, mod);
+						for (uint32_t m0 = 0; m0 < nm; m0 += RB) {
+							uint32_t mv[RB], mw[RB]; ulonglong2 rb[RB];
+							#pragma unroll
+							for (int b = 0; b < RB; b++) {
+								const uint32_t m = m0 + b;
+								mv[b] = m < nm ? (m < (uint32_t)W_KCAP ? K_idx[m][col] : K_first[m - W_KCAP][col]) : 0u;
+								mw[b] = mv[b] & 1u;
+								mv[b] = m < nm ? target + (mv[b] >> 1) : 0u;
+								rb[b] = d.srank[mv[b] >> 6];
+							}
+							#pragma unroll
+							for (int b = 0; b < RB; b++) if (m0 + b < nm) atomicAdd(&d.cnt[2ull * site_id(rb[b], mv[b]) + mw[b]], 1u);
+						}
 						}
 					}
 				}
@@ -595,7 +794,12 @@ __global__ __launch_bounds__(64 * WPB) void vg_wave_kernel(DevIndex d, const uin
 			}
 		}
 		VG_WAVE_SYNC();
+		VG_CLK(5);
 	}
+#ifdef VG_STAGE_CLOCKS
+	if (!STATS && lane == 0 && (blockIdx.x % 97u) == 0 && wv == 0)
+		printf("CLK blk %u iters %u refill %lld A %lld B0 %lld B1 %lld vote %lld walk %lld wload %lld wloop %lld watom %lld ecap %d\n", blockIdx.x, iters, clk[0], clk[1], clk[2], clk[3], clk[4], clk[5], clk[6], clk[7], clk[8], W_ECAP);
+#endif
 	if constexpr (STATS) {
 		for (int i = 0; i < S_COUNT; i++) if (tot.v[i]) atomicAdd(&stats[i], (unsigned long long)tot.v[i]);
 	}
