@@ -23,6 +23,9 @@
 #ifndef VG_WPE
 #define VG_WPE 4          // waves per SIMD the main tier is compiled for (128 VGPRs)
 #endif
+#ifndef VG_SCAN_W
+#define VG_SCAN_W 2        // further entries of a multi-entry bucket fetched together in stage A
+#endif
 #ifndef VG_WALK_BATCH
 #define VG_WALK_BATCH 1
 #endif
@@ -198,6 +201,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 					if (!live) break;
 				}
 			};
+			auto push_row_from = [&](const uint32_t *row, const uint32_t (&first)[4], uint32_t c) {   // columns 0-3 already in hand
+				bool live = true;
+				#pragma unroll
+				for (int j = 0; j < 4; j++) { live = live && first[j] != 0; if (live) push_exact(first[j], c); }
+				for (int j0 = 4; live && j0 < AUX_COLS; j0 += 4) {
+					uint32_t v[4];
+					load_row4(row, j0, v);
+					#pragma unroll
+					for (int j = 0; j < 4; j++) { live = live && v[j] != 0; if (live) push_exact(v[j], c); }
+				}
+			};
 			auto emit_exact = [&](uint32_t c, bool rhit, uint32_t rpos, uint32_t ramb, bool shit, uint32_t spos, uint32_t samb) {
 				if (rhit && rpos != POS_AMBIGUOUS) {
 					if (ramb == 0) push_exact(rpos, c);
@@ -234,33 +248,85 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 						uint64_t kq[4] = {0, 0, 0, 0};
 						if (m >= 2) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
 						if (m >= 4) chunk_kmer2(c + 2, kq[2], kq[3]); else if (m == 3) kq[2] = chunk_kmer(c + 2);
+						VG_CLKW(9);
 						uint4 bq[4];
 						#pragma unroll
 						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = d.dx[kq[z] >> 32]; }
-						auto settle = [&](uint32_t cc, uint64_t k, const uint4 b) {
-							cur.add(S_CHUNKS, 1);
-							uint32_t rpos = 0, ramb = 0, spos = 0, samb = 0;
-							bool rhit = false, shit = false;
-							if (b.z & 1u) {
-								const uint32_t key = (uint32_t)k, cnt = b.z >> 8;
-								if (b.x == key) { if (b.z & 2u) { shit = true; spos = b.y; samb = (b.z >> 2) & 1u; } else { rhit = true; rpos = b.y; ramb = (b.z >> 2) & 1u; } }
-								if (cnt > 1 && b.x <= key) {                              // entries are sorted by lo: nothing below the first
-									const uint32_t lo = b.w, hi = b.w + cnt;
-									uint32_t ea = lo + 1;
-									if (cnt > 5) { uint32_t eb = hi; while (ea < eb) { const uint32_t m = ea + ((eb - ea) >> 1); if (d.mx[m].x < key) ea = m + 1; else eb = m; } }
-									for (uint32_t e = ea; e < hi; e++) {
+						VG_CLKW(10);
+						// what each bucket's inline first entry settles; `more`: the bucket has further entries that may hold the key
+						uint32_t rp[4], sp[4], hf[4];                        // hf: 1 ref hit, 2 its ambig flag, 4 SNP hit, 8 its ambig flag
+						bool more[4];
+						#pragma unroll
+						for (uint32_t z = 0; z < 4; z++) {
+							rp[z] = sp[z] = hf[z] = 0; more[z] = false;
+							if (z < m) {
+								cur.add(S_CHUNKS, 1);
+								const uint4 b = bq[z];
+								const uint32_t key = (uint32_t)kq[z];
+								if (b.z & 1u) {
+									if (b.x == key) {
+										if (b.z & 2u) { sp[z] = b.y; hf[z] |= 4u | (((b.z >> 2) & 1u) << 3); }
+										else { rp[z] = b.y; hf[z] |= 1u | (((b.z >> 2) & 1u) << 1); }
+									}
+									more[z] = (b.z >> 8) > 1u && b.x <= key;              // entries are sorted by lo: nothing below the first
+								}
+							}
+						}
+						// the rest of a small bucket -- up to VG_SCAN_W more entries -- arrives together, two chunks at a time (one wait);
+						// anything deeper is rare and goes one by one
+						#pragma unroll
+						for (uint32_t z0 = 0; z0 < 4; z0 += 2) {
+							constexpr uint32_t SW = VG_SCAN_W;
+							uint4 sv[2][SW];
+							#pragma unroll
+							for (uint32_t y = 0; y < 2; y++) {
+								const uint32_t cnt = bq[z0 + y].z >> 8, lo = bq[z0 + y].w;
+								#pragma unroll
+								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = d.mx[lo + 1u + x]; }
+							}
+							#pragma unroll
+							for (uint32_t y = 0; y < 2; y++) {
+								const uint32_t z = z0 + y;
+								if (!more[z]) continue;
+								const uint32_t key = (uint32_t)kq[z], cnt = bq[z].z >> 8, lo = bq[z].w, hi = lo + cnt;
+								auto take = [&](const uint4 v) {
+									if (v.z & 1u) { sp[z] = v.y; hf[z] = (hf[z] & ~8u) | 4u | (((v.z >> 1) & 1u) << 3); }
+									else { rp[z] = v.y; hf[z] = (hf[z] & ~2u) | 1u | (((v.z >> 1) & 1u) << 1); }
+								};
+								#pragma unroll
+								for (uint32_t x = 0; x < SW; x++) if (x + 1u < cnt && sv[y][x].x == key) take(sv[y][x]);
+								if (cnt > SW + 1u && sv[y][SW - 1].x <= key) {          // the bucket goes on and may still hold the key
+									uint32_t e = lo + SW + 1u;
+									if (cnt > 8u) { uint32_t eb = hi; while (e < eb) { const uint32_t mm = e + ((eb - e) >> 1); if (d.mx[mm].x < key) e = mm + 1; else eb = mm; } }
+									for (; e < hi; e++) {
 										const uint4 v = d.mx[e];
 										if (v.x < key) continue;
 										if (v.x > key) break;
-										if (v.z & 1u) { shit = true; spos = v.y; samb = (v.z >> 1) & 1u; }
-										else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
+										take(v);
 									}
 								}
 							}
-							emit_exact(cc, rhit, rpos, ramb, shit, spos, samb);
-						};
+						}
+						VG_CLKW(11);
+						// The exact contexts are appended (qv.cc:850-937) chunk by chunk, reference hit first, then SNP hit.  Of the
+						// auxiliary rows a chunk needs, the first four columns are fetched together (one wait, most rows end there).
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) if (z < m) settle(c + z, kq[z], bq[z]);
+						for (uint32_t z = 0; z < 4; z++) {
+							if (z >= m) continue;
+							const bool r_ok = (hf[z] & 1u) && rp[z] != POS_AMBIGUOUS, s_ok = (hf[z] & 4u) && sp[z] != POS_AMBIGUOUS;
+							const bool r_ax = r_ok && (hf[z] & 2u), s_ax = s_ok && (hf[z] & 8u);
+							uint32_t rr[4], sr[4];
+							if (r_ax) load_row4(d.ref_aux + (uint64_t)rp[z] * AUX_COLS, 0, rr);
+							if (s_ax) load_row4(d.snp_aux_pos + (uint64_t)sp[z] * AUX_COLS, 0, sr);
+							if (r_ok) {
+								if (!r_ax) push_exact(rp[z], c + z);
+								else { cur.add(S_AUX_REF, 1); push_row_from(d.ref_aux + (uint64_t)rp[z] * AUX_COLS, rr, c + z); }
+							}
+							if (s_ok) {
+								if (!s_ax) push_exact(sp[z], c + z);
+								else { cur.add(S_AUX_SNP, 1); push_row_from(d.snp_aux_pos + (uint64_t)sp[z] * AUX_COLS, sr, c + z); }
+							}
+						}
 					}
 				} else
 				for (uint32_t c = 0; c < n; c += 2) {
@@ -798,7 +864,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 	}
 #ifdef VG_STAGE_CLOCKS
 	if (!STATS && lane == 0 && (blockIdx.x % 97u) == 0 && wv == 0)
-		printf("CLK blk %u iters %u refill %lld A %lld B0 %lld B1 %lld vote %lld walk %lld wload %lld wloop %lld watom %lld ecap %d\n", blockIdx.x, iters, clk[0], clk[1], clk[2], clk[3], clk[4], clk[5], clk[6], clk[7], clk[8], W_ECAP);
+		printf("CLK blk %u iters %u refill %lld A %lld B0 %lld B1 %lld vote %lld walk %lld wload %lld wloop %lld watom %lld Akmer %lld Adx %lld Ascan %lld ecap %d\n", blockIdx.x, iters, clk[0], clk[1], clk[2], clk[3], clk[4], clk[5], clk[6], clk[7], clk[8], clk[9], clk[10], clk[11], W_ECAP);
 #endif
 	if constexpr (STATS) {
 		for (int i = 0; i < S_COUNT; i++) if (tot.v[i]) atomicAdd(&stats[i], (unsigned long long)tot.v[i]);
