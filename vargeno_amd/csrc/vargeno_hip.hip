@@ -247,15 +247,27 @@ __global__ __launch_bounds__(256) void vg_pack_kernel(const uint8_t *__restrict_
 			uint64_t meta = 0, bad = 0;
 			if (staged) {
 				const uint8_t *p = sm + (off - base0);
-				for (uint32_t c = 0; c < n; c++) {
+				auto enc = [&](uint32_t c) -> uint64_t {
 					uint64_t w[4];
 					__builtin_memcpy(w, p + 32 * c, 32);
-					pk_kmer[(off >> 5) + c] = (uint64_t)pack8(w[0], bad) | ((uint64_t)pack8(w[1], bad) << 16) | ((uint64_t)pack8(w[2], bad) << 32) | ((uint64_t)pack8(w[3], bad) << 48);
+					return (uint64_t)pack8(w[0], bad) | ((uint64_t)pack8(w[1], bad) << 16) | ((uint64_t)pack8(w[2], bad) << 32) | ((uint64_t)pack8(w[3], bad) << 48);
+				};
+				uint64_t *dst = pk_kmer + (off >> 5);
+				uint32_t c = 0;
+				for (; c + 2 <= n; c += 2) {                             // a read's k-mers are contiguous: 16-byte stores
+					const ulonglong2 kv = make_ulonglong2(enc(c), enc(c + 1));
+					__builtin_memcpy(dst + c, &kv, 16);
 				}
+				if (c < n) dst[c] = enc(c);
 			} else {
 				for (uint32_t c = 0; c < n; c++) pk_kmer[(off >> 5) + c] = encode32(bases + off + 32 * c, bad);
 			}
-			for (uint32_t c = 0; c < n && c < 32; c++) if ((int)(int8_t)q[c] - '8' < 0) meta |= 1ull << c;
+			// quality gate bits (qv.cc:836): character c of the quality line, four characters per gather
+			for (uint32_t c0 = 0; c0 < n && c0 < 32; c0 += 4) {
+				uint32_t q4;                                              // c0 + 4 <= n + 3 <= the read's own length: never past it
+				__builtin_memcpy(&q4, q + c0, 4);
+				for (uint32_t j = 0; j < 4 && c0 + j < n && c0 + j < 32; j++) if ((int)(int8_t)(q4 >> (8 * j)) - '8' < 0) meta |= 1ull << (c0 + j);
+			}
 			if (bad) meta |= classify_bad(bases + off, n) == 1 ? PK_SKIP_N : PK_INVALID;
 			if (n > 32) meta |= PK_LONG;
 			pk_meta[r] = meta;

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 		{
 			const uint64_t freem = __ballot(!active);
 			if (freem && cursor == end && !drained) {
+				// the chunk asked for one refill ago has had a whole chunk's worth of work to arrive; ask for the one after it now
 				uint32_t c0 = 0;
 				if (lane == 0) c0 = atomicAdd(work_next, WORK_CHUNK);
 				c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
@@ -707,25 +708,30 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 			if (!ovf) {
 				uint32_t nkeys = 0;
 				int best = -1; bool amb = false;
-				// improved_index_table_add, qv.cc:132-178; keys in this lane's LDS column
+				// improved_index_table_add, qv.cc:132-178.  Key 0 -- for most reads the only key -- lives in registers, the
+				// others in this lane's LDS column.
+				uint32_t k0_idx = 0, k0_first = 0, k0_fm = 0;
 				auto vote = [&](uint32_t index, uint32_t kpos, bool neigh) {
 					int e = -1;
-					for (uint32_t i = 0; i < nkeys; i++) if (K_idx[i][col] == index) { e = (int)i; break; }
+					if (nkeys && k0_idx == index) e = 0;
+					else for (uint32_t i = 1; i < nkeys; i++) if (K_idx[i][col] == index) { e = (int)i; break; }
 					uint32_t first, fm;
 					if (e < 0) {
 						if (neigh) return;
 						if (nkeys >= (uint32_t)W_KCAP) { ovf = true; return; }
 						e = (int)nkeys++;
-						K_idx[e][col] = index; K_first[e][col] = first = kpos; fm = 0;
-					} else { first = K_first[e][col]; fm = K_fm[e][col]; }
+						first = kpos; fm = 0;
+						if (e == 0) { k0_idx = index; k0_first = kpos; } else { K_idx[e][col] = index; K_first[e][col] = kpos; }
+					} else if (e == 0) { first = k0_first; fm = k0_fm; }
+					else { first = K_first[e][col]; fm = K_fm[e][col]; }
 					const uint32_t freq = (fm + 1) & 0xFFu;
 					const uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);
-					K_fm[e][col] = (uint16_t)(freq | (multi << 8));
+					if (e == 0) k0_fm = freq | (multi << 8); else K_fm[e][col] = (uint16_t)(freq | (multi << 8));
 					if (!multi) return;
 					if (best < 0) { best = e; amb = false; }
 					else if (e == best) amb = false;
 					else {
-						const uint32_t bf = K_fm[best][col] & 0xFFu;
+						const uint32_t bf = (best == 0 ? k0_fm : (uint32_t)K_fm[best][col]) & 0xFFu;
 						if (freq == bf) amb = true;
 						else if (freq > bf) { best = e; amb = false; }
 					}
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 				VG_CLK(4);
 				if (!ovf) {
 					cur.add(S_PASSES, 1);
-					const uint32_t bfm = best >= 0 ? K_fm[best][col] : 0u, target = best >= 0 ? K_idx[best][col] : 0u;
+					const uint32_t bfm = best < 0 ? 0u : best == 0 ? k0_fm : (uint32_t)K_fm[best][col], target = best < 0 ? 0u : best == 0 ? k0_idx : K_idx[best][col];
 					processed = best >= 0 && !amb && (bfm & 0xFFu) > 1;          // qv.cc:1375
 					if (processed) {
 						cur.add(S_PASSES_OK, 1);
