@@ -458,6 +458,8 @@ struct Slot {
 struct vg_index {
 	int device = 0;
 	hipStream_t stream = nullptr, tail = nullptr;   // pack + wave tier | spill tiers of earlier batches
+	hipStream_t ingest = nullptr;                   // FASTQ framing + pack kernel of the next batch, under the current batch's wave kernel
+	bool pack_overlap = true;                       // VG_NO_PACK_OVERLAP: ingest work goes to the main stream instead
 	DevIndex d{};
 	std::vector<void *> owned;            // every device allocation of the index
 	uint64_t dev_bytes = 0;
@@ -541,6 +543,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	(void)hipSetDevice(ix->device);
 	if (ix->stream) (void)hipStreamSynchronize(ix->stream);
 	if (ix->tail) (void)hipStreamSynchronize(ix->tail);
+	if (ix->ingest) (void)hipStreamSynchronize(ix->ingest);
 	for (void *p : ix->owned) (void)hipFree(p);
 	for (Slot &sl : ix->slot) {
 		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles};
@@ -550,6 +553,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	}
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
 	if (ix->tail) (void)hipStreamDestroy(ix->tail);
+	if (ix->ingest) (void)hipStreamDestroy(ix->ingest);
 	delete ix;
 }
 
@@ -564,6 +568,8 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->tail, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&ix->ingest, hipStreamNonBlocking));
+	ix->pack_overlap = getenv("VG_NO_PACK_OVERLAP") == nullptr;
 	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); }
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -872,11 +878,15 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 	if (!ix->force_generic) {
 		// main stream: pack, then the wave tier.  (Packing batch k+1 on a third stream under batch k's wave
 		// kernel was measured and lost 12 %: two co-scheduled kernels split the CUs.)
-		HIP_TRY(hipMemsetAsync(ctr, 0, 32, ix->stream));
-		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
-		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->cus * 16);
-		vg_pack_kernel<<<pgrid, 256, 0, ix->stream>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
-		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
+		hipStream_t ps = ix->stream;
+		if (ix->pack_overlap) ps = ix->ingest;
+		HIP_TRY(hipMemsetAsync(ctr, 0, 32, ps));
+		HIP_TRY(hipEventRecord(sl.e0, ps));
+		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
+		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->cus * pack_bpc);
+		vg_pack_kernel<<<pgrid, 256, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
+		HIP_TRY(hipEventRecord(sl.e1, ps));
+		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
 		// under the head of this batch's wave kernel: its few single-wave workgroups drain while the main tier pulls its work
 		// dynamically, which costs less than holding the wave kernel back for them (0.71 -> 0.66 ms per 1 M-read step).
@@ -889,7 +899,6 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
 		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], 2u, ix->d_stats);
-		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
 		HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
@@ -1003,6 +1012,9 @@ extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbyte
 	int rc = acquire_slot(ix, &slp);
 	if (rc) return rc;
 	Slot &sl = *slp;
+	// framing runs on the ingest stream (under the wave kernel of the batch before); the host reads three small results
+	// back, each after synchronising that stream only
+	hipStream_t is = ix->pack_overlap ? ix->ingest : ix->stream;
 	const uint64_t n_tiles = (nbytes + FQ_TILE - 1) / FQ_TILE;
 	auto grow = [&](void **p, uint64_t &cap, uint64_t need, size_t elem) -> int {
 		if (need <= cap) return VG_OK;
@@ -1017,18 +1029,19 @@ extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbyte
 	if ((rc = grow((void **)&sl.fq_tiles, sl.fq_tiles_cap, n_tiles + 2, 4))) return rc;
 	HIP_TRY(hipMemcpy(sl.fq_text, text, nbytes, hipMemcpyHostToDevice));
 	// newlines per tile -> exclusive scan -> total number of complete lines
-	vg_fq_count_newlines<<<(unsigned)n_tiles, 256, 0, ix->stream>>>(sl.fq_text, nbytes, sl.fq_tiles);
-	HIP_TRY(hipMemsetAsync(sl.fq_tiles + n_tiles, 0, 4, ix->stream));
+	vg_fq_count_newlines<<<(unsigned)n_tiles, 256, 0, is>>>(sl.fq_text, nbytes, sl.fq_tiles);
+	HIP_TRY(hipMemsetAsync(sl.fq_tiles + n_tiles, 0, 4, is));
 	HIP_TRY(hipGetLastError());
-	int se = vg_dev_exclusive_scan_u32(sl.fq_tiles, sl.fq_tiles, n_tiles + 1, ix->stream);
+	int se = vg_dev_exclusive_scan_u32(sl.fq_tiles, sl.fq_tiles, n_tiles + 1, is);
 	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
 	uint32_t n_lines = 0;
+	HIP_TRY(hipStreamSynchronize(is));
 	HIP_TRY(hipMemcpy(&n_lines, sl.fq_tiles + n_tiles, 4, hipMemcpyDeviceToHost));
 	const uint64_t n_rec = n_lines / 4;
 	if (n_rec == 0) return VG_OK;
 	if ((rc = grow((void **)&sl.fq_lines, sl.fq_lines_cap, (uint64_t)n_lines + 2, 4))) return rc;
-	HIP_TRY(hipMemsetAsync(sl.fq_lines, 0, 4, ix->stream));                     // line 0 starts at byte 0
-	vg_fq_line_starts<<<(unsigned)n_tiles, 256, 0, ix->stream>>>(sl.fq_text, nbytes, sl.fq_tiles, sl.fq_lines);
+	HIP_TRY(hipMemsetAsync(sl.fq_lines, 0, 4, is));                     // line 0 starts at byte 0
+	vg_fq_line_starts<<<(unsigned)n_tiles, 256, 0, is>>>(sl.fq_text, nbytes, sl.fq_tiles, sl.fq_lines);
 	HIP_TRY(hipGetLastError());
 	// read lengths -> offsets of the flat batch
 	if (n_rec + 1 > sl.stage_reads) {
@@ -1038,13 +1051,14 @@ extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbyte
 		sl.stage_reads = n_rec + 1;
 	}
 	uint32_t *d_flag = sl.ctr + 6;                                              // spare word of the slot's counter block
-	HIP_TRY(hipMemsetAsync(d_flag, 0, 4, ix->stream));
-	vg_fq_record_lengths<<<1024, 256, 0, ix->stream>>>(sl.fq_lines, n_rec, sl.st_offsets, d_flag);
-	HIP_TRY(hipMemsetAsync(sl.st_offsets + n_rec, 0, 8, ix->stream));
+	HIP_TRY(hipMemsetAsync(d_flag, 0, 4, is));
+	vg_fq_record_lengths<<<1024, 256, 0, is>>>(sl.fq_lines, n_rec, sl.st_offsets, d_flag);
+	HIP_TRY(hipMemsetAsync(sl.st_offsets + n_rec, 0, 8, is));
 	HIP_TRY(hipGetLastError());
-	se = vg_dev_exclusive_scan_u64(sl.st_offsets, sl.st_offsets, n_rec + 1, ix->stream);
+	se = vg_dev_exclusive_scan_u64(sl.st_offsets, sl.st_offsets, n_rec + 1, is);
 	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
 	uint32_t too_long = 0; uint64_t total = 0; uint32_t edges[2] = {0, 0};
+	HIP_TRY(hipStreamSynchronize(is));
 	HIP_TRY(hipMemcpy(&too_long, d_flag, 4, hipMemcpyDeviceToHost));
 	if (too_long) return fail(VG_EBADREAD, "a FASTQ line longer than 1023 characters (reference BUF_SIZE 1024, qv.cc:700) or a quality line shorter than the read's chunk count: frame this chunk on the host");
 	HIP_TRY(hipMemcpy(&total, sl.st_offsets + n_rec, 8, hipMemcpyDeviceToHost));
@@ -1058,7 +1072,7 @@ extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbyte
 		HIP_TRY(hipMalloc((void **)&sl.st_quals, total + 64));
 		sl.stage_bytes = total + 64;
 	}
-	vg_fq_gather<<<(unsigned)std::min<uint64_t>((n_rec + 3) / 4, (uint64_t)ix->cus * 32), 256, 0, ix->stream>>>(sl.fq_text, sl.fq_lines, sl.st_offsets, n_rec, sl.st_bases, sl.st_quals);
+	vg_fq_gather<<<(unsigned)std::min<uint64_t>((n_rec + 3) / 4, (uint64_t)ix->cus * 32), 256, 0, is>>>(sl.fq_text, sl.fq_lines, sl.st_offsets, n_rec, sl.st_bases, sl.st_quals);
 	HIP_TRY(hipGetLastError());
 	*n_records = n_rec; *consumed = edges[1];
 	if (last_record_start) *last_record_start = edges[0];
