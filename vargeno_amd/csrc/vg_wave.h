@@ -26,6 +26,9 @@
 #ifndef VG_SCAN_W
 #define VG_SCAN_W 2        // further entries of a multi-entry bucket fetched together in stage A
 #endif
+#ifndef VG_MIN_CHUNK
+#define VG_MIN_CHUNK 16u    // smallest guided work chunk
+#endif
 #ifndef VG_WALK_BATCH
 #define VG_WALK_BATCH 1
 #endif
@@ -137,45 +140,53 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 
 	for (;;) {
 		// ------------------------------------------------------------------ refill free lanes
-		{
+		// every free lane gets a read as long as the launch has any: a chunk that runs out mid-refill is followed by the next
+		for (;;) {
 			const uint64_t freem = __ballot(!active);
-			if (freem && cursor == end && !drained) {
-				// the chunk asked for one refill ago has had a whole chunk's worth of work to arrive; ask for the one after it now
+			if (!freem) break;
+			if (cursor == end) {
+				if (drained) break;
+				// guided chunks: WORK_CHUNK reads while the launch is young, fewer as it runs out (judged from where this wave's
+				// previous chunk started), so that the last waves to finish differ by a handful of reads
+				uint32_t want = WORK_CHUNK;
+				if (WORK_CHUNK > VG_MIN_CHUNK) {
+					const uint64_t left = n_reads - end;                  // end = one past this wave's previous chunk (0 at first)
+					const uint64_t fair = left / (2ull * gridDim.x * WPB);
+					want = fair >= WORK_CHUNK ? WORK_CHUNK : fair <= VG_MIN_CHUNK ? VG_MIN_CHUNK : (uint32_t)fair;
+				}
 				uint32_t c0 = 0;
-				if (lane == 0) c0 = atomicAdd(work_next, WORK_CHUNK);
+				if (lane == 0) c0 = atomicAdd(work_next, want);
 				c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
-				if ((uint64_t)c0 >= n_reads) drained = true;
-				else { cursor = c0; end = (uint64_t)c0 + WORK_CHUNK < n_reads ? c0 + WORK_CHUNK : (uint32_t)n_reads; }
+				if ((uint64_t)c0 >= n_reads) { drained = true; break; }
+				cursor = c0; end = (uint64_t)c0 + want < n_reads ? c0 + want : (uint32_t)n_reads;
 			}
 			const uint32_t avail = end - cursor;
-			if (freem && avail) {
-				const uint32_t nfree = (uint32_t)__popcll(freem);
-				const uint32_t take = avail < nfree ? avail : nfree;
-				if (!active) {
-					const uint32_t rank = (uint32_t)__popcll(freem & (lane_bit - 1));
-					if (rank < take) {
-						rid = read_ids ? read_ids[cursor + rank] : (uint32_t)(cursor + rank);
-						const uint64_t off = offsets[rid];
-						const uint64_t meta = pk_meta[rid];
-						n = (uint32_t)((offsets[rid + 1] - off) >> 5);
-						slot0 = (uint32_t)(off >> 5);
-						gates = (uint32_t)meta;
-						pass = 0;
-						cur.clear();
-						cur.add(S_READS, 1);
-						cur.add(S_INGEST, 9 * n);
-						if (meta & (PK_SKIP_N | PK_INVALID)) {
-							cur.add((meta & PK_INVALID) ? S_READS_INVALID : S_READS_N, 1);
-							if constexpr (STATS) for (int i = 0; i < S_COUNT; i++) tot.v[i] += cur.v[i];
-						} else if (meta & PK_LONG) {
-							overflow_list[atomicAdd(overflow_count, 1u)] = rid;
-						} else {
-							active = true;
-						}
+			const uint32_t nfree = (uint32_t)__popcll(freem);
+			const uint32_t take = avail < nfree ? avail : nfree;
+			if (!active) {
+				const uint32_t rank = (uint32_t)__popcll(freem & (lane_bit - 1));
+				if (rank < take) {
+					rid = read_ids ? read_ids[cursor + rank] : (uint32_t)(cursor + rank);
+					const uint64_t off = offsets[rid];
+					const uint64_t meta = pk_meta[rid];
+					n = (uint32_t)((offsets[rid + 1] - off) >> 5);
+					slot0 = (uint32_t)(off >> 5);
+					gates = (uint32_t)meta;
+					pass = 0;
+					cur.clear();
+					cur.add(S_READS, 1);
+					cur.add(S_INGEST, 9 * n);
+					if (meta & (PK_SKIP_N | PK_INVALID)) {
+						cur.add((meta & PK_INVALID) ? S_READS_INVALID : S_READS_N, 1);
+						if constexpr (STATS) for (int i = 0; i < S_COUNT; i++) tot.v[i] += cur.v[i];
+					} else if (meta & PK_LONG) {
+						overflow_list[atomicAdd(overflow_count, 1u)] = rid;
+					} else {
+						active = true;
 					}
 				}
-				cursor += take;
 			}
+			cursor += take;
 		}
 		if (!__any(active)) { if (drained) break; continue; }
 		VG_CLK(0);
