@@ -26,9 +26,6 @@
 #ifndef VG_SCAN_W
 #define VG_SCAN_W 2        // further entries of a multi-entry bucket fetched together in stage A
 #endif
-#ifndef VG_MIN_CHUNK
-#define VG_MIN_CHUNK 16u    // smallest guided work chunk
-#endif
 #ifndef VG_WALK_BATCH
 #define VG_WALK_BATCH 1
 #endif
@@ -146,19 +143,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 			if (!freem) break;
 			if (cursor == end) {
 				if (drained) break;
-				// guided chunks: WORK_CHUNK reads while the launch is young, fewer as it runs out (judged from where this wave's
-				// previous chunk started), so that the last waves to finish differ by a handful of reads
-				uint32_t want = WORK_CHUNK;
-				if (WORK_CHUNK > VG_MIN_CHUNK) {
-					const uint64_t left = n_reads - end;                  // end = one past this wave's previous chunk (0 at first)
-					const uint64_t fair = left / (2ull * gridDim.x * WPB);
-					want = fair >= WORK_CHUNK ? WORK_CHUNK : fair <= VG_MIN_CHUNK ? VG_MIN_CHUNK : (uint32_t)fair;
-				}
 				uint32_t c0 = 0;
-				if (lane == 0) c0 = atomicAdd(work_next, want);
+				if (lane == 0) c0 = atomicAdd(work_next, WORK_CHUNK);
 				c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
 				if ((uint64_t)c0 >= n_reads) { drained = true; break; }
-				cursor = c0; end = (uint64_t)c0 + want < n_reads ? c0 + want : (uint32_t)n_reads;
+				cursor = c0; end = (uint64_t)c0 + WORK_CHUNK < n_reads ? c0 + WORK_CHUNK : (uint32_t)n_reads;
 			}
 			const uint32_t avail = end - cursor;
 			const uint32_t nfree = (uint32_t)__popcll(freem);
