@@ -6,10 +6,11 @@ One step = one pass of the hot path (encode -> dictionary lookups -> gated neigh
 HBM as ASCII bases + quality characters, through the C-ABI (vg_reads_process_device); for N > 1
 ranks each step ends with the path's one exchange, an RCCL all-reduce of the per-site counters.
 
-Workload (config.workload): BASELINE.json configs[1] -- chr22-scale: one 40 Mbp synthetic
-chromosome with planted repeats, ~1 M SNPs, 150 bp reads at 0.5 % error, 8 % low-quality characters
-(SURVEY.md §8d), seed 20261002.  The hg38-scale configs[2] needs an index builder that does not go
-through a single host process; see DESIGN.md "what comes next".
+Workload (config.workload): BASELINE.json configs[1] by default -- chr22-scale: one 40 Mbp synthetic
+chromosome with planted repeats, ~1 M SNPs, 1 M x 150 bp reads per step at 0.5 % error, 8 % low-quality
+characters, seed 20261002 -- about a minute end to end.  `--workload hg38` runs the
+configs[2] shape (3.1 Gbp in 24 sequences, 10 M SNPs, 8 M-read steps of its 30x reads; ~6 minutes, most of
+it building and loading the index; profiles/bench_hg38_scale_r01.json holds the committed run).
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -207,7 +208,7 @@ def main():
                                    "0.5%% error, 8%% low-quality chars, seed 20261002" % (
                                        "chr22-scale (BASELINE.json configs[1])" if g.total_len < 10 ** 9 else "hg38-scale (BASELINE.json configs[2], one batch of its 30x reads)",
                                        g.total_len, len(g.seqs), len(s.pos), r.n),
-                       "reads_per_step_per_gpu": r.n, "index_bytes_hbm": gx.device_bytes,
+                       "reads_per_step_per_gpu": r.n, "genome_bp": args.genome, "snps_requested": args.snps, "index_bytes_hbm": gx.device_bytes,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K batches" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "vg_wave_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,

@@ -27,6 +27,36 @@ for name in ("bench_default.json", "kt.json"):
     if os.path.exists(p) and os.path.getsize(p):
         out.append("== %s" % name)
         out.append(open(p).read().strip())
+# traffic of the dominant kernel for bench.py's roofline.traffic: (FETCH_SIZE + WRITE_SIZE) KB per launch, separate --pmc passes
+means = {}
+for grp in ("pmc_fetch", "pmc_write", "pmc_l2"):
+    for f in glob.glob(os.path.join(src, grp, "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "vg_wave_kernel<false, 8" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for c, v in agg.items():
+            means[c] = sum(v) / len(v)
+kt_avg = None
+for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
+    for row in csv.DictReader(open(f)):
+        if "vg_wave_kernel<false, 8" in row["Name"]:
+            kt_avg = float(row["AverageNs"])
+if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
+    wl = None
+    try:
+        cfg = json.loads(open(os.path.join(src, "kt.json")).read().strip().splitlines()[-1])["config"]
+        wl = {"genome": cfg["genome_bp"], "snps": cfg["snps_requested"], "reads": cfg["reads_per_step_per_gpu"]}
+    except Exception:
+        pass
+    tj = {"workload": wl, "kernel": "vg_wave_kernel<false, 8, 4, 4, 4>", "FETCH_SIZE_KB": means["FETCH_SIZE"], "WRITE_SIZE_KB": means["WRITE_SIZE"],
+          "traffic_bytes_per_launch": int((means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024),
+          "TCC_MISS_sum": means.get("TCC_MISS_sum"), "TCC_HIT_sum": means.get("TCC_HIT_sum"), "TCP_TCC_READ_REQ_sum": means.get("TCP_TCC_READ_REQ_sum"),
+          "kernel_trace_avg_ns": kt_avg,
+          "source": "profiles/run_prof_%s.sh -> profiles/rocprof_summary_%s_final.txt; unit check in profiles/fetch_size_calibration_r01.txt" % (tag, tag)}
+    open(os.path.join(src, "traffic_%s.json" % tag), "w").write(json.dumps(tj, indent=1) + "\n")
+    out.append("== traffic_%s.json" % tag)
+    out.append(json.dumps(tj))
 txt = "\n".join(out)
 print(txt)
 open(os.path.join(src, "summary_%s.txt" % tag), "w").write(txt + "\n")
