@@ -214,7 +214,7 @@ def main():
                          "kernel": "vg_wave_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "algorithmic_bytes_per_read": alg_bytes_per_launch / r.n},
             "cpu_baseline": cpu,
-            "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "lane_tiers_overlapped": tm["ms_tail"], "batches": tm["batches"]},
+            "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "spill_tiers_overlapped": tm["ms_tail"], "of_which_deep_list_wave_tier": tm["ms_deep_lists"], "batches": tm["batches"]},
             "reads_per_step_spilled_to_lane_tier": st["overflow_reads"], "reads_per_step_deep_scratch": st["overflow_deep"],
             "events_per_read": {k: st[k] / r.n for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
         }

@@ -59,9 +59,11 @@ typedef struct {
 	float ms_total;              /* first kernel start -> last kernel end of a batch           */
 	float ms_pack;               /* vg_pack_kernel: ASCII -> 2-bit chunk k-mers + gate bits    */
 	float ms_main;               /* vg_wave_kernel, the dominant kernel                        */
-	float ms_tail;               /* generic lane tier for the reads that outgrew the LDS lists
-	                                (runs on a second stream, under the next batch's wave tier) */
+	float ms_tail;               /* the spill tiers (deep-list wave tier + generic lane tier) for the
+	                                reads that outgrew the LDS lists: second stream, under the next
+	                                batches' kernels                                             */
 	uint32_t batches;
+	float ms_deep_lists;         /* of ms_tail: the deep-list wave tier                        */
 } vg_timing;
 
 const char *vg_last_error(void);

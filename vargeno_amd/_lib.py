@@ -30,7 +30,7 @@ class VgStats(C.Structure):
 
 
 class VgTiming(C.Structure):
-    _fields_ = [("ms_total", C.c_float), ("ms_pack", C.c_float), ("ms_main", C.c_float), ("ms_tail", C.c_float), ("batches", C.c_uint32)]
+    _fields_ = [("ms_total", C.c_float), ("ms_pack", C.c_float), ("ms_main", C.c_float), ("ms_tail", C.c_float), ("batches", C.c_uint32), ("ms_deep_lists", C.c_float)]
 
 
 u64p, u32p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)

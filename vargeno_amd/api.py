@@ -126,7 +126,7 @@ class GenoIndex:
     def timing(self):
         t = VgTiming()
         check(lib().vg_timing_get(self._h, C.byref(t)))
-        return dict(ms_total=float(t.ms_total), ms_pack=float(t.ms_pack), ms_main=float(t.ms_main), ms_tail=float(t.ms_tail), batches=int(t.batches))
+        return dict(ms_total=float(t.ms_total), ms_pack=float(t.ms_pack), ms_main=float(t.ms_main), ms_tail=float(t.ms_tail), ms_deep_lists=float(t.ms_deep_lists), batches=int(t.batches))
 
     # ---- results -------------------------------------------------------------------------
     @property

@@ -81,7 +81,7 @@ template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB == 4 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
-                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK, unsigned long long *stats)
+                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
 {
 	// narrow element types keep a wave at 6.5 KB of LDS (24 waves per CU): an exact context only needs its
 	// chunk number next to the position, a neighbour context 13 bits, a vote key 8 + 1 bits of state
@@ -107,6 +107,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 	const uint32_t col0 = wv << 6;                       // first column of this wave (scalar)
 	const uint64_t lane_bit = 1ull << lane;
 	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;
+	// A list-driven launch (the spill tier) does not know its size on the host: its chunk grows with the list, from the
+	// WORK_CHUNK_ARG reads that spread a few hundred heavy reads over all waves up to 16 when there are tens of thousands
+	uint32_t WORK_CHUNK = WORK_CHUNK_ARG;
+	if constexpr (WPB == 1) if (read_ids) {                 // (the spill tier is the single-wave instantiation)
+		const uint64_t fair = n_reads / (2ull * gridDim.x * WPB);
+		if (fair > WORK_CHUNK) WORK_CHUNK = fair < 16 ? (uint32_t)fair : 16u;
+	}
 	// work distribution: waves pull WORK_CHUNK consecutive reads at a time from one device counter (zeroed per launch), so
 	// the last waves to finish differ by one chunk instead of by the variance of a static 1/n_waves share
 	uint32_t cursor = 0, end = 0;                        // wave-uniform (kept in scalar registers); a launch holds < 2^32 reads
