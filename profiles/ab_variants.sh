@@ -15,7 +15,7 @@ for v in variants/*.so; do
 import json, sys
 try:
     j = json.load(open("gpurun_out/ab_%s_%s.json" % (sys.argv[1], sys.argv[2])))
-    print(sys.argv[1], sys.argv[2], "pack %.4f" % j["device_ms_per_step"]["pack"], "reads/s %.4g" % j["value"], "ms/step %.4f" % j["ms_per_step"], "wave ms %.4f" % j["roofline"].get("kernel_ms", -1), "frac %.3f" % j["roofline"]["frac"])
+    print(sys.argv[1], sys.argv[2], "pack %.4f" % j["device_ms_per_step"]["pack"], "reads/s %.4g" % j["value"], "ms/step %.4f" % j["ms_per_step"], "wave ms %.4f" % j["roofline"].get("kernel_ms", -1), "frac %.3f" % j["roofline"]["frac"], "spilled", j.get("reads_per_step_spilled_to_lane_tier"), "tiers %.3f" % j["device_ms_per_step"]["spill_tiers_overlapped"])
 except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY

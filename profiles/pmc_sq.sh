@@ -10,7 +10,7 @@ import csv,glob,collections
 for P in ["p1","p2","p3"]:
     for f in glob.glob("$R/gpurun_out/sq/%s/*/*_counter_collection.csv"%P):
         agg=collections.defaultdict(list)
-        for r in csv.DictReader(open(f)): agg[(r["Kernel_Name"][:44], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for r in csv.DictReader(open(f)): agg[(r["Kernel_Name"][:52], r["Counter_Name"])].append(float(r["Counter_Value"]))
         for k,v in sorted(agg.items()):
-            if "wave_kernel<false, 8" in k[0]: print(P, k[1], len(v), "%.5g"%(sum(v)/len(v)))
+            if "wave_kernel<false, " in k[0] and ", 4>" in k[0]: print(P, k[1], len(v), "%.5g"%(sum(v)/len(v)))
 PY

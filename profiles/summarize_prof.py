@@ -33,14 +33,14 @@ for grp in ("pmc_fetch", "pmc_write", "pmc_l2"):
     for f in glob.glob(os.path.join(src, grp, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "vg_wave_kernel<false, 8" in r["Kernel_Name"]:
+            if "vg_wave_kernel<false, " in r["Kernel_Name"] and ", 4>" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, v in agg.items():
             means[c] = sum(v) / len(v)
 kt_avg = None
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     for row in csv.DictReader(open(f)):
-        if "vg_wave_kernel<false, 8" in row["Name"]:
+        if "vg_wave_kernel<false, " in row["Name"] and ", 4>" in row["Name"]:
             kt_avg = float(row["AverageNs"])
 if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
     wl = None
@@ -49,7 +49,7 @@ if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
         wl = {"genome": cfg["genome_bp"], "snps": cfg["snps_requested"], "reads": cfg["reads_per_step_per_gpu"]}
     except Exception:
         pass
-    tj = {"workload": wl, "kernel": "vg_wave_kernel<false, 8, 4, 4, 4>", "FETCH_SIZE_KB": means["FETCH_SIZE"], "WRITE_SIZE_KB": means["WRITE_SIZE"],
+    tj = {"workload": wl, "kernel": "vg_wave_kernel<false, 12, 4, 4, 4>", "FETCH_SIZE_KB": means["FETCH_SIZE"], "WRITE_SIZE_KB": means["WRITE_SIZE"],
           "traffic_bytes_per_launch": int((means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024),
           "TCC_MISS_sum": means.get("TCC_MISS_sum"), "TCC_HIT_sum": means.get("TCC_HIT_sum"), "TCP_TCC_READ_REQ_sum": means.get("TCP_TCC_READ_REQ_sum"),
           "kernel_trace_avg_ns": kt_avg,

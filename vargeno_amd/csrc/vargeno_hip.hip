@@ -1126,6 +1126,13 @@ extern "C" int vg_timing_get(vg_index *ix, vg_timing *out)
 	if (!ix || !out) return fail(VG_EINVAL, "null argument");
 	memset(out, 0, sizeof *out);
 	int rc = finish_pending(ix);
+#ifdef VG_STAGE_CLOCKS
+	{
+		unsigned long long h[8];
+		if (hipMemcpyFromSymbol(h, HIP_SYMBOL(vg_dbg_ovf), sizeof h) == hipSuccess)
+			fprintf(stderr, "[dbg] list overflows (pass-level events) tier1: exact %llu neighbour %llu keys %llu | tier2: exact %llu neighbour %llu keys %llu\n", h[0], h[1], h[2], h[4], h[5], h[6]);
+	}
+#endif
 	if (rc) return rc;
 	if (!ix->t_batches) return fail(VG_EINVAL, "no batch has been processed since the last vg_timing_get");
 	const double n = (double)ix->t_batches;

@@ -39,13 +39,23 @@
 #define VG_CLKW(i) do { } while (0)
 #endif
 
+#ifdef VG_STAGE_CLOCKS
+__device__ unsigned long long vg_dbg_ovf[8];     // [tier*4 + reason]: 0 exact list, 1 neighbour list, 2 vote keys
+#define VG_OVF(r) atomicAdd(&vg_dbg_ovf[(WPB == 4 ? 0 : 4) + (r)], 1ull)
+#else
+#define VG_OVF(r) do { } while (0)
+#endif
+
 namespace vg {
 
 // List capacities per job-pass (LDS, [slot][lane]).  Two instantiations: the main tier keeps 17 waves per CU
 // resident; the second tier takes the reads that spill from it (repeat regions: aux rows, many keys)
 // with lists 6-8x deeper at 2 waves per CU -- still wave-parallel, so a heavy read costs a few dozen
 // dependent gathers instead of the thousands the sequential lane machine needs.
-constexpr int W1_ECAP = 8, W1_NCAP = 4, W1_KCAP = 4;
+#ifndef VG_W1_ECAP
+#define VG_W1_ECAP 12     // exact contexts per lane in the main tier (86 % of the spills at 8 were this list; 12 still leaves 4 workgroups per CU)
+#endif
+constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_KCAP = 4;
 constexpr int W2_ECAP = 48, W2_NCAP = 48, W2_KCAP = 32;
 constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is also what a failed query's -1 truncates to
 constexpr int PCAP = 32;         // rows of the stage-B pair table (a wave with more gate-open chunks takes several windows)
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 			// append the exact contexts of chunk c (qv.cc:850-937): reference hit first, then SNP hit; aux rows expanded
 			auto push_exact = [&](uint32_t p, uint32_t c) {
 				cur.add(S_CTX, 1);
-				if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else ovf = true;
+				if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else { if (!ovf) VG_OVF(0); ovf = true; }
 			};
 			auto push_row = [&](const uint32_t *row, uint32_t c) {               // a row ends at its first 0
 				for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 			}
 			VG_WAVE_SYNC();
 			ncnt = N_cnt[col];
-			if (N_ovf[col]) ovf = true;
+			if (N_ovf[col]) { if (!ovf) VG_OVF(1); ovf = true; }
 			if constexpr (STATS) for (int i = 0; i < NSH; i++) cur.v[SH_IDS[i]] += S_own[i][col];
 		}
 		VG_WAVE_SYNC();
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 					uint32_t first, fm;
 					if (e < 0) {
 						if (neigh) return;
-						if (nkeys >= (uint32_t)W_KCAP) { ovf = true; return; }
+						if (nkeys >= (uint32_t)W_KCAP) { if (!ovf) VG_OVF(2); ovf = true; return; }
 						e = (int)nkeys++;
 						first = kpos; fm = 0;
 						if (e == 0) { k0_idx = index; k0_first = kpos; } else { K_idx[e][col] = index; K_first[e][col] = kpos; }
