@@ -570,7 +570,14 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	ix->device = device;
 	HIP_TRY(hipSetDevice(device));
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
-	HIP_TRY(hipStreamCreateWithFlags(&ix->tail, hipStreamNonBlocking));
+	{
+		// the spill tiers are a few hundred small workgroups that can only start when main-tier workgroups retire: with a
+		// higher priority they are placed first at every such moment instead of queueing behind the next wave kernel
+		int lo_p = 0, hi_p = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+		if (getenv("VG_TAIL_PRIO") && atoi(getenv("VG_TAIL_PRIO")) == 0) hi_p = 0;
+		HIP_TRY(hipStreamCreateWithPriority(&ix->tail, hipStreamNonBlocking, hi_p));
+	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->ingest, hipStreamNonBlocking));
 	ix->pack_overlap = getenv("VG_NO_PACK_OVERLAP") == nullptr;
 	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); }
