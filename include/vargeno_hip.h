@@ -92,7 +92,8 @@ int  vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals,
                      const uint64_t *offsets, uint64_t n_reads);
 
 /* Same, for a batch already resident in device memory (hipMalloc'd by the caller on ix's device):
- * what bench.py times.  The buffers must stay valid and unchanged until the next vg_sync. */
+ * what bench.py times.  The handle works on its own non-blocking streams: the buffers must be complete when the
+ * call is made (synchronise the stream that produced them) and stay valid and unchanged until the next vg_sync. */
 int  vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals,
                              const uint64_t *d_offsets, uint64_t n_reads);
 

@@ -217,19 +217,23 @@ __device__ inline int classify_bad(const uint8_t *p, uint32_t n)
 // A workgroup takes 256 consecutive reads: their bases are one contiguous span, copied to LDS with coalesced
 // 16-byte loads (lane-per-read loads at a 150-byte stride fetched every line ~2.5 times), then each lane packs
 // its own read out of LDS.  Only the first n quality characters of a read are ever looked at.
-constexpr uint32_t PACK_LDS = 40 * 1024;       // 256 reads of up to 160 bases; longer reads take the direct path
-__global__ __launch_bounds__(256) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
+#ifndef VG_PACK_T
+#define VG_PACK_T 128
+#endif
+constexpr uint32_t PACK_T = VG_PACK_T;          // reads (= lanes) per tile
+constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bases; longer reads take the direct path
+__global__ __launch_bounds__(PACK_T) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
                                                       uint64_t n_reads, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t sm[PACK_LDS + 64];
-	for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n_reads; r0 += (uint64_t)gridDim.x * 256) {
+	for (uint64_t r0 = (uint64_t)blockIdx.x * PACK_T; r0 < n_reads; r0 += (uint64_t)gridDim.x * PACK_T) {
 		const uint64_t r = r0 + threadIdx.x;
-		const uint64_t rl = r0 + 256 < n_reads ? r0 + 256 : n_reads;
+		const uint64_t rl = r0 + PACK_T < n_reads ? r0 + PACK_T : n_reads;
 		const uint64_t base0 = offsets[r0], span = offsets[rl] - base0;
 		const bool staged = span <= PACK_LDS;
 		__syncthreads();                                              // previous tile fully consumed
 		if (staged) {
-			for (uint64_t i = (uint64_t)threadIdx.x * 16; i < span; i += 256 * 16) {
+			for (uint64_t i = (uint64_t)threadIdx.x * 16; i < span; i += PACK_T * 16) {
 				if (i + 16 <= span) {
 					uint4 v;
 					__builtin_memcpy(&v, bases + base0 + i, 16);
@@ -446,7 +450,7 @@ struct ScratchBuf {
 
 // Per-batch resources.  A handle keeps NSLOT batches in flight: the wave tier of batch k+1 runs on the
 // main stream while the (rare, latency-bound) lane tiers of batch k finish on the tail stream.
-constexpr int NSLOT = 3;
+constexpr int NSLOT = 3;            // (5 and 8 were measured: no gain at 8 M-read batches, 10-30 % slower at 1 M -- more pack kernels run ahead and get in the wave kernel's way)
 struct Slot {
 	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr;  uint64_t list_cap = 0;
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
@@ -894,8 +898,8 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipMemsetAsync(ctr, 0, 32, ps));
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
-		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->cus * pack_bpc);
-		vg_pack_kernel<<<pgrid, 256, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
+		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T - 1) / PACK_T, (uint64_t)ix->cus * pack_bpc * (256 / PACK_T));
+		vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
 		HIP_TRY(hipEventRecord(sl.e1, ps));
 		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
