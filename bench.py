@@ -121,11 +121,11 @@ def main():
         log("[bench] oracle index load: %.1fs" % (time.time() - t0))
         ns = min(args.cpu_sample, r.n)
         sub = r.slice(0, ns)
+        # bounded sample: whole passes over the first `ns` reads until about 10 s of single-thread work; the first pass is
+        # the one the parity check uses, the others follow it
         t0 = time.time()
         ox.process(sub.bases, sub.quals, sub.offsets, nthreads=1)
-        t_cpu = time.time() - t0
-        cpu = {"value": ns / t_cpu, "unit": "reads/s", "cores": 1, "kind": "port",
-               "sample": "first %d reads of the same batch, oracle/vg_oracle.c, 1 thread, %.1f s" % (ns, t_cpu)}
+        t_cpu, passes = time.time() - t0, 1
         if not args.no_check:
             if ns == r.n:
                 so = ox.sites()
@@ -143,6 +143,14 @@ def main():
                 rc2, ac2 = gx.counts()
                 assert np.array_equal(rc2, so["ref_cnt"]) and np.array_equal(ac2, so["alt_cnt"]), "timed build != oracle"
                 log("[bench] parity: %d site counters (both builds) and %d event counters identical to the oracle" % (2 * len(rc), len(want)))
+        while t_cpu < 10.0 and passes < 8:
+            ox.reset()
+            t0 = time.time()
+            ox.process(sub.bases, sub.quals, sub.offsets, nthreads=1)
+            t_cpu += time.time() - t0
+            passes += 1
+        cpu = {"value": passes * ns / t_cpu, "unit": "reads/s", "cores": 1, "kind": "port",
+               "sample": "%d pass(es) over the first %d reads of the same batch, oracle/vg_oracle.c, 1 thread, %.1f s" % (passes, ns, t_cpu)}
         ncores = os.cpu_count() or 1
         nt = min(ncores, 64)
         ox.reset()
