@@ -753,10 +753,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 						else if (freq > bf) { best = e; amb = false; }
 					}
 				};
-				uint32_t ei = 0, ni = 0;
-				for (uint32_t c = 0; c < n && !ovf; c++) {
-					while (ei < ecnt && (E_meta[ei][col] & 31u) == c) { const uint32_t p = E_kpos[ei][col]; vote(p - 32u * c, p, false); ei++; }
-					while (ni < ncnt && (N_meta[ni][col] & 31u) == c) { const uint32_t p = N_kpos[ni][col]; vote(p - 32u * c, p, true); ni++; }
+				// chunk by chunk, a chunk's exact contexts before its neighbour contexts: a merge of the two lists (each is in
+				// chunk order), one step per context
+				{
+					uint32_t ei = 0, ni = 0;
+					uint32_t ce = ecnt ? (uint32_t)(E_meta[0][col] & 31u) : 99u, cn = ncnt ? (uint32_t)(N_meta[0][col] & 31u) : 99u;
+					while ((ce != 99u || cn != 99u) && !ovf) {            // 99 = list exhausted (chunk numbers are < 32)
+						const bool ex = ce <= cn;
+						const uint32_t c = ex ? ce : cn;
+						const uint32_t p = ex ? E_kpos[ei][col] : N_kpos[ni][col];
+						if (ex) { ei++; ce = ei < ecnt ? (uint32_t)(E_meta[ei][col] & 31u) : 99u; }
+						else { ni++; cn = ni < ncnt ? (uint32_t)(N_meta[ni][col] & 31u) : 99u; }
+						vote(p - 32u * c, p, !ex);
+					}
 				}
 				VG_CLK(4);
 				if (!ovf) {
