@@ -58,6 +58,25 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
         assert tm["ms_main"] > 0 and tm["batches"] == 1
 
 
+@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_SEC", "VG_NO_PACK_OVERLAP"])
+def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
+    """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view) and runs
+    its pack kernel on a separate stream.  Each has a fallback (less HBM, one stream); all must give the reference's bits.
+    Several batches, so that slots, streams and the base-indexed counters' fold are exercised too."""
+    monkeypatch.setenv(knob, "1")
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    _, _, so = _oracle_counts(prefix, r)
+    with GenoIndex.open(prefix) as gx:
+        gx.set_stats(False)
+        step = r.n // 5 + 1
+        for lo in range(0, r.n, step):
+            sub = r.slice(lo, min(r.n, lo + step))
+            gx.submit(sub.bases, sub.quals, sub.offsets)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+
+
 def test_batching_and_reset_invariance(ftiny_dir, ftiny_reads):
     prefix = os.path.join(ftiny_dir, "idx")
     r = ftiny_reads
