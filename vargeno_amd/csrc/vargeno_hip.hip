@@ -12,12 +12,17 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace vg;
@@ -564,6 +569,30 @@ extern "C" void vg_index_close(vg_index *ix)
 	delete ix;
 }
 
+// Host loops over billions of records (hg38: 2.9 G k-mers, 3.1 G positions) are spread over threads; fn(lo, hi, t).
+static unsigned host_threads()
+{
+	static const unsigned n = [] {
+		unsigned h = std::thread::hardware_concurrency();
+		if (const char *e = getenv("VG_HOST_THREADS")) h = (unsigned)std::max(1, atoi(e));
+		return std::max(1u, std::min(h, 32u));
+	}();
+	return n;
+}
+template <class F>
+static void parallel_for(uint64_t n, F &&fn)
+{
+	const unsigned nt = n < (1ull << 20) ? 1u : host_threads();
+	if (nt == 1) { if (n) fn((uint64_t)0, n, 0u); return; }
+	const uint64_t per = ((n + nt - 1) / nt + 63) & ~63ull;          // 64-aligned shares (rank blocks never straddle two threads)
+	std::vector<std::thread> th;
+	for (unsigned t = 0; t < nt; t++) {
+		const uint64_t lo = (uint64_t)t * per, hi = std::min(n, lo + per);
+		if (lo < hi) th.emplace_back([&fn, lo, hi, t] { fn(lo, hi, t); });
+	}
+	for (auto &x : th) x.join();
+}
+
 static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 {
 	if (a->n_ref >= 0xFFFFFFFFull || a->n_snp >= 0xFFFFFFFFull) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
@@ -708,35 +737,63 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	//      i.e. 2^32+32 entries as soon as one k-mer is POS_AMBIGUOUS; only real positions are ever indexed.
 	{
 		uint64_t maxp = 0;
-		for (uint64_t i = 0; i < a->n_ref; i++) if (a->ref_amb[i] == 0 && a->ref_pos[i] != POS_AMBIGUOUS && a->ref_pos[i] > maxp) maxp = a->ref_pos[i];
-		for (uint64_t i = 0; i < a->n_ref_aux * AUX_COLS; i++) if (a->ref_aux[i] > maxp) maxp = a->ref_aux[i];
-		for (uint64_t i = 0; i < a->n_snp; i++) if (a->snp_amb[i] == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_pos[i] > maxp) maxp = a->snp_pos[i];
-		for (uint64_t i = 0; i < a->n_snp_aux * AUX_COLS; i++) if (a->snp_aux_pos[i] > maxp) maxp = a->snp_aux_pos[i];
+		{
+			std::vector<uint64_t> mx(host_threads(), 0);
+			parallel_for(a->n_ref, [&](uint64_t lo, uint64_t hi, unsigned t) { uint64_t m = 0; for (uint64_t i = lo; i < hi; i++) if (a->ref_amb[i] == 0 && a->ref_pos[i] != POS_AMBIGUOUS && a->ref_pos[i] > m) m = a->ref_pos[i]; mx[t] = std::max(mx[t], m); });
+			parallel_for(a->n_ref_aux * AUX_COLS, [&](uint64_t lo, uint64_t hi, unsigned t) { uint64_t m = 0; for (uint64_t i = lo; i < hi; i++) if (a->ref_aux[i] > m) m = a->ref_aux[i]; mx[t] = std::max(mx[t], m); });
+			parallel_for(a->n_snp, [&](uint64_t lo, uint64_t hi, unsigned t) { uint64_t m = 0; for (uint64_t i = lo; i < hi; i++) if (a->snp_amb[i] == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_pos[i] > m) m = a->snp_pos[i]; mx[t] = std::max(mx[t], m); });
+			parallel_for(a->n_snp_aux * AUX_COLS, [&](uint64_t lo, uint64_t hi, unsigned t) { uint64_t m = 0; for (uint64_t i = lo; i < hi; i++) if (a->snp_aux_pos[i] > m) m = a->snp_aux_pos[i]; mx[t] = std::max(mx[t], m); });
+			for (uint64_t m : mx) maxp = std::max(maxp, m);
+		}
 		const uint64_t plen = maxp + 64;
-		std::vector<uint32_t> pile(plen, 0);        // low nibble ref|alt<<2, bits 16.. freqs (host only)
-		for (uint64_t i = 0; i < a->n_snp; i++) {   // file order, last writer wins
-			const uint32_t info = a->snp_info[i];
-			if ((info & 4u) == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_amb[i] == 0) {
-				const uint32_t sp = a->snp_pos[i] + (info >> 3);
-				const uint32_t alt = (uint32_t)(a->snp_kmer[i] >> (2 * (info >> 3))) & 3u;
-				pile[sp] = (info & 3u) | (alt << 2) | ((uint32_t)a->snp_rf[i] << 16) | ((uint32_t)a->snp_af[i] << 24);
+		// Seeding in FILE ORDER, last writer wins (qv.cc:637-659), done in parallel: first every position learns the index of
+		// the LAST dictionary entry that seeds it (atomic max), then each position applies that one entry.
+		std::unique_ptr<uint32_t[]> pile(new uint32_t[plen]);             // winner index + 1, then: low nibble ref|alt<<2, bits 16.. freqs (host only)
+		parallel_for(plen, [&](uint64_t lo, uint64_t hi, unsigned) { memset(pile.get() + lo, 0, (hi - lo) * 4); });
+		auto seeds = [&](uint64_t i) { const uint32_t info = a->snp_info[i]; return (info & 4u) == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_amb[i] == 0; };
+		parallel_for(a->n_snp, [&](uint64_t lo, uint64_t hi, unsigned) {
+			for (uint64_t i = lo; i < hi; i++) if (seeds(i)) {
+				uint32_t *w = &pile[(uint64_t)a->snp_pos[i] + (a->snp_info[i] >> 3)];
+				const uint32_t mine = (uint32_t)(i + 1);                 // n_snp < 2^32 - 1
+				uint32_t cur = __atomic_load_n(w, __ATOMIC_RELAXED);
+				while (cur < mine && !__atomic_compare_exchange_n(w, &cur, mine, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
 			}
-		}
+		});
+		// per 64-position block: site bits; then site numbers by a prefix over the blocks; then everything that is per site
+		const uint64_t nblk = plen / 64 + 1;
 		std::vector<uint8_t> pile8(plen, 0);
-		std::vector<ulonglong2> rank(plen / 64 + 1, ulonglong2{0, 0});
-		for (uint64_t p = 0; p < plen; p++) {
-			const uint32_t w = pile[p];
-			const uint32_t r = w & 3u, al = (w >> 2) & 3u;
-			if ((p & 63) == 0) rank[p >> 6].y = ix->site_pos.size();
-			if (r != al) {
-				ix->site_pos.push_back((uint32_t)p); ix->site_ref.push_back((uint8_t)r); ix->site_alt.push_back((uint8_t)al);
-				ix->site_rf.push_back((uint8_t)(w >> 16)); ix->site_af.push_back((uint8_t)(w >> 24));
-				pile8[p] = (uint8_t)((w & 15u) | 16u);
-				rank[p >> 6].x |= 1ull << (p & 63);
-			} else {
-				pile8[p] = (uint8_t)(w & 15u);
+		std::vector<ulonglong2> rank(nblk, ulonglong2{0, 0});
+		parallel_for(plen, [&](uint64_t lo, uint64_t hi, unsigned) {
+			for (uint64_t p = lo; p < hi; p++) {
+				uint32_t w = pile[p];
+				if (w) {
+					const uint64_t i = w - 1;
+					const uint32_t info = a->snp_info[i];
+					const uint32_t alt = (uint32_t)(a->snp_kmer[i] >> (2 * (info >> 3))) & 3u;
+					w = (info & 3u) | (alt << 2) | ((uint32_t)a->snp_rf[i] << 16) | ((uint32_t)a->snp_af[i] << 24);
+					pile[p] = w;
+				}
+				const uint32_t r = w & 3u, al = (w >> 2) & 3u;
+				if (r != al) { pile8[p] = (uint8_t)((w & 15u) | 16u); rank[p >> 6].x |= 1ull << (p & 63); }
+				else pile8[p] = (uint8_t)(w & 15u);
 			}
-		}
+		});
+		uint64_t nsites = 0;
+		for (uint64_t bk = 0; bk < nblk; bk++) { rank[bk].y = nsites; nsites += (uint64_t)__builtin_popcountll(rank[bk].x); }
+		ix->site_pos.resize(nsites); ix->site_ref.resize(nsites); ix->site_alt.resize(nsites); ix->site_rf.resize(nsites); ix->site_af.resize(nsites);
+		parallel_for(nblk * 64, [&](uint64_t lo, uint64_t hi, unsigned) {
+			for (uint64_t bk = lo / 64; bk < hi / 64 && bk < nblk; bk++) {
+				uint64_t m = rank[bk].x, sidx = rank[bk].y;
+				while (m) {
+					const uint64_t p = bk * 64 + (uint64_t)__builtin_ctzll(m);
+					m &= m - 1;
+					const uint32_t w = pile[p];
+					ix->site_pos[sidx] = (uint32_t)p; ix->site_ref[sidx] = (uint8_t)(w & 3u); ix->site_alt[sidx] = (uint8_t)((w >> 2) & 3u);
+					ix->site_rf[sidx] = (uint8_t)(w >> 16); ix->site_af[sidx] = (uint8_t)(w >> 24);
+					sidx++;
+				}
+			}
+		});
 		ix->n_sites = ix->site_pos.size();
 		if (ix->n_sites >= (1ull << 31)) return fail(VG_ETOOBIG, "more than 2^31 SNP sites");
 		uint8_t *dp = nullptr; ulonglong2 *dr = nullptr; uint32_t *dc = nullptr;
@@ -779,15 +836,27 @@ extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **
 }
 
 // ---- index files (formats: SURVEY.md §8f-1; writers src/dictgen.c:63-275, sdsl int_vector.hpp:1563-1595)
-static int read_file(const std::string &path, std::vector<uint8_t> &buf)
+// whole file into an uninitialised buffer, its pieces pread() by several threads (the page cache / an NVMe array serve them
+// concurrently; one fread of the 43 GB hg38 dictionary is a single memcpy stream)
+struct RawFile { std::unique_ptr<uint8_t[]> p; size_t n = 0; const uint8_t *data() const { return p.get(); } size_t size() const { return n; } };
+static int read_file(const std::string &path, RawFile &buf)
 {
-	FILE *f = fopen(path.c_str(), "rb");
-	if (!f) return fail(VG_EIO, "cannot open %s", path.c_str());
-	fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
-	buf.resize((size_t)sz);
-	const size_t got = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
-	fclose(f);
-	if (got != (size_t)sz) return fail(VG_EIO, "short read on %s", path.c_str());
+	const int fd = open(path.c_str(), O_RDONLY);
+	if (fd < 0) return fail(VG_EIO, "cannot open %s", path.c_str());
+	struct stat st;
+	if (fstat(fd, &st) != 0) { close(fd); return fail(VG_EIO, "cannot stat %s", path.c_str()); }
+	buf.n = (size_t)st.st_size;
+	buf.p.reset(new uint8_t[buf.n + 1]);
+	std::vector<int> bad(host_threads(), 0);
+	parallel_for(buf.n, [&](uint64_t lo, uint64_t hi, unsigned t) {
+		while (lo < hi) {
+			const ssize_t g = pread(fd, buf.p.get() + lo, (size_t)std::min<uint64_t>(hi - lo, 1ull << 30), (off_t)lo);
+			if (g <= 0) { bad[t] = 1; return; }
+			lo += (uint64_t)g;
+		}
+	});
+	close(fd);
+	for (int x : bad) if (x) return fail(VG_EIO, "short read on %s", path.c_str());
 	return VG_OK;
 }
 static int read_bf(const std::string &path, uint64_t cap_bits, uint64_t &bits, std::vector<uint64_t> &words)
@@ -808,7 +877,7 @@ extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
 	if (!prefix || !out) return fail(VG_EINVAL, "null argument");
 	*out = nullptr;
 	const std::string pre(prefix);
-	std::vector<uint8_t> rd, sd;
+	RawFile rd, sd;
 	int rc;
 	if ((rc = read_file(pre + ".ref.dict", rd))) return rc;
 	if ((rc = read_file(pre + ".snp.dict", sd))) return rc;
@@ -819,27 +888,37 @@ extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
 	if (n_ref > (1ull << 32) || n_snp > (1ull << 32)) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
 	if (rd.size() != 16 + 13 * n_ref + 40 * n_ref_aux) return fail(VG_EIO, "%s.ref.dict: size does not match its header", prefix);
 	if (sd.size() != 16 + 16 * n_snp + 78 * n_snp_aux) return fail(VG_EIO, "%s.snp.dict: size does not match its header", prefix);
-	std::vector<uint64_t> rk(n_ref), sk(n_snp);
-	std::vector<uint32_t> rp(n_ref), raux(n_ref_aux * 10), sp(n_snp), sxp(n_snp_aux * 10);
-	std::vector<uint8_t> ra(n_ref), si(n_snp), sa(n_snp), srf(n_snp), saf(n_snp), sxi(n_snp_aux * 10);
-	const uint8_t *p = rd.data() + 16;
-	for (uint64_t i = 0; i < n_ref; i++, p += 13) { memcpy(&rk[i], p, 8); memcpy(&rp[i], p + 8, 4); ra[i] = p[12]; }
-	if (n_ref_aux) memcpy(raux.data(), p, n_ref_aux * 40);
-	p = sd.data() + 16;
-	for (uint64_t i = 0; i < n_snp; i++, p += 16) { memcpy(&sk[i], p, 8); memcpy(&sp[i], p + 8, 4); si[i] = p[12]; sa[i] = p[13]; srf[i] = p[14]; saf[i] = p[15]; }
-	for (uint64_t i = 0; i < n_snp_aux; i++) {
-		p += 8;
-		for (int j = 0; j < 10; j++, p += 7) { memcpy(&sxp[i * 10 + j], p, 4); sxi[i * 10 + j] = p[4]; }
+	// uninitialised: every element is written below, by the thread that first touches its page
+	std::unique_ptr<uint64_t[]> rk(new uint64_t[n_ref + 1]), sk(new uint64_t[n_snp + 1]);
+	std::unique_ptr<uint32_t[]> rp(new uint32_t[n_ref + 1]), sp(new uint32_t[n_snp + 1]);
+	std::unique_ptr<uint8_t[]> ra(new uint8_t[n_ref + 1]), si(new uint8_t[n_snp + 1]), sa(new uint8_t[n_snp + 1]), srf(new uint8_t[n_snp + 1]), saf(new uint8_t[n_snp + 1]);
+	std::vector<uint32_t> raux(n_ref_aux * 10), sxp(n_snp_aux * 10);
+	std::vector<uint8_t> sxi(n_snp_aux * 10);
+	parallel_for(n_ref, [&](uint64_t lo, uint64_t hi, unsigned) {
+		const uint8_t *q = rd.data() + 16 + 13 * lo;
+		for (uint64_t i = lo; i < hi; i++, q += 13) { memcpy(&rk[i], q, 8); memcpy(&rp[i], q + 8, 4); ra[i] = q[12]; }
+	});
+	if (n_ref_aux) memcpy(raux.data(), rd.data() + 16 + 13 * n_ref, n_ref_aux * 40);
+	parallel_for(n_snp, [&](uint64_t lo, uint64_t hi, unsigned) {
+		const uint8_t *q = sd.data() + 16 + 16 * lo;
+		for (uint64_t i = lo; i < hi; i++, q += 16) { memcpy(&sk[i], q, 8); memcpy(&sp[i], q + 8, 4); si[i] = q[12]; sa[i] = q[13]; srf[i] = q[14]; saf[i] = q[15]; }
+	});
+	{
+		const uint8_t *q = sd.data() + 16 + 16 * n_snp;
+		for (uint64_t i = 0; i < n_snp_aux; i++) {
+			q += 8;
+			for (int j = 0; j < 10; j++, q += 7) { memcpy(&sxp[i * 10 + j], q, 4); sxi[i * 10 + j] = q[4]; }
+		}
 	}
-	rd.clear(); rd.shrink_to_fit(); sd.clear(); sd.shrink_to_fit();
+	rd.p.reset(); sd.p.reset();
 	uint64_t rbits = 0, sbits = 0;
 	std::vector<uint64_t> rw, sw;
 	if ((rc = read_bf(pre + ".ref.bf", 1ull << 32, rbits, rw))) return rc;
 	if ((rc = read_bf(pre + ".snp.bf", ~0ull, sbits, sw))) return rc;
 	vg_index_arrays a{};
-	a.n_ref = n_ref; a.ref_kmer = rk.data(); a.ref_pos = rp.data(); a.ref_amb = ra.data();
+	a.n_ref = n_ref; a.ref_kmer = rk.get(); a.ref_pos = rp.get(); a.ref_amb = ra.get();
 	a.n_ref_aux = n_ref_aux; a.ref_aux = raux.data();
-	a.n_snp = n_snp; a.snp_kmer = sk.data(); a.snp_pos = sp.data(); a.snp_info = si.data(); a.snp_amb = sa.data(); a.snp_rf = srf.data(); a.snp_af = saf.data();
+	a.n_snp = n_snp; a.snp_kmer = sk.get(); a.snp_pos = sp.get(); a.snp_info = si.get(); a.snp_amb = sa.get(); a.snp_rf = srf.get(); a.snp_af = saf.get();
 	a.n_snp_aux = n_snp_aux; a.snp_aux_pos = sxp.data(); a.snp_aux_info = sxi.data();
 	a.ref_bf_bits = rbits; a.ref_bf_words = rw.data(); a.snp_bf_bits = sbits; a.snp_bf_words = sw.data();
 	return vg_index_create(&a, device, out);
