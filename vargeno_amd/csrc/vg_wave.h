@@ -58,6 +58,10 @@ namespace vg {
 constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_KCAP = 4;
 constexpr int W2_ECAP = 48, W2_NCAP = 48, W2_KCAP = 32;
 constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is also what a failed query's -1 truncates to
+#ifndef VG_SEC_W
+#define VG_SEC_W 8
+#endif
+constexpr int SEC_W = VG_SEC_W;   // entries of an LO32-view bucket fetched in one go (buckets average 1-3 entries; hg38: 2.7)
 constexpr int PCAP = 32;         // rows of the stage-B pair table (a wave with more gate-open chunks takes several windows)
 constexpr int SEC_RUN = 12;      // longest run of equal-LO32 entries one lane will walk in the LO32-ordered view
 constexpr int HCAP = 4;          // high-half reference hits per pair kept from the LO32-ordered view (more: the 48 queries are issued)
@@ -447,13 +451,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 							nh++;
 						};
 						if (use_sec && (fl & 1u) && b1 > b0) {
-							if (b1 - b0 <= 4u) {
-								// the usual bucket: its (at most four) keys and dictionary indices in one go, no search
-								uint64_t key[4]; uint32_t idx[4];
+							if (b1 - b0 <= (uint32_t)SEC_W) {
+								// the usual bucket: its (at most SEC_W) keys and dictionary indices in one go, no search
+								uint64_t key[SEC_W]; uint32_t idx[SEC_W];
 								#pragma unroll
-								for (uint32_t z = 0; z < 4; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; key[z] = d.sec_key[e]; idx[z] = d.sec_idx[e]; }
+								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; key[z] = d.sec_key[e]; idx[z] = d.sec_idx[e]; }
 								#pragma unroll
-								for (uint32_t z = 0; z < 4; z++) if (b0 + z < b1 && (uint32_t)(key[z] >> 32) == klo) sec_entry(key[z], idx[z]);
+								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) if (b0 + z < b1 && (uint32_t)(key[z] >> 32) == klo) sec_entry(key[z], idx[z]);
 							} else {
 								// k-mers with this LO32 are adjacent in the view; a popular LO32 (microsatellites, poly-A) would make
 								// one lane walk a long run while its wave waits, so past SEC_RUN entries the pair keeps its 48 queries
@@ -506,10 +510,30 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 					T = (uint32_t)__builtin_amdgcn_readlane((int)ci, 63);
 				}
 				VG_WAVE_SYNC();
-				// ---- B1: rounds of 64 items
+				// ---- B1: rounds of 64 items.  The strided-scan probe of an item (most items at hg38 scale, where a SNP bucket holds
+				// ~19 entries) is fetched one round ahead: while a round is worked on, the next round's probes are in flight.
+				auto scan_probe = [&](uint32_t g2) -> uint4 {
+					uint4 v = make_uint4(0u, 0u, 0u, 0u);
+					if (g2 < T) {
+						uint32_t p = 0;
+						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g2) p += step;
+						const uint32_t t = g2 - P_off[p][wv];
+						if (!((P_meta[p][wv] >> 13) & 1u)) {                     // not a large block
+							const uint32_t lo = P_lo[p][wv], slo = P_slo[p][wv], Lr = P_hi[p][wv] - lo, L = Lr + (P_shi[p][wv] - slo);
+							if (t < L) {
+								const bool isr = t < Lr;
+								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)t * REF_STRIDE : (uint64_t)slo + (uint64_t)(t - Lr) * SNP_STRIDE;
+								if (tt < (isr ? d.n_ref : d.n_snp)) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
+							}
+						}
+					}
+					return v;
+				};
+				uint4 scan_cur = scan_probe(lane);
 				for (uint32_t t0 = 0; t0 < T; t0 += 64) {
 					const uint32_t g = t0 + lane;
 					const bool valid = g < T;
+					const uint4 scan_next = scan_probe(g + 64u);
 					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
 					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
 					LaneStats<STATS> hs;
@@ -546,8 +570,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 								hs.add(S_SCAN_REF, isr ? 1u : 0u);
 								hs.add(S_SCAN_SNP, isr ? 0u : 1u);
 								hs.add(S_SCAN_OOB, inr ? 0u : 1u);
-								uint4 v = make_uint4(0u, 0u, 0u, 0u);
-								if (inr) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
+								const uint4 v = scan_cur;                                 // zeros when the probe fell off the array
 								const uint64_t tlo = isr ? (uint64_t)v.x : ((((uint64_t)v.y << 32) | v.x) & LO40_MASK);
 								const int dd = onebase(isr ? (uint64_t)(klo ^ v.x) : ((k & LO40_MASK) ^ tlo));
 								if (dd >= 0) {
@@ -708,6 +731,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 						}
 						if (valid && fits && seg_total && (int)lane == se_l) N_cnt[col0 + own] = (uint16_t)(curc + seg_total);
 					}
+					scan_cur = scan_next;
 					VG_WAVE_SYNC();
 				}
 				VG_CLK(3);
