@@ -1,4 +1,4 @@
-// vg_wave.h -- the wave-cooperative read-loop kernel (gfx950, one 64-lane wavefront per workgroup).
+// vg_wave.h -- the wave-cooperative read-loop kernel (gfx950; workgroups of four independent 64-lane wavefronts).
 //
 // Why not one read per lane end to end: 8 % of the 32-base chunks are "gate-open" (src/qv.cc:943) and
 // need ~100 more dictionary queries each, so in a lane-per-read kernel one lane of nearly every wave
@@ -6,12 +6,17 @@
 // repo ran at 14 G gathers/s, 29 % of the chip's measured random-gather ceiling, for that reason.
 // Here a wave keeps 64 (read, pass) jobs in flight and runs each pass in three stages:
 //   A  lane-parallel   exact ref/SNP look-ups of every chunk            (src/qv.cc:840-937)
-//   B  wave-parallel   for each gate-open chunk in the wave, its ~100 Hamming-1 neighbour queries /
-//                      strided bucket-scan probes are dealt to the 64 lanes; accepted hits are
-//                      compacted with a ballot + prefix sum into the owner's list in canonical order
-//                                                                         (src/qv.cc:943-1365)
+//   B  wave-parallel   every gate-open (owner, chunk) pair of the wave gets a table row (B0, one pair per lane);
+//                      the pairs' Hamming-1 neighbour queries / strided bucket-scan probes are laid end to end and
+//                      dealt to the lanes 64 at a time (B1); accepted hits are compacted with a ballot + segmented
+//                      prefix sum into the owner's list in canonical order   (src/qv.cc:943-1365)
 //   C  lane-parallel   the order-dependent vote is replayed per read from the two short lists, then
 //                      the supporting contexts walk the pile-up            (src/qv.cc:132-178, 1375-1502)
+// What the kernel is bound by is the number of times a wave WAITS for memory per pass, so every stage
+// issues all its independent gathers before it consumes any: four chunks' direct-table records, bucket remainders in
+// pairs of chunks, the five table words of a pair, both dictionary queries of a neighbour k-mer in lock step, the
+// rank blocks under a whole read.  Wave-uniform values are forced into scalar registers: the kernel sits exactly at
+// the 128-VGPR step of 4 waves per SIMD.
 // Lists and vote keys live in LDS ([slot][lane], conflict-free).  Neighbour contexts
 // whose implied read position is not the position of any exact hit of the same pass can neither
 // vote (qv.cc:134-139) nor support the winner, so stage B drops them -- the lists stay tiny.
@@ -48,7 +53,7 @@ __device__ unsigned long long vg_dbg_ovf[8];     // [tier*4 + reason]: 0 exact l
 
 namespace vg {
 
-// List capacities per job-pass (LDS, [slot][lane]).  Two instantiations: the main tier keeps 17 waves per CU
+// List capacities per job-pass (LDS, [slot][lane]).  Two instantiations: the main tier keeps 16 waves per CU
 // resident; the second tier takes the reads that spill from it (repeat regions: aux rows, many keys)
 // with lists 6-8x deeper at 2 waves per CU -- still wave-parallel, so a heavy read costs a few dozen
 // dependent gathers instead of the thousands the sequential lane machine needs.
