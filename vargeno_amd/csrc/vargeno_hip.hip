@@ -1030,6 +1030,7 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 	// non-blocking, so this copy does not wait for kernels in flight)
 	uint64_t total = 0;
 	HIP_TRY(hipMemcpy(&total, d_offsets + n_reads, 8, hipMemcpyDeviceToHost));
+	if (total >= (1ull << 37)) return fail(VG_ETOOBIG, "a batch of 2^37 bases or more (the kernels address a batch's 32-base slots with 32 bits)");
 	const uint64_t need_k = (total >> 5) + 2, need_m = n_reads + 1;
 	// the slot is idle (acquire_slot harvested it), so its buffers may be replaced
 	if (need_k > sl.pk_kmer_cap) { if (sl.pk_kmer) (void)hipFree(sl.pk_kmer); sl.pk_kmer = nullptr; sl.pk_kmer_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_kmer, need_k * 8)); sl.pk_kmer_cap = need_k; }
