@@ -986,8 +986,8 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		// dynamically, which costs less than holding the wave kernel back for them (0.71 -> 0.66 ms per 1 M-read step).
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));               // the wave kernel's own start
 		ix->cnt4_dirty = true;
-		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->wave_grid / 4);
-		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, 4><<<wgrid, 256, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
+		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 64 * W1_WPB - 1) / (64 * W1_WPB), (uint64_t)ix->wave_grid / W1_WPB);
+		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		// tail stream, second tier: the same kernel with deep lists over the spill list (2 waves per CU)
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));

@@ -46,7 +46,7 @@
 
 #ifdef VG_STAGE_CLOCKS
 __device__ unsigned long long vg_dbg_ovf[8];     // [tier*4 + reason]: 0 exact list, 1 neighbour list, 2 vote keys
-#define VG_OVF(r) atomicAdd(&vg_dbg_ovf[(WPB == 4 ? 0 : 4) + (r)], 1ull)
+#define VG_OVF(r) atomicAdd(&vg_dbg_ovf[(WPB > 1 ? 0 : 4) + (r)], 1ull)
 #else
 #define VG_OVF(r) do { } while (0)
 #endif
@@ -60,7 +60,10 @@ namespace vg {
 #ifndef VG_W1_ECAP
 #define VG_W1_ECAP 12     // exact contexts per lane in the main tier (86 % of the spills at 8 were this list; 12 still leaves 4 workgroups per CU)
 #endif
-constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_KCAP = 4;
+#ifndef VG_W1_WPB
+#define VG_W1_WPB 4
+#endif
+constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_KCAP = 4, W1_WPB = VG_W1_WPB;   // W1_WPB: waves per workgroup of the main tier
 constexpr int W2_ECAP = 48, W2_NCAP = 48, W2_KCAP = 32;
 constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is also what a failed query's -1 truncates to
 #ifndef VG_SEC_W
@@ -97,7 +100,7 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 // WORK_CHUNK: reads a wave pulls from the launch's work counter at a time (large for the main tier, a handful for the
 // spill tier, whose few hundred heavy reads must spread over all its waves)
 template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB == 4 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
                                                      uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
@@ -113,6 +116,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 	__shared__ uint8_t P_ecnt[PCAP][WPB];
 	__shared__ uint16_t N_cnt[64 * WPB];
 	__shared__ uint8_t N_ovf[64 * WPB];
+	__shared__ unsigned long long Q_state;              // work pool of the workgroup: hi32 = end, lo32 = cursor (may run past the end)
+	__shared__ uint32_t Q_lock, Q_done;
 	constexpr int NSH = 11;                               // event counters that helper lanes bump on behalf of an owner
 	constexpr int SH_IDS[NSH] = {S_REF_QUERY, S_SNP_QUERY, S_REF_PROBE, S_SNP_PROBE, S_SCAN_REF, S_SCAN_SNP, S_SCAN_OOB, S_AUX_REF, S_AUX_SNP, S_SITE_TEST, S_CTX};
 	__shared__ uint32_t S_own[STATS ? NSH : 1][STATS ? 64 * WPB : 1];
@@ -133,8 +138,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 		const uint64_t fair = n_reads / (2ull * gridDim.x * WPB);
 		if (fair > WORK_CHUNK) WORK_CHUNK = fair < 16 ? (uint32_t)fair : 16u;
 	}
-	// work distribution: waves pull WORK_CHUNK consecutive reads at a time from one device counter (zeroed per launch), so
-	// the last waves to finish differ by one chunk instead of by the variance of a static 1/n_waves share
+	// work distribution: a workgroup pulls POOL consecutive reads at a time from one device counter (zeroed per launch)
+	// into an LDS pool that its waves drain a refill at a time (see the refill stage), so the last waves to finish differ
+	// by part of a pool instead of by the variance of a static 1/n_waves share
+	const uint32_t POOL = WORK_CHUNK * (WPB > 1 ? WPB / 2 : 1);
+	if (threadIdx.x == 0) { Q_state = 0ull; Q_lock = 0u; Q_done = 0u; }
+	__syncthreads();
 	uint32_t cursor = 0, end = 0;                        // wave-uniform (kept in scalar registers); a launch holds < 2^32 reads
 	bool drained = false;
 
@@ -169,11 +178,46 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB ==
 			if (!freem) break;
 			if (cursor == end) {
 				if (drained) break;
-				uint32_t c0 = 0;
-				if (lane == 0) c0 = atomicAdd(work_next, WORK_CHUNK);
+				// The workgroup's waves share a pool of POOL consecutive reads taken from the launch's counter; a wave takes from
+				// the pool exactly as many reads as it has free lanes (LDS atomic), so within a workgroup a slow wave ends up
+				// with fewer reads, and the launch's counter is touched once per POOL reads.
+				uint32_t c0 = 0, c1 = 0;
+				if (lane == 0) {
+					const uint32_t want = (uint32_t)__popcll(freem);
+					for (;;) {
+						const unsigned long long old = atomicAdd(&Q_state, (unsigned long long)want);
+						if ((uint32_t)old < (uint32_t)(old >> 32)) { c0 = (uint32_t)old; c1 = (uint32_t)(old >> 32) - c0 < want ? (uint32_t)(old >> 32) : c0 + want; break; }
+						// the pool is empty: one wave refills it, the others wait for that (bounded: after a while a wave helps itself)
+						bool refilled = false;
+						for (uint32_t spin = 0; spin < 4096u && !refilled; spin++) {
+							if (atomicAdd(&Q_done, 0u)) break;
+							if (atomicCAS(&Q_lock, 0u, 1u) == 0u) {
+								const unsigned long long now = atomicAdd(&Q_state, 0ull);
+								if ((uint32_t)now >= (uint32_t)(now >> 32) && !atomicAdd(&Q_done, 0u)) {
+									const uint32_t g0 = atomicAdd(work_next, POOL);
+									if ((uint64_t)g0 >= n_reads) atomicExch(&Q_done, 1u);
+									else { const uint32_t g1 = (uint64_t)g0 + POOL < n_reads ? g0 + POOL : (uint32_t)n_reads; atomicExch(&Q_state, ((unsigned long long)g1 << 32) | g0); }
+								}
+								atomicExch(&Q_lock, 0u);
+								refilled = true;
+							} else {
+								__builtin_amdgcn_s_sleep(4);
+								const unsigned long long now = atomicAdd(&Q_state, 0ull);
+								refilled = (uint32_t)now < (uint32_t)(now >> 32);
+							}
+						}
+						if (atomicAdd(&Q_done, 0u)) { c0 = c1 = 0xFFFFFFFFu; break; }
+						if (!refilled) {                                      // (never seen) the refilling wave is taking its time: a private chunk
+							const uint32_t g0 = atomicAdd(work_next, want);
+							if ((uint64_t)g0 >= n_reads) { c0 = c1 = 0xFFFFFFFFu; } else { c0 = g0; c1 = (uint64_t)g0 + want < n_reads ? g0 + want : (uint32_t)n_reads; }
+							break;
+						}
+					}
+				}
 				c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
-				if ((uint64_t)c0 >= n_reads) { drained = true; break; }
-				cursor = c0; end = (uint64_t)c0 + WORK_CHUNK < n_reads ? c0 + WORK_CHUNK : (uint32_t)n_reads;
+				c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c1);
+				if (c0 == 0xFFFFFFFFu) { drained = true; break; }
+				cursor = c0; end = c1;
 			}
 			const uint32_t avail = end - cursor;
 			const uint32_t nfree = (uint32_t)__popcll(freem);
