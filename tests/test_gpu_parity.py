@@ -101,6 +101,32 @@ def test_batching_and_reset_invariance(ftiny_dir, ftiny_reads):
         assert rc2.max() == 63
 
 
+def test_many_ragged_batches_both_builds(ftiny_dir, ftiny_reads):
+    """Hundreds of batches of 1..400 reads (slots and streams rotate, most launches are smaller than one workgroup's work
+    pool, the base-indexed counters are folded once at the end): counters and event counts equal the oracle's, for the
+    counting build and for the timed build."""
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    ox, _, so = _oracle_counts(prefix, r)
+    rng = np.random.default_rng(11)
+    cuts = [0]
+    while cuts[-1] < r.n:
+        cuts.append(min(r.n, cuts[-1] + int(rng.integers(1, 401))))
+    want = ox.stats.as_dict()
+    for stats in (True, False):
+        with GenoIndex.open(prefix) as gx:
+            gx.set_stats(stats)
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                s = r.slice(lo, hi)
+                gx.submit(s.bases, s.quals, s.offsets)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), "stats=%s" % stats
+            if stats:
+                st = gx.stats()
+                for k in CMP_STATS:
+                    assert st[k] == want[k], k
+
+
 def test_scratch_overflow_path_is_exact(ftiny_dir, ftiny_reads, monkeypatch):
     """Generic lane tier alone, with a tiny first scratch: lanes that run out hand the read to the
     deep-scratch launch (the path the wave tiers fall back to)."""
