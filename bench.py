@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--genome", type=int, default=None)
     ap.add_argument("--snps", type=int, default=None)
     ap.add_argument("--chroms", type=int, default=None, help="number of sequences the genome is split into")
+    ap.add_argument("--lowq", type=float, default=0.08, help="fraction of low-quality (gate-open) characters; 0.5 = the stress profile of SURVEY.md §8d")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench"))
     ap.add_argument("--no-check", action="store_true", help="skip the parity check against the oracle")
@@ -81,7 +82,7 @@ def main():
     d = os.path.join(args.workdir, tag)
     prefix = os.path.join(d, "idx")
     t0 = time.time()
-    g, s, r = synth.chr22_scale(genome_len=args.genome, n_snps=args.snps, n_reads=args.reads, n_chroms=args.chroms)
+    g, s, r = synth.chr22_scale(genome_len=args.genome, n_snps=args.snps, n_reads=args.reads, n_chroms=args.chroms, lowq=args.lowq)
     if rank == 0:
         log("[bench] synthetic data: %.1fs (%d bp, %d SNPs, %d reads)" % (time.time() - t0, g.total_len, len(s.pos), r.n))
         if not os.path.exists(prefix + ".ref.dict"):
@@ -197,7 +198,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-            if tj["workload"] == {"genome": args.genome, "snps": args.snps, "reads": args.reads}:
+            if tj["workload"] == {"genome": args.genome, "snps": args.snps, "reads": args.reads} and args.lowq == 0.08:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
             pass
@@ -213,9 +214,9 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "%s: %d bp synthetic genome in %d sequence(s), %d SNPs, %d x 150 bp reads per GPU per step, "
-                                   "0.5%% error, 8%% low-quality chars, seed 20261002" % (
+                                   "0.5%% error, %g%% low-quality chars, seed 20261002" % (
                                        "chr22-scale (BASELINE.json configs[1])" if g.total_len < 10 ** 9 else "hg38-scale (BASELINE.json configs[2], one batch of its 30x reads)",
-                                       g.total_len, len(g.seqs), len(s.pos), r.n),
+                                       g.total_len, len(g.seqs), len(s.pos), r.n, 100 * args.lowq),
                        "reads_per_step_per_gpu": r.n, "genome_bp": args.genome, "snps_requested": args.snps, "index_bytes_hbm": gx.device_bytes,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K batches" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,

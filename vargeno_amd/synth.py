@@ -310,7 +310,7 @@ def f_tiny(seed=7):
     return g, s, r
 
 
-def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=1_000_000, n_chroms=1):
+def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=1_000_000, n_chroms=1, lowq=0.08):
     """BASELINE.json configs[1]: one 40 Mbp chromosome, ~1 M SNPs, 1 M x 150 bp reads (F-mid recipe).
     With genome_len = 3.1e9, n_chroms = 24, n_snps = 1e7 the same recipe gives the hg38-scale configs[2]."""
     rng = np.random.default_rng(seed)
@@ -323,5 +323,5 @@ def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=
     g = make_genome(rng, lens, names, repeats_per_mbp=50.0, repeat_len=(200, 2000),
                     repeat_div=0.02, microsat_per_mbp=12.5)
     s = make_snps(rng, g, n_snps)
-    r = make_reads(rng, g, s, n_reads, lengths=(150,), err=0.005, lowq=0.08)
+    r = make_reads(rng, g, s, n_reads, lengths=(150,), err=0.005, lowq=lowq)
     return g, s, r
