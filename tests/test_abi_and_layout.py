@@ -25,6 +25,31 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), s
 
 
+def test_ctypes_mirror_has_the_headers_struct_layout(tmp_path):
+    """The Python side mirrors three structs of the C header by hand: sizes and field offsets must agree with what a C
+    compiler makes of include/vargeno_hip.h."""
+    import subprocess
+
+    fields = {"vg_stats": list(_lib.STAT_FIELDS), "vg_timing": [f[0] for f in _lib.VgTiming._fields_],
+              "vg_index_arrays": [f[0] for f in _lib.VgIndexArrays._fields_]}
+    mirror = {"vg_stats": _lib.VgStats, "vg_timing": _lib.VgTiming, "vg_index_arrays": _lib.VgIndexArrays}
+    src = ['#include <stddef.h>', '#include <stdio.h>', '#include "vargeno_hip.h"', "int main(void) {"]
+    for st, fs in fields.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (st, st))
+        for f in fs:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (st, f, st, f))
+    src.append("return 0; }")
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, str(c)])
+    got = dict(line.split() for line in subprocess.check_output([exe]).decode().splitlines())
+    for st, fs in fields.items():
+        assert int(got[st]) == C.sizeof(mirror[st]), st
+        for f in fs:
+            assert int(got["%s.%s" % (st, f)]) == getattr(mirror[st], f).offset, (st, f)
+
+
 def test_header_cites_the_reference_interface_it_replaces():
     txt = open(os.path.join(ROOT, "include", "vargeno_hip.h")).read()
     for cite in ("qv.cc:519-695", "qv.cc:760-1558", "qv.cc:1775-1786", "generate_bf.h" if False else "dictgen.c:63-154"):
