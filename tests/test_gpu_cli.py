@@ -33,3 +33,28 @@ def test_cli_vcf_is_byte_identical_to_the_reference(name, gen, tmp_path):
 def test_cli_without_index_fails_cleanly(tmp_path):
     p = subprocess.run([BIN, "geno", "nope", "reads.fq", "snps.vcf", "out.vcf"], cwd=str(tmp_path), capture_output=True, text=True)
     assert p.returncode == 1
+
+
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "vargeno")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/vargeno (the reference built by oracle/Makefile in the build container) is not there")
+def test_cli_matches_the_reference_binary_at_scale(tmp_path):
+    """The reference ITSELF (oracle/_ref/vargeno: its own sources compiled by oracle/Makefile, carried to the GPU box as a
+    binary) and the product, both run here on the same chr22-scale index files and the same 300 000 reads: the two VCFs
+    must be the same bytes.  (The reference needs ~20 GB of host memory and ~15 s for its jump table.)"""
+    g, s, r = synth.chr22_scale(n_reads=300_000)
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    synth.write_fastq(os.path.join(d, "reads.fq"), r)
+    env = dict(os.environ, VARGENO_NO_LITE="1")
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=env, stdout=subprocess.DEVNULL)
+    p = subprocess.run([BIN, "geno", "idx", "reads.fq", "snps.vcf", "ours.vcf"], cwd=d, env=env, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    q = subprocess.run([REF_BIN, "geno", "idx", "reads.fq", "snps.vcf", "ref.vcf"], cwd=d, capture_output=True, text=True, timeout=900)
+    assert q.returncode == 0, q.stderr
+    ours = open(os.path.join(d, "ours.vcf"), "rb").read()
+    ref = open(os.path.join(d, "ref.vcf"), "rb").read()
+    assert ours.count(b"\n") > 100_000
+    assert ours == ref
