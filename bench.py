@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (0 = skip)")
     ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench"))
     ap.add_argument("--no-check", action="store_true", help="skip the parity check against the oracle")
+    ap.add_argument("--no-cpu-reference", action="store_true", help="do not also time the reference binary (oracle/_ref/vargeno) on the host")
     args = ap.parse_args()
     preset = {"chr22": dict(genome=40_000_000, snps=1_000_000, chroms=1, reads=1_000_000),
               "hg38": dict(genome=3_100_000_000, snps=10_000_000, chroms=24, reads=8_000_000)}[args.workload]
@@ -160,6 +161,25 @@ def main():
         t_all = time.time() - t0
         cpu["all_cores"] = {"value": ns / t_all, "threads": nt, "host_cores": ncores}
         ox.close()
+        # the reference itself, when its binary came along (oracle/_ref/vargeno, built from /root/reference by oracle/Makefile in
+        # the build container): `geno` wall time on the sample minus wall time on an empty FASTQ = its read loop, one thread
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "vargeno")
+        if os.path.exists(ref_bin) and not args.no_cpu_reference and args.workload == "chr22":
+            try:
+                synth.write_fastq(os.path.join(d, "cpu_sample.fq"), sub)
+                open(os.path.join(d, "cpu_empty.fq"), "w").close()
+                wall = {}
+                for name in ("cpu_empty", "cpu_sample"):
+                    t0 = time.time()
+                    subprocess.run([ref_bin, "geno", "idx", name + ".fq", "snps.vcf", name + ".vcf"], cwd=d, check=True, timeout=900,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    wall[name] = time.time() - t0
+                loop = wall["cpu_sample"] - wall["cpu_empty"]
+                if loop > 0:
+                    cpu["reference_binary"] = {"value": ns / loop, "unit": "reads/s", "cores": 1, "kind": "reference",
+                                               "sample": "oracle/_ref/vargeno geno on the same %d reads: %.1f s wall, minus %.1f s wall on an empty FASTQ (its start-up)" % (ns, wall["cpu_sample"], wall["cpu_empty"])}
+            except Exception as e:                                  # the baseline of record is the port above
+                log("[bench] reference binary not timed: %r" % (e,))
 
     # ---- timed region: K batches back to back, then (N > 1) the job's one exchange -----------------------
     gx.set_stats(False)
