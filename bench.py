@@ -115,7 +115,7 @@ def main():
     st = gx.stats()
     alg_bytes_per_launch = st["alg_bytes"]
     cpu = None
-    if rank == 0 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0:        # the CPU legs (and the parity check they feed) run at N = 1 only
         from oracle import oracle as O
 
         t0 = time.time()
