@@ -142,7 +142,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 	// into an LDS pool that its waves drain a refill at a time (see the refill stage), so the last waves to finish differ
 	// by part of a pool instead of by the variance of a static 1/n_waves share
 	const uint32_t POOL = WORK_CHUNK * (WPB > 1 ? WPB / 2 : 1);
-	if (threadIdx.x == 0) { Q_state = 0ull; Q_lock = 0u; Q_done = 0u; }
+	// the first pool of every workgroup is its own slice of the first gridDim.x * POOL reads -- no counter traffic while all
+	// workgroups start at once; the launch counter hands out what lies beyond (work_base)
+	const uint32_t work_base = gridDim.x * POOL;          // (< 2^19; a launch holds < 2^32 - 2^24 reads, so the sums below fit 32 bits)
+	if (threadIdx.x == 0) {
+		const uint64_t p0 = (uint64_t)blockIdx.x * POOL, p1 = p0 + POOL < n_reads ? p0 + POOL : n_reads;
+		Q_state = p0 < n_reads ? ((unsigned long long)p1 << 32) | p0 : 0ull;
+		Q_lock = 0u; Q_done = 0u;
+	}
 	__syncthreads();
 	uint32_t cursor = 0, end = 0;                        // wave-uniform (kept in scalar registers); a launch holds < 2^32 reads
 	bool drained = false;
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 							if (atomicCAS(&Q_lock, 0u, 1u) == 0u) {
 								const unsigned long long now = atomicAdd(&Q_state, 0ull);
 								if ((uint32_t)now >= (uint32_t)(now >> 32) && !atomicAdd(&Q_done, 0u)) {
-									const uint32_t g0 = atomicAdd(work_next, POOL);
+									const uint32_t g0 = work_base + atomicAdd(work_next, POOL);
 									if ((uint64_t)g0 >= n_reads) atomicExch(&Q_done, 1u);
 									else { const uint32_t g1 = (uint64_t)g0 + POOL < n_reads ? g0 + POOL : (uint32_t)n_reads; atomicExch(&Q_state, ((unsigned long long)g1 << 32) | g0); }
 								}
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						}
 						if (atomicAdd(&Q_done, 0u)) { c0 = c1 = 0xFFFFFFFFu; break; }
 						if (!refilled) {                                      // (never seen) the refilling wave is taking its time: a private chunk
-							const uint32_t g0 = atomicAdd(work_next, want);
+							const uint32_t g0 = work_base + atomicAdd(work_next, want);
 							if ((uint64_t)g0 >= n_reads) { c0 = c1 = 0xFFFFFFFFu; } else { c0 = g0; c1 = (uint64_t)g0 + want < n_reads ? g0 + want : (uint32_t)n_reads; }
 							break;
 						}
