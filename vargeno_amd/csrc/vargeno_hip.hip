@@ -145,8 +145,19 @@ __global__ void vg_make_mx_entries(const uint64_t *__restrict__ key, const uint3
 		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1), 0u);
 	}
 }
-// direct table: the first entry of every HI32 bucket of the merged view, inline
-__global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ dx)
+// An ambiguous k-mer (2-10 copies) points at an auxiliary row; when the row holds exactly two positions -- the usual case --
+// both fit the entry itself (flag PAIR: y = first position, w = second), and stage A needs no row gather for it.
+__device__ inline bool aux_pair(const uint32_t *__restrict__ aux, uint32_t row, uint32_t &p0, uint32_t &p1)
+{
+	if (row == POS_AMBIGUOUS) return false;
+	const uint32_t *r = aux + (uint64_t)row * AUX_COLS;
+	p0 = r[0]; p1 = r[1];
+	return p1 != 0 && r[2] == 0;
+}
+// direct table: the first entry of every HI32 bucket of the merged view, inline.  flags: 1 non-empty, 2 SNP entry, 4 ambiguous,
+// 8 PAIR (single-entry buckets only: a longer bucket needs w for the index of its entries), bits 8.. = entries in the bucket
+__global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ dx,
+                               const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos)
 {
 	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t lo = jg[h], hi = jg[h + 1];
@@ -155,8 +166,19 @@ __global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__r
 			const uint4 e = mx[lo];
 			const uint32_t cnt = hi - lo > 0xFFFFFFu ? 0xFFFFFFu : hi - lo;
 			r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (cnt << 8), lo);
+			uint32_t p0, p1;
+			if (cnt == 1u && (e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { r.y = p0; r.w = p1; r.z |= 8u; }
 		}
 		dx[h] = r;
+	}
+}
+// the same for the entries of the merged view themselves (read for buckets of several entries); mx flags: 1 SNP, 2 ambiguous, 4 PAIR
+__global__ void vg_inline_pairs(uint4 *__restrict__ mx, uint64_t n, const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		uint4 e = mx[i];
+		uint32_t p0, p1;
+		if ((e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { e.y = p0; e.w = p1; e.z |= 4u; mx[i] = e; }
 	}
 }
 __global__ void vg_iota_u32(uint32_t *v, uint64_t n) { for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i; }
@@ -709,7 +731,9 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 				size_t free_b = 0, total_b = 0;
 				uint4 *dx = nullptr;
 				if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (80ull << 30) && hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) == hipSuccess) {
-					vg_make_direct<<<ix->cus * 32, 256, 0, ix->stream>>>(mjg, mx, dx);
+					vg_make_direct<<<ix->cus * 32, 256, 0, ix->stream>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos);
+					HIP_TRY(hipGetLastError());
+					vg_inline_pairs<<<2048, 256, 0, ix->stream>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
 					HIP_TRY(hipGetLastError());
 					HIP_TRY(hipStreamSynchronize(ix->stream));
 					ix->owned.push_back(dx); ix->dev_bytes += (uint64_t)(1ull << 32) * 16;

@@ -331,27 +331,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						#pragma unroll
 						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = d.dx[kq[z] >> 32]; }
 						VG_CLKW(10);
-						// what each bucket's inline first entry settles; `more`: the bucket has further entries that may hold the key
-						uint32_t rp[4], sp[4], hf[4];                        // hf: 1 ref hit, 2 its ambig flag, 4 SNP hit, 8 its ambig flag
+						// `more`: the bucket has further entries that may hold the key (entries are sorted by lo: nothing below the first)
 						bool more[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) {
-							rp[z] = sp[z] = hf[z] = 0; more[z] = false;
-							if (z < m) {
-								cur.add(S_CHUNKS, 1);
-								const uint4 b = bq[z];
-								const uint32_t key = (uint32_t)kq[z];
-								if (b.z & 1u) {
-									if (b.x == key) {
-										if (b.z & 2u) { sp[z] = b.y; hf[z] |= 4u | (((b.z >> 2) & 1u) << 3); }
-										else { rp[z] = b.y; hf[z] |= 1u | (((b.z >> 2) & 1u) << 1); }
-									}
-									more[z] = (b.z >> 8) > 1u && b.x <= key;              // entries are sorted by lo: nothing below the first
-								}
-							}
-						}
-						// the rest of a small bucket -- up to VG_SCAN_W more entries -- arrives together, two chunks at a time (one wait);
-						// anything deeper is rare and goes one by one
+						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && (bq[z].z >> 8) > 1u && bq[z].x <= (uint32_t)kq[z];
+						// Two chunks at a time: the rest of a small bucket -- up to VG_SCAN_W more entries -- arrives together (one wait;
+						// anything deeper is rare and goes one by one); then each chunk's exact contexts are appended (qv.cc:850-937),
+						// reference hit first, then SNP hit.  An ambiguous k-mer with exactly two positions carries both in its entry
+						// (flag PAIR, set by vg_inline_pairs), so only k-mers with 3-10 copies still read their auxiliary row.
 						#pragma unroll
 						for (uint32_t z0 = 0; z0 < 4; z0 += 2) {
 							constexpr uint32_t SW = VG_SCAN_W;
@@ -365,44 +352,50 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 							#pragma unroll
 							for (uint32_t y = 0; y < 2; y++) {
 								const uint32_t z = z0 + y;
-								if (!more[z]) continue;
-								const uint32_t key = (uint32_t)kq[z], cnt = bq[z].z >> 8, lo = bq[z].w, hi = lo + cnt;
-								auto take = [&](const uint4 v) {
-									if (v.z & 1u) { sp[z] = v.y; hf[z] = (hf[z] & ~8u) | 4u | (((v.z >> 1) & 1u) << 3); }
-									else { rp[z] = v.y; hf[z] = (hf[z] & ~2u) | 1u | (((v.z >> 1) & 1u) << 1); }
-								};
-								#pragma unroll
-								for (uint32_t x = 0; x < SW; x++) if (x + 1u < cnt && sv[y][x].x == key) take(sv[y][x]);
-								if (cnt > SW + 1u && sv[y][SW - 1].x <= key) {          // the bucket goes on and may still hold the key
-									uint32_t e = lo + SW + 1u;
-									if (cnt > 8u) { uint32_t eb = hi; while (e < eb) { const uint32_t mm = e + ((eb - e) >> 1); if (d.mx[mm].x < key) e = mm + 1; else eb = mm; } }
-									for (; e < hi; e++) {
-										const uint4 v = d.mx[e];
-										if (v.x < key) continue;
-										if (v.x > key) break;
-										take(v);
+								if (z >= m) continue;
+								cur.add(S_CHUNKS, 1);
+								const uint4 b = bq[z];
+								const uint32_t key = (uint32_t)kq[z];
+								// hit state: position (or row index), second position of a PAIR, flags 1 hit, 2 ambiguous, 4 PAIR
+								uint32_t rp = 0, rp2 = 0, rf = 0, sp = 0, sp2 = 0, sf = 0;
+								if ((b.z & 1u) && b.x == key) {                        // the inline first entry (dx flags: 2 SNP, 4 ambiguous, 8 PAIR)
+									const uint32_t f = 1u | (((b.z >> 2) & 1u) << 1) | (((b.z >> 3) & 1u) << 2);
+									if (b.z & 2u) { sp = b.y; sp2 = b.w; sf = f; } else { rp = b.y; rp2 = b.w; rf = f; }
+								}
+								if (more[z]) {
+									const uint32_t cnt = b.z >> 8, lo = b.w, hi = lo + cnt;
+									auto take = [&](const uint4 v) {                     // mx flags: 1 SNP, 2 ambiguous, 4 PAIR
+										const uint32_t f = 1u | (v.z & 2u) | (v.z & 4u);
+										if (v.z & 1u) { sp = v.y; sp2 = v.w; sf = f; } else { rp = v.y; rp2 = v.w; rf = f; }
+									};
+									#pragma unroll
+									for (uint32_t x = 0; x < SW; x++) if (x + 1u < cnt && sv[y][x].x == key) take(sv[y][x]);
+									if (cnt > SW + 1u && sv[y][SW - 1].x <= key) {      // the bucket goes on and may still hold the key
+										uint32_t e = lo + SW + 1u;
+										if (cnt > 8u) { uint32_t eb = hi; while (e < eb) { const uint32_t mm = e + ((eb - e) >> 1); if (d.mx[mm].x < key) e = mm + 1; else eb = mm; } }
+										for (; e < hi; e++) {
+											const uint4 v = d.mx[e];
+											if (v.x < key) continue;
+											if (v.x > key) break;
+											take(v);
+										}
 									}
 								}
-							}
-						}
-						VG_CLKW(11);
-						// The exact contexts are appended (qv.cc:850-937) chunk by chunk, reference hit first, then SNP hit.  Of the
-						// auxiliary rows a chunk needs, the first four columns are fetched together (one wait, most rows end there).
-						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) {
-							if (z >= m) continue;
-							const bool r_ok = (hf[z] & 1u) && rp[z] != POS_AMBIGUOUS, s_ok = (hf[z] & 4u) && sp[z] != POS_AMBIGUOUS;
-							const bool r_ax = r_ok && (hf[z] & 2u), s_ax = s_ok && (hf[z] & 8u);
-							uint32_t rr[4], sr[4];
-							if (r_ax) load_row4(d.ref_aux + (uint64_t)rp[z] * AUX_COLS, 0, rr);
-							if (s_ax) load_row4(d.snp_aux_pos + (uint64_t)sp[z] * AUX_COLS, 0, sr);
-							if (r_ok) {
-								if (!r_ax) push_exact(rp[z], c + z);
-								else { cur.add(S_AUX_REF, 1); push_row_from(d.ref_aux + (uint64_t)rp[z] * AUX_COLS, rr, c + z); }
-							}
-							if (s_ok) {
-								if (!s_ax) push_exact(sp[z], c + z);
-								else { cur.add(S_AUX_SNP, 1); push_row_from(d.snp_aux_pos + (uint64_t)sp[z] * AUX_COLS, sr, c + z); }
+								const bool r_ok = (rf & 1u) && ((rf & 4u) || rp != POS_AMBIGUOUS), s_ok = (sf & 1u) && ((sf & 4u) || sp != POS_AMBIGUOUS);
+								const bool r_ax = r_ok && (rf & 6u) == 2u, s_ax = s_ok && (sf & 6u) == 2u;   // ambiguous and not a PAIR: read the row
+								uint32_t rr[4], sr[4];
+								if (r_ax) load_row4(d.ref_aux + (uint64_t)rp * AUX_COLS, 0, rr);
+								if (s_ax) load_row4(d.snp_aux_pos + (uint64_t)sp * AUX_COLS, 0, sr);
+								if (r_ok) {
+									if (rf & 2u) cur.add(S_AUX_REF, 1);
+									if (r_ax) push_row_from(d.ref_aux + (uint64_t)rp * AUX_COLS, rr, c + z);
+									else { push_exact(rp, c + z); if (rf & 4u) push_exact(rp2, c + z); }
+								}
+								if (s_ok) {
+									if (sf & 2u) cur.add(S_AUX_SNP, 1);
+									if (s_ax) push_row_from(d.snp_aux_pos + (uint64_t)sp * AUX_COLS, sr, c + z);
+									else { push_exact(sp, c + z); if (sf & 4u) push_exact(sp2, c + z); }
+								}
 							}
 						}
 					}
