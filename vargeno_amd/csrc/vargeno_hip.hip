@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <thread>
@@ -591,6 +592,20 @@ extern "C" void vg_index_close(vg_index *ix)
 	delete ix;
 }
 
+// VG_VERBOSE=1: wall time of the phases of vg_index_open / vg_index_create on stderr (start-up is §8f-4)
+struct PhaseClock {
+	const bool on = getenv("VG_VERBOSE") != nullptr;
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	void lap(const char *what)
+	{
+		if (!on) return;
+		(void)hipDeviceSynchronize();
+		const auto n = std::chrono::steady_clock::now();
+		fprintf(stderr, "[vargeno_hip] %-44s %.2f s\n", what, std::chrono::duration<double>(n - t).count());
+		t = n;
+	}
+};
+
 // Host loops over billions of records (hg38: 2.9 G k-mers, 3.1 G positions) are spread over threads; fn(lo, hi, t).
 static unsigned host_threads()
 {
@@ -649,6 +664,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	DevIndex &d = ix->d;
 	d.n_ref = a->n_ref; d.n_snp = a->n_snp;
 
+	PhaseClock pc;
 	// ---- reference dictionary: jump table + 16-byte entries, built on the device from the file's columns
 	{
 		TempDev<uint64_t> tk; TempDev<uint32_t> tp; TempDev<uint8_t> ta;
@@ -685,6 +701,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 			d.sec_key = skey; d.sec_idx = sidx; d.sec_jg = sjg; d.sec_bits = bits;
 		}
 	}
+	pc.lap("reference dictionary + LO32-ordered view");
 	// ---- SNP dictionary
 	{
 		TempDev<uint64_t> tk; TempDev<uint32_t> tp; TempDev<uint8_t> ti, ta;
@@ -748,6 +765,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 			}
 		}
 	}
+	pc.lap("SNP dictionary, merged view, direct table");
 	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first
 	//      2^32 bits of the 9.6 Gbit reference vector can ever be read (src/generate_bf.h:112-128)
 	{
@@ -757,6 +775,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		if ((rc = dev_upload(ix, &s2, a->snp_bf_words, (a->snp_bf_bits + 63) / 64))) return rc;
 		d.ref_bf = r; d.ref_bf_bits = a->ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = a->snp_bf_bits;
 	}
+	pc.lap("bit vectors");
 	// ---- pile-up sites (src/qv.cc:602-603, 637-659).  The reference sizes its table max(raw pos field)+33,
 	//      i.e. 2^32+32 entries as soon as one k-mer is POS_AMBIGUOUS; only real positions are ever indexed.
 	{
@@ -833,6 +852,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		if ((rc = dev_alloc(ix, &dc4, 4 * ix->n_sites + 4, true))) return rc;
 		d.site_ba = dba; d.cnt4 = dc4;
 	}
+	pc.lap("pile-up sites (host threads) + upload");
 	// ---- scratch of the lane tier, overflow counters, stats
 	// VG_SCRATCH_CAP / VG_SCRATCH_KCAP shrink the per-lane scratch so tests can drive every tier
 	uint32_t cap = 64, kcap = 32;
@@ -903,8 +923,10 @@ extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
 	const std::string pre(prefix);
 	RawFile rd, sd;
 	int rc;
+	PhaseClock pc;
 	if ((rc = read_file(pre + ".ref.dict", rd))) return rc;
 	if ((rc = read_file(pre + ".snp.dict", sd))) return rc;
+	pc.lap("dictionary files read");
 	if (rd.size() < 16 || sd.size() < 16) return fail(VG_EIO, "dictionary file too short: %s", prefix);
 	uint64_t n_ref, n_ref_aux, n_snp, n_snp_aux;
 	memcpy(&n_ref, rd.data(), 8); memcpy(&n_ref_aux, rd.data() + 8, 8);
@@ -935,10 +957,12 @@ extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
 		}
 	}
 	rd.p.reset(); sd.p.reset();
+	pc.lap("records unpacked");
 	uint64_t rbits = 0, sbits = 0;
 	std::vector<uint64_t> rw, sw;
 	if ((rc = read_bf(pre + ".ref.bf", 1ull << 32, rbits, rw))) return rc;
 	if ((rc = read_bf(pre + ".snp.bf", ~0ull, sbits, sw))) return rc;
+	pc.lap("bit-vector files read");
 	vg_index_arrays a{};
 	a.n_ref = n_ref; a.ref_kmer = rk.get(); a.ref_pos = rp.get(); a.ref_amb = ra.get();
 	a.n_ref_aux = n_ref_aux; a.ref_aux = raux.data();
