@@ -67,6 +67,8 @@ typedef struct {
 } vg_timing;
 
 const char *vg_last_error(void);
+/* sha256 prefix of the sources this library was compiled from (csrc/Makefile): lets a caller refuse a stale build */
+const char *vg_build_id(void);
 int  vg_device_count(void);
 
 /* Page-locked host buffers for the batches / FASTQ chunks handed to vg_reads_submit / vg_fastq_submit

@@ -12,6 +12,56 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+CSRC = os.path.join(ROOT, "vargeno_amd", "csrc")
+# the files (in this order) whose sha256 csrc/Makefile compiles into the library / the command-line tool
+LIB_SOURCES = [os.path.join(ROOT, "include", "vargeno_hip.h")] + [os.path.join(CSRC, f) for f in ("vg_device.h", "vg_wave.h", "vargeno_hip.hip", "vg_sort.hip")]
+HOST_SOURCES = [os.path.join(ROOT, "include", "vargeno_hip.h"), os.path.join(CSRC, "host", "vg_host.h")] + [
+    os.path.join(CSRC, "host", f) for f in ("main.cpp", "index_build.cpp", "fastq.cpp", "caller_vcf.cpp")]
+
+
+def source_id(files):
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+_host_binary_checked = []
+
+
+def host_binary():
+    """Path of the `vargeno` command-line tool.  The binary is a build product (not in git; it travels to the GPU box next
+    to its sources), so it is only trusted if the build id compiled into it is the hash of the sources as they are now --
+    for the tool itself and for the HIP library it links."""
+    import subprocess
+
+    path = os.path.join(CSRC, "vargeno")
+    if not _host_binary_checked:
+        assert os.path.exists(path), "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path
+        out = subprocess.run([path, "version"], capture_output=True, text=True)
+        ids = dict(ln.split() for ln in out.stdout.splitlines() if len(ln.split()) == 2)
+        assert ids.get("host") == source_id(HOST_SOURCES), "stale %s (built from other host sources: %r): rebuild with __graft_entry__.build()" % (path, ids)
+        assert ids.get("lib") == source_id(LIB_SOURCES), "stale libvargeno_hip.so (built from other sources: %r): rebuild with __graft_entry__.build()" % (ids,)
+        _host_binary_checked.append(True)
+    return path
+
+
+class _HostBinary(os.PathLike):
+    """`subprocess.run([BIN, ...])`: resolves to the verified tool the first time it is used."""
+
+    def __fspath__(self):
+        return host_binary()
+
+    def __str__(self):
+        return host_binary()
+
+
+BIN = _HostBinary()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -6,6 +6,8 @@ committed outputs.  Usage:  python tests/golden/make_golden.py [workdir]
 Produces
   ftiny.*      60 kbp / 2 951 SNPs / 4 000 reads -- committed whole: inputs, the reference-written
                dict files, the set bits of its bit-vector files, its output VCF.
+  ftiny.out.<kind>.vcf.gz   the reference's output when the SNP list it annotates is one of tests/vcf_variants.py
+               (GT already declared, FORMAT/sample columns present, "chr"-prefixed names, blank lines)
   fsmall.*     F-small of SURVEY.md §8c (300 kbp / 29 868 SNPs / 40 000 reads): inputs are a pure
                function of the seed (vargeno_amd/synth.py), so only the sha256 list and the
                reference's output VCF are committed.
@@ -71,6 +73,15 @@ def run(name, gen, work, commit_all):
             f.write("%s  %s\n" % (sha(os.path.join(d, fn)), fn))
     gz(os.path.join(d, "out.vcf"), os.path.join(OUT, name + ".out.vcf.gz"))
     if commit_all:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import vcf_variants
+
+        text = open(os.path.join(d, "snps.vcf")).read()
+        for kind in vcf_variants.KINDS:
+            with open(os.path.join(d, "snps.%s.vcf" % kind), "w") as f:
+                f.write(vcf_variants.make(text, kind))
+            subprocess.check_call([REF_BIN, "geno", "idx", "reads.fq", "snps.%s.vcf" % kind, "out.%s.vcf" % kind], cwd=d, stdout=subprocess.DEVNULL)
+            gz(os.path.join(d, "out.%s.vcf" % kind), os.path.join(OUT, "%s.out.%s.vcf.gz" % (name, kind)))
         for fn in ("ref.fa", "snps.vcf", "reads.fq", "idx.ref.dict", "idx.snp.dict"):
             gz(os.path.join(d, fn), os.path.join(OUT, "%s.%s.gz" % (name, fn)))
         shutil.copy(os.path.join(d, "idx.chrlens"), os.path.join(OUT, name + ".idx.chrlens"))

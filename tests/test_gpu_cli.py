@@ -6,11 +6,10 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN, ROOT
+from conftest import BIN, GOLDEN, ROOT
 from vargeno_amd import synth
 
 pytestmark = pytest.mark.gpu
-BIN = os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno")
 
 
 @pytest.mark.parametrize("name,gen", [("ftiny", synth.f_tiny), ("fsmall", synth.f_small)])

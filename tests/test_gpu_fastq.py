@@ -7,13 +7,12 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT
+from conftest import BIN, GOLDEN, ROOT
 from oracle import oracle as O
 from vargeno_amd._lib import VgError
 from vargeno_amd.api import GenoIndex
 
 pytestmark = pytest.mark.gpu
-BIN = os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno")
 
 
 def _counts_flat(prefix, r):

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT
+from conftest import BIN, ROOT
 from oracle import oracle as O
 from vargeno_amd import synth
 from vargeno_amd.api import GenoIndex
@@ -28,7 +28,7 @@ def chr22(tmp_path_factory):
         os.makedirs(d, exist_ok=True)
         synth.write_fasta(d + "/ref.fa", g)
         synth.write_vcf(d + "/snps.vcf", g, s)
-        subprocess.check_call([os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno"), "index", "ref.fa", "snps.vcf", "idx"], cwd=d,
+        subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d,
                               env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
     return d + "/idx", r
 

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import BIN, GOLDEN
 from oracle import oracle as O
 from vargeno_amd import index_io
 from vargeno_amd.api import GenoIndex
@@ -184,7 +184,7 @@ def test_fsmall_full_parity_through_all_tiers(tmp_path):
     d = str(tmp_path)
     synth.write_fasta(os.path.join(d, "ref.fa"), g)
     synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
-    subprocess.check_call([os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno"), "index", "ref.fa", "snps.vcf", "idx"], cwd=d,
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d,
                           env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
     prefix = os.path.join(d, "idx")
     ox, _, so = _oracle_counts(prefix, r)

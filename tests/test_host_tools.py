@@ -6,10 +6,9 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN, ROOT, read_sha256_list
+from conftest import BIN, GOLDEN, ROOT, read_sha256_list
 from vargeno_amd import synth
 
-BIN = os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno")
 
 
 def _sha(path):
@@ -139,3 +138,65 @@ def test_host_fastq_framing_matches_fgets_semantics(tmp_path):
         for g, (rlen, read, q) in zip(got, want):
             parts = g.split(b" ")
             assert int(parts[0]) == rlen and parts[1] == read and parts[2] == q.hex().encode(), (name, g[:80], rlen)
+
+
+def _oracle_counts_file(prefix, r, path):
+    """Site counters of the CPU oracle for reads `r` as the hidden `callvcf` command reads them."""
+    from oracle import oracle as O
+
+    ix = O.OracleIndex.load(prefix)
+    assert ix.process(r.bases, r.quals, r.offsets) == 0
+    s = ix.sites()
+    with open(path, "w") as f:
+        for i in range(len(s["pos"])):
+            f.write("%d %d %d %d %d\n" % (s["pos"][i], s["ref_freq"][i], s["alt_freq"][i], s["ref_cnt"][i], s["alt_cnt"][i]))
+
+
+def test_caller_and_vcf_writer_write_the_reference_bytes_on_ftiny(ftiny_dir, ftiny_reads, tmp_path):
+    """Caller + VCF annotator alone, on CPU: from the (pinned) oracle's site counters they must write, byte for byte, the
+    VCF the reference wrote for the same inputs -- 2 617 records, every GT and every truncated GQ -- and likewise for the
+    SNP-list variants that drive the other header / FORMAT branches of the pass (tests/vcf_variants.py; outputs captured
+    from the reference binary by tests/golden/make_golden.py)."""
+    import gzip
+
+    import vcf_variants
+
+    counts = str(tmp_path / "counts.txt")
+    _oracle_counts_file(os.path.join(ftiny_dir, "idx"), ftiny_reads, counts)
+    snps = os.path.join(ftiny_dir, "snps.vcf")
+    cases = [(snps, "ftiny.out.vcf.gz")]
+    text = open(snps).read()
+    for kind in vcf_variants.KINDS:
+        p = str(tmp_path / ("snps.%s.vcf" % kind))
+        with open(p, "w") as f:
+            f.write(vcf_variants.make(text, kind))
+        cases.append((p, "ftiny.out.%s.vcf.gz" % kind))
+    for threads in ("1", "3"):
+        for src, gold in cases:
+            out = str(tmp_path / "out.vcf")
+            subprocess.check_call([BIN, "callvcf", os.path.join(ftiny_dir, "idx.chrlens"), counts, src, out], env=dict(os.environ, VARGENO_THREADS=threads))
+            want = gzip.open(os.path.join(GOLDEN, gold), "rb").read()
+            assert want.count(b"\n") > 2600
+            assert open(out, "rb").read() == want, (gold, threads)
+
+
+def test_vcf_writer_refuses_what_the_reference_asserts_on(ftiny_dir, tmp_path):
+    """qv.cc:1701: the header declares GT but the first genotyped record's FORMAT has no GT -> the reference aborts."""
+    with open(tmp_path / "counts.txt", "w") as f:
+        f.write("1000 127 127 5 4\n")
+    with open(tmp_path / "in.vcf", "w") as f:
+        f.write('##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS\n')
+        f.write("1\t1000\trs1\tA\tC\t.\t.\t.\tDP\t3\n")
+    p = subprocess.run([BIN, "callvcf", os.path.join(ftiny_dir, "idx.chrlens"), str(tmp_path / "counts.txt"), str(tmp_path / "in.vcf"), str(tmp_path / "o.vcf")],
+                       capture_output=True, text=True)
+    assert p.returncode == 1 and "lacks it" in p.stderr
+    # keys are compared as text: "01000" is not position 1000, and names are prefixed with "chr" unless they start with 'c'
+    with open(tmp_path / "in2.vcf", "w") as f:
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n1\t01000\ta\tA\tC\t.\t.\t.\nchr1\t1000\tb\tA\tC\t.\t.\t.\nc1\t1000\tc\tA\tC\t.\t.\t.\n1\t1000\n")
+    subprocess.check_call([BIN, "callvcf", os.path.join(ftiny_dir, "idx.chrlens"), str(tmp_path / "counts.txt"), str(tmp_path / "in2.vcf"), str(tmp_path / "o2.vcf")])
+    body = [ln for ln in open(tmp_path / "o2.vcf").read().splitlines() if not ln.startswith("#")]
+    from oracle import oracle as O
+
+    g, _, gq = O.call(5, 4, 127, 127)
+    assert g == 3
+    assert body == ["chr1\t1000\tb\tA\tC\t.\t.\t.\tGT:GQ\t0/1:%d" % gq, "1\t1000\tGT:GQ\t0/1:%d" % gq]

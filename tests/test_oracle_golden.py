@@ -94,3 +94,37 @@ def test_edge_reads(ftiny_dir):
     assert st["reads"] == 7 and st["reads_n"] == 1 and st["reads_invalid"] == 1
     # "ACGT"*8+"N": the N sits in the dropped tail (33rd base) -> the read is processed, not skipped
     assert st["chunks"] >= 1
+
+
+def test_oracle_reproduces_reference_vcf_on_fsmall(tmp_path):
+    """The second pin (24 711 genotyped records): F-small is the fixture with >= 100-entry reference buckets, dense HI24
+    buckets, POS_AMBIGUOUS k-mers and 973 strided-scan reads past the end of the arrays.  Its index is written by the
+    product's `vargeno index` and must first match the sha256 of the files the REFERENCE wrote for the same inputs
+    (tests/golden/fsmall.sha256), so the oracle sees exactly the reference's index bytes."""
+    import subprocess
+
+    from conftest import BIN
+
+    g, s, r = synth.f_small()
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"),
+                          stdout=subprocess.DEVNULL)
+    want = read_sha256_list("fsmall")
+    for fn in ("idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf", "idx.snp.bf"):
+        assert _sha(os.path.join(d, fn)) == want[fn], fn
+    ix = O.OracleIndex.load(os.path.join(d, "idx"))
+    assert ix.process(r.bases, r.quals, r.offsets) == 0
+    mine = O.calls_by_key(ix.sites(), index_io.read_chrlens(os.path.join(d, "idx.chrlens")))
+    ref = O.parse_vcf_calls(os.path.join(GOLDEN, "fsmall.out.vcf.gz"))
+    assert len(ref) == 24711
+    assert mine == ref
+    st = ix.stats.as_dict()
+    assert st["large_block"] > 0 and st["scan_oob"] > 0 and st["aux_ref"] > 0 and st["aux_snp"] > 0
+    # B1 discrimination on this fixture too: stride 1 changes thousands of calls
+    ix.set_scan_stride(1, 1)
+    ix.reset()
+    ix.process(r.bases, r.quals, r.offsets)
+    fixed = O.calls_by_key(ix.sites(), index_io.read_chrlens(os.path.join(d, "idx.chrlens")))
+    assert sum(1 for k in ref if fixed.get(k) != ref[k]) > 1000

@@ -16,7 +16,7 @@ STAT_FIELDS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chun
                "ingest_bytes", "overflow_reads", "overflow_deep", "alg_bytes"]
 
 # every symbol include/vargeno_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
-SYMBOLS = ["vg_last_error", "vg_device_count", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_create", "vg_index_close",
+SYMBOLS = ["vg_last_error", "vg_build_id", "vg_device_count", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_create", "vg_index_close",
            "vg_index_device_bytes", "vg_reads_submit", "vg_reads_process_device", "vg_fastq_submit", "vg_sync", "vg_stats_get",
            "vg_set_stats", "vg_timing_get", "vg_num_sites", "vg_sites_fetch", "vg_counts_fetch", "vg_counts_reset",
            "vg_counts_device_ptr", "vg_counts_allreduce"]
@@ -65,6 +65,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.vg_last_error.restype = C.c_char_p
+        L.vg_build_id.restype = C.c_char_p
         L.vg_device_count.restype = C.c_int
         L.vg_index_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.vg_index_create.argtypes = [C.POINTER(VgIndexArrays), C.c_int, C.POINTER(vp)]

@@ -1,146 +1,379 @@
-// caller_vcf.cpp -- Bayesian genotype caller and VCF re-emitter with the reference's behaviour
-// (src/qv.cc:1573-1747, 1789-1848).  Double precision and libm, exactly as upstream: GQ is an
-// (int) truncation of -10*ln(confidence), so the arithmetic is kept operation for operation.
+// caller_vcf.cpp -- genotype caller and VCF annotator of the drop-in `vargeno geno`.
+//
+// Behaviour to reproduce (reference src/qv.cc:1573-1747 caller loop + VCF pass, :1789-1848 posterior):
+//   * per SNP site: likelihood of (ref_cnt, alt_cnt) under hom-ref / het / hom-alt with a 1 % error rate, Hardy-Weinberg
+//     prior from the two allele frequencies stored as n/255, times a Poisson(7.1) depth term; a site with no reads or
+//     with both counters saturated is not called; GQ = (int)(-10 ln(confidence));
+//   * the SNP list is echoed with GT:GQ for every record whose "chr<CHROM>$<POS>" names a called site; other records
+//     are dropped; FORMAT header lines are injected unless the input declares them.
+// The arithmetic is IEEE double through libm in the reference's operation order (GQ truncates, so a last-bit
+// difference can show).  Everything else is organised for a 10 M-record dbSNP file: calls live in per-chromosome sorted
+// arrays instead of a string-keyed hash map, the input is scanned in place, and record chunks are annotated by all
+// host threads.
+#include <ctype.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
-#include <fstream>
+#include <algorithm>
+#include <map>
 #include <string>
-#include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "vg_host.h"
 
 namespace vgh {
 
-static const int MAX_COV = 63;          // src/vartype.h:27
-static const double ERR_RATE = 0.01;    // src/vartype.h:13
-static const double AVG_COV = 7.1;      // src/vartype.h:14
+// ------------------------------------------------------------------------------------------------
+// posterior
+// ------------------------------------------------------------------------------------------------
+namespace {
 
-Call choose_best_genotype(int ref_cnt, int alt_cnt, uint8_t ref_freq_enc, uint8_t alt_freq_enc)
-{
-	struct G { double g0, g1, g2; };
-	static G cache[MAX_COV + 1][MAX_COV + 1];
-	static double poisson[2 * MAX_COV + 1];
-	static bool init = false;
-	if (!init) {
-		for (int r = 0; r <= MAX_COV; r++)
-			for (int a = 0; a <= MAX_COV; a++) {
-				cache[r][a].g0 = pow(1.0 - ERR_RATE, r) * pow(ERR_RATE, a);
-				cache[r][a].g1 = pow(0.5, r + a);
-				cache[r][a].g2 = pow(ERR_RATE, r) * pow(1.0 - ERR_RATE, a);
-			}
-		const double M = exp(-AVG_COV);
-		for (int i = 0; i <= 2 * MAX_COV; i++) poisson[i] = (M * pow(AVG_COV, i)) / exp(lgamma(i + 1.0));
-		init = true;
-	}
-	if ((ref_cnt == 0 && alt_cnt == 0) || (ref_cnt == MAX_COV && alt_cnt == MAX_COV)) return Call{0, 0.0};
-	const double g0 = cache[ref_cnt][alt_cnt].g0, g1 = cache[ref_cnt][alt_cnt].g1, g2 = cache[ref_cnt][alt_cnt].g2;
-	const double p = ref_freq_enc / 255.0, q = alt_freq_enc / 255.0;
-	const double p2 = p * p, q2 = q * q;
-	const double p_g0 = p2 * g0, p_g1 = (1.0 - p2 - q2) * g1, p_g2 = q2 * g2;
-	const double total = p_g0 + p_g1 + p_g2;
-	const int n = ref_cnt + alt_cnt;
-	if (p_g0 > p_g1 && p_g0 > p_g2) return Call{1, ((double)(p_g0 / total)) * poisson[n]};
-	if (p_g1 > p_g0 && p_g1 > p_g2) return Call{3, ((double)(p_g1 / total)) * poisson[n]};
-	return Call{2, ((double)(p_g2 / total)) * poisson[n]};
-}
+constexpr unsigned kCap = 63;            // counter saturation, src/vartype.h:27
+constexpr double kErr = 0.01;            // src/vartype.h:13
+constexpr double kMeanDepth = 7.1;       // src/vartype.h:14
 
-// src/qv.cc:481-499: name = leading non-space characters (at most 32), length = atol of the rest
-std::vector<ChrLen> read_chrlens(const std::string &path)
-{
-	std::vector<ChrLen> out;
-	FILE *f = fopen(path.c_str(), "r");
-	if (!f) throw Error{"cannot open " + path};
-	char buf[256];
-	while (fgets(buf, sizeof buf, f)) {
-		size_t i = 0;
-		std::string name;
-		while (buf[i] && !isspace((unsigned char)buf[i]) && i < 32) name.push_back(buf[i++]);
-		while (isspace((unsigned char)buf[i])) ++i;
-		out.push_back(ChrLen{name, (uint64_t)atol(&buf[i])});
+// Per-count factors.  The reference tabulates the three likelihoods per (ref_cnt, alt_cnt) pair; a product of two
+// tabulated powers is the same pair of libm calls and the same multiply, so 3 x 64 numbers replace 3 x 4096.
+struct Factors {
+	double keep[kCap + 1];               // (1 - e)^k
+	double flip[kCap + 1];               // e^k
+	double half[2 * kCap + 1];           // 0.5^k
+	double depth[2 * kCap + 1];          // Poisson(7.1) mass at k
+	Factors()
+	{
+		for (unsigned k = 0; k <= kCap; k++) { keep[k] = pow(1.0 - kErr, (int)k); flip[k] = pow(kErr, (int)k); }
+		const double m = exp(-kMeanDepth);
+		for (unsigned k = 0; k <= 2 * kCap; k++) {
+			half[k] = pow(0.5, (int)k);
+			depth[k] = (m * pow(kMeanDepth, (int)k)) / exp(lgamma(k + 1.0));
+		}
 	}
-	fclose(f);
+};
+const Factors &factors() { static const Factors f; return f; }
+
+}  // namespace
+
+Genotype call_genotype(unsigned ref_cnt, unsigned alt_cnt, uint8_t ref_freq, uint8_t alt_freq)
+{
+	Genotype out{GT_NONE, 0.0};
+	if (ref_cnt > kCap) ref_cnt = kCap;
+	if (alt_cnt > kCap) alt_cnt = kCap;
+	if ((ref_cnt | alt_cnt) == 0 || (ref_cnt == kCap && alt_cnt == kCap)) return out;
+	const Factors &f = factors();
+	const double pr = ref_freq / 255.0, pa = alt_freq / 255.0;
+	const double rr = pr * pr, aa = pa * pa;
+	const double w[3] = {
+		rr * (f.keep[ref_cnt] * f.flip[alt_cnt]),            // hom-ref
+		(1.0 - rr - aa) * f.half[ref_cnt + alt_cnt],         // het
+		aa * (f.flip[ref_cnt] * f.keep[alt_cnt]),            // hom-alt
+	};
+	const double sum = w[0] + w[1] + w[2];
+	// strict maximum wins, hom-ref tested before het; anything else (ties included) is hom-alt
+	int best = 2;
+	if (w[0] > w[1] && w[0] > w[2]) best = 0;
+	else if (w[1] > w[0] && w[1] > w[2]) best = 1;
+	out.gt = best == 0 ? GT_HOM_REF : best == 1 ? GT_HET : GT_HOM_ALT;
+	out.confidence = (w[best] / sum) * f.depth[ref_cnt + alt_cnt];
 	return out;
 }
 
-static std::vector<std::string> split(const std::string &text, char sep)     // src/allsome_util.cc:22-31
+int genotype_quality(double confidence) { return (int)(-10 * log(confidence)); }
+
+// ------------------------------------------------------------------------------------------------
+// chromosome table (<prefix>.chrlens: "name length" per line; a name is at most 32 non-space characters)
+// ------------------------------------------------------------------------------------------------
+std::vector<ChrLen> read_chrlens(const std::string &path)
 {
-	std::vector<std::string> tokens;
-	size_t start = 0, end = 0;
-	while ((end = text.find(sep, start)) != std::string::npos) { tokens.push_back(text.substr(start, end - start)); start = end + 1; }
-	tokens.push_back(text.substr(start));
-	return tokens;
+	FILE *f = fopen(path.c_str(), "r");
+	if (!f) throw Error{"cannot open " + path};
+	std::vector<ChrLen> table;
+	char line[256];
+	while (fgets(line, sizeof line, f)) {
+		const char *p = line;
+		while (*p && !isspace((unsigned char)*p) && p - line < 32) p++;
+		ChrLen c{std::string((const char *)line, (size_t)(p - line)), 0};
+		while (isspace((unsigned char)*p)) p++;
+		c.len = (uint64_t)atol(p);
+		table.push_back(c);
+	}
+	fclose(f);
+	return table;
+}
+
+// ------------------------------------------------------------------------------------------------
+// called sites, addressable the way the reference's "name$position" keys are
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct CalledSite {
+	uint64_t local;        // 1-based position inside its chromosome
+	uint32_t order;        // rank in genome order (a later site replaces an earlier one under the same key)
+	uint8_t gt;
+	int gq;
+};
+
+class CallBook {
+public:
+	CallBook(const SiteCounts &s, const std::vector<ChrLen> &chrs, CallSummary &sum)
+	{
+		// sites ascend over the concatenated genome: walk the chromosome table alongside them
+		size_t c = 0;
+		uint64_t before = 0;                                     // bases in chromosomes 0 .. c-1
+		for (size_t i = 0; i < s.pos.size(); i++) {
+			const uint64_t g = s.pos[i];
+			while (c < chrs.size() && g - before > chrs[c].len) before += chrs[c++].len;
+			const Genotype k = call_genotype(s.ref_cnt[i], s.alt_cnt[i], s.ref_freq[i], s.alt_freq[i]);
+			if (k.gt == GT_NONE) continue;
+			(k.gt == GT_HOM_REF ? sum.ref : k.gt == GT_HOM_ALT ? sum.alt : sum.het)++;
+			if (c == chrs.size()) continue;                      // beyond the last chromosome: no name to print it under
+			by_name_[chrs[c].name].push_back(CalledSite{g - before, (uint32_t)i, (uint8_t)k.gt, genotype_quality(k.confidence)});
+		}
+		// two chromosomes with one name share a key space; keep, per position, the site that comes last in genome order
+		for (auto &kv : by_name_) {
+			std::vector<CalledSite> &v = kv.second;
+			if (std::is_sorted(v.begin(), v.end(), [](const CalledSite &a, const CalledSite &b) { return a.local < b.local; }) &&
+			    std::adjacent_find(v.begin(), v.end(), [](const CalledSite &a, const CalledSite &b) { return a.local == b.local; }) == v.end())
+				continue;
+			std::stable_sort(v.begin(), v.end(), [](const CalledSite &a, const CalledSite &b) { return a.local != b.local ? a.local < b.local : a.order < b.order; });
+			size_t w = 0;
+			for (size_t r = 0; r < v.size(); r++) { if (w && v[w - 1].local == v[r].local) v[w - 1] = v[r]; else v[w++] = v[r]; }
+			v.resize(w);
+		}
+	}
+
+	// The reference compares the strings  name + "$" + decimal(position)  and  chrom + "$" + POS-column.  A decimal number
+	// holds no '$', so the two are equal exactly when the text after the LAST '$' of the right-hand side is the canonical
+	// decimal form of the position and the text before it is the name.
+	const CalledSite *find(const std::string &key) const
+	{
+		const size_t cut = key.rfind('$');
+		const char *d = key.c_str() + cut + 1;
+		const size_t nd = key.size() - cut - 1;
+		if (nd == 0 || nd > 19 || (d[0] == '0' && nd > 1)) return nullptr;
+		uint64_t v = 0;
+		for (size_t i = 0; i < nd; i++) { if (d[i] < '0' || d[i] > '9') return nullptr; v = v * 10 + (uint64_t)(d[i] - '0'); }
+		const auto it = by_name_.find(key.substr(0, cut));
+		if (it == by_name_.end()) return nullptr;
+		const std::vector<CalledSite> &list = it->second;
+		const auto at = std::lower_bound(list.begin(), list.end(), v, [](const CalledSite &a, uint64_t x) { return a.local < x; });
+		return at != list.end() && at->local == v ? &*at : nullptr;
+	}
+
+private:
+	std::map<std::string, std::vector<CalledSite>> by_name_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// the VCF pass
+// ------------------------------------------------------------------------------------------------
+const char kGtDecl[] = "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n";
+const char kGqDecl[] = "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype Quality\">\n";
+
+struct Span {
+	const char *b, *e;
+	size_t size() const { return (size_t)(e - b); }
+	bool is(const char *lit) const { return size() == strlen(lit) && memcmp(b, lit, size()) == 0; }
+};
+
+// What the header decided for every record that follows it.
+struct Layout {
+	bool declares_gt = false, declares_gq = false;   // the input already has "ID=GT," / "ID=GQ," meta lines
+	bool sample_columns = true;                      // the #CHROM line has FORMAT + a sample column (>= 10 fields)
+	int gt_slot = -1, gq_slot = -1;                  // sub-field of the sample column to overwrite; settled by the first annotated record
+};
+
+size_t count_fields(Span s, char sep) { return (size_t)std::count(s.b, s.e, sep) + 1; }
+Span field(Span s, char sep, size_t k)            // k-th sep-separated field (must exist)
+{
+	const char *p = s.b;
+	for (; k; k--) p = (const char *)memchr(p, sep, (size_t)(s.e - p)) + 1;
+	const char *q = (const char *)memchr(p, sep, (size_t)(s.e - p));
+	return Span{p, q ? q : s.e};
+}
+int slot_of(Span format, const char *tag)
+{
+	const size_t n = count_fields(format, ':');
+	for (size_t k = 0; k < n; k++) if (field(format, ':', k).is(tag)) return (int)k;
+	return -1;
+}
+
+const char *gt_text(uint8_t gt) { return gt == GT_HET ? "0/1" : gt == GT_HOM_ALT ? "1/1" : "0/0"; }
+
+// One data line -> `out` (nothing if its key names no called site).  Returns false if the layout's slots are still open
+// and this record would have to settle them (the caller does that on one thread, in file order).
+bool annotate(Span line, const CallBook &book, const Layout &lay, bool may_settle, Layout *settled, std::string &out)
+{
+	const size_t nf = count_fields(line, '\t');
+	if (nf < 2) return true;
+	const Span chrom = field(line, '\t', 0), pos = field(line, '\t', 1);
+	std::string key;
+	key.reserve(chrom.size() + pos.size() + 4);
+	if (chrom.size() == 0 || chrom.b[0] != 'c') key = "chr";
+	key.append(chrom.b, chrom.e).push_back('$');
+	key.append(pos.b, pos.e);
+	const CalledSite *site = book.find(key);
+	if (!site) return true;
+
+	const bool in_place = lay.sample_columns && nf >= 10;      // rewrite fields 8 and 9; otherwise append two fields
+	int gt_slot = lay.gt_slot, gq_slot = lay.gq_slot;
+	if ((lay.declares_gt && gt_slot < 0) || (lay.declares_gq && gq_slot < 0)) {
+		if (!may_settle) return false;
+		const Span fmt = in_place ? field(line, '\t', 8) : Span{line.e, line.e};
+		if (lay.declares_gt && gt_slot < 0) gt_slot = slot_of(fmt, "GT");
+		if (lay.declares_gq && gq_slot < 0) gq_slot = slot_of(fmt, "GQ");
+		// the reference asserts that a declared GT is present in the first annotated record's FORMAT (qv.cc:1701); a declared
+		// GQ drives it into an out-of-range write (it never looks the column up), so there the intent is followed instead
+		if ((lay.declares_gt && gt_slot < 0) || (lay.declares_gq && gq_slot < 0))
+			throw Error{"the SNP list declares GT/GQ in its header but the FORMAT column of a genotyped record lacks it"};
+		settled->gt_slot = gt_slot; settled->gq_slot = gq_slot;
+	}
+	char gq_text[16];
+	snprintf(gq_text, sizeof gq_text, "%d", site->gq);
+
+	std::string fmt, smp;
+	size_t n_sub = 0;
+	if (in_place) {
+		const Span f8 = field(line, '\t', 8), f9 = field(line, '\t', 9);
+		fmt.assign(f8.b, f8.e);
+		n_sub = count_fields(f9, ':');
+		for (size_t k = 0; k < n_sub; k++) {
+			if (k) smp.push_back(':');
+			if (lay.declares_gt && (int)k == gt_slot) smp += gt_text(site->gt);
+			else if (lay.declares_gq && (int)k == gq_slot) smp += gq_text;
+			else { const Span v = field(f9, ':', k); smp.append(v.b, v.e); }
+		}
+		if ((lay.declares_gt && (size_t)gt_slot >= n_sub) || (lay.declares_gq && (size_t)gq_slot >= n_sub))
+			throw Error{"a genotyped record's sample column has fewer sub-fields than its FORMAT"};
+	}
+	auto push = [&](const char *tag, const char *val) {
+		if (!fmt.empty() || n_sub) { fmt.push_back(':'); smp.push_back(':'); }
+		fmt += tag; smp += val;
+		n_sub++;
+	};
+	if (!lay.declares_gt) push("GT", gt_text(site->gt));
+	if (!lay.declares_gq) push("GQ", gq_text);
+
+	if (in_place) {
+		const Span f8 = field(line, '\t', 8), f9 = field(line, '\t', 9);
+		out.append(line.b, f8.b).append(fmt).push_back('\t');
+		out.append(smp).append(f9.e, line.e);
+	} else {
+		out.append(line.b, line.e).push_back('\t');
+		out.append(fmt).push_back('\t');
+		out.append(smp);
+	}
+	out.push_back('\n');
+	return true;
+}
+
+std::string slurp(const std::string &path, bool &ok)
+{
+	std::string text;
+	FILE *f = fopen(path.c_str(), "rb");
+	ok = f != nullptr;
+	if (!f) return text;
+	char buf[1 << 16];
+	size_t got;
+	while ((got = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, got);
+	fclose(f);
+	return text;
+}
+
+inline Span next_line(const char *&p, const char *end)
+{
+	const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+	Span s{p, nl ? nl : end};
+	p = nl ? nl + 1 : end;
+	return s;
+}
+
+}  // namespace
+
+// Lines that are read by one thread in file order: meta lines ("##..."), column headers ("#..."), and -- while the input
+// declares GT/GQ but no annotated record has shown yet which sub-field holds them -- data lines.  Stops in front of the
+// first data line that can be annotated independently of its neighbours.
+static void ordered_lines(const char *&p, const char *end, Layout &lay, const CallBook &book, std::string &dst)
+{
+	while (p < end) {
+		const char *at = p;
+		const Span ln = next_line(p, end);
+		if (ln.size() == 0) continue;
+		if (ln.b[0] != '#') {
+			const bool slots_open = (lay.declares_gt && lay.gt_slot < 0) || (lay.declares_gq && lay.gq_slot < 0);
+			if (!slots_open) { p = at; return; }
+			annotate(ln, book, lay, true, &lay, dst);
+		} else if (ln.size() > 1 && ln.b[1] == '#') {
+			dst.append(ln.b, ln.e).push_back('\n');
+			const std::string meta(ln.b, ln.e);
+			if (meta.find("ID=GT,") != std::string::npos) lay.declares_gt = true;
+			else if (meta.find("ID=GQ,") != std::string::npos) lay.declares_gq = true;
+		} else {
+			if (!lay.declares_gt) dst += kGtDecl;
+			if (!lay.declares_gq) dst += kGqDecl;
+			dst.append(ln.b, ln.e);
+			if (count_fields(ln, '\t') < 10) { lay.sample_columns = false; dst += "\tFORMAT\tDONOR"; }
+			dst.push_back('\n');
+		}
+	}
 }
 
 CallSummary write_genotyped_vcf(const SiteCounts &s, const std::vector<ChrLen> &chrlens, const std::string &vcf_in, const std::string &vcf_out)
 {
 	CallSummary sum;
-	std::unordered_map<std::string, std::pair<char, double>> snp_2_genotype;
-	for (size_t i = 0; i < s.pos.size(); i++) {                        // qv.cc:1573-1626
-		uint64_t index = s.pos[i];
-		size_t j;
-		for (j = 0; j < chrlens.size() && index > chrlens[j].len; j++) index -= chrlens[j].len;
-		const Call c = choose_best_genotype(s.ref_cnt[i], s.alt_cnt[i], s.ref_freq[i], s.alt_freq[i]);
-		if (c.genotype == 0) continue;
-		const std::string key = (j < chrlens.size() ? chrlens[j].name : std::string()) + "$" + std::to_string(index);
-		char g = '0';
-		if (c.genotype == 1) { ++sum.ref; g = '0'; } else if (c.genotype == 2) { ++sum.alt; g = '2'; } else { ++sum.het; g = '1'; }
-		snp_2_genotype[key] = std::make_pair(g, c.confidence);
+	const CallBook book(s, chrlens, sum);
+	bool ok = false;
+	const std::string text = slurp(vcf_in, ok);
+	if (!ok) { fprintf(stderr, "Error opening: %s . You have failed.\n", vcf_in.c_str()); return sum; }
+	FILE *out = fopen(vcf_out.c_str(), "wb");
+	if (!out) throw Error{"cannot write " + vcf_out};
+	unsigned threads = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+	if (const char *e = getenv("VARGENO_THREADS")) if (atoi(e) > 0) threads = (unsigned)atoi(e);
+
+	Layout lay;
+	const char *p = text.data(), *const end = p + text.size();
+	while (p < end) {
+		std::string seq;
+		ordered_lines(p, end, lay, book, seq);
+		fwrite(seq.data(), 1, seq.size(), out);
+		// a run of data lines: up to the next line that starts with '#' (the reference re-reads header lines wherever they
+		// stand, so they fence the run), cut at line starts into one piece per thread
+		const char *stop = end;
+		for (const char *q = p; q < end;) {
+			const char *h = (const char *)memchr(q, '#', (size_t)(end - q));
+			if (!h) break;
+			if (h == text.data() || h[-1] == '\n') { stop = h; break; }
+			q = h + 1;
+		}
+		const size_t bytes = (size_t)(stop - p);
+		const unsigned nt = bytes < (1u << 20) ? 1u : threads;
+		std::vector<const char *> cut(nt + 1, stop);
+		cut[0] = p;
+		for (unsigned t = 1; t < nt; t++) {
+			const char *c = p + bytes / nt * t;
+			const char *nl = (const char *)memchr(c, '\n', (size_t)(stop - c));
+			cut[t] = nl ? nl + 1 : stop;
+		}
+		std::vector<std::string> piece(nt), err(nt);
+		auto work = [&](unsigned t) {
+			const char *q = cut[t], *const e = cut[t + 1];
+			try {
+				while (q < e) { const Span ln = next_line(q, e); if (ln.size()) annotate(ln, book, lay, false, nullptr, piece[t]); }
+			} catch (const Error &x) { err[t] = x.msg; }
+		};
+		if (nt == 1) work(0);
+		else {
+			std::vector<std::thread> th;
+			for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+			for (auto &x : th) x.join();
+		}
+		for (unsigned t = 0; t < nt; t++) if (!err[t].empty()) { fclose(out); throw Error{err[t]}; }
+		for (unsigned t = 0; t < nt; t++) fwrite(piece[t].data(), 1, piece[t].size(), out);
+		p = stop;
 	}
-	std::ifstream input(vcf_in);
-	if (!input.good()) { fprintf(stderr, "Error opening: %s . You have failed.\n", vcf_in.c_str()); return sum; }
-	std::ofstream output(vcf_out);
-	std::string line;
-	bool has_gt = false, has_gq = false, head_has_gt_col = true;
-	int gt_index = -1, gq_index = -1;
-	while (std::getline(input, line)) {                                  // qv.cc:1642-1745
-		if (line.empty()) continue;
-		if (line[0] == '#' && line[1] == '#') {
-			output << line << "\n";
-			if (line.find("ID=GT,") != std::string::npos) has_gt = true;
-			else if (line.find("ID=GQ,") != std::string::npos) has_gq = true;
-			continue;
-		} else if (line[0] == '#') {
-			if (!has_gt) { output << "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">" << "\n"; gt_index = 0; }
-			if (!has_gq) { output << "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Genotype Quality\">" << "\n"; gq_index = 1; }
-			if (split(line, '\t').size() < 10) { head_has_gt_col = false; line += "\tFORMAT\tDONOR"; }
-			output << line << "\n";
-			continue;
-		}
-		std::vector<std::string> columns = split(line, '\t');
-		std::string chr_name = columns[0];
-		if (chr_name[0] != 'c') chr_name = "chr" + chr_name;
-		if (columns.size() < 2) continue;
-		const std::string key = chr_name + "$" + columns[1];
-		auto it = snp_2_genotype.find(key);
-		if (it == snp_2_genotype.end()) continue;
-		std::string genotype_string = "0/0";
-		if (it->second.first == '1') genotype_string = "0/1";
-		else if (it->second.first == '2') genotype_string = "1/1";
-		const int genotype_quality = -1 * 10 * log(it->second.second);   // qv.cc:1683, implicit double -> int
-		std::vector<std::string> format_columns, info_columns;
-		if (head_has_gt_col && columns.size() >= 10) { format_columns = split(columns[8], ':'); info_columns = split(columns[9], ':'); }
-		if (gt_index == -1 && has_gt) {
-			for (size_t i = 0; i < format_columns.size(); i++) if (format_columns[i] == "GT") { gt_index = (int)i; break; }
-		}
-		if (gt_index == -1 && has_gq) {                                  // (sic) the reference tests gt_index here too
-			for (size_t i = 0; i < format_columns.size(); i++) if (format_columns[i] == "GQ") { gq_index = (int)i; break; }
-		}
-		if (has_gt && gt_index >= 0 && (size_t)gt_index < info_columns.size()) info_columns[(size_t)gt_index] = genotype_string;
-		else if (!has_gt) { format_columns.push_back("GT"); info_columns.push_back(genotype_string); }
-		if (has_gq && gq_index >= 0 && (size_t)gq_index < info_columns.size()) info_columns[(size_t)gq_index] = std::to_string(genotype_quality);
-		else if (!has_gq) { format_columns.push_back("GQ"); info_columns.push_back(std::to_string(genotype_quality)); }
-		std::string new_format = format_columns.empty() ? std::string() : format_columns[0];
-		for (size_t i = 1; i < format_columns.size(); i++) new_format += ":" + format_columns[i];
-		std::string new_info = info_columns.empty() ? std::string() : info_columns[0];
-		for (size_t i = 1; i < info_columns.size(); i++) new_info += ":" + info_columns[i];
-		if (head_has_gt_col && columns.size() >= 10) { columns[8] = new_format; columns[9] = new_info; }
-		else { columns.push_back(new_format); columns.push_back(new_info); }
-		std::string new_line = columns[0];
-		for (size_t i = 1; i < columns.size(); i++) new_line += '\t' + columns[i];
-		output << new_line << "\n";
-	}
+	if (fclose(out) != 0) throw Error{"cannot write " + vcf_out};
 	return sum;
 }
 

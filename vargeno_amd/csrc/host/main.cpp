@@ -121,9 +121,11 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	for (auto *h : ix) VG_CHECK(vg_sync(h));
 	struct timespec t_reads; clock_gettime(CLOCK_MONOTONIC, &t_reads);
 	{
+		// util.c:103: the reference aborts on a read with a character other than ACGTN (and writes no VCF); the library counts
+		// such reads whether or not event counting is on
 		vg_stats st;
 		uint64_t invalid = 0;
-		if (env_int("VARGENO_STATS", 0)) for (auto *h : ix) { VG_CHECK(vg_stats_get(h, &st)); invalid += st.reads_invalid; }
+		for (auto *h : ix) { VG_CHECK(vg_stats_get(h, &st)); invalid += st.reads_invalid; }
 		if (invalid) { fprintf(stderr, "vargeno: %lu reads contain a character other than ACGTN (the reference aborts on these)\n", (unsigned long)invalid); return EXIT_FAILURE; }
 	}
 	if (ngpu > 1) {
@@ -215,6 +217,13 @@ int main(int argc, const char *argv[])
 			}
 			fclose(f);
 			vgh::write_genotyped_vcf(sc, vgh::read_chrlens(argv[2]), argv[4], argv[5]);
+			return EXIT_SUCCESS;
+		} else if (opt == "version") {
+			// hidden: the build ids (sha256 prefixes of the sources) of this binary and of the HIP library it loaded
+#ifndef VG_HOST_BUILD_ID
+#define VG_HOST_BUILD_ID "unknown"
+#endif
+			printf("host %s\nlib %s\n", VG_HOST_BUILD_ID, vg_build_id());
 			return EXIT_SUCCESS;
 		} else if (opt == "help") {
 			print_help();

@@ -42,12 +42,15 @@ private:
 	Impl *p;
 };
 
-// ---- caller + VCF writer (reference src/qv.cc:1573-1747, 1789-1848) ---------------------------
-struct Call {
-	int genotype;        // 0 none, 1 = 0/0 (GTYPE_REF), 2 = 1/1 (GTYPE_ALT), 3 = 0/1 (GTYPE_HET)
-	double confidence;
+// ---- caller + VCF writer (behaviour of reference src/qv.cc:1573-1747, 1789-1848) ---------------
+enum : uint8_t { GT_NONE = 0, GT_HOM_REF = 1, GT_HOM_ALT = 2, GT_HET = 3 };     // numbering of the reference's GTYPE_* (vartype.h)
+struct Genotype {
+	uint8_t gt;            // GT_*
+	double confidence;     // posterior of the winning genotype x Poisson(7.1) mass of the depth
 };
-Call choose_best_genotype(int ref_cnt, int alt_cnt, uint8_t ref_freq_enc, uint8_t alt_freq_enc);
+// counts are the 6-bit saturated pile-up counters; frequencies are the dictionary's n/255 encodings
+Genotype call_genotype(unsigned ref_cnt, unsigned alt_cnt, uint8_t ref_freq, uint8_t alt_freq);
+int genotype_quality(double confidence);                                        // the GQ column: (int)(-10 ln c)
 
 struct ChrLen { std::string name; uint64_t len; };
 std::vector<ChrLen> read_chrlens(const std::string &path);

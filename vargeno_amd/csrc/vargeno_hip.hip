@@ -43,7 +43,20 @@ static int fail(int code, const char *fmt, const char *a = "", const char *b = "
 		if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? VG_ENOMEM : VG_ENODEV, "%s: %s", #expr, hipGetErrorString(e_)); \
 	} while (0)
 
+// No C++ exception may cross the C boundary: host allocations (new[], std::vector) inside an entry point are guarded.
+template <class F>
+static int guarded(F &&body)
+{
+	try { return body(); }
+	catch (const std::bad_alloc &) { return fail(VG_ENOMEM, "host allocation failed"); }
+	catch (...) { return fail(VG_EINVAL, "unexpected C++ exception"); }
+}
+
 extern "C" const char *vg_last_error(void) { return g_err; }
+#ifndef VG_LIB_BUILD_ID
+#define VG_LIB_BUILD_ID "unknown"
+#endif
+extern "C" const char *vg_build_id(void) { return VG_LIB_BUILD_ID; }
 
 // page-locked host memory for callers without HIP headers (the CLI reads FASTQ chunks straight into it: H2D then runs
 // at link speed instead of through the runtime's pageable staging)
@@ -158,7 +171,7 @@ __device__ inline bool aux_pair(const uint32_t *__restrict__ aux, uint32_t row, 
 // direct table: the first entry of every HI32 bucket of the merged view, inline.  flags: 1 non-empty, 2 SNP entry, 4 ambiguous,
 // 8 PAIR (single-entry buckets only: a longer bucket needs w for the index of its entries), bits 8.. = entries in the bucket
 __global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ dx,
-                               const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos)
+                               const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos, uint32_t *__restrict__ too_big)
 {
 	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t lo = jg[h], hi = jg[h + 1];
@@ -166,6 +179,7 @@ __global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__r
 		if (hi > lo) {
 			const uint4 e = mx[lo];
 			const uint32_t cnt = hi - lo > 0xFFFFFFu ? 0xFFFFFFu : hi - lo;
+			if (hi - lo > 0xFFFFFFu) atomicOr(too_big, 1u);          // the count field is 24 bits wide: the host keeps the jump-table form
 			r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (cnt << 8), lo);
 			uint32_t p0, p1;
 			if (cnt == 1u && (e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { r.y = p0; r.w = p1; r.z |= 8u; }
@@ -251,7 +265,7 @@ __device__ inline int classify_bad(const uint8_t *p, uint32_t n)
 constexpr uint32_t PACK_T = VG_PACK_T;          // reads (= lanes) per tile
 constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bases; longer reads take the direct path
 __global__ __launch_bounds__(PACK_T) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
-                                                      uint64_t n_reads, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta)
+                                                      uint64_t n_reads, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta, uint32_t *__restrict__ invalid_reads)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t sm[PACK_LDS + 64];
 	for (uint64_t r0 = (uint64_t)blockIdx.x * PACK_T; r0 < n_reads; r0 += (uint64_t)gridDim.x * PACK_T) {
@@ -301,6 +315,7 @@ __global__ __launch_bounds__(PACK_T) void vg_pack_kernel(const uint8_t *__restri
 				for (uint32_t j = 0; j < 4 && c0 + j < n && c0 + j < 32; j++) if ((int)(int8_t)(q4 >> (8 * j)) - '8' < 0) meta |= 1ull << (c0 + j);
 			}
 			if (bad) meta |= classify_bad(bases + off, n) == 1 ? PK_SKIP_N : PK_INVALID;
+			if (meta & PK_INVALID) atomicAdd(invalid_reads, 1u);       // the reference aborts on such a read (util.c:103): the caller is told
 			if (n > 32) meta |= PK_LONG;
 			pk_meta[r] = meta;
 		}
@@ -323,7 +338,7 @@ __global__ void vg_fold_counters(uint32_t *__restrict__ cnt4, const uint8_t *__r
 
 __global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 {
-	cum[0] += ctr[0]; cum[1] += ctr[1]; cum[2] += ctr[2];     // wave-tier overflow, lane-tier overflow, lost
+	cum[0] += ctr[0]; cum[1] += ctr[1]; cum[2] += ctr[2]; cum[3] += ctr[3];     // wave-tier overflow, lane-tier overflow, lost, reads with a non-ACGTN character
 }
 
 // One lane = one read: forward pass, then the reverse-complement retry (src/qv.cc:1504-1510).
@@ -332,7 +347,7 @@ __global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 template <bool STATS>
 __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
                                                       const uint64_t *__restrict__ offsets, uint64_t n_reads_arg, const uint32_t *__restrict__ read_ids,
-                                                      const uint32_t *__restrict__ n_ids, uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats)
+                                                      const uint32_t *__restrict__ n_ids, uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats, uint32_t *invalid_reads)
 {
 	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;       // a list launch is sized on the device: no host round trip between tiers
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 		int cls = 0;
 		if (bad) cls = classify_bad(p, n);
 		if (cls == 1) L.st.add(S_READS_N, 1);
-		if (cls == 2) L.st.add(S_READS_INVALID, 1);
+		if (cls == 2) { L.st.add(S_READS_INVALID, 1); if (invalid_reads) atomicAdd(invalid_reads, 1u); }
 		if (cls == 0) {
 			bool ok = false;
 			L.reset_pass();
@@ -747,9 +762,18 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 				kout.release(); vout.release(); rp.release(); ra.release();
 				size_t free_b = 0, total_b = 0;
 				uint4 *dx = nullptr;
+				TempDev<uint32_t> big;
+				if ((rc = big.alloc(1))) return rc;
+				HIP_TRY(hipMemsetAsync(big.p, 0, 4, ix->stream));
+				uint32_t too_big = 0;
 				if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (80ull << 30) && hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) == hipSuccess) {
-					vg_make_direct<<<ix->cus * 32, 256, 0, ix->stream>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos);
+					vg_make_direct<<<ix->cus * 32, 256, 0, ix->stream>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
 					HIP_TRY(hipGetLastError());
+					HIP_TRY(hipStreamSynchronize(ix->stream));
+					HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
+				}
+				if (dx && too_big) { (void)hipFree(dx); dx = nullptr; }          // a bucket of more than 2^24 - 1 entries: jump-table form
+				if (dx) {
 					vg_inline_pairs<<<2048, 256, 0, ix->stream>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
 					HIP_TRY(hipGetLastError());
 					HIP_TRY(hipStreamSynchronize(ix->stream));
@@ -873,7 +897,7 @@ extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **
 	*out = nullptr;
 	vg_index *ix = new (std::nothrow) vg_index();
 	if (!ix) return fail(VG_ENOMEM, "host allocation failed");
-	int rc = create_impl(a, device, ix);
+	int rc = guarded([&] { return create_impl(a, device, ix); });
 	if (rc) { vg_index_close(ix); return rc; }
 	*out = ix;
 	return VG_OK;
@@ -916,10 +940,15 @@ static int read_bf(const std::string &path, uint64_t cap_bits, uint64_t &bits, s
 	return VG_OK;
 }
 
+static int open_impl(const char *prefix, int device, vg_index **out);
 extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
 {
 	if (!prefix || !out) return fail(VG_EINVAL, "null argument");
 	*out = nullptr;
+	return guarded([&] { return open_impl(prefix, device, out); });
+}
+static int open_impl(const char *prefix, int device, vg_index **out)
+{
 	const std::string pre(prefix);
 	RawFile rd, sd;
 	int rc;
@@ -932,6 +961,9 @@ extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
 	memcpy(&n_ref, rd.data(), 8); memcpy(&n_ref_aux, rd.data() + 8, 8);
 	memcpy(&n_snp, sd.data(), 8); memcpy(&n_snp_aux, sd.data() + 8, 8);
 	if (n_ref > (1ull << 32) || n_snp > (1ull << 32)) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
+	// every count is bounded by the file it came from before it is multiplied (a corrupt header must not wrap the size check)
+	if (n_ref > rd.size() / 13 || n_ref_aux > rd.size() / 40) return fail(VG_EIO, "%s.ref.dict: size does not match its header", prefix);
+	if (n_snp > sd.size() / 16 || n_snp_aux > sd.size() / 78) return fail(VG_EIO, "%s.snp.dict: size does not match its header", prefix);
 	if (rd.size() != 16 + 13 * n_ref + 40 * n_ref_aux) return fail(VG_EIO, "%s.ref.dict: size does not match its header", prefix);
 	if (sd.size() != 16 + 16 * n_snp + 78 * n_snp_aux) return fail(VG_EIO, "%s.snp.dict: size does not match its header", prefix);
 	// uninitialised: every element is written below, by the thread that first touches its page
@@ -1013,7 +1045,7 @@ static int finish_pending(vg_index *ix)
 // One batch = pack -> wave tier on the main stream, then lane tier (mid scratch) -> lane tier (deep scratch)
 // on the tail stream; the list launches size themselves from device counters, so nothing waits for the host.
 template <bool STATS>
-static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
+static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on)
 {
 	uint32_t *ctr = sl.ctr;
 	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
@@ -1026,7 +1058,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T - 1) / PACK_T, (uint64_t)ix->cus * pack_bpc * (256 / PACK_T));
-		vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta);
+		vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3]);
 		HIP_TRY(hipEventRecord(sl.e1, ps));
 		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
@@ -1043,17 +1075,21 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], 2u, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
+		if (produced_on && produced_on != ix->stream) {             // a batch gathered by vg_fastq_submit on the ingest stream
+			HIP_TRY(hipEventRecord(sl.e1, produced_on));
+			HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
+		}
 		HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
-		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, nullptr, sl.listB, &ctr[1], ix->d_stats);
+		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, nullptr, sl.listB, &ctr[1], ix->d_stats, &ctr[3]);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	}
 	// ... then the generic lane machine with the deep HBM scratch for whatever is left
-	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats);
+	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr);
 	vg_accumulate_counters<<<1, 1, 0, ix->tail>>>(ctr, ix->d_cum);
 	HIP_TRY(hipEventRecord(sl.e3, ix->tail));
 	HIP_TRY(hipGetLastError());
@@ -1071,7 +1107,8 @@ static int acquire_slot(vg_index *ix, Slot **out)
 	return VG_OK;
 }
 
-static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
+// produced_on: the stream whose earlier work fills the batch buffers (nullptr: they are complete already)
+static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on = nullptr)
 {
 	if (n_reads >= (1ull << 32) - (1ull << 24)) return fail(VG_EINVAL, "more than 2^32 - 2^24 reads in one batch");
 	// packed-read buffers are sized from the batch's total length (8 bytes from the device; the handle's streams are
@@ -1085,11 +1122,13 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 	if (need_m > sl.pk_meta_cap) { if (sl.pk_meta) (void)hipFree(sl.pk_meta); sl.pk_meta = nullptr; sl.pk_meta_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_meta, need_m * 8)); sl.pk_meta_cap = need_m; }
 	if (n_reads > sl.list_cap) {
 		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC};
-		for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4)); }
+		sl.list_cap = 0;                                        // a failed allocation below must not leave the old size behind
+		for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; }
+		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));
 		sl.list_cap = n_reads;
 	}
-	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_offsets, n_reads)
-	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_offsets, n_reads);
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_offsets, n_reads, produced_on)
+	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_offsets, n_reads, produced_on);
 }
 
 extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
@@ -1103,10 +1142,15 @@ extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, con
 	return launch_batch(ix, *sl, d_bases, d_quals, d_offsets, n_reads);
 }
 
+static int submit_impl(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads);
 extern "C" int vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads)
 {
 	if (!ix || !offsets) return fail(VG_EINVAL, "null argument");
 	if (n_reads == 0) return VG_OK;
+	return guarded([&] { return submit_impl(ix, bases, quals, offsets, n_reads); });
+}
+static int submit_impl(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads)
+{
 	HIP_TRY(hipSetDevice(ix->device));
 	const uint64_t base0 = offsets[0];
 	const uint64_t total = offsets[n_reads] - base0;
@@ -1221,7 +1265,7 @@ extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbyte
 	HIP_TRY(hipGetLastError());
 	*n_records = n_rec; *consumed = edges[1];
 	if (last_record_start) *last_record_start = edges[0];
-	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, n_rec);
+	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, n_rec, is);
 }
 
 extern "C" int vg_sync(vg_index *ix)
@@ -1252,7 +1296,7 @@ extern "C" int vg_stats_get(vg_index *ix, vg_stats *out)
 	out->scan_ref = h[S_SCAN_REF]; out->scan_snp = h[S_SCAN_SNP]; out->scan_oob = h[S_SCAN_OOB];
 	out->aux_ref = h[S_AUX_REF]; out->aux_snp = h[S_AUX_SNP]; out->site_test = h[S_SITE_TEST]; out->ctx = h[S_CTX];
 	out->walks = h[S_WALKS]; out->incr = h[S_INCR]; out->ingest_bytes = h[S_INGEST];
-	{ uint32_t c[4]; HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[0]; out->overflow_deep = c[1]; }
+	{ uint32_t c[4]; HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[0]; out->overflow_deep = c[1]; out->reads_invalid = c[3]; }
 	const uint64_t scans = out->gate_open - out->large_block;
 	out->alg_bytes = out->ingest_bytes + 8 * (out->ref_query + out->snp_query) + 9 * out->ref_probe + 11 * out->snp_probe
 	               + 16 * out->gate_open + 16 * scans + 9 * out->scan_ref + 11 * out->scan_snp
@@ -1299,13 +1343,15 @@ extern "C" int vg_counts_fetch(vg_index *ix, uint8_t *ref_cnt, uint8_t *alt_cnt)
 	if (!ix || !ref_cnt || !alt_cnt) return fail(VG_EINVAL, "null argument");
 	int rc = vg_sync(ix);
 	if (rc) return rc;
-	std::vector<uint32_t> h(2 * ix->n_sites);
-	if (ix->n_sites) HIP_TRY(hipMemcpy(h.data(), ix->d.cnt, h.size() * 4, hipMemcpyDeviceToHost));
-	for (uint64_t s = 0; s < ix->n_sites; s++) {       // MAX_COV saturation, src/vartype.h:27, qv.cc:1411, 1419
-		ref_cnt[s] = (uint8_t)std::min<uint32_t>(63u, h[2 * s]);
-		alt_cnt[s] = (uint8_t)std::min<uint32_t>(63u, h[2 * s + 1]);
-	}
-	return VG_OK;
+	return guarded([&] {
+		std::vector<uint32_t> h(2 * ix->n_sites);
+		if (ix->n_sites) HIP_TRY(hipMemcpy(h.data(), ix->d.cnt, h.size() * 4, hipMemcpyDeviceToHost));
+		for (uint64_t s = 0; s < ix->n_sites; s++) {       // MAX_COV saturation, src/vartype.h:27, qv.cc:1411, 1419
+			ref_cnt[s] = (uint8_t)std::min<uint32_t>(63u, h[2 * s]);
+			alt_cnt[s] = (uint8_t)std::min<uint32_t>(63u, h[2 * s + 1]);
+		}
+		return (int)VG_OK;
+	});
 }
 
 extern "C" int vg_counts_reset(vg_index *ix)
