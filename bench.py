@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s of the `vargeno geno` read loop on MI355X (BASELINE.json metric).
 
-One step = one pass of the hot path (encode -> dictionary lookups -> gated neighbour search -> vote
--> pile-up counter updates) over one batch of synthetic 150 bp reads that is ALREADY RESIDENT in
-HBM as ASCII bases + quality characters, through the C-ABI (vg_reads_process_device); for N > 1
-ranks each step ends with the path's one exchange, an RCCL all-reduce of the per-site counters.
+One step = one pass of the hot path (encode -> dictionary lookups -> gated neighbour search -> vote -> pile-up
+counter updates) over one batch of synthetic 150 bp reads that is ALREADY RESIDENT in HBM as ASCII bases + quality
+characters, through the C-ABI (vg_reads_process_device).  The steps rotate over NB distinct resident batches of the
+workload's read stream (default 4), so a step does not replay the cache lines of the step before.  For N > 1 ranks
+every rank works on its own batches (disjoint seeds of the same 30x stream, index replicated) and the job ends with
+the path's one exchange, an RCCL all-reduce of the per-site counters.
 
-Workload (config.workload): BASELINE.json configs[1] by default -- chr22-scale: one 40 Mbp synthetic
-chromosome with planted repeats, ~1 M SNPs, 1 M x 150 bp reads per step at 0.5 % error, 8 % low-quality
-characters, seed 20261002 -- about a minute end to end.  `--workload hg38` runs the
-configs[2] shape (3.1 Gbp in 24 sequences, 10 M SNPs, 8 M-read steps of its 30x reads; ~6 minutes, most of
-it building and loading the index; profiles/bench_hg38_scale_r01.json holds the committed run).
+Workload (config.workload): BASELINE.json configs[2] by default -- hg38-scale: 3.1 Gbp synthetic genome in 24
+sequences with planted repeats, ~10 M SNPs, 8 M x 150 bp reads per step at 0.5 % error, 8 % low-quality characters
+(SURVEY.md §8d), seed 20261002; the index (~240 GB with its re-laid-out views) is resident in HBM.  `--workload chr22`
+runs configs[1] (40 Mbp, 1 M SNPs, 1 M-read steps; about a minute end to end).
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--reads R]
-        python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg38|chr22]
+`--gpus N` with N > 1 starts the N ranks itself (one per GPU, `python -m torch.distributed.run`, before anything in this
+process touches a GPU); under an external torchrun (WORLD_SIZE set) it runs as one rank of that job.
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -26,92 +29,165 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+BIN = os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno")
+
+PRESETS = {"chr22": dict(genome=40_000_000, snps=1_000_000, chroms=1, reads=1_000_000, cpu_sample=1_000_000),
+           "hg38": dict(genome=3_100_000_000, snps=10_000_000, chroms=24, reads=8_000_000, cpu_sample=2_000_000)}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=["chr22", "hg38"], default="chr22",
-                    help="chr22 = BASELINE.json configs[1] (default, about a minute end to end); hg38 = configs[2] shape: 3.1 Gbp in 24 "
-                         "sequences, 10 M SNPs, 8 M-read batches of its 30x reads (index build + load take ~4 minutes, ~190 GB of HBM)")
+    ap.add_argument("--workload", choices=sorted(PRESETS), default="hg38",
+                    help="hg38 = BASELINE.json configs[2] (default: 3.1 Gbp in 24 sequences, 10 M SNPs, 8 M-read steps of its 30x reads; ~240 GB of HBM); "
+                         "chr22 = configs[1] (40 Mbp, 1 M SNPs, 1 M-read steps)")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps rotate over")
     ap.add_argument("--genome", type=int, default=None)
     ap.add_argument("--snps", type=int, default=None)
     ap.add_argument("--chroms", type=int, default=None, help="number of sequences the genome is split into")
     ap.add_argument("--lowq", type=float, default=0.08, help="fraction of low-quality (gate-open) characters; 0.5 = the stress profile of SURVEY.md §8d")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="reads timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="reads timed on one host thread of the CPU oracle (0 = skip the CPU legs and the parity check)")
     ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench"))
     ap.add_argument("--no-check", action="store_true", help="skip the parity check against the oracle")
-    ap.add_argument("--no-cpu-reference", action="store_true", help="do not also time the reference binary (oracle/_ref/vargeno) on the host")
+    ap.add_argument("--cpu-reference", choices=["auto", "yes", "no"], default="auto",
+                    help="also time the reference binary (oracle/_ref/vargeno) on the host: auto = chr22 workload only (at hg38 scale its start-up alone takes minutes)")
+    ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
     args = ap.parse_args()
-    preset = {"chr22": dict(genome=40_000_000, snps=1_000_000, chroms=1, reads=1_000_000),
-              "hg38": dict(genome=3_100_000_000, snps=10_000_000, chroms=24, reads=8_000_000)}[args.workload]
-    for k, v in preset.items():
+    for k, v in PRESETS[args.workload].items():
         if getattr(args, k) is None:
             setattr(args, k, v)
-    args.cpu_sample = min(args.cpu_sample, args.reads) if args.cpu_sample else 0
+    args.cpu_sample = min(args.cpu_sample, args.reads)
+    return args
 
-    import torch
-    import torch.distributed as dist
+
+def self_launch(args):
+    """--gpus N without a launcher: start N ranks as a CHILD job (this process has not touched a GPU and never will)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def build_index_files(args, g, s, d, prefix):
+    """rank 0: FASTA + VCF + `vargeno index` (host tool), unless the work directory already holds them."""
+    from vargeno_amd import synth
+
+    if os.path.exists(prefix + ".done"):
+        return
+    os.makedirs(d, exist_ok=True)
+    t0 = time.time()
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    log("[bench] FASTA + VCF written: %.1fs" % (time.time() - t0))
+    t0 = time.time()
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    log("[bench] vargeno index: %.1fs" % (time.time() - t0))
+    open(prefix + ".done", "w").close()
+
+
+def gather_ceiling():
+    """The chip's random-gather ceiling (SURVEY.md §8d asks for it beside the 8 TB/s line): best rate of tools/gather_probe
+    over its lane/ILP shapes on a 16 GiB table.  Runs as a child process before this one opens the index."""
+    exe = os.path.join(ROOT, "vargeno_amd", "csrc", "tools", "gather_probe")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "16"], capture_output=True, text=True, timeout=120).stdout
+        rows = [json.loads(ln) for ln in out.splitlines() if ln.startswith("{")]
+        best = max(rows, key=lambda r: r["Gloads_per_s"])
+        return {"gathers_per_s": best["Gloads_per_s"] * 1e9, "table_GiB": best["table_GiB"], "lanes": best["lanes"], "ilp": best["ilp"], "dependent": best["dependent"]}
+    except Exception as e:
+        log("[bench] gather probe failed: %r" % (e,))
+        return None
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    from vargeno_amd import synth
+
+    # ---- data set + index files: host only (rank 0 builds, the others wait for its marker file) ----------------------------
+    tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms)
+    d = os.path.join(args.workdir, tag)
+    prefix = os.path.join(d, "idx")
+    t0 = time.time()
+    g, s, _ = synth.genome_and_snps(genome_len=args.genome, n_snps=args.snps, n_chroms=args.chroms)
+    if rank == 0:
+        log("[bench] synthetic genome + SNP list: %.1fs (%d bp, %d SNPs)" % (time.time() - t0, g.total_len, len(s.pos)))
+        build_index_files(args, g, s, d, prefix)
+    else:
+        while not os.path.exists(prefix + ".done"):
+            time.sleep(1.0)
+    ceiling = None
+    if rank == 0 and not args.no_gather_probe:
+        ceiling = gather_ceiling()                        # child process, before this one holds 240 GB of the device
+
+    # ---- GPU from here on --------------------------------------------------------------------------------------------------
+    import torch
+    import torch.distributed as dist
+
     ndev = torch.cuda.device_count()
-    dev_index = local_rank % max(ndev, 1)               # one rank per GPU; (VG_BENCH_BACKEND=gloo lets ranks share a GPU for plumbing tests)
+    dev_index = local_rank % max(ndev, 1)               # one rank per GPU (VG_BENCH_BACKEND=gloo lets ranks share a GPU for plumbing tests)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev                                      # where the small bookkeeping collectives live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
         backend = os.environ.get("VG_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    dev = torch.device("cuda", dev_index)
+            coll_dev = torch.device("cpu")
+        one = torch.ones(1, dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(one)
+        n_seen = int(one.item())                          # ranks the collective library actually connected
+    else:
+        n_seen = 1
 
-    from vargeno_amd import synth
-    from vargeno_amd.api import GenoIndex, all_reduce_counts
+    from vargeno_amd.api import GenoIndex, all_reduce_counts, shard_range
 
-    # ---- data set + index files (rank 0 builds, everyone loads a replica) ------------------------
-    tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms)
-    d = os.path.join(args.workdir, tag)
-    prefix = os.path.join(d, "idx")
+    # reads resident in HBM: NB batches of this rank's part of the read stream + (N > 1) one stream every rank knows
     t0 = time.time()
-    g, s, r = synth.chr22_scale(genome_len=args.genome, n_snps=args.snps, n_reads=args.reads, n_chroms=args.chroms, lowq=args.lowq)
+    src = synth.DeviceReadSource(g, s, dev)
+    del g, s
+    batches = [src.batch(rank * 1000 + b, args.reads, lowq=args.lowq) for b in range(args.batches)]
+    common = src.batch(999_999, min(args.reads, 1_000_000), lowq=args.lowq) if world > 1 else None
+    src.release()
+    del src
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
     if rank == 0:
-        log("[bench] synthetic data: %.1fs (%d bp, %d SNPs, %d reads)" % (time.time() - t0, g.total_len, len(s.pos), r.n))
-        if not os.path.exists(prefix + ".ref.dict"):
-            os.makedirs(d, exist_ok=True)
-            t0 = time.time()
-            synth.write_fasta(os.path.join(d, "ref.fa"), g)
-            synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
-            env = dict(os.environ, VARGENO_NO_LITE="1")
-            subprocess.check_call([os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno"), "index", "ref.fa", "snps.vcf", "idx"],
-                                  cwd=d, env=env, stdout=subprocess.DEVNULL)
-            log("[bench] vargeno index: %.1fs" % (time.time() - t0))
-    if world > 1:
-        dist.barrier()
+        log("[bench] %d batches of %d reads generated on the device: %.1fs" % (args.batches, args.reads, time.time() - t0))
+
     t0 = time.time()
     gx = GenoIndex.open(prefix, device=dev_index)
     if rank == 0:
         log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (time.time() - t0, gx.device_bytes / 1e9, gx.num_sites))
 
-    # ---- reads resident in HBM --------------------------------------------------------------------
-    d_bases = torch.from_numpy(r.bases).to(dev)
-    d_quals = torch.from_numpy(r.quals).to(dev)
-    d_offs = torch.from_numpy(r.offsets.astype(np.int64)).to(dev)
-    torch.cuda.synchronize(dev)
+    def run(b):
+        gx.process_device(b[0], b[1], b[2], len(b[2]) - 1)
 
-    # ---- one counted pass: event counts -> algorithmic bytes; parity against the oracle -----------
+    # ---- one counted pass over batch 0: event counts -> algorithmic bytes; parity against the oracle ------------------------
     gx.set_stats(True)
     gx.reset()
-    gx.process_device(d_bases, d_quals, d_offs, r.n)
+    run(batches[0])
     st = gx.stats()
     alg_bytes_per_launch = st["alg_bytes"]
     cpu = None
@@ -121,57 +197,54 @@ def main():
         t0 = time.time()
         ox = O.OracleIndex.load(prefix)
         log("[bench] oracle index load: %.1fs" % (time.time() - t0))
-        ns = min(args.cpu_sample, r.n)
-        sub = r.slice(0, ns)
-        # bounded sample: whole passes over the first `ns` reads until about 10 s of single-thread work; the first pass is
-        # the one the parity check uses, the others follow it
+        r0 = synth.reads_to_host(*batches[0])
+        ncores = os.cpu_count() or 1
+        nt = min(ncores, 64)
+        # every host core first: the whole batch, which is also what the parity check compares
         t0 = time.time()
-        ox.process(sub.bases, sub.quals, sub.offsets, nthreads=1)
-        t_cpu, passes = time.time() - t0, 1
+        ox.process(r0.bases, r0.quals, r0.offsets, nthreads=nt)
+        t_all = time.time() - t0
         if not args.no_check:
-            if ns == r.n:
-                so = ox.sites()
-                rc, ac = gx.counts()
-                bad = int((rc != so["ref_cnt"]).sum() + (ac != so["alt_cnt"]).sum())
-                assert bad == 0, "HIP counters != oracle at %d of %d site counters" % (bad, 2 * len(rc))
-                want = ox.stats.as_dict()
-                for k, v in want.items():
-                    assert st[k] == v, "event counter %s: hip %d oracle %d" % (k, st[k], v)
-                # the timed build (event counting off; it answers the high-half neighbour queries from the
-                # LO32-ordered view) must give the same counters
-                gx.set_stats(False)
-                gx.reset()
-                gx.process_device(d_bases, d_quals, d_offs, r.n)
-                rc2, ac2 = gx.counts()
-                assert np.array_equal(rc2, so["ref_cnt"]) and np.array_equal(ac2, so["alt_cnt"]), "timed build != oracle"
-                log("[bench] parity: %d site counters (both builds) and %d event counters identical to the oracle" % (2 * len(rc), len(want)))
-        while t_cpu < 10.0 and passes < 8:
+            so = ox.sites()
+            rc, ac = gx.counts()
+            bad = int((rc != so["ref_cnt"]).sum() + (ac != so["alt_cnt"]).sum())
+            assert bad == 0, "HIP counters != oracle at %d of %d site counters" % (bad, 2 * len(rc))
+            want = ox.stats.as_dict()
+            for k, v in want.items():
+                assert st[k] == v, "event counter %s: hip %d oracle %d" % (k, st[k], v)
+            # the timed build (event counting off; it reads the re-laid-out views) must give the same counters
+            gx.set_stats(False)
+            gx.reset()
+            run(batches[0])
+            rc2, ac2 = gx.counts()
+            assert np.array_equal(rc2, so["ref_cnt"]) and np.array_equal(ac2, so["alt_cnt"]), "timed build != oracle"
+            log("[bench] parity: %d site counters (both builds) and %d event counters identical to the oracle on the %d reads of batch 0" % (2 * len(rc), len(want), r0.n))
+        # one thread on a bounded sample (the reference is single-threaded: this is the baseline of record)
+        ns = args.cpu_sample
+        sub = r0.slice(0, ns)
+        t_cpu, passes = 0.0, 0
+        while passes == 0 or (t_cpu < 10.0 and passes < 8):
             ox.reset()
             t0 = time.time()
             ox.process(sub.bases, sub.quals, sub.offsets, nthreads=1)
             t_cpu += time.time() - t0
             passes += 1
         cpu = {"value": passes * ns / t_cpu, "unit": "reads/s", "cores": 1, "kind": "port",
-               "sample": "%d pass(es) over the first %d reads of the same batch, oracle/vg_oracle.c, 1 thread, %.1f s" % (passes, ns, t_cpu)}
-        ncores = os.cpu_count() or 1
-        nt = min(ncores, 64)
-        ox.reset()
-        t0 = time.time()
-        ox.process(sub.bases, sub.quals, sub.offsets, nthreads=nt)
-        t_all = time.time() - t0
-        cpu["all_cores"] = {"value": ns / t_all, "threads": nt, "host_cores": ncores}
+               "sample": "%d pass(es) over the first %d reads of batch 0, oracle/vg_oracle.c, 1 thread, %.1f s" % (passes, ns, t_cpu),
+               "all_cores": {"value": r0.n / t_all, "threads": nt, "host_cores": ncores, "sample": "batch 0 (%d reads), %.1f s" % (r0.n, t_all)}}
         ox.close()
         # the reference itself, when its binary came along (oracle/_ref/vargeno, built from /root/reference by oracle/Makefile in
         # the build container): `geno` wall time on the sample minus wall time on an empty FASTQ = its read loop, one thread
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "vargeno")
-        if os.path.exists(ref_bin) and not args.no_cpu_reference and args.workload == "chr22":
+        want_ref = args.cpu_reference == "yes" or (args.cpu_reference == "auto" and args.workload == "chr22")
+        if os.path.exists(ref_bin) and want_ref:
             try:
                 synth.write_fastq(os.path.join(d, "cpu_sample.fq"), sub)
                 open(os.path.join(d, "cpu_empty.fq"), "w").close()
                 wall = {}
                 for name in ("cpu_empty", "cpu_sample"):
                     t0 = time.time()
-                    subprocess.run([ref_bin, "geno", "idx", name + ".fq", "snps.vcf", name + ".vcf"], cwd=d, check=True, timeout=900,
+                    subprocess.run([ref_bin, "geno", "idx", name + ".fq", "snps.vcf", name + ".vcf"], cwd=d, check=True, timeout=1500,
                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                     wall[name] = time.time() - t0
                 loop = wall["cpu_sample"] - wall["cpu_empty"]
@@ -180,23 +253,53 @@ def main():
                                                "sample": "oracle/_ref/vargeno geno on the same %d reads: %.1f s wall, minus %.1f s wall on an empty FASTQ (its start-up)" % (ns, wall["cpu_sample"], wall["cpu_empty"])}
             except Exception as e:                                  # the baseline of record is the port above
                 log("[bench] reference binary not timed: %r" % (e,))
+        del r0, sub
 
-    # ---- timed region: K batches back to back, then (N > 1) the job's one exchange -----------------------
+    # ---- N > 1: the sharded path must reproduce one rank.  Every rank takes its shard of one common stream; the all-reduced
+    #      counters must equal what rank 0 gets from the whole stream alone. ---------------------------------------------------
+    verification = None
+    if world > 1:
+        gx.set_stats(False)
+        cb, cq, co = common
+        n_c = len(co) - 1
+        whole = None
+        if rank == 0:
+            gx.reset()
+            gx.process_device(cb, cq, co, n_c)
+            whole = gx.counts_tensor().clone()
+        gx.reset()
+        lo, hi = shard_range(n_c, rank, world)
+        if hi > lo:
+            b0, b1 = int(co[lo].item()), int(co[hi].item())
+            so = (co[lo:hi + 1] - co[lo]).contiguous()
+            gx.process_device(cb[b0:b1], cq[b0:b1], so, hi - lo)
+        all_reduce_counts(gx)
+        if rank == 0:
+            got = gx.counts_tensor().clone()
+            assert torch.equal(got, whole), "all-reduced counters of %d read shards != one rank on the whole stream" % world
+            verification = {"sharded_equals_single_rank": True, "reads": n_c, "site_counters": int(got.numel()), "increments": int(got.sum().item())}
+            log("[bench] %d ranks, %d reads sharded: all-reduced counters identical to one rank on the whole stream" % (world, n_c))
+
+    # ---- timed region: K steps back to back over the rotating batches, then (N > 1) the job's one exchange --------------------
     gx.set_stats(False)
     gx.reset()
-    for _ in range(args.warmup):
-        gx.process_device(d_bases, d_quals, d_offs, r.n)
+    for i in range(args.warmup):
+        run(batches[i % args.batches])
     if world > 1:
         all_reduce_counts(gx)
     gx.sync()
     gx.timing()                                         # drop the warm-up batches from the event averages
+    gx.reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gx.process_device(d_bases, d_quals, d_offs, r.n)
+    for i in range(args.steps):
+        run(batches[i % args.batches])
+    local_sum = None
     if world > 1:
+        gx.sync()
+        local_sum = gx.counts_tensor().sum(dtype=torch.int64).reshape(1).to(coll_dev)      # this rank's increments, before the exchange (checked below)
         all_reduce_counts(gx)                           # one RCCL all-reduce of the per-site counters over xGMI
     gx.sync()
     torch.cuda.synchronize(dev)
@@ -205,47 +308,61 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = gx.timing()                                    # HIP events on the library's own streams, averaged over the K batches
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # checksum of checksums: the reduced counters hold exactly the increments of all ranks
+        dist.all_reduce(local_sum)
+        total_after = int(gx.counts_tensor().sum(dtype=torch.int64).item())
+        assert total_after == int(local_sum.item()), "reduced counters hold %d increments, the ranks made %d" % (total_after, int(local_sum.item()))
+        if rank == 0:
+            verification["timed_region_increments"] = total_after
 
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         k_ms = tm["ms_main"]
         achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel cannot be counted inside a timed run: it comes from the separate
+        # HBM traffic and L2 misses of the dominant kernel cannot be counted inside a timed run: they come from the separate
         # rocprofv3 --pmc passes of this same command, committed under profiles/ (null for any other workload)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-            if tj["workload"] == {"genome": args.genome, "snps": args.snps, "reads": args.reads} and args.lowq == 0.08:
-                traffic = tj["traffic_bytes_per_launch"]
-        except Exception:
-            pass
+        traffic, misses = None, None
+        for name in ("traffic_r02.json",):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if tj["workload"] == {"genome": args.genome, "snps": args.snps, "reads": args.reads} and args.lowq == 0.08:
+                    traffic, misses = tj["traffic_bytes_per_launch"], tj.get("TCC_MISS_sum")
+            except Exception:
+                pass
+        gc = None
+        if ceiling:
+            gc = {"peak": ceiling["gathers_per_s"], "unit": "random 8-byte gathers/s (tools/gather_probe, 16 GiB table, measured in this run)",
+                  "l2_misses_per_launch": misses, "achieved": (misses / (k_ms * 1e-3)) if misses else None}
+            gc["frac"] = (gc["achieved"] / gc["peak"]) if misses else None
         out = {
-            "metric": "reads/sec genotyped (whole node), hg38+dbSNP 30\u00d7; achieved HBM GB/s vs peak",
-            "value": world * r.n * args.steps / elapsed,
+            "metric": "reads/sec genotyped (whole node), hg38+dbSNP 30×; achieved HBM GB/s vs peak",
+            "value": world * args.reads * args.steps / elapsed,
             "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "%s: %d bp synthetic genome in %d sequence(s), %d SNPs, %d x 150 bp reads per GPU per step, "
-                                   "0.5%% error, %g%% low-quality chars, seed 20261002" % (
-                                       "chr22-scale (BASELINE.json configs[1])" if g.total_len < 10 ** 9 else "hg38-scale (BASELINE.json configs[2], one batch of its 30x reads)",
-                                       g.total_len, len(g.seqs), len(s.pos), r.n, 100 * args.lowq),
-                       "reads_per_step_per_gpu": r.n, "genome_bp": args.genome, "snps_requested": args.snps, "index_bytes_hbm": gx.device_bytes,
-                       "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K batches" % world},
+            "config": {"workload": "%s: %d bp synthetic genome in %d sequence(s), %d SNPs requested, %d x 150 bp reads per GPU per step rotating over %d "
+                                   "distinct resident batches of the read stream, 0.5%% error, %g%% low-quality chars, seed 20261002" % (
+                                       "hg38-scale (BASELINE.json configs[2])" if args.genome >= 10 ** 9 else "chr22-scale (BASELINE.json configs[1])",
+                                       args.genome, args.chroms, args.snps, args.reads, args.batches, 100 * args.lowq),
+                       "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps,
+                       "index_bytes_hbm": gx.device_bytes,
+                       "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "vg_wave_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "algorithmic_bytes_per_read": alg_bytes_per_launch / r.n},
+                         "algorithmic_bytes_per_read": alg_bytes_per_launch / args.reads, "gather_ceiling": gc},
             "cpu_baseline": cpu,
             "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "spill_tiers_overlapped": tm["ms_tail"], "of_which_deep_list_wave_tier": tm["ms_deep_lists"], "batches": tm["batches"]},
             "reads_per_step_spilled_to_lane_tier": st["overflow_reads"], "reads_per_step_deep_scratch": st["overflow_deep"],
-            "events_per_read": {k: st[k] / r.n for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
+            "events_per_read": {k: st[k] / args.reads for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
+            "multi_gpu_verification": verification,
         }
         print(json.dumps(out), flush=True)
     gx.close()

@@ -135,6 +135,11 @@ int  vg_counts_device_ptr(vg_index *ix, void **d_counts, uint64_t *n_u32);
  * void*), on the handle's stream. */
 int  vg_counts_allreduce(vg_index *ix, void *nccl_comm);
 
+/* The same exchange for ONE process that drives n devices (one handle each, all replicas of one index): builds an RCCL
+ * communicator over the handles' devices, all-reduces every replica's counters in place, tears the communicator down.
+ * This is what `vargeno geno` calls with VARGENO_GPUS=n.  n = 1 is the identity (and still goes through RCCL). */
+int  vg_counts_allreduce_devices(vg_index **handles, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+"""The N > 1 paths on hardware: reads shard by index, each rank (or device) works on a full index replica,
+the only exchange is one all-reduce (sum) of the per-site counters, min(63, .) afterwards.
+
+What a one-GPU box can run: RCCL itself through the library's multi-device entry point with one device (the identity, but
+it goes through dlopen, ncclCommInitAll, ncclAllReduce with the library's data type / operator and the handle's stream);
+two RANKS sharing the GPU over gloo through GenoIndex.counts_tensor() / all_reduce_counts(); bench.py --gpus 2 starting its
+own ranks.  With two or more GPUs visible the same tests run over RCCL proper (ranks on distinct devices; the CLI with
+VARGENO_GPUS=2)."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import BIN, GOLDEN, ROOT
+from oracle import oracle as O
+from vargeno_amd.api import GenoIndex, all_reduce_devices
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(prefix, r, times=1):
+    ox = O.OracleIndex.load(prefix)
+    for _ in range(times):
+        ox.process(r.bases, r.quals, r.offsets)
+    return ox.sites()
+
+
+def test_rccl_allreduce_over_one_device_is_the_identity(ftiny_dir, ftiny_reads):
+    prefix = os.path.join(ftiny_dir, "idx")
+    so = _oracle(prefix, ftiny_reads)
+    with GenoIndex.open(prefix) as gx:
+        gx.submit(ftiny_reads.bases, ftiny_reads.quals, ftiny_reads.offsets)
+        before = gx.counts_tensor().clone()
+        all_reduce_devices([gx])
+        assert torch.equal(gx.counts_tensor(), before)
+        rc, ac = gx.counts()
+    assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+
+
+def test_cli_counters_through_rccl_give_the_golden_vcf(ftiny_dir, tmp_path):
+    ngpu = min(2, torch.cuda.device_count())
+    env = dict(os.environ, VARGENO_GPUS=str(ngpu), VARGENO_FORCE_RCCL="1", VARGENO_BATCH="500", VARGENO_CHUNK_MB="1")
+    p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), os.path.join(ftiny_dir, "reads.fq"), os.path.join(ftiny_dir, "snps.vcf"), str(tmp_path / "out.vcf")],
+                       env=env, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(tmp_path / "out.vcf", "rb").read() == gzip.open(os.path.join(GOLDEN, "ftiny.out.vcf.gz"), "rb").read()
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+rank, world, prefix, out, backend, times = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
+import numpy as np, torch, torch.distributed as dist
+from vargeno_amd import synth
+from vargeno_amd.api import GenoIndex, all_reduce_counts, shard_range
+dev = rank % torch.cuda.device_count() if backend == "nccl" else 0
+torch.cuda.set_device(dev)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+else:
+    dist.init_process_group(backend)
+r = synth.f_tiny()[2]
+lo, hi = shard_range(r.n, rank, world)
+sub = r.slice(lo, hi)
+with GenoIndex.open(prefix, device=dev) as gx:
+    gx.set_stats(False)
+    for _ in range(times):
+        gx.submit(sub.bases, sub.quals, sub.offsets)
+    all_reduce_counts(gx)
+    rc, ac = gx.counts()
+    raw = gx.counts_tensor().clone().cpu().numpy()
+np.savez(os.path.join(out, "rank%d.npz" % rank), rc=rc, ac=ac, raw=raw)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run_ranks(tmp_path, prefix, backend, times):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = 29600 + os.getpid() % 1500
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(script), ROOT, prefix, str(tmp_path), backend, str(times)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-4000:]
+    return [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(2)]
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_shard_and_all_reduce_equal_one_rank(backend, ftiny_dir, ftiny_reads, tmp_path):
+    """Two processes, each with its own index replica, each on its shard of the reads, 7 passes so that the 6-bit clamp
+    matters; after GenoIndex.counts_tensor() / all_reduce_counts() every rank holds the counters of one rank on all
+    reads.  gloo: both ranks share GPU 0 (any box); nccl = RCCL: needs two GPUs."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL refuses two ranks on one device; this box has %d GPU(s)" % torch.cuda.device_count())
+    prefix = os.path.join(ftiny_dir, "idx")
+    so = _oracle(prefix, ftiny_reads, times=7)
+    got = _run_ranks(tmp_path, prefix, backend, 7)
+    for g in got:
+        assert np.array_equal(g["rc"], so["ref_cnt"]) and np.array_equal(g["ac"], so["alt_cnt"])
+        assert np.array_equal(g["raw"], got[0]["raw"])
+    assert got[0]["rc"].max() == 63 and got[0]["raw"].max() > 63           # exact sums cross the ranks, the clamp comes after
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`bench.py --gpus 2` with no launcher around it must run two ranks (not one), check the sharded path against one
+    rank, and report the rank count the collective saw.  Two GPUs: RCCL; one GPU: the ranks share it over gloo."""
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = dict(os.environ, VG_BENCH_BACKEND=backend, VG_BENCH_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "chr22", "--genome", "3000000", "--snps", "30000",
+                        "--reads", "20000", "--batches", "2", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--no-gather-probe"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-4000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3
+    v = line["multi_gpu_verification"]
+    assert v["sharded_equals_single_rank"] and v["increments"] > 0 and v["timed_region_increments"] > 0
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0

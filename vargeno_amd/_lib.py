@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libvargeno_hip.so")
+# VARGENO_HIP_LIB: development aid -- load another build of the same library (A/B runs of kernel variants, profiles/*.sh)
+LIB_PATH = os.environ.get("VARGENO_HIP_LIB") or os.path.join(HERE, "csrc", "libvargeno_hip.so")
 
 VG_ERRORS = {-1: "VG_EINVAL", -2: "VG_EIO", -3: "VG_ENOMEM", -4: "VG_ENODEV", -5: "VG_ETOOBIG", -6: "VG_EBADREAD"}
 
@@ -19,7 +20,7 @@ STAT_FIELDS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chun
 SYMBOLS = ["vg_last_error", "vg_build_id", "vg_device_count", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_create", "vg_index_close",
            "vg_index_device_bytes", "vg_reads_submit", "vg_reads_process_device", "vg_fastq_submit", "vg_sync", "vg_stats_get",
            "vg_set_stats", "vg_timing_get", "vg_num_sites", "vg_sites_fetch", "vg_counts_fetch", "vg_counts_reset",
-           "vg_counts_device_ptr", "vg_counts_allreduce"]
+           "vg_counts_device_ptr", "vg_counts_allreduce", "vg_counts_allreduce_devices"]
 
 
 class VgStats(C.Structure):
@@ -87,6 +88,7 @@ def lib():
         L.vg_counts_reset.argtypes = [vp]
         L.vg_counts_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.vg_counts_allreduce.argtypes = [vp, vp]
+        L.vg_counts_allreduce_devices.argtypes = [C.POINTER(vp), C.c_int]
         _lib = L
     return _lib
 

@@ -171,6 +171,13 @@ class GenoIndex:
         return torch.as_tensor(_Alias(), device="cuda:%d" % self.device)
 
 
+def all_reduce_devices(indexes):
+    """One process, several devices (what `vargeno geno` does with VARGENO_GPUS=n): RCCL communicator over the handles'
+    devices + one grouped all-reduce of their counters, inside the library."""
+    arr = (C.c_void_p * len(indexes))(*[ix._h for ix in indexes])
+    check(lib().vg_counts_allreduce_devices(arr, len(indexes)))
+
+
 def all_reduce_sum_(tensor, group=None):
     """In-place sum over ranks of an integer tensor (device or host); no-op for a single process."""
     import torch.distributed as dist
@@ -187,22 +194,25 @@ def clamp_counts(summed):
 
 
 def all_reduce_counts(index, group=None):
-    """The path's one exchange step: sum the per-site counters over the ranks that
-    each processed a shard of the reads.  RCCL (backend 'nccl') over xGMI on GPUs."""
+    """The path's one exchange step: sum the per-site counters over the ranks that each processed a
+    shard of the reads.  RCCL (backend 'nccl') over xGMI on GPUs.
+
+    The collective runs on a torch-owned staging tensor, the library's array is copied into it and back (two device
+    copies of 8 bytes per site): every rank issues exactly the same collective sequence whatever its allocator thinks
+    of memory it does not own, so a refusal on one rank cannot desynchronise the job."""
     import torch
     import torch.distributed as dist
 
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     index.sync()
-    t = index.counts_tensor()
-    try:
-        all_reduce_sum_(t, group)
-    except RuntimeError:
-        # a backend that refuses memory it did not allocate: reduce a torch-owned copy and write it back
-        tmp = t.clone()
-        all_reduce_sum_(tmp, group)
-        t.copy_(tmp)
+    mine = index.counts_tensor()                       # alias of the library's u32 array (as int32: same bits under a sum)
+    # RCCL reduces device memory; any other backend (gloo in the CPU / shared-GPU plumbing tests) gets a host copy
+    on_device = dist.get_backend(group) == "nccl"
+    stage = torch.empty_like(mine) if on_device else torch.empty(mine.shape, dtype=mine.dtype)
+    stage.copy_(mine)
+    all_reduce_sum_(stage, group)
+    mine.copy_(stage)
     torch.cuda.synchronize(index.device)
 
 

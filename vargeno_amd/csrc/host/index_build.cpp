@@ -9,7 +9,7 @@
 //   * a VCF chromosome the bit-vector side cannot find leaves the PREVIOUS chromosome's sequence in
 //     use (src/generate_bf.cc:214-222);
 //   * `freq_index` is sticky across VCF lines (src/dictgen.c:716-735).
-// Written from scratch: rolling 2-bit encoding, parallel stable sort, one buffered write per file.
+// Written from scratch: rolling 2-bit encoding, two-level radix partition + per-bucket sorts, positioned parallel writes.
 #include <errno.h>
 #include <fcntl.h>
 #include <stdio.h>
@@ -20,7 +20,6 @@
 #include <unistd.h>
 
 #include <algorithm>
-#include <parallel/algorithm>
 #include <string>
 #include <vector>
 
@@ -37,6 +36,13 @@ static const uint32_t POS_AMBIGUOUS = 0xFFFFFFFFu;
 static const int AUX_COLS = 10;
 
 [[noreturn]] static void die(const std::string &m) { throw Error{m}; }
+
+// VARGENO_VERBOSE=1: wall time of the phases on stderr
+struct PhaseTimer {
+	const bool on = getenv("VARGENO_VERBOSE") != nullptr && atoi(getenv("VARGENO_VERBOSE")) != 0;
+	double t0 = omp_get_wtime();
+	void lap(const char *what) { if (!on) return; const double t = omp_get_wtime(); fprintf(stderr, "[vargeno index] %-40s %.2f s\n", what, t - t0); t0 = t; }
+};
 
 static std::string slurp(const std::string &path)
 {
@@ -187,17 +193,86 @@ static void for_each_kmer(const std::string &s, size_t lo, size_t hi, bool stric
 	}
 }
 
+
+// ---- dictionary construction at genome scale ------------------------------------------------------
+// Both dictionaries are "all k-mers, sorted by k-mer, equal k-mers in input order".  hg38 has 2.9 G of them, so the
+// sort is a two-level radix partition instead of one comparison sort over 50 GB: producers (chunks of the input, in
+// input order) are run twice -- once to count their k-mers per bucket (top PART_BITS bits of the k-mer), once to drop
+// every record at its final bucket slot -- and each bucket (a few MB, cache resident, already in input order) is then
+// sorted on its own.  Buckets are also the unit of record emission and of the (parallel, positioned) file writes, so
+// no second copy of the dictionary is ever assembled in memory.
+static const int PART_BITS = 12;
+static const size_t N_PART = (size_t)1 << PART_BITS;
+
+template <class T>
+struct Partitioned {
+	T *data = nullptr;                       // uninitialised storage, first touched by the threads that fill it
+	size_t n = 0;
+	std::vector<size_t> begin;               // N_PART + 1 bucket bounds
+	~Partitioned() { free(data); }
+};
+
+// produce(chunk, sink): calls sink(const T &) for every record of the chunk, in input order; must be repeatable
+template <class T, class Produce>
+static void partition_records(size_t n_chunks, Produce &&produce, Partitioned<T> &out)
+{
+	std::vector<uint32_t> cnt(n_chunks * N_PART, 0);                 // a chunk holds < 2^32 records
+	#pragma omp parallel for schedule(dynamic, 1)
+	for (long c = 0; c < (long)n_chunks; c++) {
+		uint32_t *row = &cnt[(size_t)c * N_PART];
+		produce((size_t)c, [&](const T &r) { row[r.kmer >> (64 - PART_BITS)]++; });
+	}
+	// slot of (bucket b, chunk c) = records in earlier buckets + records of bucket b in earlier chunks
+	out.begin.assign(N_PART + 1, 0);
+	std::vector<size_t> at(n_chunks * N_PART);
+	size_t total = 0;
+	for (size_t b = 0; b < N_PART; b++) {
+		out.begin[b] = total;
+		for (size_t c = 0; c < n_chunks; c++) { at[c * N_PART + b] = total; total += cnt[c * N_PART + b]; }
+	}
+	out.begin[N_PART] = total;
+	out.n = total;
+	out.data = (T *)malloc(std::max<size_t>(total, 1) * sizeof(T));
+	if (!out.data) die("out of memory while building a dictionary");
+	#pragma omp parallel for schedule(dynamic, 1)
+	for (long c = 0; c < (long)n_chunks; c++) {
+		size_t *row = &at[(size_t)c * N_PART];
+		T *dst = out.data;
+		produce((size_t)c, [&](const T &r) { dst[row[r.kmer >> (64 - PART_BITS)]++] = r; });
+	}
+}
+
+// A dictionary file under construction: fixed-size records region + auxiliary rows region, filled piecewise by many threads
+// through a shared mapping of the (pre-sized) file -- page-cache pages are faulted in and copied to in parallel, where
+// write() calls on one file take turns on its inode lock.  VARGENO_WRITE_MODE=pwrite uses positioned writes instead.
+struct DictFile {
+	int fd = -1; std::string path; uint8_t *map = nullptr; size_t size = 0;
+	DictFile(const std::string &p, size_t bytes) : path(p), size(bytes)
+	{
+		fd = open(p.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+		if (fd < 0) die("cannot write " + p);
+		if (ftruncate(fd, (off_t)bytes) != 0) die("cannot size " + p);
+		const char *mode = getenv("VARGENO_WRITE_MODE");
+		if (!(mode && strcmp(mode, "pwrite") == 0)) {
+			void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+			if (m != MAP_FAILED) map = (uint8_t *)m;             // (a file system without shared mappings: positioned writes)
+		}
+	}
+	~DictFile() { if (map) munmap(map, size); if (fd >= 0) close(fd); }
+	void write_at(const void *src, size_t n, uint64_t off) const
+	{
+		if (map) { memcpy(map + off, src, n); return; }
+		const char *p = (const char *)src;
+		while (n) {
+			const ssize_t w = pwrite(fd, p, n, (off_t)off);
+			if (w <= 0) die("write failed: " + path);
+			p += w; n -= (size_t)w; off += (uint64_t)w;
+		}
+	}
+};
+
 struct KP { uint64_t kmer; uint32_t pos; uint32_t pad; };
 struct SK { uint64_t kmer; uint32_t pos; uint8_t snp, rf, af, pad; };
-
-static void put(std::vector<uint8_t> &o, const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; o.insert(o.end(), b, b + n); }
-static void write_file(const std::string &path, const std::vector<uint8_t> &data)
-{
-	FILE *f = fopen(path.c_str(), "wb");
-	if (!f) die("cannot write " + path);
-	if (!data.empty() && fwrite(data.data(), 1, data.size(), f) != data.size()) { fclose(f); die("write failed: " + path); }
-	fclose(f);
-}
 
 // ---- VCF line access with the reference's pointer semantics ------------------------------------
 struct Fields {
@@ -225,12 +300,15 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 	}
 	const int nthreads = opt.threads > 0 ? opt.threads : omp_get_max_threads();
 	omp_set_num_threads(nthreads);
+	PhaseTimer pt;
 	const std::string fa = slurp(fasta);
 	const std::string vcf_text = slurp(vcf);
+	pt.lap("inputs read");
 
 	// =============================== bit vectors (BFGenerator) ===============================
 	{
 		std::vector<Seq> g = parse_fasta_bf(fa);
+		pt.lap("FASTA parsed (bit-vector side)");
 		BitVec bf(REF_BF_BITS);
 		BitVec lite(opt.write_lite ? REF_LITE_BF_BITS : 64);
 		for (const Seq &s : g) {
@@ -257,8 +335,10 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 			printf("[BloomFilter constructBfFromGenomeseq] bit vector: %llu/%llu\n", (unsigned long long)bf.count(), (unsigned long long)REF_BF_BITS);
 			if (opt.write_lite) printf("[BloomFilter constructBfFromGenomeseq] lite bit vector: %llu/%llu\n", (unsigned long long)lite.count(), (unsigned long long)REF_LITE_BF_BITS);
 		}
+		pt.lap("reference bit vector filled");
 		bf.save(prefix + ".ref.bf");
 		if (opt.write_lite) lite.save(prefix + ".ref.bf.lite.bf");
+		pt.lap("reference bit vector written");
 
 		// constructBfFromVcf, generate_bf.cc:179-277
 		BitVec sbf(SNP_BF_BITS);
@@ -312,10 +392,12 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 		}
 		if (!opt.quiet) printf("[BloomFilter constructBfFromVCF] bit vector: %llu/%llu\n", (unsigned long long)sbf.count(), (unsigned long long)SNP_BF_BITS);
 		sbf.save(prefix + ".snp.bf");
+		pt.lap("SNP bit vector");
 	}
 
 	// =============================== dictionaries (dictgen.c) ===============================
 	std::vector<Seq> ref = parse_fasta_dict(fa);
+	pt.lap("FASTA parsed (dictionary side)");
 	{
 		FILE *f = fopen((prefix + ".chrlens").c_str(), "w");
 		if (!f) die("cannot write " + prefix + ".chrlens");
@@ -326,7 +408,8 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 
 	// ---- SNP dictionary: make_snp_dict_from_vcf, dictgen.c:561-794
 	{
-		std::vector<SK> kmers;
+		struct SnpRec { const Seq *chrom; uint32_t index, start_index; uint8_t ref_u, alt, f1, f2; };     // one accepted VCF line
+		std::vector<SnpRec> snps;
 		const bool ref_has_chr = !ref[0].name.empty() && ref[0].name[0] == 'c';
 		int freq_index = -1; bool has_freq = true;
 		const Seq *chrom = nullptr; uint32_t start_index = 1;
@@ -404,154 +487,158 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 			}
 			const uint8_t f1 = (uint8_t)(freq1 * 0xff), f2 = (uint8_t)(freq2 * 0xff);
 			if (a2 == ref_base) continue;
+			// the 32 k-mers over the SNP exist only if the 63 bases around it are ACGT (dictgen.c:751-790)
 			const std::string &seq = chrom->seq;
-			uint64_t k = 0; bool had_n = false;
-			for (int j = 31; j >= 0; j--) {
-				const int c = base_code((unsigned char)seq[index - 32 + (unsigned)j]);
-				if (c >= 4) { had_n = true; break; }
-				k = (k << 2) | (uint64_t)c;
-			}
-			if (had_n) continue;
-			SK tmp[32]; bool ok = true;
-			for (unsigned t = 0; t < 32; t++) {
-				const char nb = t ? seq[index + t] : a2;
-				const int c = base_code((unsigned char)nb);
-				if (c >= 4) { ok = false; break; }
-				k = (k >> 2) | ((uint64_t)c << 62);
-				tmp[t] = SK{k, start_index + index - 32 + 1 + t, (uint8_t)((((31 - t) & 0x1F) << 3) | ((unsigned)ref_u & 7)), f1, f2, 0};
-			}
-			if (!ok) continue;
-			kmers.insert(kmers.end(), tmp, tmp + 32);
+			bool clean = true;
+			for (unsigned j = 0; j < 63 && clean; j++) if (j != 31 && base_code((unsigned char)seq[index - 31 + j]) >= 4) clean = false;
+			if (base_code((unsigned char)seq[index - 32]) >= 4) clean = false;
+			if (!clean) continue;
+			snps.push_back(SnpRec{chrom, index, start_index, (uint8_t)ref_u, (uint8_t)base_code((unsigned char)a2), f1, f2});
 		}
-		// qsort (glibc merge sort: stable) by k-mer; ties keep VCF order
-		__gnu_parallel::stable_sort(kmers.begin(), kmers.end(), [](const SK &a, const SK &b) { return a.kmer < b.kmer; });
-		std::vector<uint8_t> out, aux;
-		out.reserve(16 + kmers.size() * 16);
-		uint64_t zero = 0; put(out, &zero, 8); put(out, &zero, 8);
-		uint64_t written = 0, aux_count = 0, unamb = 0, amb_unique = 0, amb_total = 0;
-		for (size_t a = 0; a < kmers.size();) {
-			size_t b = a + 1;
-			while (b < kmers.size() && kmers[b].kmer == kmers[a].kmer) b++;
-			put(out, &kmers[a].kmer, 8);
-			const uint8_t z8 = 0, one = 1;
-			if (b - a == 1) {
-				unamb++;
-				put(out, &kmers[a].pos, 4); put(out, &kmers[a].snp, 1); put(out, &z8, 1); put(out, &kmers[a].rf, 1); put(out, &kmers[a].af, 1);
-			} else {
-				amb_unique++; amb_total += b - a;
-				uint32_t posv;
-				if (b - a > (size_t)AUX_COLS) posv = POS_AMBIGUOUS;
-				else {
-					posv = (uint32_t)aux_count++;
-					put(aux, &kmers[a].kmer, 8);
-					for (int j = 0; j < AUX_COLS; j++) {
-						if (a + (size_t)j < b) { const SK &s = kmers[a + (size_t)j]; put(aux, &s.pos, 4); put(aux, &s.snp, 1); put(aux, &s.rf, 1); put(aux, &s.af, 1); }
-						else { const uint32_t z = 0; put(aux, &z, 4); put(aux, &z8, 1); put(aux, &z8, 1); put(aux, &z8, 1); }
-					}
+		pt.lap("SNP list parsed");
+		// k-mer t of a SNP covers bases [index - 31 + t, index + t], the SNP's alt base at offset 31 - t
+		const size_t SNP_CHUNK = 1 << 15;
+		const size_t n_chunks = (snps.size() + SNP_CHUNK - 1) / SNP_CHUNK;
+		Partitioned<SK> part;
+		partition_records<SK>(n_chunks, [&](size_t c, auto &&sink) {
+			const size_t hi = std::min(snps.size(), (c + 1) * SNP_CHUNK);
+			for (size_t i = c * SNP_CHUNK; i < hi; i++) {
+				const SnpRec &r = snps[i];
+				const std::string &seq = r.chrom->seq;
+				uint64_t k = 0;
+				for (int j = 31; j >= 0; j--) k = (k << 2) | (uint64_t)base_code((unsigned char)seq[r.index - 32 + (unsigned)j]);
+				for (unsigned t = 0; t < 32; t++) {
+					const uint64_t c2 = t ? (uint64_t)base_code((unsigned char)seq[r.index + t]) : (uint64_t)r.alt;
+					k = (k >> 2) | (c2 << 62);
+					sink(SK{k, r.start_index + r.index - 32 + 1 + t, (uint8_t)((((31 - t) & 0x1F) << 3) | (r.ref_u & 7u)), r.f1, r.f2, 0});
 				}
-				put(out, &posv, 4); put(out, &z8, 1); put(out, &one, 1); put(out, &z8, 1); put(out, &z8, 1);
 			}
-			written++;
-			a = b;
+		}, part);
+		pt.lap("SNP k-mers made and partitioned");
+		// per bucket: stable sort by k-mer (qsort is glibc's stable merge sort: ties keep VCF order), then count its records and rows
+		std::vector<uint64_t> n_rec(N_PART + 1, 0), n_aux(N_PART + 1, 0);
+		#pragma omp parallel for schedule(dynamic, 8)
+		for (long b = 0; b < (long)N_PART; b++) {
+			SK *lo = part.data + part.begin[(size_t)b], *hi = part.data + part.begin[(size_t)b + 1];
+			std::stable_sort(lo, hi, [](const SK &x, const SK &y) { return x.kmer < y.kmer; });
+			uint64_t rec = 0, aux = 0;
+			for (SK *p = lo; p < hi;) { SK *q = p + 1; while (q < hi && q->kmer == p->kmer) q++; rec++; aux += (q - p >= 2 && q - p <= AUX_COLS); p = q; }
+			n_rec[(size_t)b + 1] = rec; n_aux[(size_t)b + 1] = aux;
 		}
-		memcpy(&out[0], &written, 8); memcpy(&out[8], &aux_count, 8);
-		out.insert(out.end(), aux.begin(), aux.end());
-		write_file(prefix + ".snp.dict", out);
+		for (size_t b = 0; b < N_PART; b++) { n_rec[b + 1] += n_rec[b]; n_aux[b + 1] += n_aux[b]; }
+		const uint64_t written = n_rec[N_PART], aux_count = n_aux[N_PART];
+		pt.lap("SNP k-mers sorted");
+		// records: k-mer u64, pos u32, snp u8, ambig u8, ref_freq u8, alt_freq u8; rows: k-mer u64 + 10 x {pos u32, snp, rf, af}
+		DictFile out(prefix + ".snp.dict", 16 + 16 * written + 78 * aux_count);
+		{ uint64_t head[2] = {written, aux_count}; out.write_at(head, 16, 0); }
+		uint64_t unamb = 0, amb_unique = 0, amb_total = 0;
+		#pragma omp parallel for schedule(dynamic, 8) reduction(+ : unamb, amb_unique, amb_total)
+		for (long b = 0; b < (long)N_PART; b++) {
+			const SK *lo = part.data + part.begin[(size_t)b], *hi = part.data + part.begin[(size_t)b + 1];
+			std::vector<uint8_t> rec((size_t)(n_rec[(size_t)b + 1] - n_rec[(size_t)b]) * 16), rows((size_t)(n_aux[(size_t)b + 1] - n_aux[(size_t)b]) * 78, 0);
+			uint8_t *w = rec.data(), *x = rows.data();
+			uint64_t ax = n_aux[(size_t)b];
+			for (const SK *p = lo; p < hi;) {
+				const SK *q = p + 1;
+				while (q < hi && q->kmer == p->kmer) q++;
+				const size_t L = (size_t)(q - p);
+				memcpy(w, &p->kmer, 8);
+				if (L == 1) {
+					unamb++;
+					memcpy(w + 8, &p->pos, 4); w[12] = p->snp; w[13] = 0; w[14] = p->rf; w[15] = p->af;
+				} else {
+					amb_unique++; amb_total += L;
+					uint32_t posv = POS_AMBIGUOUS;
+					if (L <= (size_t)AUX_COLS) {
+						posv = (uint32_t)ax++;
+						memcpy(x, &p->kmer, 8);
+						for (size_t j = 0; j < L; j++) { uint8_t *e = x + 8 + 7 * j; memcpy(e, &p[j].pos, 4); e[4] = p[j].snp; e[5] = p[j].rf; e[6] = p[j].af; }
+						x += 78;
+					}
+					memcpy(w + 8, &posv, 4); w[12] = 0; w[13] = 1; w[14] = 0; w[15] = 0;
+				}
+				w += 16;
+				p = q;
+			}
+			if (!rec.empty()) out.write_at(rec.data(), rec.size(), 16 + 16 * n_rec[(size_t)b]);
+			if (!rows.empty()) out.write_at(rows.data(), rows.size(), 16 + 16 * written + 78 * n_aux[(size_t)b]);
+		}
+		pt.lap("SNP dictionary written");
 		if (!opt.quiet) {
 			printf("SNP Dictionary\nTotal k-mers:        %lu\nUnambig k-mers:      %lu\nAmbig unique k-mers: %lu\nAmbig total k-mers:  %lu\n",
-			       (unsigned long)kmers.size(), (unsigned long)unamb, (unsigned long)amb_unique, (unsigned long)amb_total);
+			       (unsigned long)part.n, (unsigned long)unamb, (unsigned long)amb_unique, (unsigned long)amb_total);
 		}
 	}
 
 	// ---- reference dictionary: make_ref_dict, dictgen.c:277-301
 	{
 		for (const Seq &s : ref) if (s.seq.size() < 32) die("reference sequence shorter than 32 bases: " + s.name);   // assert, dictgen.c:17
-		// count, then fill in parallel, chunk by chunk in position order
-		struct Chunk { size_t seq, lo, hi; uint32_t base; size_t count, at; };
+		struct Chunk { size_t seq, lo, hi; uint32_t base; };
 		std::vector<Chunk> chunks;
 		uint32_t base = 1;
 		for (size_t si = 0; si < ref.size(); si++) {
 			const size_t nwin = ref[si].seq.size() - 31;
 			const size_t step = 1 << 22;
-			for (size_t lo = 0; lo < nwin; lo += step) chunks.push_back(Chunk{si, lo, std::min(nwin, lo + step), base, 0, 0});
+			for (size_t lo = 0; lo < nwin; lo += step) chunks.push_back(Chunk{si, lo, std::min(nwin, lo + step), base});
 			base += (uint32_t)ref[si].seq.size();
 		}
-		#pragma omp parallel for schedule(dynamic, 1)
-		for (long c = 0; c < (long)chunks.size(); c++) {
-			size_t cnt = 0;
-			for_each_kmer(ref[chunks[(size_t)c].seq].seq, chunks[(size_t)c].lo, chunks[(size_t)c].hi, false, [&](uint64_t, size_t) { cnt++; });
-			chunks[(size_t)c].count = cnt;
+		Partitioned<KP> part;
+		partition_records<KP>(chunks.size(), [&](size_t c, auto &&sink) {
+			const Chunk &ch = chunks[c];
+			for_each_kmer(ref[ch.seq].seq, ch.lo, ch.hi, false, [&](uint64_t k, size_t off) { sink(KP{k, ch.base + (uint32_t)off, 0}); });
+		}, part);
+		if (part.n >= (1ull << 32)) die("more than 2^32 32-mers in the reference");
+		pt.lap("reference k-mers made and partitioned");
+		// per bucket: order by (k-mer, position) -- what a stable sort by k-mer gives, a bucket being in position order already
+		std::vector<uint64_t> n_rec(N_PART + 1, 0), n_aux(N_PART + 1, 0);
+		#pragma omp parallel for schedule(dynamic, 8)
+		for (long b = 0; b < (long)N_PART; b++) {
+			KP *lo = part.data + part.begin[(size_t)b], *hi = part.data + part.begin[(size_t)b + 1];
+			std::sort(lo, hi, [](const KP &x, const KP &y) { return x.kmer < y.kmer || (x.kmer == y.kmer && x.pos < y.pos); });
+			uint64_t rec = 0, aux = 0;
+			for (KP *p = lo; p < hi;) { KP *q = p + 1; while (q < hi && q->kmer == p->kmer) q++; rec++; aux += (q - p >= 2 && q - p <= AUX_COLS); p = q; }
+			n_rec[(size_t)b + 1] = rec; n_aux[(size_t)b + 1] = aux;
 		}
-		size_t total = 0;
-		for (Chunk &c : chunks) { c.at = total; total += c.count; }
-		std::vector<KP> kmers(total);
-		#pragma omp parallel for schedule(dynamic, 1)
-		for (long c = 0; c < (long)chunks.size(); c++) {
-			const Chunk &ch = chunks[(size_t)c];
-			size_t at = ch.at;
-			for_each_kmer(ref[ch.seq].seq, ch.lo, ch.hi, false, [&](uint64_t k, size_t off) { kmers[at++] = KP{k, ch.base + (uint32_t)off, 0}; });
-		}
-		// stable by k-mer == ascending position within equal k-mers
-		__gnu_parallel::sort(kmers.begin(), kmers.end(), [](const KP &a, const KP &b) { return a.kmer < b.kmer || (a.kmer == b.kmer && a.pos < b.pos); });
-		// write_kmers (dictgen.c:63-154) in parallel: run starts -> unique index, runs of 2..10 -> aux row index
-		const size_t nk = kmers.size();
-		const int T = std::max(1, nthreads);
-		std::vector<size_t> c_runs((size_t)T + 1, 0), c_aux((size_t)T + 1, 0);
-		auto chunk_lo = [&](int t) { return nk * (size_t)t / (size_t)T; };
-		#pragma omp parallel for schedule(static, 1)
-		for (int t = 0; t < T; t++) {
-			size_t runs = 0;
-			for (size_t i = chunk_lo(t); i < chunk_lo(t + 1); i++) runs += (i == 0 || kmers[i].kmer != kmers[i - 1].kmer);
-			c_runs[(size_t)t + 1] = runs;
-		}
-		for (int t = 0; t < T; t++) c_runs[(size_t)t + 1] += c_runs[(size_t)t];
-		const uint64_t written = c_runs[(size_t)T];
-		std::vector<uint32_t> S(written + 1);                           // start of run r (nk < 2^32 is checked by geno's loader anyway)
-		S[written] = (uint32_t)nk;
-		#pragma omp parallel for schedule(static, 1)
-		for (int t = 0; t < T; t++) {
-			size_t r = c_runs[(size_t)t];
-			for (size_t i = chunk_lo(t); i < chunk_lo(t + 1); i++) if (i == 0 || kmers[i].kmer != kmers[i - 1].kmer) S[r++] = (uint32_t)i;
-		}
-		if (nk >= (1ull << 32)) die("more than 2^32 32-mers in the reference");
-		auto run_lo = [&](int t) { return (size_t)written * (size_t)t / (size_t)T; };
-		#pragma omp parallel for schedule(static, 1)
-		for (int t = 0; t < T; t++) {
-			size_t na = 0;
-			for (size_t r = run_lo(t); r < run_lo(t + 1); r++) { const uint32_t L = S[r + 1] - S[r]; na += (L >= 2 && L <= (uint32_t)AUX_COLS); }
-			c_aux[(size_t)t + 1] = na;
-		}
-		for (int t = 0; t < T; t++) c_aux[(size_t)t + 1] += c_aux[(size_t)t];
-		const uint64_t aux_count = c_aux[(size_t)T];
-		std::vector<uint8_t> out(16 + written * 13 + aux_count * 40);
-		memcpy(&out[0], &written, 8); memcpy(&out[8], &aux_count, 8);
+		for (size_t b = 0; b < N_PART; b++) { n_rec[b + 1] += n_rec[b]; n_aux[b + 1] += n_aux[b]; }
+		const uint64_t written = n_rec[N_PART], aux_count = n_aux[N_PART];
+		pt.lap("reference k-mers sorted");
+		// write_kmers (dictgen.c:63-154): records k-mer u64, pos u32, ambig u8; a k-mer with 2..10 copies points at a row of 10 u32
+		// positions, one with more gets POS_AMBIGUOUS
+		DictFile out(prefix + ".ref.dict", 16 + 13 * written + 40 * aux_count);
+		{ uint64_t head[2] = {written, aux_count}; out.write_at(head, 16, 0); }
 		uint64_t unamb = 0, amb_unique = 0, amb_total = 0;
-		#pragma omp parallel for schedule(static, 1) reduction(+ : unamb, amb_unique, amb_total)
-		for (int t = 0; t < T; t++) {
-			size_t ax = c_aux[(size_t)t];
-			for (size_t r = run_lo(t); r < run_lo(t + 1); r++) {
-				const size_t a = S[r], bnd = S[r + 1], L = bnd - a;
-				uint8_t *rec = &out[16 + r * 13];
-				memcpy(rec, &kmers[a].kmer, 8);
-				uint32_t posv; uint8_t flag;
-				if (L == 1) { unamb++; posv = kmers[a].pos; flag = 0; }
+		#pragma omp parallel for schedule(dynamic, 8) reduction(+ : unamb, amb_unique, amb_total)
+		for (long b = 0; b < (long)N_PART; b++) {
+			const KP *lo = part.data + part.begin[(size_t)b], *hi = part.data + part.begin[(size_t)b + 1];
+			std::vector<uint8_t> rec((size_t)(n_rec[(size_t)b + 1] - n_rec[(size_t)b]) * 13), rows((size_t)(n_aux[(size_t)b + 1] - n_aux[(size_t)b]) * 40, 0);
+			uint8_t *w = rec.data(), *x = rows.data();
+			uint64_t ax = n_aux[(size_t)b];
+			for (const KP *p = lo; p < hi;) {
+				const KP *q = p + 1;
+				while (q < hi && q->kmer == p->kmer) q++;
+				const size_t L = (size_t)(q - p);
+				uint32_t posv = p->pos;
+				if (L == 1) unamb++;
 				else {
-					amb_unique++; amb_total += L; flag = 1;
-					if (L > (size_t)AUX_COLS) posv = POS_AMBIGUOUS;
-					else {
-						posv = (uint32_t)ax;
-						uint8_t *row = &out[16 + written * 13 + ax * 40];
-						for (int j = 0; j < AUX_COLS; j++) { const uint32_t v = (size_t)j < L ? kmers[a + (size_t)j].pos : 0u; memcpy(row + 4 * j, &v, 4); }
-						ax++;
+					amb_unique++; amb_total += L;
+					posv = POS_AMBIGUOUS;
+					if (L <= (size_t)AUX_COLS) {
+						posv = (uint32_t)ax++;
+						for (size_t j = 0; j < L; j++) memcpy(x + 4 * j, &p[j].pos, 4);
+						x += 40;
 					}
 				}
-				memcpy(rec + 8, &posv, 4); rec[12] = flag;
+				memcpy(w, &p->kmer, 8); memcpy(w + 8, &posv, 4); w[12] = L > 1;
+				w += 13;
+				p = q;
 			}
+			if (!rec.empty()) out.write_at(rec.data(), rec.size(), 16 + 13 * n_rec[(size_t)b]);
+			if (!rows.empty()) out.write_at(rows.data(), rows.size(), 16 + 13 * written + 40 * n_aux[(size_t)b]);
 		}
-		write_file(prefix + ".ref.dict", out);
+		pt.lap("reference dictionary written");
 		if (!opt.quiet) {
 			printf("Ref Dictionary\nTotal k-mers:        %lu\nUnambig k-mers:      %lu\nAmbig unique k-mers: %lu\nAmbig total k-mers:  %lu\n",
-			       (unsigned long)total, (unsigned long)unamb, (unsigned long)amb_unique, (unsigned long)amb_total);
+			       (unsigned long)part.n, (unsigned long)unamb, (unsigned long)amb_unique, (unsigned long)amb_total);
 		}
 	}
 }

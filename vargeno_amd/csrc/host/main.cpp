@@ -7,7 +7,6 @@
 //   VARGENO_GPUS=n        shard read batches over n GPUs of this node (default 1), counters summed with RCCL
 //   VARGENO_BATCH=n       reads per submitted batch (default 4194304)
 //   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
-#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -128,29 +127,9 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		for (auto *h : ix) { VG_CHECK(vg_stats_get(h, &st)); invalid += st.reads_invalid; }
 		if (invalid) { fprintf(stderr, "vargeno: %lu reads contain a character other than ACGTN (the reference aborts on these)\n", (unsigned long)invalid); return EXIT_FAILURE; }
 	}
-	if (ngpu > 1) {
-		// one process, n devices: ncclCommInitAll + one all-reduce of the per-site counters over xGMI
-		void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-		if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-		if (!lib) { fprintf(stderr, "vargeno: cannot load librccl: %s\n", dlerror()); return EXIT_FAILURE; }
-		typedef int (*init_all_fn)(void **, int, const int *);
-		typedef int (*group_fn)();
-		typedef int (*destroy_fn)(void *);
-		init_all_fn init_all = (init_all_fn)dlsym(lib, "ncclCommInitAll");
-		group_fn gstart = (group_fn)dlsym(lib, "ncclGroupStart"), gend = (group_fn)dlsym(lib, "ncclGroupEnd");
-		destroy_fn destroy = (destroy_fn)dlsym(lib, "ncclCommDestroy");
-		if (!init_all || !gstart || !gend) { fprintf(stderr, "vargeno: RCCL symbols missing\n"); return EXIT_FAILURE; }
-		std::vector<void *> comms((size_t)ngpu, nullptr);
-		std::vector<int> devs;
-		for (int g = 0; g < ngpu; g++) devs.push_back(g);
-		if (init_all(comms.data(), ngpu, devs.data()) != 0) { fprintf(stderr, "vargeno: ncclCommInitAll failed\n"); return EXIT_FAILURE; }
-		std::vector<std::thread> th;
-		std::vector<int> rcs((size_t)ngpu, 0);
-		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_counts_allreduce(ix[(size_t)g], comms[(size_t)g]); });
-		for (auto &t : th) t.join();
-		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) { fprintf(stderr, "vargeno: counter all-reduce failed on GPU %d\n", g); return EXIT_FAILURE; }
-		if (destroy) for (void *c : comms) destroy(c);
-	}
+	// one process, n devices: one RCCL all-reduce of the per-site counters over xGMI (VARGENO_FORCE_RCCL=1 also sends a
+	// single device through it, which is the identity)
+	if (ngpu > 1 || env_int("VARGENO_FORCE_RCCL", 0)) VG_CHECK(vg_counts_allreduce_devices(ix.data(), ngpu));
 	vgh::SiteCounts sc;
 	const uint64_t ns = vg_num_sites(ix[0]);
 	sc.pos.resize(ns); sc.ref_freq.resize(ns); sc.alt_freq.resize(ns); sc.ref_cnt.resize(ns); sc.alt_cnt.resize(ns);

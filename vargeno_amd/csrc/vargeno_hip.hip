@@ -1373,24 +1373,86 @@ extern "C" int vg_counts_device_ptr(vg_index *ix, void **d_counts, uint64_t *n_u
 	return VG_OK;
 }
 
-// RCCL is resolved lazily so that the library loads (and the rest of the ABI works) on single-GPU hosts.
+// RCCL is resolved lazily (dlopen) so that the library loads, and the rest of the ABI works, on hosts without it; types,
+// enumerators and prototypes come from its own header.
+#include <rccl/rccl.h>
+namespace {
+struct Rccl {
+	decltype(&ncclAllReduce) all_reduce = nullptr;
+	decltype(&ncclCommInitAll) comm_init_all = nullptr;
+	decltype(&ncclCommDestroy) comm_destroy = nullptr;
+	decltype(&ncclGroupStart) group_start = nullptr;
+	decltype(&ncclGroupEnd) group_end = nullptr;
+	decltype(&ncclGetErrorString) error_string = nullptr;
+	bool ok = false;
+};
+const Rccl &rccl()
+{
+	static const Rccl r = [] {
+		Rccl x;
+		void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!h) return x;
+		x.all_reduce = (decltype(x.all_reduce))dlsym(h, "ncclAllReduce");
+		x.comm_init_all = (decltype(x.comm_init_all))dlsym(h, "ncclCommInitAll");
+		x.comm_destroy = (decltype(x.comm_destroy))dlsym(h, "ncclCommDestroy");
+		x.group_start = (decltype(x.group_start))dlsym(h, "ncclGroupStart");
+		x.group_end = (decltype(x.group_end))dlsym(h, "ncclGroupEnd");
+		x.error_string = (decltype(x.error_string))dlsym(h, "ncclGetErrorString");
+		x.ok = x.all_reduce && x.comm_init_all && x.comm_destroy && x.group_start && x.group_end && x.error_string;
+		return x;
+	}();
+	return r;
+}
+}  // namespace
+
 extern "C" int vg_counts_allreduce(vg_index *ix, void *nccl_comm)
 {
 	if (!ix || !nccl_comm) return fail(VG_EINVAL, "null argument");
-	typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
-	static allreduce_fn fn = nullptr;
-	if (!fn) {
-		void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-		if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-		if (!h) return fail(VG_ENODEV, "cannot load librccl: %s", dlerror());
-		fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
-		if (!fn) return fail(VG_ENODEV, "ncclAllReduce not found in librccl");
-	}
+	const Rccl &R = rccl();
+	if (!R.ok) return fail(VG_ENODEV, "cannot load librccl (or it lacks the collective entry points)");
 	{ int rc = finish_pending(ix); if (rc) return rc; }
 	if (ix->n_sites == 0) return VG_OK;
-	const int ncclUint32 = 3, ncclSum = 0;            // rccl.h: ncclDataType_t / ncclRedOp_t
-	const int rc = fn(ix->d.cnt, ix->d.cnt, (size_t)(2 * ix->n_sites), ncclUint32, ncclSum, nccl_comm, ix->stream);
-	if (rc != 0) return fail(VG_ENODEV, "ncclAllReduce failed");
+	const ncclResult_t rc = R.all_reduce(ix->d.cnt, ix->d.cnt, (size_t)(2 * ix->n_sites), ncclUint32, ncclSum, (ncclComm_t)nccl_comm, ix->stream);
+	if (rc != ncclSuccess) return fail(VG_ENODEV, "ncclAllReduce: %s", R.error_string(rc));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	return VG_OK;
+}
+
+// One process driving n devices (the CLI with VARGENO_GPUS=n): communicator over the handles' devices, one grouped in-place
+// all-reduce of every replica's counters, communicator torn down.  n = 1 is the identity and still goes through RCCL.
+extern "C" int vg_counts_allreduce_devices(vg_index **handles, int n)
+{
+	if (!handles || n <= 0) return fail(VG_EINVAL, "null argument");
+	for (int i = 0; i < n; i++) {
+		if (!handles[i]) return fail(VG_EINVAL, "null handle");
+		if (handles[i]->n_sites != handles[0]->n_sites) return fail(VG_EINVAL, "the handles do not hold replicas of one index");
+		for (int j = 0; j < i; j++) if (handles[j]->device == handles[i]->device) return fail(VG_EINVAL, "two handles on one device");
+	}
+	const Rccl &R = rccl();
+	if (!R.ok) return fail(VG_ENODEV, "cannot load librccl (or it lacks the collective entry points)");
+	for (int i = 0; i < n; i++) { int rc = finish_pending(handles[i]); if (rc) return rc; }
+	if (handles[0]->n_sites == 0) return VG_OK;
+	return guarded([&]() -> int {
+		std::vector<int> devs((size_t)n);
+		for (int i = 0; i < n; i++) devs[(size_t)i] = handles[i]->device;
+		std::vector<ncclComm_t> comms((size_t)n, nullptr);
+		ncclResult_t rc = R.comm_init_all(comms.data(), n, devs.data());
+		if (rc != ncclSuccess) return fail(VG_ENODEV, "ncclCommInitAll: %s", R.error_string(rc));
+		rc = R.group_start();
+		for (int i = 0; i < n && rc == ncclSuccess; i++) {
+			vg_index *ix = handles[i];
+			if (hipSetDevice(ix->device) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
+			rc = R.all_reduce(ix->d.cnt, ix->d.cnt, (size_t)(2 * ix->n_sites), ncclUint32, ncclSum, comms[(size_t)i], ix->stream);
+		}
+		const ncclResult_t rc2 = R.group_end();
+		int out = VG_OK;
+		if (rc != ncclSuccess || rc2 != ncclSuccess) out = fail(VG_ENODEV, "RCCL all-reduce of the site counters: %s", R.error_string(rc != ncclSuccess ? rc : rc2));
+		for (int i = 0; i < n; i++) {
+			if (hipSetDevice(handles[i]->device) == hipSuccess && hipStreamSynchronize(handles[i]->stream) != hipSuccess && out == VG_OK)
+				out = fail(VG_ENODEV, "stream synchronisation after the all-reduce failed");
+		}
+		for (ncclComm_t c : comms) if (c) (void)R.comm_destroy(c);
+		return out;
+	});
 }

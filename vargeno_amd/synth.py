@@ -254,10 +254,59 @@ VCF_HEADER = (
 )
 
 
+def _decimal_columns(v, width):
+    """uint8[len(v), width]: decimal digits of v right-aligned, 0 bytes in front (dropped when the lines are assembled)."""
+    v = np.asarray(v, dtype=np.int64)
+    out = np.zeros((len(v), width), dtype=np.uint8)
+    rest = v.copy()
+    for k in range(width - 1, -1, -1):
+        live = (rest > 0) | (k == width - 1)          # the last digit is always written (the value 0 prints as "0")
+        out[live, k] = (48 + rest % 10)[live]
+        rest //= 10
+    return out
+
+
+def _write_vcf_vectorised(path, vnames, snps, with_caf):
+    """Same lines as the loop in write_vcf() -- canonical decimals, "%.4f" frequencies -- assembled as byte columns."""
+    n = len(snps.pos)
+    name_w = max(len(v) for v in vnames)
+    names = np.zeros((len(vnames), name_w), dtype=np.uint8)
+    for i, v in enumerate(vnames):
+        names[i, :len(v)] = np.frombuffer(v.encode(), dtype=np.uint8)
+    ids = np.arange(1, n + 1, dtype=np.int64)
+
+    def lit(text):
+        return np.broadcast_to(np.frombuffer(text.encode(), dtype=np.uint8), (n, len(text)))
+
+    def freq(x):                                     # "%.4f" of a value in [0, 10): d.dddd
+        q = np.floor(np.asarray(x, dtype=np.float64) * 10000.0 + 0.5).astype(np.int64)
+        c = np.empty((n, 6), dtype=np.uint8)
+        c[:, 0] = 48 + q // 10000
+        c[:, 1] = ord(".")
+        for k in range(4):
+            c[:, 2 + k] = 48 + (q // 10 ** (3 - k)) % 10
+        return c
+
+    cols = [names[snps.chrom], lit("\t"), _decimal_columns(snps.pos, 10), lit("\trs"), _decimal_columns(ids, 9), lit("\t"),
+            snps.ref.reshape(-1, 1), lit("\t"), snps.alt.reshape(-1, 1), lit("\t.\t.\tRS="), _decimal_columns(ids, 9)]
+    if with_caf:
+        cols += [lit(";CAF="), freq(snps.caf_ref), lit(","), freq(snps.caf_alt), lit(";COMMON=1\n")]
+    else:
+        cols += [lit("\n")]
+    with open(path, "wb") as f:
+        f.write(VCF_HEADER.encode())
+        step = 1 << 20
+        for lo in range(0, n, step):
+            blk = np.concatenate([c[lo:lo + step] for c in cols], axis=1).reshape(-1)
+            f.write(blk[blk != 0].tobytes())
+
+
 def write_vcf(path, genome, snps, *, strip_chr=True):
     names = genome.short_names
     vnames = [n[3:] if (strip_chr and n.startswith("chr")) else n for n in names]
     with_caf = getattr(snps, "_with_caf", True)
+    if len(snps.pos) > 200_000:                      # the bench-scale lists: millions of lines
+        return _write_vcf_vectorised(path, vnames, snps, with_caf)
     buf = io.StringIO()
     buf.write(VCF_HEADER)
     for i in range(len(snps.pos)):
@@ -310,9 +359,10 @@ def f_tiny(seed=7):
     return g, s, r
 
 
-def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=1_000_000, n_chroms=1, lowq=0.08):
-    """BASELINE.json configs[1]: one 40 Mbp chromosome, ~1 M SNPs, 1 M x 150 bp reads (F-mid recipe).
-    With genome_len = 3.1e9, n_chroms = 24, n_snps = 1e7 the same recipe gives the hg38-scale configs[2]."""
+def genome_and_snps(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_chroms=1):
+    """Genome + SNP list of the bench workloads (F-mid recipe scaled by length): BASELINE.json configs[1] by default; with
+    genome_len = 3.1e9, n_chroms = 24, n_snps = 1e7 the hg38-scale configs[2].  Returns (genome, snps, rng): the generator is
+    left where make_reads() continues from."""
     rng = np.random.default_rng(seed)
     if n_chroms == 1:
         lens, names = [genome_len], ["chr22"]
@@ -323,5 +373,79 @@ def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=
     g = make_genome(rng, lens, names, repeats_per_mbp=50.0, repeat_len=(200, 2000),
                     repeat_div=0.02, microsat_per_mbp=12.5)
     s = make_snps(rng, g, n_snps)
+    return g, s, rng
+
+
+def chr22_scale(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_reads=1_000_000, n_chroms=1, lowq=0.08):
+    """BASELINE.json configs[1]: one 40 Mbp chromosome, ~1 M SNPs, 1 M x 150 bp reads (F-mid recipe)."""
+    g, s, rng = genome_and_snps(seed, genome_len, n_snps, n_chroms)
     r = make_reads(rng, g, s, n_reads, lengths=(150,), err=0.005, lowq=lowq)
     return g, s, r
+
+
+# ----------------------------------------------------------------------------- device-side read generator (bench.py)
+
+class DeviceReadSource:
+    """The recipe of make_reads() (150 bp, uniform start / haplotype / strand, substitution errors, the two quality
+    ranges) evaluated with torch on the GPU, for bench.py: a step of the hg38-scale workload is 8 M reads and the bench
+    keeps several distinct batches of its 30x stream resident, which numpy takes minutes to draw.  The two donor
+    haplotypes stay on the device between calls.  Seeded (torch.Generator on the device): the same (seed, batch id)
+    gives the same reads.  Plumbing only -- nothing here is on the measured path."""
+
+    def __init__(self, genome, snps, device, seed=20261002):
+        import torch
+
+        self.torch = torch
+        self.dev = device
+        h0, h1, _ = haplotypes(genome, snps)
+        self.h0 = torch.from_numpy(h0).to(device)
+        self.h1 = torch.from_numpy(h1).to(device)
+        self.G = int(len(h0))
+        self.seed = int(seed)
+        self.acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+        code = np.full(256, 4, dtype=np.uint8)
+        comp = np.zeros(256, dtype=np.uint8)
+        for i, c in enumerate(b"ACGT"):
+            code[c] = i
+        for a, b in zip(b"ACGTN", b"TGCAN"):
+            comp[a] = b
+        self.code = torch.from_numpy(code).to(device)
+        self.comp = torch.from_numpy(comp).to(device)
+
+    def batch(self, batch_id, n, length=150, err=0.005, lowq=0.08, piece=1 << 20):
+        """-> (bases uint8[n*length], quals uint8[n*length], offsets int64[n+1]) on the device."""
+        torch = self.torch
+        gen = torch.Generator(device=self.dev)
+        gen.manual_seed(self.seed * 1000003 + int(batch_id))
+        bases = torch.empty(n * length, dtype=torch.uint8, device=self.dev)
+        quals = torch.empty(n * length, dtype=torch.uint8, device=self.dev)
+        ar = torch.arange(length, device=self.dev)
+        for lo in range(0, n, piece):
+            m = min(piece, n - lo)
+            st = torch.randint(0, self.G - length, (m,), generator=gen, device=self.dev)
+            hap = torch.randint(0, 2, (m,), generator=gen, device=self.dev).bool()
+            gi = st[:, None] + ar[None, :]
+            b = torch.where(hap[:, None], self.h1[gi], self.h0[gi])
+            e = torch.rand((m, length), generator=gen, device=self.dev) < err
+            sub = (self.code[b.long()] + torch.randint(1, 4, (m, length), generator=gen, device=self.dev, dtype=torch.uint8)) % 4
+            b = torch.where(e, self.acgt[sub.long()], b)
+            rv = torch.rand((m,), generator=gen, device=self.dev) < 0.5
+            b = torch.where(rv[:, None], self.comp[b.flip(1).long()], b)
+            bases[lo * length:(lo + m) * length] = b.reshape(-1)
+            q_hi = torch.randint(ord(":"), ord("I") + 1, (m * length,), generator=gen, device=self.dev, dtype=torch.uint8)
+            q_lo = torch.randint(ord("#"), ord("7") + 1, (m * length,), generator=gen, device=self.dev, dtype=torch.uint8)
+            low = torch.rand((m * length,), generator=gen, device=self.dev) < lowq
+            quals[lo * length:(lo + m) * length] = torch.where(low, q_lo, q_hi)
+        offsets = torch.arange(0, (n + 1) * length, length, dtype=torch.int64, device=self.dev)
+        return bases, quals, offsets
+
+    def release(self):
+        self.h0 = self.h1 = None
+
+
+def reads_to_host(bases, quals, offsets, lo=0, hi=None):
+    """Device batch (or a [lo, hi) slice of it) -> Reads on the host."""
+    o = offsets.cpu().numpy().astype(np.uint64)
+    hi = len(o) - 1 if hi is None else hi
+    b0, b1 = int(o[lo]), int(o[hi])
+    return Reads(bases[b0:b1].cpu().numpy(), quals[b0:b1].cpu().numpy(), (o[lo:hi + 1] - o[lo]).astype(np.uint64))
