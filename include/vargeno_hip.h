@@ -99,13 +99,25 @@ int  vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals,
 int  vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals,
                              const uint64_t *d_offsets, uint64_t n_reads);
 
-/* Same again, starting from raw FASTQ text (host memory): replaces the four fgets() + strlen of
- * qv.cc:760-784 for a chunk of the file.  The device frames the complete 4-line records of the chunk,
- * and runs them through the read loop.  *consumed = bytes used (the rest, an incomplete last record,
- * is the caller's to resubmit with the next chunk); *last_record_start = offset of the last complete
- * record (a host reader that must reproduce the reference's stale-buffer behaviour on a truncated
- * final record starts there).  VG_EBADREAD: some line exceeds fgets' 1023 characters -- frame this chunk on
- * the host (vg_reads_submit); nothing was processed. */
+/* Same again, starting from raw FASTQ text (host memory): replaces the four fgets() + strlen of qv.cc:760-784.
+ *
+ * Stream form -- the caller only moves bytes.  vg_fastq_stream_push takes the next chunk of the file, cut anywhere; the device
+ * frames the complete 4-line records (carrying the unfinished last record of a chunk over to the next one by itself) and runs
+ * them through the read loop.  The call returns when the chunk has been copied to the device (its buffer is free again; pinned
+ * memory copies at link speed); framing and processing are only enqueued, and nothing is reported back until
+ * vg_fastq_stream_end: records framed, bytes consumed (= offset of the first byte the device did not process: the incomplete tail
+ * of the file, or everything from the first chunk it refused), offset of the last framed record (a host reader that must
+ * reproduce the reference's stale-buffer behaviour on a truncated final record starts there), and whether a chunk was refused.
+ * A chunk is refused -- and with it everything after it -- when it holds a line longer than fgets' 1023 characters, a quality
+ * line shorter than the read's chunk count, or lines shorter than 8 bytes on average: frame the rest on the host
+ * (vg_reads_submit).  One stream at a time per handle; chunks of less than 2 GiB. */
+int  vg_fastq_stream_begin(vg_index *ix);
+int  vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t nbytes);
+int  vg_fastq_stream_end(vg_index *ix, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start, int *refused);
+
+/* One self-contained chunk, synchronously: *consumed = bytes used (the rest, an incomplete last record, is the caller's to
+ * resubmit with the next chunk); waits for the framing, not for the read loop.  VG_EBADREAD: the chunk was refused (see above);
+ * nothing was processed. */
 int  vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbytes,
                      uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start);
 

@@ -11,6 +11,8 @@ Produces
   fsmall.*     F-small of SURVEY.md §8c (300 kbp / 29 868 SNPs / 40 000 reads): inputs are a pure
                function of the seed (vargeno_amd/synth.py), so only the sha256 list and the
                reference's output VCF are committed.
+  fdense.*     dense-bucket fixture (synth.f_dense: ~150 SNP k-mers per HI24 bucket, the bucket shape of hg38 + full dbSNP):
+               sha256 list + the reference's output VCF.
 Fixtures are data (inputs and reference outputs); no reference source text is stored here.
 """
 import gzip
@@ -95,11 +97,13 @@ if __name__ == "__main__":
     work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/vg_golden"
     if not os.path.exists(REF_BIN):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall"]
+    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall", "fdense"]
     if "ftiny" in which:
         run("ftiny", synth.f_tiny, work, True)
     if "fsmall" in which:
         run("fsmall", synth.f_small, work, False)
+    if "fdense" in which:
+        run("fdense", synth.f_dense, work, False)
     # the reference's own test data (test/snp.vcf, test/expected_output): data files, copied verbatim
     if os.path.isdir("/root/reference/test"):
         shutil.copy("/root/reference/test/snp.vcf", os.path.join(OUT, "reftest.snp.vcf"))

@@ -57,3 +57,39 @@ def test_cli_matches_the_reference_binary_at_scale(tmp_path):
     ref = open(os.path.join(d, "ref.vcf"), "rb").read()
     assert ours.count(b"\n") > 100_000
     assert ours == ref
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/vargeno (the reference built by oracle/Makefile in the build container) is not there")
+def test_cli_matches_the_reference_binary_at_hg38_scale(tmp_path):
+    """BASELINE.json configs[2] shape end to end: the reference binary and the product's `vargeno geno`, both on the hg38-scale
+    index files (shared with bench.py / test_gpu_fullsize.py through VG_BENCH_DIR) and the same 200 000 reads, must write the
+    same bytes.  The reference spends ~4 minutes of its run loading the 43 GB dictionary field by field."""
+    import torch
+
+    d = os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench") + "/g3100000000_s10000000_c24"
+    g, s, _ = synth.genome_and_snps(genome_len=3_100_000_000, n_snps=10_000_000, n_chroms=24)
+    if not os.path.exists(d + "/idx.done"):
+        os.makedirs(d, exist_ok=True)
+        synth.write_fasta(d + "/ref.fa", g)
+        synth.write_vcf(d + "/snps.vcf", g, s)
+        subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+        open(d + "/idx.done", "w").close()
+    src = synth.DeviceReadSource(g, s, torch.device("cuda", 0))
+    del g, s
+    r = synth.reads_to_host(*src.batch(777, 200_000))
+    src.release()
+    del src
+    torch.cuda.empty_cache()
+    fq = str(tmp_path / "reads.fq")
+    synth.write_fastq(fq, r)
+    ref = subprocess.Popen([REF_BIN, "geno", "idx", fq, "snps.vcf", str(tmp_path / "ref.vcf")], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        p = subprocess.run([BIN, "geno", "idx", fq, "snps.vcf", str(tmp_path / "ours.vcf")], cwd=d, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert ref.wait(timeout=900) == 0
+    finally:
+        if ref.poll() is None:
+            ref.kill()
+    ours = open(tmp_path / "ours.vcf", "rb").read()
+    assert ours.count(b"\n") > 50_000
+    assert ours == open(tmp_path / "ref.vcf", "rb").read()

@@ -80,3 +80,68 @@ def test_cli_truncated_final_record_matches_the_reference(ftiny_dir, tmp_path, h
                        env=env, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert (tmp_path / "out.vcf").read_bytes() == gzip.open(want_path, "rb").read()
+
+
+def test_stream_frames_records_across_arbitrary_cuts(ftiny_dir, ftiny_reads):
+    """vg_fastq_stream_*: the file cut into chunks anywhere -- mid-line, mid-record, one byte, a whole megabyte -- gives the
+    counters and event counts of the flat batch; the device carries the unfinished record over by itself and the host
+    gets its only answer at the end."""
+    prefix = os.path.join(ftiny_dir, "idx")
+    text = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read()
+    (rc0, ac0), st0 = _counts_flat(prefix, ftiny_reads)
+    rng = np.random.default_rng(3)
+    for trial in range(3):
+        cuts = [0]
+        while cuts[-1] < len(text):
+            step = int(rng.choice([1, 2, 7, 311, 4096, 65_537, 300_000, 1_000_000]))
+            cuts.append(min(len(text), cuts[-1] + step))
+            if len(cuts) > 400:                                       # keep the tiny steps to the head of the file
+                cuts.append(len(text))
+        with GenoIndex.open(prefix) as gx:
+            n, used, last, refused = gx.fastq_stream(text[a:b] for a, b in zip(cuts[:-1], cuts[1:]))
+            assert (n, used, refused) == (ftiny_reads.n, len(text), False)
+            assert text[last:last + 1] == b"@" and text[last:].count(b"\n") == 4
+            rc, ac = gx.counts()
+            st = gx.stats()
+        assert np.array_equal(rc, rc0) and np.array_equal(ac, ac0), trial
+        for k in ("reads", "reads_n", "passes", "chunks", "gate_open", "ctx", "walks", "incr"):
+            assert st[k] == st0[k], (trial, k)
+
+
+def test_stream_stops_at_the_first_chunk_it_cannot_frame(ftiny_dir):
+    prefix = os.path.join(ftiny_dir, "idx")
+    rec = b"@r\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40 + b"\n"
+    long_rec = b"@r\n" + b"A" * 1023 + b"\n+\n" + b"I" * 1023 + b"\n"
+    with GenoIndex.open(prefix) as gx:
+        # an incomplete tail is simply not consumed
+        n, used, last, refused = gx.fastq_stream([rec * 2 + rec[:17], rec[17:] + b"@r\nAC"])
+        assert (n, used, last, refused) == (3, 3 * len(rec), 2 * len(rec), False)
+        assert gx.stats()["reads"] == 3
+        # a line of 1024 characters in the second chunk: the first chunk's complete records are done, nothing after them is
+        gx.reset()
+        head = rec * 5 + rec[:30]
+        n, used, last, refused = gx.fastq_stream([head, rec[30:] + long_rec + rec * 4, rec * 100])
+        assert refused and (n, used, last) == (5, 5 * len(rec), 4 * len(rec))
+        assert gx.stats()["reads"] == 5
+        # the handle is usable afterwards
+        n, used, last, refused = gx.fastq_stream([rec * 7])
+        assert (n, used, refused) == (7, 7 * len(rec), False)
+
+
+def test_cli_long_line_in_the_middle_of_the_file_falls_back_to_host_framing(ftiny_dir, tmp_path):
+    """A 1500-base record in the middle of the file: fgets() splits its lines and shifts the reference's framing of everything
+    after it.  The device refuses from that chunk on and the host reader takes over there; both routes must write the same
+    VCF as framing the whole file on the host."""
+    lines = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read().split(b"\n")[:-1]
+    k = 4 * 1500
+    odd = [b"@long", b"ACGT" * 375, b"+", b"I" * 1500]
+    fq = tmp_path / "reads_long.fq"
+    fq.write_bytes(b"\n".join(lines[:k] + odd + lines[k:]) + b"\n")
+    outs = []
+    for host in ("1", "0"):
+        out = tmp_path / ("out%s.vcf" % host)
+        env = dict(os.environ, VARGENO_HOST_FASTQ=host, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_READERS="3")
+        p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(out)], env=env, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] and outs[0].count(b"\n") > 2000

@@ -74,3 +74,66 @@ def test_sample_against_oracle_at_full_index_size(chr22):
         gx.submit(s.bases, s.quals, s.offsets)
         rc, ac = gx.counts()
     assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+
+
+# ---- BASELINE.json configs[2]: hg38-scale (3.1 Gbp in 24 sequences, ~10 M SNPs), the index bench.py's default run uses ------------
+
+@pytest.fixture(scope="module")
+def hg38():
+    """Index files shared with bench.py through VG_BENCH_DIR (built once per box: ~2 minutes of host work, 48 GB of files)."""
+    d = os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench") + "/g3100000000_s10000000_c24"
+    g, s, _ = synth.genome_and_snps(genome_len=3_100_000_000, n_snps=10_000_000, n_chroms=24)
+    if not os.path.exists(d + "/idx.done"):
+        os.makedirs(d, exist_ok=True)
+        synth.write_fasta(d + "/ref.fa", g)
+        synth.write_vcf(d + "/snps.vcf", g, s)
+        subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+        open(d + "/idx.done", "w").close()
+    dev = torch.device("cuda", 0)
+    src = synth.DeviceReadSource(g, s, dev)
+    del g, s
+    big = src.batch(4242, 8_000_000)                 # one step of the bench
+    src.release()
+    del src
+    torch.cuda.empty_cache()
+    return d, big
+
+
+def test_hg38_sample_against_oracle_and_linearity_at_full_batch(hg38):
+    d, (tb, tq, to) = hg38
+    prefix = d + "/idx"
+    n = len(to) - 1
+    sample = synth.reads_to_host(tb, tq, to, 1_000_000, 1_100_000)
+    ox = O.OracleIndex.load(prefix)
+    ox.process(sample.bases, sample.quals, sample.offsets, nthreads=min(32, os.cpu_count() or 1))
+    so, want = ox.sites(), ox.stats.as_dict()
+    ox.close()
+    with GenoIndex.open(prefix) as gx:
+        assert gx.device_bytes > 150e9                               # the whole index, with its views, is resident
+        b0, b1 = int(to[1_000_000].item()), int(to[1_100_000].item())
+        so_dev = (to[1_000_000:1_100_001] - to[1_000_000]).contiguous()
+        for stats in (True, False):                                  # counting build, then the timed build
+            gx.reset()
+            gx.set_stats(stats)
+            gx.process_device(tb[b0:b1], tq[b0:b1], so_dev, 100_000)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), "stats=%s" % stats
+            if stats:
+                st = gx.stats()
+                for k, v in want.items():
+                    assert st[k] == v, k
+        # the full 8 M-read step: uneven shards in reverse order add up to the whole; the clamp is min(63, sum)
+        gx.reset()
+        gx.set_stats(False)
+        gx.process_device(tb, tq, to, n)
+        whole = _raw(gx)
+        assert whole.sum() > 2 * n
+        gx.reset()
+        cuts = [0, 1, 3_000_001, 3_000_002, 7_654_321, n]
+        for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
+            c0, c1 = int(to[lo].item()), int(to[hi].item())
+            gx.process_device(tb[c0:c1], tq[c0:c1], (to[lo:hi + 1] - to[lo]).contiguous(), hi - lo)
+            gx.sync()
+        assert np.array_equal(_raw(gx), whole)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, np.minimum(whole[0::2], 63)) and np.array_equal(ac, np.minimum(whole[1::2], 63))

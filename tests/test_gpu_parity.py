@@ -58,7 +58,7 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
         assert tm["ms_main"] > 0 and tm["batches"] == 1
 
 
-@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_SEC", "VG_NO_PACK_OVERLAP"])
+@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_SEC", "VG_NO_PACK_OVERLAP", "VG_NO_PROBE_VIEW"])
 def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
     """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view) and runs
     its pack kernel on a separate stream.  Each has a fallback (less HBM, one stream); all must give the reference's bits.
@@ -198,6 +198,50 @@ def test_fsmall_full_parity_through_all_tiers(tmp_path):
             assert st[k] == want[k], k
         assert st["overflow_reads"] > 0 and st["large_block"] > 0 and st["scan_oob"] > 0
         print("fsmall tiers: spilled %d of %d reads, %d to the lane tier" % (st["overflow_reads"], r.n, st["overflow_deep"]))
+
+
+def test_dense_snp_buckets_parity_all_layouts(tmp_path, monkeypatch):
+    """synth.f_dense: ~150 SNP-dictionary entries per HI24 bucket (the bucket shape of BASELINE.json configs[4], hg38 + full
+    dbSNP) and dense HI32 / LO32 buckets -- stage B's strided scans run hundreds of probes per gate-open chunk, merged-view
+    buckets need the bisection path, LO32-view runs exceed what one lane walks.  Counters and event counts equal the
+    oracle's (itself pinned on this fixture against the reference, tests/test_oracle_golden.py) for the counting build, the
+    timed build, and the layout a > 2^32-entry index falls back to (no merged view / direct table)."""
+    import subprocess
+    import time
+
+    from vargeno_amd import synth
+
+    g, s, r = synth.f_dense()
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    prefix = os.path.join(d, "idx")
+    ox = O.OracleIndex.load(prefix)
+    ox.process(r.bases, r.quals, r.offsets, nthreads=8)
+    so = ox.sites()
+    want = ox.stats.as_dict()
+    assert want["scan_snp"] > 100 * want["gate_open"]
+    rows = []
+    for label, env in (("all views", {}), ("no merged view (the > 2^32-entry fallback)", {"VG_NO_MX": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with GenoIndex.open(prefix) as gx:
+            gx.submit(r.bases, r.quals, r.offsets)                   # counting build
+            rc, ac = gx.counts()
+            st = gx.stats()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), label
+            for k in CMP_STATS:
+                assert st[k] == want[k], (label, k)
+            gx.reset()
+            gx.set_stats(False)                                      # timed build
+            t0 = time.time()
+            gx.submit(r.bases, r.quals, r.offsets)
+            rc, ac = gx.counts()
+            rows.append((label, time.time() - t0, gx.timing()["ms_main"], st["overflow_reads"]))
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), label
+    for row in rows:
+        print("f_dense %-45s %.3f s wall, wave kernel %.3f ms, %d of %d reads spilled" % (row + (r.n,)))
 
 
 def test_edge_reads(ftiny_dir):

@@ -128,3 +128,30 @@ def test_oracle_reproduces_reference_vcf_on_fsmall(tmp_path):
     ix.process(r.bases, r.quals, r.offsets)
     fixed = O.calls_by_key(ix.sites(), index_io.read_chrlens(os.path.join(d, "idx.chrlens")))
     assert sum(1 for k in ref if fixed.get(k) != ref[k]) > 1000
+
+
+def test_oracle_reproduces_reference_vcf_on_fdense(tmp_path):
+    """Third pin: the dense-bucket fixture (synth.f_dense: ~150 SNP k-mers per HI24 bucket, the shape of hg38 + full dbSNP,
+    where iterate_snp_dict's strided scan walks hundreds of entries per gate-open chunk).  Index by the product's `vargeno
+    index`, proven byte-identical to the reference's files first; then GT and GQ of every record the reference called."""
+    import subprocess
+
+    from conftest import BIN
+
+    g, s, r = synth.f_dense()
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    want = read_sha256_list("fdense")
+    for fn in ("ref.fa", "snps.vcf", "idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf", "idx.snp.bf"):
+        assert _sha(os.path.join(d, fn)) == want[fn], fn
+    ix = O.OracleIndex.load(os.path.join(d, "idx"))
+    assert ix.process(r.bases, r.quals, r.offsets, nthreads=4) == 0
+    mine = O.calls_by_key(ix.sites(), index_io.read_chrlens(os.path.join(d, "idx.chrlens")))
+    ref = O.parse_vcf_calls(os.path.join(GOLDEN, "fdense.out.vcf.gz"))
+    assert len(ref) > 10_000
+    assert mine == ref
+    st = ix.stats.as_dict()
+    assert st["scan_snp"] > 100 * st["gate_open"]              # the scans are two orders of magnitude longer than on F-tiny
+    assert st["large_block"] > 0 and st["aux_snp"] > 0

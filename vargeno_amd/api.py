@@ -107,6 +107,18 @@ class GenoIndex:
         check(lib().vg_fastq_submit(self._h, _ptr(text), len(text), C.byref(n), C.byref(used), C.byref(last)))
         return int(n.value), int(used.value), int(last.value)
 
+    def fastq_stream(self, chunks):
+        """FASTQ text as a stream of byte chunks cut anywhere (numpy uint8 arrays / bytes; pinned host memory copies at link
+        speed): the device frames records across the cuts.  Returns (records, bytes consumed, start of the last framed
+        record, refused) once everything pushed has been processed."""
+        check(lib().vg_fastq_stream_begin(self._h))
+        for ch in chunks:
+            a = np.frombuffer(ch, dtype=np.uint8) if isinstance(ch, (bytes, bytearray, memoryview)) else np.ascontiguousarray(ch, dtype=np.uint8)
+            check(lib().vg_fastq_stream_push(self._h, _ptr(a), len(a)))
+        n, used, last, refused = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        check(lib().vg_fastq_stream_end(self._h, C.byref(n), C.byref(used), C.byref(last), C.byref(refused)))
+        return int(n.value), int(used.value), int(last.value), bool(refused.value)
+
     def process_device(self, d_bases, d_quals, d_offsets, n_reads):
         """Device-resident batch: torch CUDA tensors (uint8, uint8, int64/uint64 offsets[n+1])."""
         check(lib().vg_reads_process_device(self._h, C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_quals.data_ptr()),
@@ -169,6 +181,24 @@ class GenoIndex:
             __cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2, "strides": None}
 
         return torch.as_tensor(_Alias(), device="cuda:%d" % self.device)
+
+
+def pinned_buffer(nbytes):
+    """Page-locked host memory: (numpy uint8 view, owner).  Keep `owner` alive as long as the view is used."""
+    p = lib().vg_host_alloc_pinned(int(nbytes))
+    if not p:
+        raise MemoryError("vg_host_alloc_pinned(%d)" % nbytes)
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+            self.buf = (C.c_uint8 * int(nbytes)).from_address(ptr)
+
+        def __del__(self):
+            lib().vg_host_free_pinned(self.ptr)
+
+    own = _Owner(p)
+    return np.ctypeslib.as_array(own.buf), own
 
 
 def all_reduce_devices(indexes):

@@ -20,6 +20,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -130,9 +134,11 @@ struct BitVec {
 	// 0.14 GB whatever the genome size, and for small genomes almost every page stays untouched.
 	static constexpr size_t BLK_WORDS = 1 << 17;           // 1 MiB
 	uint64_t bits; size_t nwords; uint64_t *w; std::vector<uint8_t> dirty;
-	explicit BitVec(uint64_t b) : bits(b), nwords((size_t)((b + 63) / 64)), w(nullptr), dirty((nwords + BLK_WORDS - 1) / BLK_WORDS, 0)
+	// dense: nearly every page will be touched (a genome of hundreds of Mbp) -- populate the mapping up front, in one go, instead
+	// of taking a page fault per 4 KiB from every thread at once
+	explicit BitVec(uint64_t b, bool dense = false) : bits(b), nwords((size_t)((b + 63) / 64)), w(nullptr), dirty((nwords + BLK_WORDS - 1) / BLK_WORDS, 0)
 	{
-		void *p = mmap(nullptr, nwords * 8, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+		void *p = mmap(nullptr, nwords * 8, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | (dense ? MAP_POPULATE : MAP_NORESERVE), -1, 0);
 		if (p == MAP_FAILED) die("cannot map a bit vector");
 		w = (uint64_t *)p;
 	}
@@ -242,33 +248,81 @@ static void partition_records(size_t n_chunks, Produce &&produce, Partitioned<T>
 	}
 }
 
-// A dictionary file under construction: fixed-size records region + auxiliary rows region, filled piecewise by many threads
-// through a shared mapping of the (pre-sized) file -- page-cache pages are faulted in and copied to in parallel, where
-// write() calls on one file take turns on its inode lock.  VARGENO_WRITE_MODE=pwrite uses positioned writes instead.
+// A dictionary file under construction: fixed-size records region + auxiliary rows region, produced bucket by bucket by many
+// threads.  How the bytes reach the file (VARGENO_WRITE_MODE), measured on the MI355X host (256 threads, overlayfs and
+// tmpfs alike, 5.2 GB dictionary; profiles/io_probe.sh):
+//   pwrite  (default)     every producer writes its own buffers at their offsets: 2.4 GB/s (the file's inode lock serialises the
+//                         copies, but nothing else waits);
+//   stream                producers hand buffers to ONE writer thread: 1.0 GB/s;
+//   mmap                  producers copy into a shared mapping of the pre-sized file: 0.4 GB/s (page-fault bound; 150 s for the
+//                         43 GB hg38 dictionary).
 struct DictFile {
-	int fd = -1; std::string path; uint8_t *map = nullptr; size_t size = 0;
+	enum Mode { STREAM, PWRITE, MMAP };
+	int fd = -1; std::string path; uint8_t *map = nullptr; size_t size = 0; Mode mode = PWRITE;
+	struct Piece { std::vector<uint8_t> data; uint64_t off; };
+	std::deque<Piece> queue; size_t queued = 0; bool closing = false; std::string error;
+	std::mutex mu; std::condition_variable cv_push, cv_pop; std::thread writer;
+	static constexpr size_t QUEUE_BYTES = (size_t)2 << 30;
+
 	DictFile(const std::string &p, size_t bytes) : path(p), size(bytes)
 	{
 		fd = open(p.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
 		if (fd < 0) die("cannot write " + p);
 		if (ftruncate(fd, (off_t)bytes) != 0) die("cannot size " + p);
-		const char *mode = getenv("VARGENO_WRITE_MODE");
-		if (!(mode && strcmp(mode, "pwrite") == 0)) {
+		if (const char *m = getenv("VARGENO_WRITE_MODE")) mode = !strcmp(m, "mmap") ? MMAP : !strcmp(m, "pwrite") ? PWRITE : !strcmp(m, "stream") ? STREAM : mode;
+		if (mode == MMAP) {
 			void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-			if (m != MAP_FAILED) map = (uint8_t *)m;             // (a file system without shared mappings: positioned writes)
+			if (m != MAP_FAILED) map = (uint8_t *)m; else mode = PWRITE;
 		}
+		if (mode == STREAM) writer = std::thread([this] { drain(); });
 	}
-	~DictFile() { if (map) munmap(map, size); if (fd >= 0) close(fd); }
-	void write_at(const void *src, size_t n, uint64_t off) const
+	~DictFile() { finish_nothrow(); if (map) munmap(map, size); if (fd >= 0) close(fd); }
+	void pwrite_all(const void *src, size_t n, uint64_t off)
 	{
-		if (map) { memcpy(map + off, src, n); return; }
 		const char *p = (const char *)src;
 		while (n) {
 			const ssize_t w = pwrite(fd, p, n, (off_t)off);
-			if (w <= 0) die("write failed: " + path);
+			if (w <= 0) { std::lock_guard<std::mutex> g(mu); if (error.empty()) error = "write failed: " + path; return; }
 			p += w; n -= (size_t)w; off += (uint64_t)w;
 		}
 	}
+	void drain()
+	{
+		for (;;) {
+			Piece pc;
+			{
+				std::unique_lock<std::mutex> g(mu);
+				cv_pop.wait(g, [&] { return !queue.empty() || closing; });
+				if (queue.empty()) return;
+				pc = std::move(queue.front()); queue.pop_front();
+				queued -= pc.data.size();
+			}
+			cv_push.notify_all();
+			pwrite_all(pc.data.data(), pc.data.size(), pc.off);
+		}
+	}
+	// takes the buffer (left empty)
+	void write_at(std::vector<uint8_t> &buf, uint64_t off)
+	{
+		if (buf.empty()) return;
+		if (mode == MMAP) { memcpy(map + off, buf.data(), buf.size()); return; }
+		if (mode == PWRITE) { pwrite_all(buf.data(), buf.size(), off); return; }
+		std::unique_lock<std::mutex> g(mu);
+		cv_push.wait(g, [&] { return queued < QUEUE_BYTES; });
+		queued += buf.size();
+		queue.push_back(Piece{std::move(buf), off});
+		g.unlock();
+		cv_pop.notify_one();
+	}
+	void finish_nothrow()
+	{
+		if (writer.joinable()) {
+			{ std::lock_guard<std::mutex> g(mu); closing = true; }
+			cv_pop.notify_all();
+			writer.join();
+		}
+	}
+	void finish() { finish_nothrow(); if (!error.empty()) die(error); }
 };
 
 struct KP { uint64_t kmer; uint32_t pos; uint32_t pad; };
@@ -309,8 +363,9 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 	{
 		std::vector<Seq> g = parse_fasta_bf(fa);
 		pt.lap("FASTA parsed (bit-vector side)");
-		BitVec bf(REF_BF_BITS);
-		BitVec lite(opt.write_lite ? REF_LITE_BF_BITS : 64);
+		const bool dense = fa.size() > ((size_t)256 << 20);
+		BitVec bf(REF_BF_BITS, dense);
+		BitVec lite(opt.write_lite ? REF_LITE_BF_BITS : 64, dense && opt.write_lite);
 		for (const Seq &s : g) {
 			if (s.seq.size() < 32) die("reference sequence shorter than 32 bases: " + s.name);      // assert, generate_bf.cc:104
 			const size_t nwin = s.seq.size() - 31;
@@ -530,7 +585,7 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 		pt.lap("SNP k-mers sorted");
 		// records: k-mer u64, pos u32, snp u8, ambig u8, ref_freq u8, alt_freq u8; rows: k-mer u64 + 10 x {pos u32, snp, rf, af}
 		DictFile out(prefix + ".snp.dict", 16 + 16 * written + 78 * aux_count);
-		{ uint64_t head[2] = {written, aux_count}; out.write_at(head, 16, 0); }
+		{ std::vector<uint8_t> head(16); memcpy(&head[0], &written, 8); memcpy(&head[8], &aux_count, 8); out.write_at(head, 0); }
 		uint64_t unamb = 0, amb_unique = 0, amb_total = 0;
 		#pragma omp parallel for schedule(dynamic, 8) reduction(+ : unamb, amb_unique, amb_total)
 		for (long b = 0; b < (long)N_PART; b++) {
@@ -560,9 +615,10 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 				w += 16;
 				p = q;
 			}
-			if (!rec.empty()) out.write_at(rec.data(), rec.size(), 16 + 16 * n_rec[(size_t)b]);
-			if (!rows.empty()) out.write_at(rows.data(), rows.size(), 16 + 16 * written + 78 * n_aux[(size_t)b]);
+			out.write_at(rec, 16 + 16 * n_rec[(size_t)b]);
+			out.write_at(rows, 16 + 16 * written + 78 * n_aux[(size_t)b]);
 		}
+		out.finish();
 		pt.lap("SNP dictionary written");
 		if (!opt.quiet) {
 			printf("SNP Dictionary\nTotal k-mers:        %lu\nUnambig k-mers:      %lu\nAmbig unique k-mers: %lu\nAmbig total k-mers:  %lu\n",
@@ -605,7 +661,7 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 		// write_kmers (dictgen.c:63-154): records k-mer u64, pos u32, ambig u8; a k-mer with 2..10 copies points at a row of 10 u32
 		// positions, one with more gets POS_AMBIGUOUS
 		DictFile out(prefix + ".ref.dict", 16 + 13 * written + 40 * aux_count);
-		{ uint64_t head[2] = {written, aux_count}; out.write_at(head, 16, 0); }
+		{ std::vector<uint8_t> head(16); memcpy(&head[0], &written, 8); memcpy(&head[8], &aux_count, 8); out.write_at(head, 0); }
 		uint64_t unamb = 0, amb_unique = 0, amb_total = 0;
 		#pragma omp parallel for schedule(dynamic, 8) reduction(+ : unamb, amb_unique, amb_total)
 		for (long b = 0; b < (long)N_PART; b++) {
@@ -632,9 +688,10 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 				w += 13;
 				p = q;
 			}
-			if (!rec.empty()) out.write_at(rec.data(), rec.size(), 16 + 13 * n_rec[(size_t)b]);
-			if (!rows.empty()) out.write_at(rows.data(), rows.size(), 16 + 13 * written + 40 * n_aux[(size_t)b]);
+			out.write_at(rec, 16 + 13 * n_rec[(size_t)b]);
+			out.write_at(rows, 16 + 13 * written + 40 * n_aux[(size_t)b]);
 		}
+		out.finish();
 		pt.lap("reference dictionary written");
 		if (!opt.quiet) {
 			printf("Ref Dictionary\nTotal k-mers:        %lu\nUnambig k-mers:      %lu\nAmbig unique k-mers: %lu\nAmbig total k-mers:  %lu\n",

@@ -5,13 +5,23 @@
 // HIP library through the C-ABI of include/vargeno_hip.h only.  Extra knobs come from the
 // environment so that the argument list stays the reference's:
 //   VARGENO_GPUS=n        shard read batches over n GPUs of this node (default 1), counters summed with RCCL
-//   VARGENO_BATCH=n       reads per submitted batch (default 4194304)
+//   VARGENO_BATCH=n       reads per batch of the host-framed path (default 4194304)
+//   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk sent to the device (default 64; 256 with several GPUs)
+//   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default 8)
+//   VARGENO_HOST_FASTQ=1  frame the FASTQ on the host (the reference's four fgets per record) instead of on the device
 //   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
+#include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -66,13 +76,82 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	fprintf(stderr, "Processing...\n");
 	struct timespec t_loaded; clock_gettime(CLOCK_MONOTONIC, &t_loaded);
 	uint64_t total = 0; int next_gpu = 0;
-	// Default ingest: the file is read in large chunks and FRAMED ON THE DEVICE (vg_fastq_submit); the host only moves
-	// bytes.  A chunk with a line beyond fgets' 1023 characters, and the (possibly truncated) tail of the file, go
-	// through the host reader, which reproduces the reference's four-fgets framing exactly, stale buffers included.
+	// Default ingest: the file is read in large chunks and FRAMED ON THE DEVICE; the host only moves bytes.  Whatever the
+	// device refuses (from the first chunk with a line beyond fgets' 1023 characters on), and the (possibly truncated) tail of
+	// the file, go through the host reader, which reproduces the reference's four-fgets framing exactly, stale buffers included.
 	const bool host_framing = env_int("VARGENO_HOST_FASTQ", 0) != 0;
 	uint64_t host_from = 0;                    // file offset the host reader takes over from
 	uint64_t prime_from = UINT64_MAX;          // start of the last record the device framed (to prime the stale buffers)
-	if (!host_framing) {
+	if (!host_framing && ngpu == 1) {
+		// One GPU: the file is a byte stream to the device.  Reader threads pread() it piecewise into a ring of pinned chunk
+		// buffers; this thread pushes the chunks in file order (vg_fastq_stream_push returns as soon as a chunk is on the
+		// device) and learns what was framed only at the end.
+		const int fd = open(fastq.c_str(), O_RDONLY);
+		if (fd < 0) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
+		struct stat sb;
+		if (fstat(fd, &sb) != 0) { close(fd); fprintf(stderr, "vargeno: cannot stat %s\n", fastq.c_str()); return EXIT_FAILURE; }
+		const uint64_t fsize = (uint64_t)sb.st_size;
+		const uint64_t chunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", 64)) << 20;
+		const uint64_t piece = std::min<uint64_t>(chunk, 8ull << 20);
+		const uint64_t n_chunks = (fsize + chunk - 1) / chunk;
+		const int NBUF = 4;
+		std::vector<uint8_t *> ring((size_t)NBUF, nullptr);
+		std::vector<std::vector<uint8_t>> pageable((size_t)NBUF);
+		for (int i = 0; i < NBUF; i++) {
+			ring[(size_t)i] = (uint8_t *)vg_host_alloc_pinned((size_t)chunk);
+			if (!ring[(size_t)i]) { pageable[(size_t)i].resize((size_t)chunk); ring[(size_t)i] = pageable[(size_t)i].data(); }
+		}
+		std::mutex mu; std::condition_variable cv;
+		std::vector<uint32_t> left((size_t)n_chunks);               // pieces of chunk i still to be read
+		for (uint64_t i = 0; i < n_chunks; i++) { const uint64_t len = std::min(chunk, fsize - i * chunk); left[(size_t)i] = (uint32_t)((len + piece - 1) / piece); }
+		uint64_t pushed = 0;                                        // chunks handed to the device (their buffers are free again)
+		std::atomic<uint64_t> next_piece{0};
+		const uint64_t ppc = (chunk + piece - 1) / piece;           // pieces per (full) chunk
+		bool io_error = false;
+		const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", 8), 64));
+		std::vector<std::thread> readers;
+		for (int t = 0; t < n_readers; t++) readers.emplace_back([&] {
+			for (;;) {
+				const uint64_t p = next_piece.fetch_add(1);
+				const uint64_t ci = p / ppc, off = ci * chunk + (p % ppc) * piece;
+				if (ci >= n_chunks) return;
+				if (off >= std::min(fsize, (ci + 1) * chunk)) continue;
+				{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ci < pushed + (uint64_t)NBUF || io_error; }); if (io_error) return; }
+				uint64_t n = std::min(piece, std::min(fsize, (ci + 1) * chunk) - off), done = 0;
+				uint8_t *dst = ring[(size_t)(ci % NBUF)] + (off - ci * chunk);
+				while (done < n) {
+					const ssize_t g = pread(fd, dst + done, (size_t)(n - done), (off_t)(off + done));
+					if (g <= 0) break;
+					done += (uint64_t)g;
+				}
+				std::lock_guard<std::mutex> g(mu);
+				if (done < n) io_error = true;
+				left[(size_t)ci]--;
+				cv.notify_all();
+			}
+		});
+		int rc = vg_fastq_stream_begin(ix[0]);
+		for (uint64_t i = 0; i < n_chunks && rc == VG_OK; i++) {
+			{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return left[(size_t)i] == 0 || io_error; }); if (io_error) break; }
+			rc = vg_fastq_stream_push(ix[0], ring[(size_t)(i % NBUF)], std::min(chunk, fsize - i * chunk));
+			{ std::lock_guard<std::mutex> g(mu); pushed = i + 1; }
+			cv.notify_all();
+		}
+		{ std::lock_guard<std::mutex> g(mu); if (rc != VG_OK) io_error = true; pushed = n_chunks; }
+		cv.notify_all();
+		for (auto &t : readers) t.join();
+		close(fd);
+		if (rc != VG_OK) { fprintf(stderr, "vargeno: FASTQ stream failed (%d): %s\n", rc, vg_last_error()); exit(EXIT_FAILURE); }
+		if (io_error) { fprintf(stderr, "vargeno: error reading %s\n", fastq.c_str()); exit(EXIT_FAILURE); }
+		uint64_t nrec = 0, used = 0, last = 0; int refused = 0;
+		VG_CHECK(vg_fastq_stream_end(ix[0], &nrec, &used, &last, &refused));
+		for (int i = 0; i < NBUF; i++) if (pageable[(size_t)i].empty()) vg_host_free_pinned(ring[(size_t)i]);
+		total += nrec;
+		if (nrec) prime_from = last;
+		host_from = used;                                           // the incomplete tail, or everything from a refused chunk on
+	} else if (!host_framing) {
+		// Several GPUs: chunks go round robin and each is framed on its own (the carry-over of a stream lives on one device), so
+		// the host learns what a chunk consumed before it reads the next.
 		FILE *f = fopen(fastq.c_str(), "rb");
 		if (!f) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
 		const size_t chunk = (size_t)env_int("VARGENO_CHUNK_MB", 256) << 20;

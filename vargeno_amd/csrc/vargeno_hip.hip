@@ -169,7 +169,8 @@ __device__ inline bool aux_pair(const uint32_t *__restrict__ aux, uint32_t row, 
 	return p1 != 0 && r[2] == 0;
 }
 // direct table: the first entry of every HI32 bucket of the merged view, inline.  flags: 1 non-empty, 2 SNP entry, 4 ambiguous,
-// 8 PAIR (single-entry buckets only: a longer bucket needs w for the index of its entries), bits 8.. = entries in the bucket
+// 8 PAIR (single-entry buckets only: a longer bucket needs w for the index of its entries), 16 TIE (the second entry has the
+// first one's k-mer: a query that matches the first entry of a bucket without it needs no further entry), bits 8.. = entries
 __global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ dx,
                                const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos, uint32_t *__restrict__ too_big)
 {
@@ -181,6 +182,7 @@ __global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__r
 			const uint32_t cnt = hi - lo > 0xFFFFFFu ? 0xFFFFFFu : hi - lo;
 			if (hi - lo > 0xFFFFFFu) atomicOr(too_big, 1u);          // the count field is 24 bits wide: the host keeps the jump-table form
 			r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (cnt << 8), lo);
+			if (cnt > 1u && mx[lo + 1].x == e.x) r.z |= 16u;            // TIE: the second entry carries the same k-mer (reference + SNP dictionary)
 			uint32_t p0, p1;
 			if (cnt == 1u && (e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { r.y = p0; r.w = p1; r.z |= 8u; }
 		}
@@ -194,6 +196,15 @@ __global__ void vg_inline_pairs(uint4 *__restrict__ mx, uint64_t n, const uint32
 		uint4 e = mx[i];
 		uint32_t p0, p1;
 		if ((e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { e.y = p0; e.w = p1; e.z |= 4u; mx[i] = e; }
+	}
+}
+// strided-probe view of the SNP dictionary (DevIndex::snp_probe)
+__global__ void vg_make_snp_probe(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ jg, uint64_t n, uint64_t *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t slo = jg[kmer[i] >> 40];
+		const uint64_t t = slo + (i - slo) * SNP_STRIDE;
+		out[i] = t < n ? (kmer[t] & LO40_MASK) : 0ull;
 	}
 }
 __global__ void vg_iota_u32(uint32_t *v, uint64_t n) { for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i; }
@@ -265,9 +276,11 @@ __device__ inline int classify_bad(const uint8_t *p, uint32_t n)
 constexpr uint32_t PACK_T = VG_PACK_T;          // reads (= lanes) per tile
 constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bases; longer reads take the direct path
 __global__ __launch_bounds__(PACK_T) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
-                                                      uint64_t n_reads, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta, uint32_t *__restrict__ invalid_reads)
+                                                      uint64_t n_reads_arg, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta, uint32_t *__restrict__ invalid_reads,
+                                                      const uint32_t *__restrict__ n_reads_dev)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t sm[PACK_LDS + 64];
+	const uint64_t n_reads = n_reads_dev ? (uint64_t)*n_reads_dev : n_reads_arg;     // a batch framed on the device knows its size there
 	for (uint64_t r0 = (uint64_t)blockIdx.x * PACK_T; r0 < n_reads; r0 += (uint64_t)gridDim.x * PACK_T) {
 		const uint64_t r = r0 + threadIdx.x;
 		const uint64_t rl = r0 + PACK_T < n_reads ? r0 + PACK_T : n_reads;
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
                                                       const uint64_t *__restrict__ offsets, uint64_t n_reads_arg, const uint32_t *__restrict__ read_ids,
                                                       const uint32_t *__restrict__ n_ids, uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats, uint32_t *invalid_reads)
 {
-	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;       // a list launch is sized on the device: no host round trip between tiers
+	const uint64_t n_reads = n_ids ? (uint64_t)*n_ids : n_reads_arg;          // a list launch (or a device-framed batch) is sized on the device: no host round trip
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t stride = gridDim.x * blockDim.x;
 	Lane<STATS> L(d, s, gtid);
@@ -410,32 +423,73 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 
 // ------------------------------------------------------------------------------------------------
 // kernels: FASTQ framing on the device (reference src/qv.cc:760-784: four fgets() per record)
+//
+// The text arrives as a STREAM of arbitrary byte chunks (vg_fastq_stream_push).  Everything a chunk's framing needs to know
+// about its predecessor -- the bytes of the record the previous chunk ended in the middle of -- stays on the device, so the
+// host never waits for a result: it only moves bytes.  A chunk's buffer keeps FQ_CARRY bytes free in front of the copied
+// text; the carried bytes are put right before it and the chunk's text starts there.
 // ------------------------------------------------------------------------------------------------
-int vg_dev_exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream);   // vg_sort.hip
-int vg_dev_exclusive_scan_u64(const uint64_t *in, uint64_t *out, size_t n, hipStream_t stream);
+size_t vg_dev_scan_temp_bytes(size_t n_u32, size_t n_u64);                                             // vg_sort.hip
+int vg_dev_exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, hipStream_t stream, void *tmp, size_t tmp_bytes);
+int vg_dev_exclusive_scan_u64(const uint64_t *in, uint64_t *out, size_t n, hipStream_t stream, void *tmp, size_t tmp_bytes);
 
 constexpr uint32_t FQ_TILE = 4096;                   // bytes per workgroup tile (256 lanes x 16 bytes)
+constexpr uint32_t FQ_CARRY = 1u << 16;              // room in front of a chunk for the unfinished record of the chunk before (4 lines <= 4 KiB)
 
-// newlines per 4 KiB tile
-__global__ __launch_bounds__(256) void vg_fq_count_newlines(const uint8_t *__restrict__ text, uint64_t nbytes, uint32_t *__restrict__ tile_cnt)
+struct FqStream {                                    // one per handle, device resident
+	unsigned long long consumed;                     // bytes of the stream framed into complete records so far
+	unsigned long long records;                      // ... and their number
+	unsigned long long last_record;                  // stream offset of the last of them
+	uint32_t carry;                                  // bytes of the previous chunk's text that belong to its unfinished last record
+	uint32_t poisoned;                               // a chunk could not be framed here: it and everything after it is left to the host
+};
+struct FqChunk {                                     // one per batch slot, device resident
+	uint32_t start, len;                             // the chunk's text is buf[start, start + len)
+	uint32_t n_reads;                                // complete records framed (0 when refused)
+	uint32_t bad;                                    // this chunk needs the host's framing (a line beyond fgets' 1023 characters, ...)
+	unsigned long long total;                        // bases of the batch
+};
+
+// carried bytes in front of the new text; start / length of the chunk's text
+__global__ __launch_bounds__(256) void vg_fqs_prepare(const FqStream *__restrict__ st, FqChunk *__restrict__ ck, const uint8_t *__restrict__ prev_end, uint8_t *__restrict__ buf, uint32_t nbytes)
+{
+	const uint32_t c = prev_end ? st->carry : 0u;
+	for (uint32_t i = threadIdx.x; i < c; i += 256) buf[FQ_CARRY - c + i] = prev_end[(int64_t)i - (int64_t)c];
+	if (threadIdx.x == 0) { ck->start = FQ_CARRY - c; ck->len = c + nbytes; ck->n_reads = 0; ck->bad = st->poisoned; ck->total = 0; }
+}
+
+// newlines per 4 KiB tile of the buffer (bytes outside the chunk's text do not count)
+__global__ __launch_bounds__(256) void vg_fq_count_newlines(const uint8_t *__restrict__ buf, const FqChunk *__restrict__ ck, uint32_t *__restrict__ tile_cnt)
 {
 	__shared__ uint32_t wsum[4];
-	const uint64_t base = (uint64_t)blockIdx.x * FQ_TILE + (uint64_t)threadIdx.x * 16;
+	const uint32_t lo = ck->start, hi = lo + ck->len;
+	const uint32_t base = blockIdx.x * FQ_TILE + threadIdx.x * 16;
 	uint32_t c = 0;
-	for (uint32_t j = 0; j < 16; j++) if (base + j < nbytes && text[base + j] == '\n') c++;
+	if (base + 16 > lo && base < hi) {
+		uint4 v;
+		__builtin_memcpy(&v, buf + base, 16);                     // the buffer is padded to a whole tile
+		const uint8_t *b = (const uint8_t *)&v;
+		for (uint32_t j = 0; j < 16; j++) if (base + j >= lo && base + j < hi && b[j] == '\n') c++;
+	}
 	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
 	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
 	__syncthreads();
 	if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// line_start[g + 1] = byte after the g-th newline (line_start[0] = 0 is set by the host side)
-__global__ __launch_bounds__(256) void vg_fq_line_starts(const uint8_t *__restrict__ text, uint64_t nbytes, const uint32_t *__restrict__ tile_off, uint32_t *__restrict__ line_start)
+// line_start[g + 1] = byte after the g-th newline; line_start[0] = start of the text
+__global__ __launch_bounds__(256) void vg_fq_line_starts(const uint8_t *__restrict__ buf, FqChunk *__restrict__ ck, const uint32_t *__restrict__ tile_off, uint32_t *__restrict__ line_start, uint32_t cap_lines)
 {
 	__shared__ uint32_t wsum[4];
-	const uint64_t base = (uint64_t)blockIdx.x * FQ_TILE + (uint64_t)threadIdx.x * 16;
+	const uint32_t lo = ck->start, hi = lo + ck->len;
+	const uint32_t base = blockIdx.x * FQ_TILE + threadIdx.x * 16;
 	uint32_t mask = 0;
-	for (uint32_t j = 0; j < 16; j++) if (base + j < nbytes && text[base + j] == '\n') mask |= 1u << j;
+	if (base + 16 > lo && base < hi) {
+		uint4 v;
+		__builtin_memcpy(&v, buf + base, 16);
+		const uint8_t *b = (const uint8_t *)&v;
+		for (uint32_t j = 0; j < 16; j++) if (base + j >= lo && base + j < hi && b[j] == '\n') mask |= 1u << j;
+	}
 	const uint32_t c = (uint32_t)__popc(mask);
 	uint32_t incl = c;
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -444,32 +498,60 @@ __global__ __launch_bounds__(256) void vg_fq_line_starts(const uint8_t *__restri
 	__syncthreads();
 	uint32_t g = tile_off[blockIdx.x] + incl - c;
 	for (uint32_t w = 0; w < wv; w++) g += wsum[w];
+	if (blockIdx.x == 0 && threadIdx.x == 0) line_start[0] = lo;
 	while (mask) {
 		const uint32_t j = (uint32_t)__ffs((int)mask) - 1;
 		mask &= mask - 1;
-		line_start[++g] = (uint32_t)(base + j + 1);
+		++g;
+		if (g < cap_lines) line_start[g] = base + j + 1; else ck->bad = 1u;     // lines shorter than 8 bytes on average: host framing
 	}
 }
 
-// one lane per record: read length = strlen(read line) - 1 (qv.cc:778); flags a line longer than fgets' 1023 characters
-__global__ void vg_fq_record_lengths(const uint32_t *__restrict__ line_start, uint64_t n_rec, uint64_t *__restrict__ rlen, uint32_t *too_long)
+// one lane per record: read length = strlen(read line) - 1 (qv.cc:778); slots past the last record get length 0 (the scan
+// that follows runs over the whole capacity).  A line longer than fgets' 1023 characters, or a quality line without a
+// character for every chunk (it would expose the reference's stale buffer contents), refuses the chunk.
+__global__ void vg_fq_record_lengths(const uint32_t *__restrict__ line_start, const uint32_t *__restrict__ n_lines_p, FqChunk *__restrict__ ck, uint64_t *__restrict__ rlen, uint32_t cap_rec, uint32_t cap_lines)
 {
-	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += (uint64_t)gridDim.x * blockDim.x) {
-		bool bad = false;
-		for (int l = 0; l < 4; l++) bad |= (line_start[4 * r + l + 1] - line_start[4 * r + l]) > 1023u;
-		const uint32_t len = line_start[4 * r + 2] - line_start[4 * r + 1] - 1u;   // the line's length minus its newline
-		// a quality line without a character for every chunk would expose the reference's stale buffer contents: host framing
-		bad |= (line_start[4 * r + 4] - line_start[4 * r + 3] - 1u) < (len >> 5);
-		if (bad) atomicOr(too_long, 1u);
+	const uint32_t n_lines = *n_lines_p;
+	const uint32_t n_rec = n_lines + 1 <= cap_lines ? n_lines / 4 : 0u;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && (n_lines + 1 > cap_lines || n_rec > cap_rec)) ck->bad = 1u;
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r <= cap_rec; r += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t len = 0;
+		if (r < n_rec && r < cap_rec) {
+			bool bad = false;
+			for (int l = 0; l < 4; l++) bad |= (line_start[4 * r + l + 1] - line_start[4 * r + l]) > 1023u;
+			len = line_start[4 * r + 2] - line_start[4 * r + 1] - 1u;             // the line's length minus its newline
+			bad |= (line_start[4 * r + 4] - line_start[4 * r + 3] - 1u) < (len >> 5);
+			if (bad) ck->bad = 1u;
+		}
 		rlen[r] = len;
 	}
+}
+
+// after the offsets scan: the chunk's verdict, and the stream's state for the next chunk
+__global__ void vg_fqs_finish(FqStream *__restrict__ st, FqChunk *__restrict__ ck, const uint32_t *__restrict__ n_lines_p, const uint32_t *__restrict__ line_start,
+                              const uint64_t *__restrict__ offsets, uint32_t cap_rec)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	if (st->poisoned || ck->bad) { st->poisoned = 1u; ck->bad = 1u; ck->n_reads = 0; ck->total = 0; return; }
+	const uint32_t n_rec = *n_lines_p / 4;
+	const uint32_t end = n_rec ? line_start[4 * n_rec] : ck->start;               // first byte after the last complete record
+	const uint32_t used = end - ck->start, left = ck->len - used;
+	if (left > FQ_CARRY) { st->poisoned = 1u; ck->bad = 1u; return; }            // an unfinished record of more than 64 KiB
+	if (n_rec) st->last_record = st->consumed + (line_start[4 * (n_rec - 1)] - ck->start);
+	st->consumed += used;
+	st->records += n_rec;
+	st->carry = left;
+	ck->n_reads = n_rec;
+	ck->total = offsets[n_rec < cap_rec ? n_rec : cap_rec];
 }
 
 // gather bases and quality characters of every record into the flat batch layout; a quality line shorter than the
 // read keeps what the reference's buffer would hold there: its newline, then NULs (qv.cc:763, 836)
 __global__ __launch_bounds__(256) void vg_fq_gather(const uint8_t *__restrict__ text, const uint32_t *__restrict__ line_start, const uint64_t *__restrict__ offsets,
-                                                    uint64_t n_rec, uint8_t *__restrict__ bases, uint8_t *__restrict__ quals)
+                                                    const FqChunk *__restrict__ ck, uint8_t *__restrict__ bases, uint8_t *__restrict__ quals)
 {
+	const uint64_t n_rec = ck->n_reads;
 	const uint32_t lane = threadIdx.x & 63;
 	const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
 	for (uint64_t r = wave; r < n_rec; r += n_waves) {                          // one wave per record: coalesced copies
@@ -500,6 +582,9 @@ struct Slot {
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
 	uint8_t *fq_text = nullptr; uint32_t *fq_lines = nullptr, *fq_tiles = nullptr; uint64_t fq_text_cap = 0, fq_lines_cap = 0, fq_tiles_cap = 0;   // FASTQ framing
+	void *fq_tmp = nullptr; uint64_t fq_tmp_cap = 0;                 // scan scratch (grow-only: no allocation per chunk)
+	FqChunk *fq_chunk = nullptr;                                     // this chunk's framing results, device resident
+	uint64_t fq_text_len = 0;                                        // bytes of text copied into fq_text (after the FQ_CARRY gap)
 	uint64_t stage_bytes = 0, stage_reads = 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
 	bool busy = false;
@@ -528,6 +613,8 @@ struct vg_index {
 	int cus = 256;
 	int lane_grid_blocks = 0, wave_grid = 0;
 	uint32_t work_chunk = 128;            // reads a main-tier wave pulls from the launch's work counter at a time (VG_WORK_CHUNK)
+	FqStream *d_fq = nullptr;             // FASTQ stream state (vg_fastq_stream_*)
+	bool fq_open = false; int fq_prev_slot = -1;
 };
 
 template <class T>
@@ -596,7 +683,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (ix->ingest) (void)hipStreamSynchronize(ix->ingest);
 	for (void *p : ix->owned) (void)hipFree(p);
 	for (Slot &sl : ix->slot) {
-		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles};
+		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
 		for (void *p : extra) if (p) (void)hipFree(p);
 		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -734,6 +821,14 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		if ((rc = dev_upload(ix, &xp, a->snp_aux_pos, a->n_snp_aux * AUX_COLS))) return rc;
 		if ((rc = dev_upload(ix, &xi, a->snp_aux_info, a->n_snp_aux * AUX_COLS))) return rc;
 		d.snp_jg = jg; d.snp = ent; d.snp_aux_pos = xp; d.snp_aux_info = xi;
+		if (!getenv("VG_NO_PROBE_VIEW")) {
+			uint64_t *pv = nullptr;
+			if ((rc = dev_alloc(ix, &pv, a->n_snp))) return rc;
+			vg_make_snp_probe<<<2048, 256, 0, ix->stream>>>(tk.p, jg, a->n_snp, pv);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(ix->stream));
+			d.snp_probe = pv;
+		}
 		// merged exact-match view (both dictionaries behind one HI32 jump table)
 		const uint64_t nm = a->n_ref + a->n_snp;
 		if (!getenv("VG_NO_MX") && nm < (1ull << 32)) {
@@ -886,6 +981,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
 	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 8, true))) return rc;       // [0..2] spill counts, [4],[5] work counters of the two wave tiers
 	if ((rc = dev_alloc(ix, &ix->d_cum, 4, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	return VG_OK;
@@ -1044,8 +1140,9 @@ static int finish_pending(vg_index *ix)
 
 // One batch = pack -> wave tier on the main stream, then lane tier (mid scratch) -> lane tier (deep scratch)
 // on the tail stream; the list launches size themselves from device counters, so nothing waits for the host.
+// n_reads: the batch's size, or (d_n_reads given) an upper bound of the size the device holds at d_n_reads
 template <bool STATS>
-static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on)
+static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on, const uint32_t *d_n_reads)
 {
 	uint32_t *ctr = sl.ctr;
 	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
@@ -1058,7 +1155,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T - 1) / PACK_T, (uint64_t)ix->cus * pack_bpc * (256 / PACK_T));
-		vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3]);
+		vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads);
 		HIP_TRY(hipEventRecord(sl.e1, ps));
 		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
@@ -1067,12 +1164,12 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));               // the wave kernel's own start
 		ix->cnt4_dirty = true;
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 64 * W1_WPB - 1) / (64 * W1_WPB), (uint64_t)ix->wave_grid / W1_WPB);
-		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_KCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, nullptr, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
+		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		// tail stream, second tier: the same kernel with deep lists over the spill list (2 waves per CU)
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
-		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, W2_KCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], 2u, ix->d_stats);
+		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], 2u, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by vg_fastq_submit on the ingest stream
@@ -1083,7 +1180,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
-		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, nullptr, sl.listB, &ctr[1], ix->d_stats, &ctr[3]);
+		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, &ctr[3]);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
@@ -1107,14 +1204,16 @@ static int acquire_slot(vg_index *ix, Slot **out)
 	return VG_OK;
 }
 
-// produced_on: the stream whose earlier work fills the batch buffers (nullptr: they are complete already)
-static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on = nullptr)
+// produced_on: the stream whose earlier work fills the batch buffers (nullptr: they are complete already).
+// d_n_reads: the batch was framed on the device and only the device knows its size; n_reads and total_bases are then upper bounds.
+static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on = nullptr,
+                        const uint32_t *d_n_reads = nullptr, uint64_t total_bases = 0)
 {
 	if (n_reads >= (1ull << 32) - (1ull << 24)) return fail(VG_EINVAL, "more than 2^32 - 2^24 reads in one batch");
 	// packed-read buffers are sized from the batch's total length (8 bytes from the device; the handle's streams are
 	// non-blocking, so this copy does not wait for kernels in flight)
-	uint64_t total = 0;
-	HIP_TRY(hipMemcpy(&total, d_offsets + n_reads, 8, hipMemcpyDeviceToHost));
+	uint64_t total = total_bases;
+	if (!d_n_reads) HIP_TRY(hipMemcpy(&total, d_offsets + n_reads, 8, hipMemcpyDeviceToHost));
 	if (total >= (1ull << 37)) return fail(VG_ETOOBIG, "a batch of 2^37 bases or more (the kernels address a batch's 32-base slots with 32 bits)");
 	const uint64_t need_k = (total >> 5) + 2, need_m = n_reads + 1;
 	// the slot is idle (acquire_slot harvested it), so its buffers may be replaced
@@ -1127,8 +1226,8 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));
 		sl.list_cap = n_reads;
 	}
-	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_offsets, n_reads, produced_on)
-	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_offsets, n_reads, produced_on);
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_offsets, n_reads, produced_on, d_n_reads)
+	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_offsets, n_reads, produced_on, d_n_reads);
 }
 
 extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
@@ -1186,86 +1285,139 @@ static int submit_impl(vg_index *ix, const uint8_t *bases, const uint8_t *quals,
 	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, n_reads);
 }
 
-// FASTQ text in, framed and processed on the device.  Replaces the four fgets() + strlen of qv.cc:760-784 for a chunk
-// of the file: complete 4-line records are framed (newline scan + prefix sums), gathered into the flat batch layout
-// and run through the read loop; the bytes after the last complete record are the caller's to resubmit.
+// ---- FASTQ text in, framed and processed on the device (replaces the four fgets() + strlen of qv.cc:760-784) ---------------
+template <class T>
+static int grow_dev(T **p, uint64_t &cap, uint64_t need)
+{
+	if (need <= cap) return VG_OK;
+	if (*p) (void)hipFree(*p);
+	*p = nullptr; cap = 0;
+	hipError_t e = hipMalloc((void **)p, (size_t)need * sizeof(T));
+	if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(FASTQ staging): %s", hipGetErrorString(e));
+	cap = need;
+	return VG_OK;
+}
+
+extern "C" int vg_fastq_stream_begin(vg_index *ix)
+{
+	if (!ix) return fail(VG_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(ix->device));
+	hipStream_t is = ix->pack_overlap ? ix->ingest : ix->stream;
+	HIP_TRY(hipMemsetAsync(ix->d_fq, 0, sizeof(FqStream), is));
+	ix->fq_open = true; ix->fq_prev_slot = -1;
+	return VG_OK;
+}
+
+// One chunk of the stream: a blocking host-to-device copy (the caller's buffer is free when the call returns), then framing
+// and the read loop are only ENQUEUED -- record counts stay on the device until vg_fastq_stream_end.
+extern "C" int vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t nbytes)
+{
+	if (!ix || (!text && nbytes)) return fail(VG_EINVAL, "null argument");
+	if (!ix->fq_open) return fail(VG_EINVAL, "vg_fastq_stream_push without vg_fastq_stream_begin");
+	if (nbytes == 0) return VG_OK;
+	if (nbytes >= (1ull << 31)) return fail(VG_EINVAL, "FASTQ chunk of 2 GiB or more");
+	HIP_TRY(hipSetDevice(ix->device));
+	const int slot_no = ix->next_slot;
+	Slot *slp = nullptr;
+	int rc = acquire_slot(ix, &slp);
+	if (rc) return rc;
+	Slot &sl = *slp;
+	hipStream_t is = ix->pack_overlap ? ix->ingest : ix->stream;
+	// capacities follow from the chunk's size alone: lines average at least 8 bytes (or the chunk is refused), a record has four
+	const uint64_t span = (uint64_t)FQ_CARRY + nbytes;
+	const uint64_t n_tiles = (span + FQ_TILE - 1) / FQ_TILE;
+	const uint64_t cap_lines = span / 8 + 16, cap_rec = cap_lines / 4 + 1;
+	if ((rc = grow_dev(&sl.fq_text, sl.fq_text_cap, n_tiles * FQ_TILE + 64))) return rc;
+	if ((rc = grow_dev(&sl.fq_tiles, sl.fq_tiles_cap, n_tiles + 2))) return rc;
+	if ((rc = grow_dev(&sl.fq_lines, sl.fq_lines_cap, cap_lines + 2))) return rc;
+	if (!sl.fq_chunk) { uint64_t one = 0; if ((rc = grow_dev(&sl.fq_chunk, one, 1))) return rc; }
+	if (cap_rec + 2 > sl.stage_reads) {
+		if (sl.st_offsets) (void)hipFree(sl.st_offsets);
+		sl.st_offsets = nullptr; sl.stage_reads = 0;
+		HIP_TRY(hipMalloc((void **)&sl.st_offsets, (cap_rec + 2) * 8));
+		sl.stage_reads = cap_rec + 2;
+	}
+	if (span + 64 > sl.stage_bytes) {                               // bases and quality characters of a chunk are each shorter than its text
+		if (sl.st_bases) (void)hipFree(sl.st_bases);
+		if (sl.st_quals) (void)hipFree(sl.st_quals);
+		sl.st_bases = sl.st_quals = nullptr; sl.stage_bytes = 0;
+		HIP_TRY(hipMalloc((void **)&sl.st_bases, span + 64));
+		HIP_TRY(hipMalloc((void **)&sl.st_quals, span + 64));
+		sl.stage_bytes = span + 64;
+	}
+	{
+		uint8_t *tmp = (uint8_t *)sl.fq_tmp;
+		const uint64_t need = vg_dev_scan_temp_bytes(n_tiles + 1, cap_rec + 1);
+		if ((rc = grow_dev(&tmp, sl.fq_tmp_cap, need))) { sl.fq_tmp = tmp; return rc; }
+		sl.fq_tmp = tmp;
+	}
+	HIP_TRY(hipMemcpy(sl.fq_text + FQ_CARRY, text, nbytes, hipMemcpyHostToDevice));
+	sl.fq_text_len = nbytes;
+	const uint8_t *prev_end = nullptr;
+	if (ix->fq_prev_slot >= 0) { const Slot &pv = ix->slot[ix->fq_prev_slot]; prev_end = pv.fq_text + FQ_CARRY + pv.fq_text_len; }
+	vg_fqs_prepare<<<1, 256, 0, is>>>(ix->d_fq, sl.fq_chunk, prev_end, sl.fq_text, (uint32_t)nbytes);
+	vg_fq_count_newlines<<<(unsigned)n_tiles, 256, 0, is>>>(sl.fq_text, sl.fq_chunk, sl.fq_tiles);
+	HIP_TRY(hipMemsetAsync(sl.fq_tiles + n_tiles, 0, 4, is));
+	HIP_TRY(hipGetLastError());
+	int se = vg_dev_exclusive_scan_u32(sl.fq_tiles, sl.fq_tiles, n_tiles + 1, is, sl.fq_tmp, sl.fq_tmp_cap);
+	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
+	const uint32_t *d_n_lines = sl.fq_tiles + n_tiles;
+	vg_fq_line_starts<<<(unsigned)n_tiles, 256, 0, is>>>(sl.fq_text, sl.fq_chunk, sl.fq_tiles, sl.fq_lines, (uint32_t)cap_lines);
+	vg_fq_record_lengths<<<1024, 256, 0, is>>>(sl.fq_lines, d_n_lines, sl.fq_chunk, sl.st_offsets, (uint32_t)cap_rec, (uint32_t)cap_lines);
+	HIP_TRY(hipGetLastError());
+	se = vg_dev_exclusive_scan_u64(sl.st_offsets, sl.st_offsets, cap_rec + 1, is, sl.fq_tmp, sl.fq_tmp_cap);
+	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
+	vg_fqs_finish<<<1, 1, 0, is>>>(ix->d_fq, sl.fq_chunk, d_n_lines, sl.fq_lines, sl.st_offsets, (uint32_t)cap_rec);
+	vg_fq_gather<<<(unsigned)std::min<uint64_t>((cap_rec + 3) / 4, (uint64_t)ix->cus * 32), 256, 0, is>>>(sl.fq_text, sl.fq_lines, sl.st_offsets, sl.fq_chunk, sl.st_bases, sl.st_quals);
+	HIP_TRY(hipGetLastError());
+	ix->fq_prev_slot = slot_no;
+	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, cap_rec, is, &sl.fq_chunk->n_reads, span);
+}
+
+static int fq_collect(vg_index *ix, bool drain, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start, int *refused)
+{
+	HIP_TRY(hipSetDevice(ix->device));
+	if (drain) { int rc = finish_pending(ix); if (rc) return rc; }
+	else HIP_TRY(hipStreamSynchronize(ix->pack_overlap ? ix->ingest : ix->stream));       // framing only: the read loop runs on
+	FqStream h;
+	HIP_TRY(hipMemcpy(&h, ix->d_fq, sizeof h, hipMemcpyDeviceToHost));
+	if (n_records) *n_records = h.records;
+	if (consumed) *consumed = h.consumed;
+	if (last_record_start) *last_record_start = h.last_record;
+	if (refused) *refused = h.poisoned ? 1 : 0;
+	return VG_OK;
+}
+
+extern "C" int vg_fastq_stream_end(vg_index *ix, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start, int *refused)
+{
+	if (!ix) return fail(VG_EINVAL, "null argument");
+	if (!ix->fq_open) return fail(VG_EINVAL, "vg_fastq_stream_end without vg_fastq_stream_begin");
+	ix->fq_open = false;
+	return fq_collect(ix, true, n_records, consumed, last_record_start, refused);
+}
+
+// One self-contained chunk (a stream of one push): the older, synchronous form of the above -- the caller learns what was
+// framed before it sends the next chunk (and resubmits the unconsumed tail itself).  Waits for the framing, not for the read loop.
 extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbytes, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start)
 {
 	if (!ix || (!text && nbytes) || !n_records || !consumed) return fail(VG_EINVAL, "null argument");
 	*n_records = 0; *consumed = 0;
 	if (last_record_start) *last_record_start = 0;
 	if (nbytes == 0) return VG_OK;
-	if (nbytes >= (1ull << 32) - 64) return fail(VG_EINVAL, "FASTQ chunk of 4 GiB or more");
-	HIP_TRY(hipSetDevice(ix->device));
-	Slot *slp = nullptr;
-	int rc = acquire_slot(ix, &slp);
+	if (ix->fq_open) return fail(VG_EINVAL, "vg_fastq_submit inside an open FASTQ stream");
+	int rc = vg_fastq_stream_begin(ix);
 	if (rc) return rc;
-	Slot &sl = *slp;
-	// framing runs on the ingest stream (under the wave kernel of the batch before); the host reads three small results
-	// back, each after synchronising that stream only
-	hipStream_t is = ix->pack_overlap ? ix->ingest : ix->stream;
-	const uint64_t n_tiles = (nbytes + FQ_TILE - 1) / FQ_TILE;
-	auto grow = [&](void **p, uint64_t &cap, uint64_t need, size_t elem) -> int {
-		if (need <= cap) return VG_OK;
-		if (*p) (void)hipFree(*p);
-		*p = nullptr; cap = 0;
-		hipError_t e = hipMalloc(p, (size_t)need * elem);
-		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(FASTQ staging): %s", hipGetErrorString(e));
-		cap = need;
-		return VG_OK;
-	};
-	if ((rc = grow((void **)&sl.fq_text, sl.fq_text_cap, nbytes + 64, 1))) return rc;
-	if ((rc = grow((void **)&sl.fq_tiles, sl.fq_tiles_cap, n_tiles + 2, 4))) return rc;
-	HIP_TRY(hipMemcpy(sl.fq_text, text, nbytes, hipMemcpyHostToDevice));
-	// newlines per tile -> exclusive scan -> total number of complete lines
-	vg_fq_count_newlines<<<(unsigned)n_tiles, 256, 0, is>>>(sl.fq_text, nbytes, sl.fq_tiles);
-	HIP_TRY(hipMemsetAsync(sl.fq_tiles + n_tiles, 0, 4, is));
-	HIP_TRY(hipGetLastError());
-	int se = vg_dev_exclusive_scan_u32(sl.fq_tiles, sl.fq_tiles, n_tiles + 1, is);
-	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
-	uint32_t n_lines = 0;
-	HIP_TRY(hipStreamSynchronize(is));
-	HIP_TRY(hipMemcpy(&n_lines, sl.fq_tiles + n_tiles, 4, hipMemcpyDeviceToHost));
-	const uint64_t n_rec = n_lines / 4;
-	if (n_rec == 0) return VG_OK;
-	if ((rc = grow((void **)&sl.fq_lines, sl.fq_lines_cap, (uint64_t)n_lines + 2, 4))) return rc;
-	HIP_TRY(hipMemsetAsync(sl.fq_lines, 0, 4, is));                     // line 0 starts at byte 0
-	vg_fq_line_starts<<<(unsigned)n_tiles, 256, 0, is>>>(sl.fq_text, nbytes, sl.fq_tiles, sl.fq_lines);
-	HIP_TRY(hipGetLastError());
-	// read lengths -> offsets of the flat batch
-	if (n_rec + 1 > sl.stage_reads) {
-		if (sl.st_offsets) (void)hipFree(sl.st_offsets);
-		sl.st_offsets = nullptr; sl.stage_reads = 0;
-		HIP_TRY(hipMalloc((void **)&sl.st_offsets, (n_rec + 1) * 8));
-		sl.stage_reads = n_rec + 1;
+	rc = vg_fastq_stream_push(ix, text, nbytes);
+	ix->fq_open = false;
+	if (rc) return rc;
+	int refused = 0;
+	rc = fq_collect(ix, false, n_records, consumed, last_record_start, &refused);
+	if (rc) return rc;
+	if (refused) {
+		*n_records = 0; *consumed = 0;
+		return fail(VG_EBADREAD, "a FASTQ line longer than 1023 characters (reference BUF_SIZE 1024, qv.cc:700), a quality line shorter than the read's chunk count, or lines of fewer than 8 bytes on average: frame this chunk on the host");
 	}
-	uint32_t *d_flag = sl.ctr + 6;                                              // spare word of the slot's counter block
-	HIP_TRY(hipMemsetAsync(d_flag, 0, 4, is));
-	vg_fq_record_lengths<<<1024, 256, 0, is>>>(sl.fq_lines, n_rec, sl.st_offsets, d_flag);
-	HIP_TRY(hipMemsetAsync(sl.st_offsets + n_rec, 0, 8, is));
-	HIP_TRY(hipGetLastError());
-	se = vg_dev_exclusive_scan_u64(sl.st_offsets, sl.st_offsets, n_rec + 1, is);
-	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
-	uint32_t too_long = 0; uint64_t total = 0; uint32_t edges[2] = {0, 0};
-	HIP_TRY(hipStreamSynchronize(is));
-	HIP_TRY(hipMemcpy(&too_long, d_flag, 4, hipMemcpyDeviceToHost));
-	if (too_long) return fail(VG_EBADREAD, "a FASTQ line longer than 1023 characters (reference BUF_SIZE 1024, qv.cc:700) or a quality line shorter than the read's chunk count: frame this chunk on the host");
-	HIP_TRY(hipMemcpy(&total, sl.st_offsets + n_rec, 8, hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(&edges[0], sl.fq_lines + 4 * (n_rec - 1), 4, hipMemcpyDeviceToHost));
-	HIP_TRY(hipMemcpy(&edges[1], sl.fq_lines + 4 * n_rec, 4, hipMemcpyDeviceToHost));
-	if (total + 64 > sl.stage_bytes) {
-		if (sl.st_bases) (void)hipFree(sl.st_bases);
-		if (sl.st_quals) (void)hipFree(sl.st_quals);
-		sl.st_bases = sl.st_quals = nullptr; sl.stage_bytes = 0;
-		HIP_TRY(hipMalloc((void **)&sl.st_bases, total + 64));
-		HIP_TRY(hipMalloc((void **)&sl.st_quals, total + 64));
-		sl.stage_bytes = total + 64;
-	}
-	vg_fq_gather<<<(unsigned)std::min<uint64_t>((n_rec + 3) / 4, (uint64_t)ix->cus * 32), 256, 0, is>>>(sl.fq_text, sl.fq_lines, sl.st_offsets, n_rec, sl.st_bases, sl.st_quals);
-	HIP_TRY(hipGetLastError());
-	*n_records = n_rec; *consumed = edges[1];
-	if (last_record_start) *last_record_start = edges[0];
-	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, n_rec, is);
+	return VG_OK;
 }
 
 extern "C" int vg_sync(vg_index *ix)

@@ -47,7 +47,8 @@ struct DevIndex {
 	const uint32_t *mx_jg;         // [2^32 + 1]   (dropped when the direct table below could be allocated)
 	const uint4 *mx;               // [n_ref + n_snp]
 	// direct table over HI32: one 16-byte record per bucket = the bucket's FIRST merged entry inline {lo32, pos, flags,
-	// index of that entry in mx}, flags bit 0 = bucket non-empty, bit 1 = SNP entry, bit 2 = ambig_flag, bit 3 = PAIR (single-
+	// index of that entry in mx}, flags bit 0 = bucket non-empty, bit 1 = SNP entry, bit 2 = ambig_flag, bit 4 = TIE (the second
+	// entry has the same k-mer), bit 3 = PAIR (single-
 	// entry buckets only: then the last word is the second position), bits 8.. = entries in the bucket.  A bucket with one entry -- the common case -- is settled, hit or miss, by ONE gather.  64 GiB.
 	const uint4 *dx;
 	// SNP dictionary (src/qv.cc:606-695)
@@ -56,6 +57,10 @@ struct DevIndex {
 	const uint32_t *snp_aux_pos;   // [n_snp_aux][10]
 	const uint8_t  *snp_aux_info;  // [n_snp_aux][10]
 	uint64_t n_snp;
+	// strided-probe view of the SNP dictionary: snp_probe[i] = LO40 of entry slo + 11 (i - slo), slo = start of i's HI24 bucket
+	// (0 where that index lies beyond the array) -- exactly the values iterate_snp_dict's scan (bug B1, qv.cc:447-455) tests for a
+	// bucket, laid side by side: at hg38 scale a bucket holds ~19 entries, i.e. 19 lines 176 bytes apart become 3 adjacent ones.
+	const uint64_t *snp_probe;     // [n_snp] (timed build only; nullptr: the probes read `snp` itself)
 	// bit vectors (src/generate_bf.h:112-142)
 	const uint64_t *ref_bf; uint64_t ref_bf_bits;
 	const uint64_t *snp_bf; uint64_t snp_bf_bits;

@@ -58,13 +58,13 @@ namespace vg {
 // with lists 6-8x deeper at 2 waves per CU -- still wave-parallel, so a heavy read costs a few dozen
 // dependent gathers instead of the thousands the sequential lane machine needs.
 #ifndef VG_W1_ECAP
-#define VG_W1_ECAP 12     // exact contexts per lane in the main tier (86 % of the spills at 8 were this list; 12 still leaves 4 workgroups per CU)
+#define VG_W1_ECAP 14     // exact contexts per lane in the main tier (the most that still leaves 4 workgroups per CU; vote keys live with them)
 #endif
 #ifndef VG_W1_WPB
 #define VG_W1_WPB 4
 #endif
-constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_KCAP = 4, W1_WPB = VG_W1_WPB;   // W1_WPB: waves per workgroup of the main tier
-constexpr int W2_ECAP = 48, W2_NCAP = 48, W2_KCAP = 32;
+constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_WPB = VG_W1_WPB;   // W1_WPB: waves per workgroup of the main tier
+constexpr int W2_ECAP = 48, W2_NCAP = 48;
 constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is also what a failed query's -1 truncates to
 #ifndef VG_SEC_W
 #define VG_SEC_W 8
@@ -99,16 +99,19 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 
 // WORK_CHUNK: reads a wave pulls from the launch's work counter at a time (large for the main tier, a handful for the
 // spill tier, whose few hundred heavy reads must spread over all its waves)
-template <bool STATS, int W_ECAP, int W_NCAP, int W_KCAP, int WPB>
+template <bool STATS, int W_ECAP, int W_NCAP, int WPB>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
                                                      uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
 {
-	// narrow element types keep a wave at 6.5 KB of LDS (24 waves per CU): an exact context only needs its
-	// chunk number next to the position, a neighbour context 13 bits, a vote key 8 + 1 bits of state
-	__shared__ uint32_t E_kpos[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB], K_idx[W_KCAP][64 * WPB], K_first[W_KCAP][64 * WPB];
-	__shared__ uint16_t N_meta[W_NCAP][64 * WPB], K_fm[W_KCAP][64 * WPB];
+	// narrow element types: an exact context only needs its chunk number next to the position, a neighbour context 13 bits.
+	// A vote key (qv.cc:132-178) is always created by an exact context -- neighbour contexts never open one, :134-139 -- so its
+	// state lives in that context's slot: implied position = E_kpos - 32 chunk, first position seen = E_kpos, and E_fm holds
+	// frequency (8 bits) | "several positions" (bit 8); E_fm == 0: the context opened no key.  Keys can therefore never
+	// outnumber the list they live in (at hg38 scale 83 % of the reads that left the main tier had run out of 4 key slots).
+	__shared__ uint32_t E_kpos[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB];
+	__shared__ uint16_t N_meta[W_NCAP][64 * WPB], E_fm[W_ECAP][64 * WPB];
 	__shared__ uint8_t E_meta[W_ECAP][64 * WPB];
 	// stage B pair table: one row per gate-open (owner, chunk) pair of the wave, PCAP rows at a time
 	__shared__ uint32_t P_klo[PCAP][WPB], P_khi[PCAP][WPB], P_lo[PCAP][WPB], P_hi[PCAP][WPB], P_slo[PCAP][WPB], P_shi[PCAP][WPB];
@@ -126,11 +129,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 	// build keeps the 48 individual queries because the event counters price each of them.
 	const bool use_sec = !STATS && d.sec_key != nullptr;
 	const bool use_mx = !STATS && d.mx != nullptr;
+	const bool use_probe = !STATS && d.snp_probe != nullptr;
 	const uint32_t lane = threadIdx.x & 63u;             // lane in the wave
 	const uint32_t col = threadIdx.x;                    // this lane's LDS column
 	const uint32_t col0 = wv << 6;                       // first column of this wave (scalar)
-	const uint64_t lane_bit = 1ull << lane;
-	const uint64_t n_reads = read_ids ? (uint64_t)*n_ids : n_reads_arg;
+	const uint64_t n_reads = n_ids ? (uint64_t)*n_ids : n_reads_arg;     // (n_ids without read_ids: a batch framed on the device, which alone knows its size)
 	// A list-driven launch (the spill tier) does not know its size on the host: its chunk grows with the list, from the
 	// WORK_CHUNK_ARG reads that spread a few hundred heavy reads over all waves up to 16 when there are tens of thousands
 	uint32_t WORK_CHUNK = WORK_CHUNK_ARG;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 			const uint32_t nfree = (uint32_t)__popcll(freem);
 			const uint32_t take = avail < nfree ? avail : nfree;
 			if (!active) {
-				const uint32_t rank = (uint32_t)__popcll(freem & (lane_bit - 1));
+				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freem, 0u));   // free lanes below this one
 				if (rank < take) {
 					rid = read_ids ? read_ids[cursor + rank] : (uint32_t)(cursor + rank);
 					const uint64_t off = offsets[rid];
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 			// append the exact contexts of chunk c (qv.cc:850-937): reference hit first, then SNP hit; aux rows expanded
 			auto push_exact = [&](uint32_t p, uint32_t c) {
 				cur.add(S_CTX, 1);
-				if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; ecnt++; } else { if (!ovf) VG_OVF(0); ovf = true; }
+				if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; E_fm[ecnt][col] = 0; ecnt++; } else { if (!ovf) VG_OVF(0); ovf = true; }
 			};
 			auto push_row = [&](const uint32_t *row, uint32_t c) {               // a row ends at its first 0
 				for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
@@ -331,10 +334,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						#pragma unroll
 						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = d.dx[kq[z] >> 32]; }
 						VG_CLKW(10);
-						// `more`: the bucket has further entries that may hold the key (entries are sorted by lo: nothing below the first)
+						// `more`: the bucket has further entries that may hold the key (entries are sorted by lo: nothing below the first; a
+						// match on the first entry is final unless the table says its successor has the same k-mer -- flag TIE)
 						bool more[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && (bq[z].z >> 8) > 1u && bq[z].x <= (uint32_t)kq[z];
+						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && (bq[z].z >> 8) > 1u && (bq[z].x < (uint32_t)kq[z] || (bq[z].x == (uint32_t)kq[z] && (bq[z].z & 16u)));
 						// Two chunks at a time: the rest of a small bucket -- up to VG_SCAN_W more entries -- arrives together (one wait;
 						// anything deeper is rare and goes one by one); then each chunk's exact contexts are appended (qv.cc:850-937),
 						// reference hit first, then SNP hit.  An ambiguous k-mer with exactly two positions carries both in its entry
@@ -572,7 +576,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 							if (t < L) {
 								const bool isr = t < Lr;
 								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)t * REF_STRIDE : (uint64_t)slo + (uint64_t)(t - Lr) * SNP_STRIDE;
-								if (tt < (isr ? d.n_ref : d.n_snp)) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
+								if (!isr && use_probe) {                            // the probed LO40 values of a bucket lie side by side
+									uint2 q;
+									__builtin_memcpy(&q, d.snp_probe + ((uint64_t)slo + (t - Lr)), 8);
+									v.x = q.x; v.y = q.y;
+								} else if (tt < (isr ? d.n_ref : d.n_snp)) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
 							}
 						}
 					}
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((int)lane >= o) incl += y; }
 						const uint32_t prev = __shfl_up(own, 1);
 						const uint64_t smask = __ballot(lane == 0 || own != prev);
-						const uint64_t upto = lane == 63 ? ~0ull : ((lane_bit << 1) - 1);
+						const uint64_t upto = ~0ull >> (63u - lane);              // lanes 0 .. this one
 						const int ss = 63 - __clzll((long long)(smask & upto));
 						const uint64_t above = smask & ~upto;
 						const int se_l = above ? (__ffsll((long long)above) - 2) : 63;
@@ -796,32 +804,34 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 		if (active) {
 			bool processed = false;
 			if (!ovf) {
-				uint32_t nkeys = 0;
 				int best = -1; bool amb = false;
-				// improved_index_table_add, qv.cc:132-178.  Key 0 -- for most reads the only key -- lives in registers, the
-				// others in this lane's LDS column.
-				uint32_t k0_idx = 0, k0_first = 0, k0_fm = 0;
-				auto vote = [&](uint32_t index, uint32_t kpos, bool neigh) {
+				// improved_index_table_add, qv.cc:132-178.  A key is named by the exact context that opened it ("home").  The first
+				// exact context always opens key 0 -- for most reads the only key -- which lives in registers; the others keep
+				// their state in E_fm[home].  `upto`: exact contexts consumed so far (homes lie below it; an exact context that opens
+				// a key is number `upto` itself).
+				uint32_t k0_idx = 0, k0_fm = 0;
+				auto vote = [&](uint32_t index, uint32_t kpos, bool neigh, uint32_t upto) {
 					int e = -1;
-					if (nkeys && k0_idx == index) e = 0;
-					else for (uint32_t i = 1; i < nkeys; i++) if (K_idx[i][col] == index) { e = (int)i; break; }
+					if (k0_fm && k0_idx == index) e = 0;
+					else for (uint32_t i = 1; i < upto; i++) if (E_fm[i][col] && E_kpos[i][col] - 32u * (E_meta[i][col] & 31u) == index) { e = (int)i; break; }
 					uint32_t first, fm;
 					if (e < 0) {
-						if (neigh) return;
-						if (nkeys >= (uint32_t)W_KCAP) { if (!ovf) VG_OVF(2); ovf = true; return; }
-						e = (int)nkeys++;
+						if (neigh) return;                                                // :134-139
+						e = (int)upto;                                                    // this exact context (number `upto`) opens the key
 						first = kpos; fm = 0;
-						if (e == 0) { k0_idx = index; k0_first = kpos; } else { K_idx[e][col] = index; K_first[e][col] = kpos; }
-					} else if (e == 0) { first = k0_first; fm = k0_fm; }
-					else { first = K_first[e][col]; fm = K_fm[e][col]; }
-					const uint32_t freq = (fm + 1) & 0xFFu;
-					const uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);
-					if (e == 0) k0_fm = freq | (multi << 8); else K_fm[e][col] = (uint16_t)(freq | (multi << 8));
+						if (e == 0) k0_idx = index;
+					} else if (e == 0) { first = E_kpos[0][col]; fm = k0_fm; }
+					else { first = E_kpos[e][col]; fm = E_fm[e][col]; }
+					const uint32_t freq = (fm + 1) & 0xFFu;                                 // uint8_t freq, :146
+					const uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);           // |set| >= 2, :163-165
+					// (a frequency that wraps to 0 with a single position would read as "no key": 256 contexts on one key cannot happen
+					// with at most W_ECAP + W_NCAP contexts in the lists)
+					if (e == 0) k0_fm = freq | (multi << 8); else E_fm[e][col] = (uint16_t)(freq | (multi << 8));
 					if (!multi) return;
 					if (best < 0) { best = e; amb = false; }
 					else if (e == best) amb = false;
 					else {
-						const uint32_t bf = (best == 0 ? k0_fm : (uint32_t)K_fm[best][col]) & 0xFFu;
+						const uint32_t bf = (best == 0 ? k0_fm : (uint32_t)E_fm[best][col]) & 0xFFu;
 						if (freq == bf) amb = true;
 						else if (freq > bf) { best = e; amb = false; }
 					}
@@ -831,19 +841,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 				{
 					uint32_t ei = 0, ni = 0;
 					uint32_t ce = ecnt ? (uint32_t)(E_meta[0][col] & 31u) : 99u, cn = ncnt ? (uint32_t)(N_meta[0][col] & 31u) : 99u;
-					while ((ce != 99u || cn != 99u) && !ovf) {            // 99 = list exhausted (chunk numbers are < 32)
+					while (ce != 99u || cn != 99u) {                       // 99 = list exhausted (chunk numbers are < 32)
 						const bool ex = ce <= cn;
 						const uint32_t c = ex ? ce : cn;
 						const uint32_t p = ex ? E_kpos[ei][col] : N_kpos[ni][col];
+						vote(p - 32u * c, p, !ex, ei);                     // exact contexts consumed so far = where a new key would live
 						if (ex) { ei++; ce = ei < ecnt ? (uint32_t)(E_meta[ei][col] & 31u) : 99u; }
 						else { ni++; cn = ni < ncnt ? (uint32_t)(N_meta[ni][col] & 31u) : 99u; }
-						vote(p - 32u * c, p, !ex);
 					}
 				}
 				VG_CLK(4);
 				if (!ovf) {
 					cur.add(S_PASSES, 1);
-					const uint32_t bfm = best < 0 ? 0u : best == 0 ? k0_fm : (uint32_t)K_fm[best][col], target = best < 0 ? 0u : best == 0 ? k0_idx : K_idx[best][col];
+					const uint32_t bfm = best < 0 ? 0u : best == 0 ? k0_fm : (uint32_t)E_fm[best][col];
+					const uint32_t target = best < 0 ? 0u : best == 0 ? k0_idx : E_kpos[best][col] - 32u * (E_meta[best][col] & 31u);
 					processed = best >= 0 && !amb && (bfm & 0xFFu) > 1;          // qv.cc:1375
 					if (processed) {
 						cur.add(S_PASSES_OK, 1);
@@ -899,21 +910,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 							VG_CLK(7);
 							VG_CLKW(8);
 						} else {
-						// The walks of a read are batched so that the wave waits for memory three times, not three times per
-						// context: (1) k-mers + pile windows of up to WB supporting contexts in one go, matches parked in the
-						// vote's (now free) LDS key slots; (2) the rank blocks of up to WB matches in one go; (3) atomics, unwaited.
-						constexpr int WB = VG_WALK_BATCH, RB = 4;
-						constexpr uint32_t MCAP = 2u * (uint32_t)W_KCAP;
-						uint32_t it = 0, nm = 0;
+						// Reads of more than four chunks, and the counting build: the byte-per-position walk of qv.cc:1386-1436 -- per
+						// supporting context its k-mer and its 32-byte pile window (up to WB contexts' gathers go out together), then
+						// one rank-block gather + atomic per counted base.
+						constexpr int WB = VG_WALK_BATCH;
+						uint32_t it = 0;
 						const uint32_t nctx = ecnt + ncnt;
-						auto park = [&](uint32_t p, uint32_t which) {
-							cur.add(S_INCR, 1);
-							if (nm < MCAP) {
-								const uint32_t v = ((p - target) << 1) | which;      // a site of this read lies < 32 * 33 past its start
-								if (nm < (uint32_t)W_KCAP) K_idx[nm][col] = v; else K_first[nm - W_KCAP][col] = v;
-								nm++;
-							} else bump_site(d, p, which);
-						};
+						auto count = [&](uint32_t p, uint32_t which) { cur.add(S_INCR, 1); bump_site(d, p, which); };
 						while (it < nctx) {
 							bool h[WB]; uint32_t wp[WB], wc[WB], wm[WB], wn[WB];
 							#pragma unroll
@@ -934,21 +937,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 							for (int b = 0; b < WB; b++) if (h[b]) {
 								uint64_t kk = kf[b];
 								if (wm[b] < 32u) kk = (kk & ~(3ull << (2 * wm[b]))) | ((uint64_t)wn[b] << (2 * wm[b]));
-								walk_matches(pw[b], kk, wp[b], wm[b], park);
+								walk_matches(pw[b], kk, wp[b], wm[b], count);
 							}
-						}
-						for (uint32_t m0 = 0; m0 < nm; m0 += RB) {
-							uint32_t mv[RB], mw[RB]; ulonglong2 rb[RB];
-							#pragma unroll
-							for (int b = 0; b < RB; b++) {
-								const uint32_t m = m0 + b;
-								mv[b] = m < nm ? (m < (uint32_t)W_KCAP ? K_idx[m][col] : K_first[m - W_KCAP][col]) : 0u;
-								mw[b] = mv[b] & 1u;
-								mv[b] = m < nm ? target + (mv[b] >> 1) : 0u;
-								rb[b] = d.srank[mv[b] >> 6];
-							}
-							#pragma unroll
-							for (int b = 0; b < RB; b++) if (m0 + b < nm) atomicAdd(&d.cnt[2ull * site_id(rb[b], mv[b]) + mw[b]], 1u);
 						}
 						}
 					}

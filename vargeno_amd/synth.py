@@ -347,6 +347,31 @@ def f_small(seed=20261002):
     return g, s, r
 
 
+def f_dense(seed=424242):
+    """Dense-bucket fixture: the bucket shapes of BASELINE.json configs[4] (hg38 + full dbSNP: ~190 SNP-dictionary entries
+    per HI24 bucket) on a genome small enough for the reference to index in seconds.  Each chromosome is random over a
+    TWO-letter alphabet ({A,C} / {G,T}), so only 2^12 distinct 12-mers end its k-mers: 60 k SNPs (one base in ten) put
+    ~150 k-mers into each of those SNP buckets, reference buckets (HI32: 2^16 distinct 16-mers) hold ~5 entries, the
+    LO32-ordered view is as dense, and the reverse complement of a chr1 read looks like chr2 text.  The strided bucket
+    scans (B1, qv.cc:316-376, 413-464) walk hundreds of entries per gate-open chunk here."""
+    rng = np.random.default_rng(seed)
+    lens = [360_000, 240_000]
+    seqs = []
+    for L, ab in zip(lens, (b"AC", b"GT")):
+        letters = np.frombuffer(ab, dtype=np.uint8)
+        seqs.append(letters[rng.integers(0, 2, size=L, dtype=np.uint8)])
+    s0 = seqs[0]
+    mer = random_bases(rng, 16)
+    for d in rng.choice(np.arange(64, len(s0) - 64, 48), size=130, replace=False):      # one reference bucket of >= 100 entries
+        s0[d + 16:d + 32] = mer
+    for sq in seqs:
+        sq[:200] = ord("N")
+    g = Genome(["chr1", "chr2"], seqs)
+    s = make_snps(rng, g, 60_000)
+    r = make_reads(rng, g, s, 15_000, lengths=(150, 150, 101, 250), err=0.01, lowq=0.30)
+    return g, s, r
+
+
 def f_tiny(seed=7):
     """A few-second data set for CPU unit tests: 60 kbp, 3 k SNPs, 4 k reads."""
     rng = np.random.default_rng(seed)
