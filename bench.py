@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--cpu-reference", choices=["auto", "yes", "no"], default="auto",
                     help="also time the reference binary (oracle/_ref/vargeno) on the host: auto = chr22 workload only (at hg38 scale its start-up alone takes minutes)")
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the secondary end-to-end number (FASTQ text in pinned host memory -> counters)")
     args = ap.parse_args()
     for k, v in PRESETS[args.workload].items():
         if getattr(args, k) is None:
@@ -109,6 +110,53 @@ def gather_ceiling():
     except Exception as e:
         log("[bench] gather probe failed: %r" % (e,))
         return None
+
+
+def measure_ingest(gx, batch, log, chunk_mb=64, reps=3):
+    """Batch 0 as FASTQ text in page-locked host memory, streamed to the device in 64 MiB chunks `reps` times; the counters of
+    the first pass must equal those of the resident batch.  Returns the secondary bench number."""
+    import torch
+
+    from vargeno_amd import synth
+    from vargeno_amd.api import pinned_buffer
+
+    tb, tq, to = batch
+    n = len(to) - 1
+    L = int(to[1].item())
+    gx.set_stats(False)
+    gx.reset()
+    gx.process_device(tb, tq, to, n)
+    want = gx.counts_tensor().clone()
+    # fixed-width records: "@r%08d\n" bases "\n+\n" quals "\n"
+    rec = 10 + 1 + L + 3 + L + 1
+    text, owner = pinned_buffer(n * rec)
+    m = text.reshape(n, rec)
+    ids = np.arange(n, dtype=np.int64)
+    m[:, 0] = ord("@"); m[:, 1] = ord("r")
+    for k in range(8):
+        m[:, 2 + k] = 48 + (ids // 10 ** (7 - k)) % 10
+    m[:, 10] = 10
+    m[:, 11:11 + L] = tb.cpu().numpy().reshape(n, L)
+    m[:, 11 + L] = 10; m[:, 12 + L] = ord("+"); m[:, 13 + L] = 10
+    m[:, 14 + L:14 + 2 * L] = tq.cpu().numpy().reshape(n, L)
+    m[:, 14 + 2 * L] = 10
+    step = chunk_mb << 20
+    chunks = [text[a:a + step] for a in range(0, len(text), step)]
+    gx.reset()
+    got = gx.fastq_stream(chunks)
+    assert got[0] == n and got[1] == len(text) and not got[3], "FASTQ stream framed %r of %d records" % (got, n)
+    assert torch.equal(gx.counts_tensor(), want), "counters through the FASTQ stream != counters of the resident batch"
+    gx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gx.fastq_stream(chunks)
+    dt = time.perf_counter() - t0
+    del m, text, owner
+    out = {"value": reps * n / dt, "unit": "reads/s", "text_GB_per_s": reps * n * rec / dt / 1e9, "reads": reps * n, "bytes_per_read": rec,
+           "path": "FASTQ text in pinned host memory -> vg_fastq_stream_push (%d MiB chunks: H2D over PCIe, record framing on the device) -> read loop -> counters; "
+                   "counters of the first pass identical to the resident batch" % chunk_mb}
+    log("[bench] ingest end to end: %.3g reads/s (%.1f GB/s of FASTQ text)" % (out["value"], out["text_GB_per_s"]))
+    return out
 
 
 def main():
@@ -255,6 +303,12 @@ def main():
                 log("[bench] reference binary not timed: %r" % (e,))
         del r0, sub
 
+    # ---- secondary number (N = 1): end to end from FASTQ text in pinned HOST memory -- H2D over PCIe, framing on the device, the
+    #      read loop -- through vg_fastq_stream_push.  Never `value`: the metric is quoted on batches resident in HBM. -------------
+    ingest = None
+    if rank == 0 and world == 1 and not args.no_ingest:
+        ingest = measure_ingest(gx, batches[0], log)
+
     # ---- N > 1: the sharded path must reproduce one rank.  Every rank takes its shard of one common stream; the all-reduced
     #      counters must equal what rank 0 gets from the whole stream alone. ---------------------------------------------------
     verification = None
@@ -362,6 +416,7 @@ def main():
             "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "spill_tiers_overlapped": tm["ms_tail"], "of_which_deep_list_wave_tier": tm["ms_deep_lists"], "batches": tm["batches"]},
             "reads_per_step_spilled_to_lane_tier": st["overflow_reads"], "reads_per_step_deep_scratch": st["overflow_deep"],
             "events_per_read": {k: st[k] / args.reads for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
+            "ingest_end_to_end": ingest,
             "multi_gpu_verification": verification,
         }
         print(json.dumps(out), flush=True)

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Development aid: A/B of kernel variants / knobs on the hg38-scale workload within ONE box lease (the index is built once).
+#   bash profiles/ab_hg38_r02.sh <tag>    -> gpurun_out/ab_<tag>/*.json + summary.txt
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:-ab}
+OUT=$R/gpurun_out/ab_$TAG
+mkdir -p $OUT
+cd $R
+ARGS="--cpu-sample 0 --no-gather-probe --no-ingest --steps 20 --warmup 5"
+run() {   # name, env assignments...
+	local name=$1; shift
+	env "$@" VARGENO_VERBOSE=1 python3 bench.py $ARGS > $OUT/$name.json 2> $OUT/$name.err
+	python3 - $OUT/$name.json $name <<'PY' | tee -a $OUT/summary.txt
+import json, sys
+try:
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    d = j["device_ms_per_step"]
+    print("%-12s reads/s %.4g  ms/step %.3f  wave %.3f  pack %.3f  tiers %.3f (deep %.3f)  frac %.3f  spilled %s" % (sys.argv[2], j["value"], j["ms_per_step"], d["wave"], d["pack"], d["spill_tiers_overlapped"], d["of_which_deep_list_wave_tier"], j["roofline"]["frac"], j["reads_per_step_spilled_to_lane_tier"]))
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+}
+run base
+grep -E "vargeno index|\[vargeno index\]|FASTA|resident" $OUT/base.err | tee -a $OUT/summary.txt
+run noprobe VG_NO_PROBE_VIEW=1
+run w2chunk2 VG_W2_CHUNK=2
+run w2wpc1 VG_W2_WPC=1
+run nopackovl VG_NO_PACK_OVERLAP=1
+for v in $R/variants/*.so; do
+	n=$(basename $v .so)
+	[ "$n" = clk ] && continue
+	run $n VARGENO_HIP_LIB=$v
+done
+if [ -f $R/variants/clk.so ]; then
+	VARGENO_HIP_LIB=$R/variants/clk.so VG_NO_PACK_OVERLAP=1 python3 bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
+	grep "dbg" $OUT/clk.err | tail -1 | tee -a $OUT/summary.txt
+fi
+( time python3 -m pytest tests -x -q -m gpu -k "hg38" ) > $OUT/pytest_hg38.log 2>&1
+tail -4 $OUT/pytest_hg38.log | tee -a $OUT/summary.txt

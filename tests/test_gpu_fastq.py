@@ -129,19 +129,24 @@ def test_stream_stops_at_the_first_chunk_it_cannot_frame(ftiny_dir):
 
 
 def test_cli_long_line_in_the_middle_of_the_file_falls_back_to_host_framing(ftiny_dir, tmp_path):
-    """A 1500-base record in the middle of the file: fgets() splits its lines and shifts the reference's framing of everything
-    after it.  The device refuses from that chunk on and the host reader takes over there; both routes must write the same
-    VCF as framing the whole file on the host."""
+    """A record with lines beyond fgets' 1023 characters in the middle of the file.  fgets() splits such lines, so the reference
+    frames this record as TWO records made of the pieces (built here so that the pieces in read position are ACGT text -- the
+    reference would abort otherwise -- and the file is back in step afterwards: 8 fgets lines).  The device refuses from that
+    chunk on and the host reader takes over there; the VCF must equal the one from framing the whole file on the host."""
     lines = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read().split(b"\n")[:-1]
     k = 4 * 1500
-    odd = [b"@long", b"ACGT" * 375, b"+", b"I" * 1500]
+    odd = [b"@" + b"ACGT" * 300,            # 1201 characters: fgets pieces of 1023 and 178 (+ newline); the second is read as a READ
+           b"ACGT" * 20,                    # lands in separator position
+           b"+",                            # lands in quality position: a 1-character quality line, the gate sees stale buffer contents
+           b"ACGT" * 800]                   # 3200 characters: four pieces = id / read (1023 characters, 31 chunks) / separator / quality
     fq = tmp_path / "reads_long.fq"
     fq.write_bytes(b"\n".join(lines[:k] + odd + lines[k:]) + b"\n")
     outs = []
     for host in ("1", "0"):
         out = tmp_path / ("out%s.vcf" % host)
-        env = dict(os.environ, VARGENO_HOST_FASTQ=host, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_READERS="3")
+        env = dict(os.environ, VARGENO_HOST_FASTQ=host, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_READERS="3", VARGENO_VERBOSE="1")
         p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(out)], env=env, capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
+        assert "reads: %d " % (len(lines) // 4 + 2) in p.stderr, p.stderr       # the odd record counts as two
         outs.append(out.read_bytes())
     assert outs[0] == outs[1] and outs[0].count(b"\n") > 2000

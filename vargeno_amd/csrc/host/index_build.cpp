@@ -248,6 +248,34 @@ static void partition_records(size_t n_chunks, Produce &&produce, Partitioned<T>
 	}
 }
 
+// Sort one bucket of a partitioned dictionary by k-mer, equal k-mers keeping their order (the bucket is in input order).  The
+// records of a bucket share the top PART_BITS bits of the k-mer: one stable counting pass on the next SUB_BITS bits into a
+// scratch buffer leaves groups of a few hundred records, which are finished by a stable comparison sort in cache -- about
+// three sweeps over the bucket where a comparison sort of the whole 12 MB bucket makes twenty.
+template <class T>
+static void sort_bucket(T *lo, T *hi, std::vector<T> &tmp, std::vector<uint32_t> &cnt)
+{
+	const size_t n = (size_t)(hi - lo);
+	constexpr int SUB_BITS = 12;
+	constexpr size_t NS = (size_t)1 << SUB_BITS;
+	const auto less = [](const T &a, const T &b) { return a.kmer < b.kmer; };
+	if (n < 4 * NS) { std::stable_sort(lo, hi, less); return; }
+	const auto digit = [](const T &r) { return (size_t)((r.kmer >> (64 - PART_BITS - SUB_BITS)) & (NS - 1)); };
+	cnt.assign(NS + 1, 0);
+	for (const T *p = lo; p < hi; p++) cnt[digit(*p) + 1]++;
+	for (size_t d = 0; d < NS; d++) cnt[d + 1] += cnt[d];
+	if (tmp.size() < n) tmp.resize(n);
+	{
+		std::vector<uint32_t> at(cnt.begin(), cnt.end() - 1);
+		for (const T *p = lo; p < hi; p++) tmp[at[digit(*p)]++] = *p;
+	}
+	for (size_t d = 0; d < NS; d++) {
+		T *a = tmp.data() + cnt[d], *b = tmp.data() + cnt[d + 1];
+		if (b - a > 1) std::stable_sort(a, b, less);
+	}
+	memcpy((void *)lo, (const void *)tmp.data(), n * sizeof(T));
+}
+
 // A dictionary file under construction: fixed-size records region + auxiliary rows region, produced bucket by bucket by many
 // threads.  How the bytes reach the file (VARGENO_WRITE_MODE), measured on the MI355X host (256 threads, overlayfs and
 // tmpfs alike, 5.2 GB dictionary; profiles/io_probe.sh):
@@ -572,13 +600,17 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 		pt.lap("SNP k-mers made and partitioned");
 		// per bucket: stable sort by k-mer (qsort is glibc's stable merge sort: ties keep VCF order), then count its records and rows
 		std::vector<uint64_t> n_rec(N_PART + 1, 0), n_aux(N_PART + 1, 0);
-		#pragma omp parallel for schedule(dynamic, 8)
+		#pragma omp parallel
+		{
+		std::vector<SK> tmp; std::vector<uint32_t> cnt;
+		#pragma omp for schedule(dynamic, 1)
 		for (long b = 0; b < (long)N_PART; b++) {
 			SK *lo = part.data + part.begin[(size_t)b], *hi = part.data + part.begin[(size_t)b + 1];
-			std::stable_sort(lo, hi, [](const SK &x, const SK &y) { return x.kmer < y.kmer; });
+			sort_bucket(lo, hi, tmp, cnt);
 			uint64_t rec = 0, aux = 0;
 			for (SK *p = lo; p < hi;) { SK *q = p + 1; while (q < hi && q->kmer == p->kmer) q++; rec++; aux += (q - p >= 2 && q - p <= AUX_COLS); p = q; }
 			n_rec[(size_t)b + 1] = rec; n_aux[(size_t)b + 1] = aux;
+		}
 		}
 		for (size_t b = 0; b < N_PART; b++) { n_rec[b + 1] += n_rec[b]; n_aux[b + 1] += n_aux[b]; }
 		const uint64_t written = n_rec[N_PART], aux_count = n_aux[N_PART];
@@ -645,15 +677,19 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 		}, part);
 		if (part.n >= (1ull << 32)) die("more than 2^32 32-mers in the reference");
 		pt.lap("reference k-mers made and partitioned");
-		// per bucket: order by (k-mer, position) -- what a stable sort by k-mer gives, a bucket being in position order already
+		// per bucket: stable sort by k-mer = order by (k-mer, position), a bucket being in position order already
 		std::vector<uint64_t> n_rec(N_PART + 1, 0), n_aux(N_PART + 1, 0);
-		#pragma omp parallel for schedule(dynamic, 8)
+		#pragma omp parallel
+		{
+		std::vector<KP> tmp; std::vector<uint32_t> cnt;
+		#pragma omp for schedule(dynamic, 1)
 		for (long b = 0; b < (long)N_PART; b++) {
 			KP *lo = part.data + part.begin[(size_t)b], *hi = part.data + part.begin[(size_t)b + 1];
-			std::sort(lo, hi, [](const KP &x, const KP &y) { return x.kmer < y.kmer || (x.kmer == y.kmer && x.pos < y.pos); });
+			sort_bucket(lo, hi, tmp, cnt);
 			uint64_t rec = 0, aux = 0;
 			for (KP *p = lo; p < hi;) { KP *q = p + 1; while (q < hi && q->kmer == p->kmer) q++; rec++; aux += (q - p >= 2 && q - p <= AUX_COLS); p = q; }
 			n_rec[(size_t)b + 1] = rec; n_aux[(size_t)b + 1] = aux;
+		}
 		}
 		for (size_t b = 0; b < N_PART; b++) { n_rec[b + 1] += n_rec[b]; n_aux[b + 1] += n_aux[b]; }
 		const uint64_t written = n_rec[N_PART], aux_count = n_aux[N_PART];

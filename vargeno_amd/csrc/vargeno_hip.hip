@@ -585,6 +585,7 @@ struct Slot {
 	void *fq_tmp = nullptr; uint64_t fq_tmp_cap = 0;                 // scan scratch (grow-only: no allocation per chunk)
 	FqChunk *fq_chunk = nullptr;                                     // this chunk's framing results, device resident
 	uint64_t fq_text_len = 0;                                        // bytes of text copied into fq_text (after the FQ_CARRY gap)
+	hipEvent_t e_fq = nullptr; bool fq_tail_wanted = false;          // the NEXT chunk's prepare kernel reads this text's tail: recorded after it
 	uint64_t stage_bytes = 0, stage_reads = 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
 	bool busy = false;
@@ -613,6 +614,7 @@ struct vg_index {
 	int cus = 256;
 	int lane_grid_blocks = 0, wave_grid = 0;
 	uint32_t work_chunk = 128;            // reads a main-tier wave pulls from the launch's work counter at a time (VG_WORK_CHUNK)
+	uint32_t w2_chunk = 8, w2_wpc = 2;    // deep-list tier: reads a wave pulls at a time (VG_W2_CHUNK), workgroups per CU of its grid (VG_W2_WPC)
 	FqStream *d_fq = nullptr;             // FASTQ stream state (vg_fastq_stream_*)
 	bool fq_open = false; int fq_prev_slot = -1;
 };
@@ -685,7 +687,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	for (Slot &sl : ix->slot) {
 		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
 		for (void *p : extra) if (p) (void)hipFree(p);
-		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5};
+		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5, sl.e_fq};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 	}
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -752,7 +754,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->ingest, hipStreamNonBlocking));
 	ix->pack_overlap = getenv("VG_NO_PACK_OVERLAP") == nullptr;
-	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); }
+	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); HIP_TRY(hipEventCreateWithFlags(&sl.e_fq, hipEventDisableTiming)); }
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	ix->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -762,6 +764,8 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	ix->wave_grid = ix->cus * wpc;
 	if (const char *e = getenv("VG_FORCE_GENERIC")) ix->force_generic = atoi(e) != 0;
 	if (const char *e = getenv("VG_WORK_CHUNK")) ix->work_chunk = (uint32_t)std::max(1, atoi(e));
+	if (const char *e = getenv("VG_W2_CHUNK")) ix->w2_chunk = (uint32_t)std::max(1, atoi(e));
+	if (const char *e = getenv("VG_W2_WPC")) ix->w2_wpc = (uint32_t)std::max(1, atoi(e));
 	int rc;
 	DevIndex &d = ix->d;
 	d.n_ref = a->n_ref; d.n_snp = a->n_snp;
@@ -1168,8 +1172,10 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		// tail stream, second tier: the same kernel with deep lists over the spill list (2 waves per CU)
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
-		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
-		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], 2u, ix->d_stats);
+		// (its workgroups hold 42 KB of LDS each while they live, in the way of the next batch's main tier: a wave takes at least
+		// w2_chunk reads at a time, so a few hundred spilled reads wake few of them)
+		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
+		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by vg_fastq_submit on the ingest stream
@@ -1323,6 +1329,9 @@ extern "C" int vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t 
 	if (rc) return rc;
 	Slot &sl = *slp;
 	hipStream_t is = ix->pack_overlap ? ix->ingest : ix->stream;
+	// the chunk after this slot's last one copied the tail of its text on the ingest stream: that must have happened before
+	// the text is overwritten (the slot's own batch being finished does not imply it)
+	if (sl.fq_tail_wanted) { HIP_TRY(hipEventSynchronize(sl.e_fq)); sl.fq_tail_wanted = false; }
 	// capacities follow from the chunk's size alone: lines average at least 8 bytes (or the chunk is refused), a record has four
 	const uint64_t span = (uint64_t)FQ_CARRY + nbytes;
 	const uint64_t n_tiles = (span + FQ_TILE - 1) / FQ_TILE;
@@ -1356,6 +1365,7 @@ extern "C" int vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t 
 	const uint8_t *prev_end = nullptr;
 	if (ix->fq_prev_slot >= 0) { const Slot &pv = ix->slot[ix->fq_prev_slot]; prev_end = pv.fq_text + FQ_CARRY + pv.fq_text_len; }
 	vg_fqs_prepare<<<1, 256, 0, is>>>(ix->d_fq, sl.fq_chunk, prev_end, sl.fq_text, (uint32_t)nbytes);
+	if (ix->fq_prev_slot >= 0) { Slot &pv = ix->slot[ix->fq_prev_slot]; HIP_TRY(hipEventRecord(pv.e_fq, is)); pv.fq_tail_wanted = true; }
 	vg_fq_count_newlines<<<(unsigned)n_tiles, 256, 0, is>>>(sl.fq_text, sl.fq_chunk, sl.fq_tiles);
 	HIP_TRY(hipMemsetAsync(sl.fq_tiles + n_tiles, 0, 4, is));
 	HIP_TRY(hipGetLastError());
