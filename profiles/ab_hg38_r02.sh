@@ -22,10 +22,21 @@ PY
 }
 run base
 grep -E "vargeno index|\[vargeno index\]|FASTA|resident" $OUT/base.err | tee -a $OUT/summary.txt
-run noprobe VG_NO_PROBE_VIEW=1
-run w2chunk2 VG_W2_CHUNK=2
-run w2wpc1 VG_W2_WPC=1
 run nopackovl VG_NO_PACK_OVERLAP=1
+run nomx VG_NO_MX=1
+# L2 misses per launch of the wave kernel (separate --pmc pass of the same command)
+( cd /tmp && TMPDIR=/tmp rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 $R/bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 10 --warmup 2 > $OUT/pmc_l2.json 2> $OUT/pmc_l2.err )
+python3 - $OUT <<'PY' | tee -a $OUT/summary.txt
+import csv, glob, collections, sys
+agg = collections.defaultdict(list)
+for f in glob.glob(sys.argv[1] + "/pmc_l2/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "vg_wave_kernel<false" in r["Kernel_Name"] and ", 4>" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in sorted(agg.items()):
+    print("pmc base %-22s n=%d mean=%.6g" % (k, len(v), sum(v) / len(v)))
+PY
+rm -rf $OUT/pmc_l2
 for v in $R/variants/*.so; do
 	n=$(basename $v .so)
 	[ "$n" = clk ] && continue

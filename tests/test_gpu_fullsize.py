@@ -127,7 +127,7 @@ def test_hg38_sample_against_oracle_and_linearity_at_full_batch(hg38):
         gx.set_stats(False)
         gx.process_device(tb, tq, to, n)
         whole = _raw(gx)
-        assert whole.sum() > 2 * n
+        assert whole.sum() > n // 4                                  # ~0.34 increments per read: one SNP per 310 bp here
         gx.reset()
         cuts = [0, 1, 3_000_001, 3_000_002, 7_654_321, n]
         for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):

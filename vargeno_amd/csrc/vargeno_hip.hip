@@ -271,7 +271,7 @@ __device__ inline int classify_bad(const uint8_t *p, uint32_t n)
 // 16-byte loads (lane-per-read loads at a 150-byte stride fetched every line ~2.5 times), then each lane packs
 // its own read out of LDS.  Only the first n quality characters of a read are ever looked at.
 #ifndef VG_PACK_T
-#define VG_PACK_T 128
+#define VG_PACK_T 64       // (128: 3.5 % fewer reads/s at hg38 scale -- smaller tiles keep more workgroups, i.e. more loads, in flight)
 #endif
 constexpr uint32_t PACK_T = VG_PACK_T;          // reads (= lanes) per tile
 constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bases; longer reads take the direct path
@@ -716,7 +716,7 @@ static unsigned host_threads()
 	static const unsigned n = [] {
 		unsigned h = std::thread::hardware_concurrency();
 		if (const char *e = getenv("VG_HOST_THREADS")) h = (unsigned)std::max(1, atoi(e));
-		return std::max(1u, std::min(h, 32u));
+		return std::max(1u, std::min(h, 64u));
 	}();
 	return n;
 }

@@ -63,6 +63,9 @@ namespace vg {
 #ifndef VG_W1_WPB
 #define VG_W1_WPB 4
 #endif
+#ifndef VG_W1_KMAX
+#define VG_W1_KMAX 0      // keys a main-tier lane may open before its read goes to the deep tier (0: as many as it has exact contexts).
+#endif                    // The vote of a lane with k keys costs ~k^2 / 2 LDS probes while its 63 neighbours wait.
 constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_WPB = VG_W1_WPB;   // W1_WPB: waves per workgroup of the main tier
 constexpr int W2_ECAP = 48, W2_NCAP = 48;
 constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is also what a failed query's -1 truncates to
@@ -107,10 +110,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 {
 	// narrow element types: an exact context only needs its chunk number next to the position, a neighbour context 13 bits.
 	// A vote key (qv.cc:132-178) is always created by an exact context -- neighbour contexts never open one, :134-139 -- so its
-	// state lives in that context's slot: implied position = E_kpos - 32 chunk, first position seen = E_kpos, and E_fm holds
+	// state lives in that context's slot.  E_idx holds the IMPLIED READ POSITION of a context (k-mer position - 32 chunk; the
+	// k-mer position is recomputed where the walk needs it): that is what the key filter of stage B and the vote compare, one
+	// LDS read per candidate.  First position seen by a key = that of its home context, and E_fm holds
 	// frequency (8 bits) | "several positions" (bit 8); E_fm == 0: the context opened no key.  Keys can therefore never
 	// outnumber the list they live in (at hg38 scale 83 % of the reads that left the main tier had run out of 4 key slots).
-	__shared__ uint32_t E_kpos[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB];
+	__shared__ uint32_t E_idx[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB];
 	__shared__ uint16_t N_meta[W_NCAP][64 * WPB], E_fm[W_ECAP][64 * WPB];
 	__shared__ uint8_t E_meta[W_ECAP][64 * WPB];
 	// stage B pair table: one row per gate-open (owner, chunk) pair of the wave, PCAP rows at a time
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 			// append the exact contexts of chunk c (qv.cc:850-937): reference hit first, then SNP hit; aux rows expanded
 			auto push_exact = [&](uint32_t p, uint32_t c) {
 				cur.add(S_CTX, 1);
-				if (ecnt < W_ECAP) { E_kpos[ecnt][col] = p; E_meta[ecnt][col] = (uint8_t)c; E_fm[ecnt][col] = 0; ecnt++; } else { if (!ovf) VG_OVF(0); ovf = true; }
+				if (ecnt < W_ECAP) { E_idx[ecnt][col] = p - 32u * c; E_meta[ecnt][col] = (uint8_t)c; E_fm[ecnt][col] = 0; ecnt++; } else { if (!ovf) VG_OVF(0); ovf = true; }
 			};
 			auto push_row = [&](const uint32_t *row, uint32_t c) {               // a row ends at its first 0
 				for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 					// is `position` the implied read position of one of the owner's exact hits?
 					auto in_keys = [&](uint32_t position) -> bool {
 						bool f = false;
-						for (uint32_t e = 0; e < o_ecnt; e++) f |= (E_kpos[e][col0 + own] - 32u * (E_meta[e][col0 + own] & 31u)) == position;
+						for (uint32_t e = 0; e < o_ecnt; e++) f |= E_idx[e][col0 + own] == position;
 						return f;
 					};
 					// acceptance (site / SNP-base tests) + key filter -> bit j: ref candidate j kept, bit 10+j: snp candidate j kept.
@@ -810,18 +815,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 				// their state in E_fm[home].  `upto`: exact contexts consumed so far (homes lie below it; an exact context that opens
 				// a key is number `upto` itself).
 				uint32_t k0_idx = 0, k0_fm = 0;
+				[[maybe_unused]] uint32_t nkeys = 0;
 				auto vote = [&](uint32_t index, uint32_t kpos, bool neigh, uint32_t upto) {
 					int e = -1;
 					if (k0_fm && k0_idx == index) e = 0;
-					else for (uint32_t i = 1; i < upto; i++) if (E_fm[i][col] && E_kpos[i][col] - 32u * (E_meta[i][col] & 31u) == index) { e = (int)i; break; }
+					else for (uint32_t i = 1; i < upto; i++) if (E_idx[i][col] == index && E_fm[i][col]) { e = (int)i; break; }
 					uint32_t first, fm;
 					if (e < 0) {
 						if (neigh) return;                                                // :134-139
 						e = (int)upto;                                                    // this exact context (number `upto`) opens the key
 						first = kpos; fm = 0;
 						if (e == 0) k0_idx = index;
-					} else if (e == 0) { first = E_kpos[0][col]; fm = k0_fm; }
-					else { first = E_kpos[e][col]; fm = E_fm[e][col]; }
+						if constexpr (WPB > 1 && VG_W1_KMAX > 0) { if (++nkeys > (uint32_t)VG_W1_KMAX) { if (!ovf) VG_OVF(2); ovf = true; } }
+					} else if (e == 0) { first = k0_idx + 32u * (E_meta[0][col] & 31u); fm = k0_fm; }
+					else { first = index + 32u * (E_meta[e][col] & 31u); fm = E_fm[e][col]; }
 					const uint32_t freq = (fm + 1) & 0xFFu;                                 // uint8_t freq, :146
 					const uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);           // |set| >= 2, :163-165
 					// (a frequency that wraps to 0 with a single position would read as "no key": 256 contexts on one key cannot happen
@@ -841,11 +848,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 				{
 					uint32_t ei = 0, ni = 0;
 					uint32_t ce = ecnt ? (uint32_t)(E_meta[0][col] & 31u) : 99u, cn = ncnt ? (uint32_t)(N_meta[0][col] & 31u) : 99u;
-					while (ce != 99u || cn != 99u) {                       // 99 = list exhausted (chunk numbers are < 32)
+					while ((ce != 99u || cn != 99u) && !ovf) {             // 99 = list exhausted (chunk numbers are < 32)
 						const bool ex = ce <= cn;
 						const uint32_t c = ex ? ce : cn;
-						const uint32_t p = ex ? E_kpos[ei][col] : N_kpos[ni][col];
-						vote(p - 32u * c, p, !ex, ei);                     // exact contexts consumed so far = where a new key would live
+						const uint32_t q = ex ? E_idx[ei][col] : N_kpos[ni][col] - 32u * c;     // implied read position
+						vote(q, q + 32u * c, !ex, ei);                     // exact contexts consumed so far = where a new key would live
 						if (ex) { ei++; ce = ei < ecnt ? (uint32_t)(E_meta[ei][col] & 31u) : 99u; }
 						else { ni++; cn = ni < ncnt ? (uint32_t)(N_meta[ni][col] & 31u) : 99u; }
 					}
@@ -854,7 +861,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 				if (!ovf) {
 					cur.add(S_PASSES, 1);
 					const uint32_t bfm = best < 0 ? 0u : best == 0 ? k0_fm : (uint32_t)E_fm[best][col];
-					const uint32_t target = best < 0 ? 0u : best == 0 ? k0_idx : E_kpos[best][col] - 32u * (E_meta[best][col] & 31u);
+					const uint32_t target = best < 0 ? 0u : best == 0 ? k0_idx : E_idx[best][col];
 					processed = best >= 0 && !amb && (bfm & 0xFFu) > 1;          // qv.cc:1375
 					if (processed) {
 						cur.add(S_PASSES_OK, 1);
@@ -885,7 +892,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 							const uint32_t nctx = ecnt + ncnt;
 							for (uint32_t i = 0; i < nctx; i++) {
 								uint32_t p, c, mod = NOMOD;
-								if (i < ecnt) { p = E_kpos[i][col]; c = E_meta[i][col] & 31u; }
+								if (i < ecnt) { c = E_meta[i][col] & 31u; p = E_idx[i][col] + 32u * c; }
 								else { const uint32_t mt = N_meta[i - ecnt][col]; p = N_kpos[i - ecnt][col]; c = mt & 31u; mod = (mt >> 5) & 31u; }
 								if (p - 32u * c != target) continue;
 								const uint32_t fi = pass ? n - 1u - c : c;
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 								h[b] = false; wp[b] = 0; wc[b] = 0; wm[b] = NOMOD; wn[b] = 0;
 								while (it < nctx && !h[b]) {
 									const uint32_t i = it++;
-									if (i < ecnt) { wp[b] = E_kpos[i][col]; wc[b] = E_meta[i][col] & 31u; wm[b] = NOMOD; }
+									if (i < ecnt) { wc[b] = E_meta[i][col] & 31u; wp[b] = E_idx[i][col] + 32u * wc[b]; wm[b] = NOMOD; }
 									else { const uint32_t mt = N_meta[i - ecnt][col]; wp[b] = N_kpos[i - ecnt][col]; wc[b] = mt & 31u; wm[b] = (mt >> 5) & 31u; wn[b] = (mt >> 11) & 3u; }
 									h[b] = wp[b] - 32u * wc[b] == target;
 								}
