@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -411,52 +412,52 @@ void vgo_trace_read(vgo_index *ix, const uint8_t *bases, const uint8_t *quals, u
 
 /* ---------------------------------------------------------------- index construction (qv.cc:519-695) */
 
-vgo_index *vgo_index_from_arrays(
-	uint64_t n_ref, const uint64_t *ref_kmer, const uint32_t *ref_pos, const uint8_t *ref_amb,
-	uint64_t n_ref_aux, const uint32_t *ref_aux,
-	uint64_t n_snp, const uint64_t *snp_kmer, const uint32_t *snp_pos, const uint8_t *snp_info,
-	const uint8_t *snp_amb, const uint8_t *snp_rf, const uint8_t *snp_af,
-	uint64_t n_snp_aux, const uint32_t *snp_aux_pos, const uint8_t *snp_aux_info,
-	uint64_t ref_bf_bits, const uint64_t *ref_bf_words, uint64_t snp_bf_bits, const uint64_t *snp_bf_words)
+/* builds the look-up structures around arrays the index OWNS (malloc'd by the caller, freed by vgo_index_free) */
+static vgo_index *index_from_owned(
+	uint64_t n_ref, uint64_t *ref_kmer, uint32_t *ref_pos, uint8_t *ref_amb,
+	uint64_t n_ref_aux, uint32_t *ref_aux,
+	uint64_t n_snp, uint64_t *snp_kmer, uint32_t *snp_pos, uint8_t *snp_info,
+	uint8_t *snp_amb, const uint8_t *snp_rf, const uint8_t *snp_af,
+	uint64_t n_snp_aux, uint32_t *snp_aux_pos, uint8_t *snp_aux_info,
+	uint64_t ref_bf_bits, uint64_t *ref_bf_words, uint64_t snp_bf_bits, uint64_t *snp_bf_words)
 {
 	vgo_index *ix = calloc(1, sizeof *ix);
 	if (!ix) return NULL;
 	ix->n_ref = n_ref; ix->n_ref_aux = n_ref_aux; ix->n_snp = n_snp; ix->n_snp_aux = n_snp_aux;
 	ix->ref_stride = 9; ix->snp_stride = 11;
-	ix->ref_kmer = xdup(ref_kmer, n_ref * 8); ix->ref_pos = xdup(ref_pos, n_ref * 4); ix->ref_amb = xdup(ref_amb, n_ref);
-	ix->ref_aux = xdup(ref_aux, n_ref_aux * AUX_COLS * 4);
-	ix->snp_kmer = xdup(snp_kmer, n_snp * 8); ix->snp_pos = xdup(snp_pos, n_snp * 4); ix->snp_info = xdup(snp_info, n_snp); ix->snp_amb = xdup(snp_amb, n_snp);
-	ix->snp_aux_pos = xdup(snp_aux_pos, n_snp_aux * AUX_COLS * 4); ix->snp_aux_info = xdup(snp_aux_info, n_snp_aux * AUX_COLS);
+	ix->ref_kmer = ref_kmer; ix->ref_pos = ref_pos; ix->ref_amb = ref_amb; ix->ref_aux = ref_aux;
+	ix->snp_kmer = snp_kmer; ix->snp_pos = snp_pos; ix->snp_info = snp_info; ix->snp_amb = snp_amb;
+	ix->snp_aux_pos = snp_aux_pos; ix->snp_aux_info = snp_aux_info;
 	/* the reference addresses bit (hash % bv_size); only words below that are ever read.  hash32 is 32-bit. */
 	ix->ref_bf_bits = ref_bf_bits; ix->snp_bf_bits = snp_bf_bits;
 	uint64_t rbits = ref_bf_bits < (1ull << 32) ? ref_bf_bits : (1ull << 32);
 	ix->ref_bf_nwords = (rbits + 63) / 64; ix->snp_bf_nwords = (snp_bf_bits + 63) / 64;
-	ix->ref_bf = xdup(ref_bf_words, ix->ref_bf_nwords * 8); ix->snp_bf = xdup(snp_bf_words, ix->snp_bf_nwords * 8);
+	ix->ref_bf = ref_bf_words; ix->snp_bf = snp_bf_words;
 
-	/* coarse ref jump table: cj[c] = first entry with (HI32 >> 8) >= c */
+	/* coarse ref jump table: cj[c] = first entry with (HI32 >> 8) >= c; SNP jump table over HI24 likewise
+	 * (a lower bound per slot: the arrays are sorted by k-mer) */
 	ix->ref_cj = xmalloc(((1u << 24) + 1) * sizeof(uint32_t));
-	{
-		uint64_t i = 0;
-		for (uint64_t c = 0; c <= (1u << 24); c++) {
-			while (i < n_ref && (ref_kmer[i] >> 40) < c) i++;
-			ix->ref_cj[c] = (uint32_t)i;
-		}
-	}
 	ix->snp_jg = xmalloc(((1u << 24) + 1) * sizeof(uint32_t));
-	{
-		uint64_t i = 0;
-		for (uint64_t c = 0; c <= (1u << 24); c++) {
-			while (i < n_snp && (snp_kmer[i] >> 40) < c) i++;
-			ix->snp_jg[c] = (uint32_t)i;
-		}
+	#pragma omp parallel for schedule(static)
+	for (int64_t c = 0; c <= (int64_t)(1u << 24); c++) {
+		uint64_t lo = 0, hi = n_ref;
+		while (lo < hi) { uint64_t m = lo + ((hi - lo) >> 1); if ((ref_kmer[m] >> 40) < (uint64_t)c) lo = m + 1; else hi = m; }
+		ix->ref_cj[c] = (uint32_t)lo;
+		lo = 0; hi = n_snp;
+		while (lo < hi) { uint64_t m = lo + ((hi - lo) >> 1); if ((snp_kmer[m] >> 40) < (uint64_t)c) lo = m + 1; else hi = m; }
+		ix->snp_jg[c] = (uint32_t)lo;
 	}
 	/* pileup table.  The reference sizes it max(raw pos field)+33 (qv.cc:554-555, 602-603), which is
 	 * 2^32+32 as soon as one k-mer is POS_AMBIGUOUS; only real positions are ever indexed, so size by those. */
 	uint64_t maxp = 0;
-	for (uint64_t i = 0; i < n_ref; i++) if (ref_amb[i] == 0 && ref_pos[i] != POS_AMBIGUOUS && ref_pos[i] > maxp) maxp = ref_pos[i];
-	for (uint64_t i = 0; i < n_ref_aux * AUX_COLS; i++) if (ref_aux[i] > maxp) maxp = ref_aux[i];
-	for (uint64_t i = 0; i < n_snp; i++) if (snp_amb[i] == 0 && snp_pos[i] != POS_AMBIGUOUS && snp_pos[i] > maxp) maxp = snp_pos[i];
-	for (uint64_t i = 0; i < n_snp_aux * AUX_COLS; i++) if (snp_aux_pos[i] > maxp) maxp = snp_aux_pos[i];
+	#pragma omp parallel for reduction(max : maxp)
+	for (int64_t i = 0; i < (int64_t)n_ref; i++) if (ref_amb[i] == 0 && ref_pos[i] != POS_AMBIGUOUS && ref_pos[i] > maxp) maxp = ref_pos[i];
+	#pragma omp parallel for reduction(max : maxp)
+	for (int64_t i = 0; i < (int64_t)(n_ref_aux * AUX_COLS); i++) if (ref_aux[i] > maxp) maxp = ref_aux[i];
+	#pragma omp parallel for reduction(max : maxp)
+	for (int64_t i = 0; i < (int64_t)n_snp; i++) if (snp_amb[i] == 0 && snp_pos[i] != POS_AMBIGUOUS && snp_pos[i] > maxp) maxp = snp_pos[i];
+	#pragma omp parallel for reduction(max : maxp)
+	for (int64_t i = 0; i < (int64_t)(n_snp_aux * AUX_COLS); i++) if (snp_aux_pos[i] > maxp) maxp = snp_aux_pos[i];
 	ix->pile_len = maxp + 64;
 	ix->pile = calloc(ix->pile_len, sizeof(uint32_t));
 	if (!ix->pile) abort();
@@ -474,14 +475,44 @@ vgo_index *vgo_index_from_arrays(
 	return ix;
 }
 
+vgo_index *vgo_index_from_arrays(
+	uint64_t n_ref, const uint64_t *ref_kmer, const uint32_t *ref_pos, const uint8_t *ref_amb,
+	uint64_t n_ref_aux, const uint32_t *ref_aux,
+	uint64_t n_snp, const uint64_t *snp_kmer, const uint32_t *snp_pos, const uint8_t *snp_info,
+	const uint8_t *snp_amb, const uint8_t *snp_rf, const uint8_t *snp_af,
+	uint64_t n_snp_aux, const uint32_t *snp_aux_pos, const uint8_t *snp_aux_info,
+	uint64_t ref_bf_bits, const uint64_t *ref_bf_words, uint64_t snp_bf_bits, const uint64_t *snp_bf_words)
+{
+	const uint64_t rbits = ref_bf_bits < (1ull << 32) ? ref_bf_bits : (1ull << 32);
+	return index_from_owned(n_ref, xdup(ref_kmer, n_ref * 8), xdup(ref_pos, n_ref * 4), xdup(ref_amb, n_ref),
+	                        n_ref_aux, xdup(ref_aux, n_ref_aux * AUX_COLS * 4),
+	                        n_snp, xdup(snp_kmer, n_snp * 8), xdup(snp_pos, n_snp * 4), xdup(snp_info, n_snp), xdup(snp_amb, n_snp), snp_rf, snp_af,
+	                        n_snp_aux, xdup(snp_aux_pos, n_snp_aux * AUX_COLS * 4), xdup(snp_aux_info, n_snp_aux * AUX_COLS),
+	                        ref_bf_bits, xdup(ref_bf_words, ((rbits + 63) / 64) * 8), snp_bf_bits, xdup(snp_bf_words, ((snp_bf_bits + 63) / 64) * 8));
+}
+
 static int read_all(const char *path, void **buf, uint64_t *len)
 {
 	FILE *f = fopen(path, "rb");
 	if (!f) return -1;
 	fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
-	*buf = xmalloc((size_t)sz);
-	if (fread(*buf, 1, (size_t)sz, f) != (size_t)sz) { fclose(f); free(*buf); return -1; }
-	fclose(f); *len = (uint64_t)sz;
+	*buf = xmalloc((size_t)sz + 1);
+	/* pieces are read concurrently (a 43 GB hg38 dictionary through one fread is a single memcpy stream) */
+	const int fd = fileno(f);
+	const int64_t piece = 64 << 20, n_piece = ((int64_t)sz + piece - 1) / piece;
+	int bad = 0;
+	#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
+	for (int64_t k = 0; k < n_piece; k++) {
+		int64_t off = k * piece, end = off + piece < (int64_t)sz ? off + piece : (int64_t)sz;
+		while (off < end) {
+			ssize_t g = pread(fd, (char *)*buf + off, (size_t)(end - off), (off_t)off);
+			if (g <= 0) { bad = 1; break; }
+			off += g;
+		}
+	}
+	fclose(f);
+	if (bad) { free(*buf); return -1; }
+	*len = (uint64_t)sz;
 	return 0;
 }
 
@@ -509,14 +540,18 @@ vgo_index *vgo_index_load(const char *prefix)
 	const uint8_t *p = rd;
 	uint64_t n_ref, n_ref_aux; memcpy(&n_ref, p, 8); memcpy(&n_ref_aux, p + 8, 8); p += 16;
 	uint64_t *rk = xmalloc(n_ref * 8); uint32_t *rp = xmalloc(n_ref * 4); uint8_t *ra = xmalloc(n_ref);
-	for (uint64_t i = 0; i < n_ref; i++, p += 13) { memcpy(&rk[i], p, 8); memcpy(&rp[i], p + 8, 4); ra[i] = p[12]; }   /* dictgen.c:63-154 */
-	uint32_t *raux = xmalloc(n_ref_aux * 40); memcpy(raux, p, n_ref_aux * 40);
+	#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n_ref; i++) { const uint8_t *q = p + 13 * i; memcpy(&rk[i], q, 8); memcpy(&rp[i], q + 8, 4); ra[i] = q[12]; }   /* dictgen.c:63-154 */
+	p += 13 * n_ref;
+	uint32_t *raux = xmalloc(n_ref_aux * 40 + 8); memcpy(raux, p, n_ref_aux * 40);
 	p = sd;
 	uint64_t n_snp, n_snp_aux; memcpy(&n_snp, p, 8); memcpy(&n_snp_aux, p + 8, 8); p += 16;
 	uint64_t *sk = xmalloc(n_snp * 8); uint32_t *sp = xmalloc(n_snp * 4);
 	uint8_t *si = xmalloc(n_snp), *sa = xmalloc(n_snp), *srf = xmalloc(n_snp), *saf = xmalloc(n_snp);
-	for (uint64_t i = 0; i < n_snp; i++, p += 16) { memcpy(&sk[i], p, 8); memcpy(&sp[i], p + 8, 4); si[i] = p[12]; sa[i] = p[13]; srf[i] = p[14]; saf[i] = p[15]; }   /* dictgen.c:156-275 */
-	uint32_t *sap = xmalloc(n_snp_aux * 40); uint8_t *sai = xmalloc(n_snp_aux * 10);
+	#pragma omp parallel for schedule(static)
+	for (int64_t i = 0; i < (int64_t)n_snp; i++) { const uint8_t *q = p + 16 * i; memcpy(&sk[i], q, 8); memcpy(&sp[i], q + 8, 4); si[i] = q[12]; sa[i] = q[13]; srf[i] = q[14]; saf[i] = q[15]; }   /* dictgen.c:156-275 */
+	p += 16 * n_snp;
+	uint32_t *sap = xmalloc(n_snp_aux * 40 + 8); uint8_t *sai = xmalloc(n_snp_aux * 10 + 8);
 	for (uint64_t i = 0; i < n_snp_aux; i++) {
 		p += 8;                                                              /* k-mer, unused by geno (qv.cc:682-683) */
 		for (int j = 0; j < AUX_COLS; j++, p += 7) { memcpy(&sap[i * 10 + j], p, 4); sai[i * 10 + j] = p[4]; }
@@ -524,10 +559,11 @@ vgo_index *vgo_index_load(const char *prefix)
 	uint64_t rbits = 0, sbits = 0; uint64_t *rw = NULL, *sw = NULL;
 	snprintf(path, sizeof path, "%s.ref.bf", prefix); if (read_bf(path, &rbits, &rw, 1ull << 32)) return NULL;
 	snprintf(path, sizeof path, "%s.snp.bf", prefix); if (read_bf(path, &sbits, &sw, ~0ull)) return NULL;
-	vgo_index *ix = vgo_index_from_arrays(n_ref, rk, rp, ra, n_ref_aux, raux, n_snp, sk, sp, si, sa, srf, saf,
-	                                      n_snp_aux, sap, sai, rbits, rw, sbits, sw);
-	free(rd); free(sd); free(rk); free(rp); free(ra); free(raux); free(sk); free(sp); free(si); free(sa); free(srf); free(saf);
-	free(sap); free(sai); free(rw); free(sw);
+	free(rd); free(sd);
+	/* the unpacked columns become the index's own arrays (no second copy of 37 GB at hg38 scale) */
+	vgo_index *ix = index_from_owned(n_ref, rk, rp, ra, n_ref_aux, raux, n_snp, sk, sp, si, sa, srf, saf,
+	                                 n_snp_aux, sap, sai, rbits, rw, sbits, sw);
+	free(srf); free(saf);
 	return ix;
 }
 

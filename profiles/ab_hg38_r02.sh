@@ -22,8 +22,7 @@ PY
 }
 run base
 grep -E "vargeno index|\[vargeno index\]|FASTA|resident" $OUT/base.err | tee -a $OUT/summary.txt
-run nopackovl VG_NO_PACK_OVERLAP=1
-run nomx VG_NO_MX=1
+run packovl VG_PACK_OVERLAP=1
 # L2 misses per launch of the wave kernel (separate --pmc pass of the same command)
 ( cd /tmp && TMPDIR=/tmp rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 $R/bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 10 --warmup 2 > $OUT/pmc_l2.json 2> $OUT/pmc_l2.err )
 python3 - $OUT <<'PY' | tee -a $OUT/summary.txt
@@ -39,12 +38,12 @@ PY
 rm -rf $OUT/pmc_l2
 for v in $R/variants/*.so; do
 	n=$(basename $v .so)
-	[ "$n" = clk ] && continue
-	run $n VARGENO_HIP_LIB=$v
+	case $n in clk*) continue;; esac
+	run $n VARGENO_HIP_LIB=$v VG_NO_PACK_OVERLAP=1
 done
 if [ -f $R/variants/clk.so ]; then
-	VARGENO_HIP_LIB=$R/variants/clk.so VG_NO_PACK_OVERLAP=1 python3 bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
+	VARGENO_HIP_LIB=$R/variants/clk.so python3 bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
 	grep "dbg" $OUT/clk.err | tail -1 | tee -a $OUT/summary.txt
 fi
-( time python3 -m pytest tests -x -q -m gpu -k "hg38" ) > $OUT/pytest_hg38.log 2>&1
-tail -4 $OUT/pytest_hg38.log | tee -a $OUT/summary.txt
+( time python3 -m pytest tests -x -q -m gpu ) > $OUT/pytest_all.log 2>&1
+tail -4 $OUT/pytest_all.log | tee -a $OUT/summary.txt

@@ -19,7 +19,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 python3 $R/profiles/summarize_prof.py $OUT $TAG > /dev/null
 # per-stage cycle shares and list-overflow reasons (development build with -DVG_STAGE_CLOCKS, if it came along)
 if [ -f $R/variants/clk.so ]; then
-	VARGENO_HIP_LIB=$R/variants/clk.so VG_NO_PACK_OVERLAP=1 python3 $R/bench.py --cpu-sample 0 --no-gather-probe --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
+	VARGENO_HIP_LIB=$R/variants/clk.so python3 $R/bench.py --cpu-sample 0 --no-gather-probe --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
 fi
 # keep the merge small: the raw traces stay on the box
 rm -rf $OUT/kt/*/*_kernel_trace.csv $OUT/kt/*/*agent_info.csv

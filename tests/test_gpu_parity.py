@@ -58,10 +58,10 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
         assert tm["ms_main"] > 0 and tm["batches"] == 1
 
 
-@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_SEC", "VG_NO_PACK_OVERLAP", "VG_NO_PROBE_VIEW"])
+@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_SEC", "VG_PACK_OVERLAP", "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW"])
 def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
-    """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view) and runs
-    its pack kernel on a separate stream.  Each has a fallback (less HBM, one stream); all must give the reference's bits.
+    """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view, strided-probe
+    view); the pack kernel can run on the ingest stream.  Each has a fallback / alternative; all must give the reference's bits.
     Several batches, so that slots, streams and the base-indexed counters' fold are exercised too."""
     monkeypatch.setenv(knob, "1")
     prefix = os.path.join(ftiny_dir, "idx")

@@ -218,15 +218,18 @@ struct Partitioned {
 	~Partitioned() { free(data); }
 };
 
-// produce(chunk, sink): calls sink(const T &) for every record of the chunk, in input order; must be repeatable
-template <class T, class Produce>
-static void partition_records(size_t n_chunks, Produce &&produce, Partitioned<T> &out)
+struct ByKmerTop { template <class T> size_t operator()(const T &r) const { return (size_t)(r.kmer >> (64 - PART_BITS)); } };
+
+// produce(chunk, sink): calls sink(const T &) for every record of the chunk, in input order; must be repeatable.
+// bucket_of(record) < N_PART.
+template <class T, class Produce, class Bucket = ByKmerTop>
+static void partition_records(size_t n_chunks, Produce &&produce, Partitioned<T> &out, Bucket bucket_of = Bucket())
 {
 	std::vector<uint32_t> cnt(n_chunks * N_PART, 0);                 // a chunk holds < 2^32 records
 	#pragma omp parallel for schedule(dynamic, 1)
 	for (long c = 0; c < (long)n_chunks; c++) {
 		uint32_t *row = &cnt[(size_t)c * N_PART];
-		produce((size_t)c, [&](const T &r) { row[r.kmer >> (64 - PART_BITS)]++; });
+		produce((size_t)c, [&](const T &r) { row[bucket_of(r)]++; });
 	}
 	// slot of (bucket b, chunk c) = records in earlier buckets + records of bucket b in earlier chunks
 	out.begin.assign(N_PART + 1, 0);
@@ -244,7 +247,7 @@ static void partition_records(size_t n_chunks, Produce &&produce, Partitioned<T>
 	for (long c = 0; c < (long)n_chunks; c++) {
 		size_t *row = &at[(size_t)c * N_PART];
 		T *dst = out.data;
-		produce((size_t)c, [&](const T &r) { dst[row[r.kmer >> (64 - PART_BITS)]++] = r; });
+		produce((size_t)c, [&](const T &r) { dst[row[bucket_of(r)]++] = r; });
 	}
 }
 
@@ -394,25 +397,38 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 		const bool dense = fa.size() > ((size_t)256 << 20);
 		BitVec bf(REF_BF_BITS, dense);
 		BitVec lite(opt.write_lite ? REF_LITE_BF_BITS : 64, dense && opt.write_lite);
-		for (const Seq &s : g) {
-			if (s.seq.size() < 32) die("reference sequence shorter than 32 bases: " + s.name);      // assert, generate_bf.cc:104
-			const size_t nwin = s.seq.size() - 31;
-			const size_t chunk = std::max<size_t>(1 << 20, (nwin + nthreads - 1) / nthreads);
-			const long nchunks = (long)((nwin + chunk - 1) / chunk);
-			std::string err;
-			#pragma omp parallel for schedule(dynamic, 1)
-			for (long c = 0; c < nchunks; c++) {
-				try {
-					for_each_kmer(s.seq, (size_t)c * chunk, std::min(nwin, (size_t)(c + 1) * chunk), true, [&](uint64_t k, size_t) {
-						bf.set_atomic((uint64_t)hash32((uint32_t)k) % REF_BF_BITS);
-						if (opt.write_lite) lite.set_atomic(hash40(k & 0xFFFFFFFFFFull) % REF_LITE_BF_BITS);
-					});
-				} catch (const Error &e) {
-					#pragma omp critical
-					err = e.msg;
-				}
+		// Bits to set: hash32(first 16 bases) of every N-free 32-mer -- 3.1 G scattered bits at hg38 scale.  Setting them with
+		// atomics from all threads took 22 s there (every bit a cache miss on a line other cores are writing); instead the bit
+		// numbers are radix-partitioned by their top 12 bits first, and each 128 KiB slice of the vector is then filled by one
+		// thread out of its own list.  (The lite vector, which `geno` never reads, keeps the atomic path.)
+		struct Chunk { size_t seq, lo, hi; };
+		std::vector<Chunk> chunks;
+		for (size_t si = 0; si < g.size(); si++) {
+			if (g[si].seq.size() < 32) die("reference sequence shorter than 32 bases: " + g[si].name);      // assert, generate_bf.cc:104
+			const size_t nwin = g[si].seq.size() - 31;
+			for (size_t lo = 0; lo < nwin; lo += (size_t)1 << 22) chunks.push_back(Chunk{si, lo, std::min(nwin, lo + ((size_t)1 << 22))});
+		}
+		std::string err;
+		struct Bit { uint32_t at; };
+		Partitioned<Bit> part;
+		partition_records<Bit>(chunks.size(), [&](size_t c, auto &&sink) {
+			try {
+				for_each_kmer(g[chunks[c].seq].seq, chunks[c].lo, chunks[c].hi, true, [&](uint64_t k, size_t) {
+					sink(Bit{hash32((uint32_t)k)});                      // (hash32 < 2^32 <= REF_BF_BITS: the reference's modulo never fires)
+					if (opt.write_lite) lite.set_atomic(hash40(k & 0xFFFFFFFFFFull) % REF_LITE_BF_BITS);
+				});
+			} catch (const Error &e) {
+				#pragma omp critical
+				err = e.msg;
 			}
-			if (!err.empty()) die(err);
+		}, part, [](const Bit &b) { return (size_t)(b.at >> (32 - PART_BITS)); });
+		if (!err.empty()) die(err);
+		#pragma omp parallel for schedule(dynamic, 4)
+		for (long b = 0; b < (long)N_PART; b++) {
+			const Bit *lo = part.data + part.begin[(size_t)b], *hi = part.data + part.begin[(size_t)b + 1];
+			if (lo == hi) continue;
+			for (const Bit *p = lo; p < hi; p++) bf.w[p->at >> 6] |= 1ull << (p->at & 63);
+			bf.dirty[((size_t)b << (32 - PART_BITS - 6)) / BitVec::BLK_WORDS] = 1;       // a slice lies inside one dirty block
 		}
 		if (!opt.quiet) {
 			printf("[BloomFilter constructBfFromGenomeseq] bit vector: %llu/%llu\n", (unsigned long long)bf.count(), (unsigned long long)REF_BF_BITS);

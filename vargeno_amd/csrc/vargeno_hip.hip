@@ -585,6 +585,7 @@ struct Slot {
 	void *fq_tmp = nullptr; uint64_t fq_tmp_cap = 0;                 // scan scratch (grow-only: no allocation per chunk)
 	FqChunk *fq_chunk = nullptr;                                     // this chunk's framing results, device resident
 	uint64_t fq_text_len = 0;                                        // bytes of text copied into fq_text (after the FQ_CARRY gap)
+	hipEvent_t e_in = nullptr;                                       // the batch's buffers are complete (when another stream produced them)
 	hipEvent_t e_fq = nullptr; bool fq_tail_wanted = false;          // the NEXT chunk's prepare kernel reads this text's tail: recorded after it
 	uint64_t stage_bytes = 0, stage_reads = 0;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
@@ -595,7 +596,11 @@ struct vg_index {
 	int device = 0;
 	hipStream_t stream = nullptr, tail = nullptr;   // pack + wave tier | spill tiers of earlier batches
 	hipStream_t ingest = nullptr;                   // FASTQ framing + pack kernel of the next batch, under the current batch's wave kernel
-	bool pack_overlap = true;                       // VG_NO_PACK_OVERLAP: ingest work goes to the main stream instead
+	bool pack_overlap = false;                      // VG_PACK_OVERLAP=1: the pack kernel of batch k+1 goes to the ingest stream, under batch k's wave kernel.
+	                                                // Off by default: nothing fits beside a full set of main-tier workgroups (4 x 128 VGPRs per SIMD), so the
+	                                                // two kernels only take turns on the CUs -- same reads/s (hg38 scale: 4.21 vs 4.26 ms per 8 M reads), but the
+	                                                // wave kernel's duration then includes the time it spent waiting for the pack kernel (4.18 vs 3.55 ms)
+	bool ingest_stream = true;                      // VG_NO_INGEST_STREAM: FASTQ framing on the main stream too
 	DevIndex d{};
 	std::vector<void *> owned;            // every device allocation of the index
 	uint64_t dev_bytes = 0;
@@ -687,7 +692,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	for (Slot &sl : ix->slot) {
 		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
 		for (void *p : extra) if (p) (void)hipFree(p);
-		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5, sl.e_fq};
+		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5, sl.e_fq, sl.e_in};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
 	}
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -753,8 +758,9 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		HIP_TRY(hipStreamCreateWithPriority(&ix->tail, hipStreamNonBlocking, hi_p));
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->ingest, hipStreamNonBlocking));
-	ix->pack_overlap = getenv("VG_NO_PACK_OVERLAP") == nullptr;
-	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); HIP_TRY(hipEventCreateWithFlags(&sl.e_fq, hipEventDisableTiming)); }
+	if (const char *e = getenv("VG_PACK_OVERLAP")) ix->pack_overlap = atoi(e) != 0;
+	ix->ingest_stream = getenv("VG_NO_INGEST_STREAM") == nullptr;
+	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); HIP_TRY(hipEventCreateWithFlags(&sl.e_fq, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming)); }
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	ix->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1155,6 +1161,10 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		// kernel was measured and lost 12 %: two co-scheduled kernels split the CUs.)
 		hipStream_t ps = ix->stream;
 		if (ix->pack_overlap) ps = ix->ingest;
+		if (produced_on && produced_on != ps) {                     // a batch gathered by the FASTQ framing on the ingest stream
+			HIP_TRY(hipEventRecord(sl.e_in, produced_on));
+			HIP_TRY(hipStreamWaitEvent(ps, sl.e_in, 0));
+		}
 		HIP_TRY(hipMemsetAsync(ctr, 0, 32, ps));
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
@@ -1178,9 +1188,9 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
-		if (produced_on && produced_on != ix->stream) {             // a batch gathered by vg_fastq_submit on the ingest stream
-			HIP_TRY(hipEventRecord(sl.e1, produced_on));
-			HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
+		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream
+			HIP_TRY(hipEventRecord(sl.e_in, produced_on));
+			HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e_in, 0));
 		}
 		HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
@@ -1308,7 +1318,7 @@ extern "C" int vg_fastq_stream_begin(vg_index *ix)
 {
 	if (!ix) return fail(VG_EINVAL, "null argument");
 	HIP_TRY(hipSetDevice(ix->device));
-	hipStream_t is = ix->pack_overlap ? ix->ingest : ix->stream;
+	hipStream_t is = ix->ingest_stream ? ix->ingest : ix->stream;
 	HIP_TRY(hipMemsetAsync(ix->d_fq, 0, sizeof(FqStream), is));
 	ix->fq_open = true; ix->fq_prev_slot = -1;
 	return VG_OK;
@@ -1328,7 +1338,7 @@ extern "C" int vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t 
 	int rc = acquire_slot(ix, &slp);
 	if (rc) return rc;
 	Slot &sl = *slp;
-	hipStream_t is = ix->pack_overlap ? ix->ingest : ix->stream;
+	hipStream_t is = ix->ingest_stream ? ix->ingest : ix->stream;
 	// the chunk after this slot's last one copied the tail of its text on the ingest stream: that must have happened before
 	// the text is overwritten (the slot's own batch being finished does not imply it)
 	if (sl.fq_tail_wanted) { HIP_TRY(hipEventSynchronize(sl.e_fq)); sl.fq_tail_wanted = false; }
@@ -1388,7 +1398,7 @@ static int fq_collect(vg_index *ix, bool drain, uint64_t *n_records, uint64_t *c
 {
 	HIP_TRY(hipSetDevice(ix->device));
 	if (drain) { int rc = finish_pending(ix); if (rc) return rc; }
-	else HIP_TRY(hipStreamSynchronize(ix->pack_overlap ? ix->ingest : ix->stream));       // framing only: the read loop runs on
+	else HIP_TRY(hipStreamSynchronize(ix->ingest_stream ? ix->ingest : ix->stream));       // framing only: the read loop runs on
 	FqStream h;
 	HIP_TRY(hipMemcpy(&h, ix->d_fq, sizeof h, hipMemcpyDeviceToHost));
 	if (n_records) *n_records = h.records;

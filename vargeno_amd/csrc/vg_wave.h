@@ -450,7 +450,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 		// (owner, chunk) pairs in (lane, chunk) order -> one table row each (LDS), their work items laid end to end and dealt
 		// to the lanes 64 at a time, so a round is full whatever the size of each chunk's neighbourhood.
 		{
-			const uint32_t pend = (active && !ovf) ? (n >= 32 ? gates : (gates & ((1u << n) - 1u))) : 0u;
+			// A pass without a single exact hit has no vote key, and neighbour contexts cannot open one (qv.cc:134-139): nothing its
+			// gate-open chunks could find would vote or be walked.  That is the whole forward pass of every reverse-strand read -- a
+			// third of all passes -- so the timed build skips stage B for it (the counting build runs it: its events are priced).
+#ifdef VG_NO_HOPELESS_SKIP
+			const bool hopeless = false;
+#else
+			const bool hopeless = !STATS && ecnt == 0;
+#endif
+			const uint32_t pend = (active && !ovf && !hopeless) ? (n >= 32 ? gates : (gates & ((1u << n) - 1u))) : 0u;
 			const uint32_t my_np = (uint32_t)__popc(pend);
 			uint32_t pincl = my_np;
 			for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(pincl, o); if ((int)lane >= o) pincl += y; }
