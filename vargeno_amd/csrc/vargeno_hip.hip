@@ -201,7 +201,8 @@ __global__ void vg_inline_pairs(uint4 *__restrict__ mx, uint64_t n, const uint32
 // strided-probe view of the SNP dictionary (DevIndex::snp_probe)
 __global__ void vg_make_snp_probe(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ jg, uint64_t n, uint64_t *__restrict__ out)
 {
-	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
+		if (i == n) { out[i] = 0ull; continue; }                    // (the kernel reads the view two entries at a time)
 		const uint64_t slo = jg[kmer[i] >> 40];
 		const uint64_t t = slo + (i - slo) * SNP_STRIDE;
 		out[i] = t < n ? (kmer[t] & LO40_MASK) : 0ull;
@@ -833,7 +834,7 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 		d.snp_jg = jg; d.snp = ent; d.snp_aux_pos = xp; d.snp_aux_info = xi;
 		if (!getenv("VG_NO_PROBE_VIEW")) {
 			uint64_t *pv = nullptr;
-			if ((rc = dev_alloc(ix, &pv, a->n_snp))) return rc;
+			if ((rc = dev_alloc(ix, &pv, a->n_snp + 1))) return rc;
 			vg_make_snp_probe<<<2048, 256, 0, ix->stream>>>(tk.p, jg, a->n_snp, pv);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(ix->stream));

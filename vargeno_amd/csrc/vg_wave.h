@@ -524,7 +524,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; key[z] = d.sec_key[e]; idx[z] = d.sec_idx[e]; }
 								#pragma unroll
 								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) if (b0 + z < b1 && (uint32_t)(key[z] >> 32) == klo) sec_entry(key[z], idx[z]);
-							} else {
+							}
+#ifdef VG_SEC_NOWALK
+							else sec_ok = false;                                  // (experiment: a bucket beyond SEC_W entries keeps its 48 queries)
+#else
+							else {
 								// k-mers with this LO32 are adjacent in the view; a popular LO32 (microsatellites, poly-A) would make
 								// one lane walk a long run while its wave waits, so past SEC_RUN entries the pair keeps its 48 queries
 								uint32_t ea = b0, eb = b1;
@@ -537,12 +541,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 									if (onebase((uint64_t)((uint32_t)key ^ khi)) >= 0) sec_entry(key, d.sec_idx[e]);
 								}
 							}
+#endif
 						}
 						uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
 						if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
 						else if (sec_ok && s_hi == s_lo) { mode = 1; nhigh = nh; }
 						else { u_lo = 0; nhigh = 48; }
-						const uint32_t L = large ? 48u : (hi - lo) + (shi - slo);
+						// items of the strided scans: one per reference-bucket entry; SNP-bucket entries two per item when their probed values
+						// lie side by side (strided-probe view): the SNP scan is most of stage B's items at hg38 scale, and every round of 64
+						// items pays the full chain of dependent waits of the few items in it that do have something to look up
+						const uint32_t Lsn = shi - slo;
+						const uint32_t L = large ? 48u : (hi - lo) + (use_probe ? (Lsn + 1u) >> 1 : Lsn);
 						P_klo[p][wv] = klo; P_khi[p][wv] = khi; P_lo[p][wv] = lo; P_hi[p][wv] = hi; P_slo[p][wv] = slo; P_shi[p][wv] = shi;
 						P_meta[p][wv] = own | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
 						P_cnt[p][wv] = L + nhigh;
@@ -585,15 +594,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g2) p += step;
 						const uint32_t t = g2 - P_off[p][wv];
 						if (!((P_meta[p][wv] >> 13) & 1u)) {                     // not a large block
-							const uint32_t lo = P_lo[p][wv], slo = P_slo[p][wv], Lr = P_hi[p][wv] - lo, L = Lr + (P_shi[p][wv] - slo);
+							const uint32_t lo = P_lo[p][wv], slo = P_slo[p][wv], Lr = P_hi[p][wv] - lo, Lsn = P_shi[p][wv] - slo;
+							const uint32_t L = Lr + (use_probe ? (Lsn + 1u) >> 1 : Lsn);
 							if (t < L) {
 								const bool isr = t < Lr;
 								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)t * REF_STRIDE : (uint64_t)slo + (uint64_t)(t - Lr) * SNP_STRIDE;
-								if (!isr && use_probe) {                            // the probed LO40 values of a bucket lie side by side
-									uint2 q;
-									__builtin_memcpy(&q, d.snp_probe + ((uint64_t)slo + (t - Lr)), 8);
-									v.x = q.x; v.y = q.y;
-								} else if (tt < (isr ? d.n_ref : d.n_snp)) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
+								if (!isr && use_probe) __builtin_memcpy(&v, d.snp_probe + ((uint64_t)slo + 2u * (t - Lr)), 16);   // two probed LO40 values, side by side
+								else if (tt < (isr ? d.n_ref : d.n_snp)) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
 							}
 						}
 					}
@@ -618,7 +625,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						own = meta & 63u; c = (meta >> 6) & 31u;
 						const uint32_t fl = (meta >> 11) & 3u, mode = (meta >> 14) & 1u, nh = (meta >> 16) & 7u, u_lo = (meta >> 19) & 63u;
 						const bool large = (meta >> 13) & 1u, sec_ok = (meta >> 15) & 1u;
-						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (shi - slo);
+						const uint32_t Lsn = shi - slo;
+						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (use_probe ? (Lsn + 1u) >> 1 : Lsn);
 						const uint32_t rsb = (fl & 1u) ? 64u : 32u, ssb = (fl & 2u) ? 64u : 40u;
 						o_ecnt = P_ecnt[p][wv];
 						bool q_r = false, q_s = false;                          // dictionary queries of the neighbour k-mer qk, issued together below
@@ -634,18 +642,28 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 								// iterate_ref_dict, qv.cc:316-376 / iterate_snp_dict, qv.cc:413-464   (B1): entry lo + 9u (slo + 11u) is
 								// tested, entry lo + u (slo + u) recorded.  Both dictionaries hold 16-byte entries: one gather site.
 								const bool isr = t < Lr;
+								const uint4 v = scan_cur;                                 // zeros when the probe fell off the array
+								if (!isr && use_probe) {
+									// two consecutive entries of the SNP bucket per item (timed build only: no event counts here)
+									const uint32_t u0 = 2u * (t - Lr);
+									const uint64_t t0 = (((uint64_t)v.y << 32) | v.x) & LO40_MASK, t1 = (((uint64_t)v.w << 32) | v.z) & LO40_MASK;
+									const int d0 = onebase((k & LO40_MASK) ^ t0), d1 = u0 + 1u < Lsn ? onebase((k & LO40_MASK) ^ t1) : -1;
+									if (d0 >= 0 && d1 >= 0) N_ovf[col0 + own] = 1;        // two hits in one item (repeats): the read goes to the next tier
+									else if (d0 >= 0) { si = slo + u0; mod = (uint32_t)d0; nbase = (uint32_t)(t0 >> (2 * d0)) & 3u; }
+									else if (d1 >= 0) { si = slo + u0 + 1u; mod = (uint32_t)d1; nbase = (uint32_t)(t1 >> (2 * d1)) & 3u; }
+								} else {
 								const uint32_t u = isr ? t : t - Lr;
 								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)u * REF_STRIDE : (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
 								const bool inr = tt < (isr ? d.n_ref : d.n_snp);
 								hs.add(S_SCAN_REF, isr ? 1u : 0u);
 								hs.add(S_SCAN_SNP, isr ? 0u : 1u);
 								hs.add(S_SCAN_OOB, inr ? 0u : 1u);
-								const uint4 v = scan_cur;                                 // zeros when the probe fell off the array
 								const uint64_t tlo = isr ? (uint64_t)v.x : ((((uint64_t)v.y << 32) | v.x) & LO40_MASK);
 								const int dd = onebase(isr ? (uint64_t)(klo ^ v.x) : ((k & LO40_MASK) ^ tlo));
 								if (dd >= 0) {
 									if (isr) ri = lo + u; else si = slo + u;
 									mod = (uint32_t)dd; nbase = (uint32_t)(tlo >> (2 * dd)) & 3u;
+								}
 								}
 							}
 						} else {                                                 // qv.cc:1213-1365
@@ -827,7 +845,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 				auto vote = [&](uint32_t index, uint32_t kpos, bool neigh, uint32_t upto) {
 					int e = -1;
 					if (k0_fm && k0_idx == index) e = 0;
-					else for (uint32_t i = 1; i < upto; i++) if (E_idx[i][col] == index && E_fm[i][col]) { e = (int)i; break; }
+					else {
+						// the first exact context below `upto` with this implied position IS the key's home (whichever context came first
+						// opened the key): four candidates per LDS round trip, no look at E_fm
+						for (uint32_t i0 = 1; i0 < upto && e < 0; i0 += 4) {
+							uint32_t v[4];
+							#pragma unroll
+							for (uint32_t z = 0; z < 4; z++) v[z] = E_idx[i0 + z < (uint32_t)W_ECAP ? i0 + z : (uint32_t)W_ECAP - 1][col];
+							#pragma unroll
+							for (uint32_t z = 0; z < 4; z++) if (e < 0 && i0 + z < upto && v[z] == index) e = (int)(i0 + z);
+						}
+					}
 					uint32_t first, fm;
 					if (e < 0) {
 						if (neigh) return;                                                // :134-139
