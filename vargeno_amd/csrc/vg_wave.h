@@ -74,7 +74,6 @@ constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is 
 #endif
 constexpr int SEC_W = VG_SEC_W;   // entries of an LO32-view bucket fetched in one go (buckets average 1-3 entries; hg38: 2.7)
 constexpr int PCAP = 32;         // rows of the stage-B pair table (a wave with more gate-open chunks takes several windows)
-constexpr int SEC_RUN = 12;      // longest run of equal-LO32 entries one lane will walk in the LO32-ordered view
 constexpr int HCAP = 4;          // high-half reference hits per pair kept from the LO32-ordered view (more: the 48 queries are issued)
 
 // packed reads: chunk k-mers at [offsets[r] >> 5 ...), one flag word per read
@@ -135,6 +134,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 	const bool use_sec = !STATS && d.sec_key != nullptr;
 	const bool use_mx = !STATS && d.mx != nullptr;
 	const bool use_probe = !STATS && d.snp_probe != nullptr;
+	// two SNP-scan probes per stage-B item, in the main tier only: an item with two hits sends its read to the next tier, and the
+	// deep-list tier must be able to finish such a read itself (the lane tier behind it takes milliseconds per read)
+	const bool probe2 = use_probe && WPB > 1;
 	const uint32_t lane = threadIdx.x & 63u;             // lane in the wave
 	const uint32_t col = threadIdx.x;                    // this lane's LDS column
 	const uint32_t col0 = wv << 6;                       // first column of this wave (scalar)
@@ -525,23 +527,9 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 								#pragma unroll
 								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) if (b0 + z < b1 && (uint32_t)(key[z] >> 32) == klo) sec_entry(key[z], idx[z]);
 							}
-#ifdef VG_SEC_NOWALK
-							else sec_ok = false;                                  // (experiment: a bucket beyond SEC_W entries keeps its 48 queries)
-#else
-							else {
-								// k-mers with this LO32 are adjacent in the view; a popular LO32 (microsatellites, poly-A) would make
-								// one lane walk a long run while its wave waits, so past SEC_RUN entries the pair keeps its 48 queries
-								uint32_t ea = b0, eb = b1;
-								const uint64_t want = (uint64_t)klo << 32;
-								while (ea < eb) { const uint32_t m = ea + ((eb - ea) >> 1); if (d.sec_key[m] < want) ea = m + 1; else eb = m; }
-								for (uint32_t e = ea; e < b1 && sec_ok; e++) {
-									const uint64_t key = d.sec_key[e];
-									if ((uint32_t)(key >> 32) != klo) break;
-									if (e - ea >= (uint32_t)SEC_RUN) { sec_ok = false; break; }
-									if (onebase((uint64_t)((uint32_t)key ^ khi)) >= 0) sec_entry(key, d.sec_idx[e]);
-								}
-							}
-#endif
+							// A longer bucket keeps its 48 queries, dealt to 48 lanes in stage B1: walking a popular LO32's run of entries here
+							// (bisection + up to a dozen dependent loads) made one lane hold up its wave -- 4 % of the kernel at hg38 scale.
+							else sec_ok = false;
 						}
 						uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
 						if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
@@ -551,7 +539,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						// lie side by side (strided-probe view): the SNP scan is most of stage B's items at hg38 scale, and every round of 64
 						// items pays the full chain of dependent waits of the few items in it that do have something to look up
 						const uint32_t Lsn = shi - slo;
-						const uint32_t L = large ? 48u : (hi - lo) + (use_probe ? (Lsn + 1u) >> 1 : Lsn);
+						const uint32_t L = large ? 48u : (hi - lo) + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
 						P_klo[p][wv] = klo; P_khi[p][wv] = khi; P_lo[p][wv] = lo; P_hi[p][wv] = hi; P_slo[p][wv] = slo; P_shi[p][wv] = shi;
 						P_meta[p][wv] = own | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
 						P_cnt[p][wv] = L + nhigh;
@@ -595,11 +583,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						const uint32_t t = g2 - P_off[p][wv];
 						if (!((P_meta[p][wv] >> 13) & 1u)) {                     // not a large block
 							const uint32_t lo = P_lo[p][wv], slo = P_slo[p][wv], Lr = P_hi[p][wv] - lo, Lsn = P_shi[p][wv] - slo;
-							const uint32_t L = Lr + (use_probe ? (Lsn + 1u) >> 1 : Lsn);
+							const uint32_t L = Lr + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
 							if (t < L) {
 								const bool isr = t < Lr;
 								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)t * REF_STRIDE : (uint64_t)slo + (uint64_t)(t - Lr) * SNP_STRIDE;
-								if (!isr && use_probe) __builtin_memcpy(&v, d.snp_probe + ((uint64_t)slo + 2u * (t - Lr)), 16);   // two probed LO40 values, side by side
+								if (!isr && probe2) __builtin_memcpy(&v, d.snp_probe + ((uint64_t)slo + 2u * (t - Lr)), 16);   // two probed LO40 values, side by side
+								else if (!isr && use_probe) { uint2 q; __builtin_memcpy(&q, d.snp_probe + ((uint64_t)slo + (t - Lr)), 8); v.x = q.x; v.y = q.y; }
 								else if (tt < (isr ? d.n_ref : d.n_snp)) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
 							}
 						}
@@ -626,7 +615,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						const uint32_t fl = (meta >> 11) & 3u, mode = (meta >> 14) & 1u, nh = (meta >> 16) & 7u, u_lo = (meta >> 19) & 63u;
 						const bool large = (meta >> 13) & 1u, sec_ok = (meta >> 15) & 1u;
 						const uint32_t Lsn = shi - slo;
-						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (use_probe ? (Lsn + 1u) >> 1 : Lsn);
+						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
 						const uint32_t rsb = (fl & 1u) ? 64u : 32u, ssb = (fl & 2u) ? 64u : 40u;
 						o_ecnt = P_ecnt[p][wv];
 						bool q_r = false, q_s = false;                          // dictionary queries of the neighbour k-mer qk, issued together below
@@ -643,7 +632,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 								// tested, entry lo + u (slo + u) recorded.  Both dictionaries hold 16-byte entries: one gather site.
 								const bool isr = t < Lr;
 								const uint4 v = scan_cur;                                 // zeros when the probe fell off the array
-								if (!isr && use_probe) {
+								if (!isr && probe2) {
 									// two consecutive entries of the SNP bucket per item (timed build only: no event counts here)
 									const uint32_t u0 = 2u * (t - Lr);
 									const uint64_t t0 = (((uint64_t)v.y << 32) | v.x) & LO40_MASK, t1 = (((uint64_t)v.w << 32) | v.z) & LO40_MASK;
