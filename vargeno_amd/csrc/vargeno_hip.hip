@@ -20,6 +20,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -740,10 +743,141 @@ static void parallel_for(uint64_t n, F &&fn)
 	for (auto &x : th) x.join();
 }
 
-static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
+// ------------------------------------------------------------------------------------------------
+// index construction.  Everything from the dictionaries' columns onward happens on the device: the host only brings
+// bytes (from the caller's arrays, or straight from the files -- read by several threads into pinned staging buffers and
+// copied up while the next piece is being read; the packed records are unpacked by a kernel).
+// ------------------------------------------------------------------------------------------------
+
+// unpack the reference dictionary's 13-byte records {u64 k-mer, u32 pos, u8 ambig} (dictgen.c:63-154): a workgroup stages the
+// 3 328 contiguous bytes of 256 records in LDS with 16-byte loads, then every lane takes its own record out of LDS
+__global__ __launch_bounds__(256) void vg_unpack_ref(const uint8_t *__restrict__ raw, uint64_t n, uint64_t *__restrict__ kmer, uint32_t *__restrict__ pos, uint8_t *__restrict__ amb)
 {
-	if (a->n_ref >= 0xFFFFFFFFull || a->n_snp >= 0xFFFFFFFFull) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
-	if (a->ref_bf_bits == 0 || a->snp_bf_bits == 0) return fail(VG_EINVAL, "empty bit vector");
+	__shared__ __attribute__((aligned(16))) uint8_t sm[256 * 13 + 48];
+	for (uint64_t r0 = (uint64_t)blockIdx.x * 256; r0 < n; r0 += (uint64_t)gridDim.x * 256) {
+		const uint64_t b0 = 13 * r0, a0 = b0 & ~15ull;              // the tile's first byte, and the 16-byte boundary below it (raw itself is aligned)
+		const uint32_t shift = (uint32_t)(b0 - a0);
+		const uint64_t nrec = n - r0 < 256 ? n - r0 : 256;
+		const uint32_t nbytes = shift + 13u * (uint32_t)nrec;
+		__syncthreads();                                            // previous tile fully consumed
+		for (uint32_t i = threadIdx.x * 16; i < nbytes; i += 256 * 16) *reinterpret_cast<uint4 *>(sm + i) = *reinterpret_cast<const uint4 *>(raw + a0 + i);   // (the buffer has slack behind its last byte)
+		__syncthreads();
+		if (threadIdx.x < nrec) {
+			const uint8_t *q = sm + shift + 13 * threadIdx.x;
+			uint64_t k; uint32_t p2;
+			__builtin_memcpy(&k, q, 8); __builtin_memcpy(&p2, q + 8, 4);
+			const uint64_t i = r0 + threadIdx.x;
+			kmer[i] = k; pos[i] = p2; amb[i] = q[12];
+		}
+	}
+}
+// ... the SNP dictionary's 16-byte records {u64 k-mer, u32 pos, u8 snp_info, ambig, ref_freq, alt_freq} (dictgen.c:156-275): one aligned 16-byte load each
+__global__ void vg_unpack_snp(const uint8_t *__restrict__ raw, uint64_t n, uint64_t *__restrict__ kmer, uint32_t *__restrict__ pos,
+                              uint8_t *__restrict__ info, uint8_t *__restrict__ amb, uint8_t *__restrict__ rf, uint8_t *__restrict__ af)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 v = *reinterpret_cast<const uint4 *>(raw + 16 * i);
+		kmer[i] = ((uint64_t)v.y << 32) | v.x; pos[i] = v.z;
+		info[i] = (uint8_t)v.w; amb[i] = (uint8_t)(v.w >> 8); rf[i] = (uint8_t)(v.w >> 16); af[i] = (uint8_t)(v.w >> 24);
+	}
+}
+// ... auxiliary rows: the reference dictionary's are 10 x u32 already (copied bytewise: the file offset is not aligned); the SNP
+// dictionary's are {u64 k-mer, 10 x {u32 pos, u8 snp_info, u8 ref_freq, u8 alt_freq}} = 78 bytes, of which the path reads pos and snp_info
+__global__ void vg_unpack_ref_aux(const uint8_t *__restrict__ raw, uint64_t n_words, uint32_t *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint8_t *q = raw + 4 * i;
+		out[i] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+	}
+}
+__global__ void vg_unpack_snp_aux(const uint8_t *__restrict__ raw, uint64_t n_rows, uint32_t *__restrict__ pos, uint8_t *__restrict__ info)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * AUX_COLS; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint8_t *q = raw + 78 * (i / AUX_COLS) + 8 + 7 * (i % AUX_COLS);
+		pos[i] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+		info[i] = q[4];
+	}
+}
+
+// largest genome position any entry names (the reference sizes its pile-up table max(raw pos field) + 33, i.e. 2^32 + 32 entries as soon
+// as one k-mer is POS_AMBIGUOUS; only real positions are ever indexed)
+__global__ void vg_max_pos(const uint32_t *__restrict__ pos, const uint8_t *__restrict__ amb, uint64_t n, unsigned long long *out)
+{
+	unsigned long long m = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t p = pos[i];
+		if ((!amb || amb[i] == 0) && p != POS_AMBIGUOUS && p > m) m = p;
+	}
+	for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(m, o); m = y > m ? y : m; }
+	if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+// Pile-up seeding in FILE ORDER, last writer wins (qv.cc:637-659): every position first learns the index of the LAST SNP-dictionary
+// entry that seeds it ...
+__global__ void vg_site_winner(const uint32_t *__restrict__ pos, const uint8_t *__restrict__ info, const uint8_t *__restrict__ amb, uint64_t n, uint32_t *__restrict__ winner)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t f = info[i];
+		if ((f & 4u) == 0 && pos[i] != POS_AMBIGUOUS && amb[i] == 0) atomicMax(&winner[(uint64_t)pos[i] + (f >> 3)], (uint32_t)(i + 1));   // n < 2^32 - 1
+	}
+}
+// ... then every position applies that one entry: one wave per 64-position block -- the ballot of "is a site" is the block's rank mask
+__global__ __launch_bounds__(256) void vg_site_blocks(const uint32_t *__restrict__ winner, const uint64_t *__restrict__ kmer, const uint8_t *__restrict__ info,
+                                                      uint64_t plen, uint8_t *__restrict__ pile, ulonglong2 *__restrict__ rank, uint64_t *__restrict__ blk_sites)
+{
+	const uint64_t nblk = plen / 64 + 1;
+	const uint32_t lane = threadIdx.x & 63;
+	for (uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nblk; b += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
+		const uint64_t p = b * 64 + lane;
+		uint32_t w = 0;
+		if (p < plen) {
+			const uint32_t win = winner[p];
+			if (win) {
+				const uint32_t f = info[win - 1];
+				w = (f & 3u) | (((uint32_t)(kmer[win - 1] >> (2 * (f >> 3))) & 3u) << 2);
+			}
+		}
+		const bool site = (w & 3u) != ((w >> 2) & 3u);
+		if (p < plen) pile[p] = (uint8_t)(w | (site ? 16u : 0u));
+		const uint64_t m = __ballot(site);
+		if (lane == 0) { rank[b] = make_ulonglong2(m, 0ull); blk_sites[b] = (uint64_t)__popcll(m); }
+	}
+}
+__global__ __launch_bounds__(256) void vg_site_tables(const uint32_t *__restrict__ winner, const uint8_t *__restrict__ pile, const uint8_t *__restrict__ rf, const uint8_t *__restrict__ af,
+                                                      uint64_t plen, ulonglong2 *__restrict__ rank, const uint64_t *__restrict__ blk_before,
+                                                      uint32_t *__restrict__ s_pos, uint8_t *__restrict__ s_ref, uint8_t *__restrict__ s_alt, uint8_t *__restrict__ s_rf, uint8_t *__restrict__ s_af, uint8_t *__restrict__ s_ba)
+{
+	const uint64_t nblk = plen / 64 + 1;
+	const uint32_t lane = threadIdx.x & 63;
+	for (uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < nblk; b += ((uint64_t)gridDim.x * blockDim.x) >> 6) {
+		const uint64_t before = blk_before[b], m = rank[b].x;
+		if (lane == 0) rank[b].y = before;
+		if ((m >> lane) & 1ull) {
+			const uint64_t p = b * 64 + lane, s = before + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+			const uint32_t w = pile[p], win = winner[p];
+			s_pos[s] = (uint32_t)p; s_ref[s] = (uint8_t)(w & 3u); s_alt[s] = (uint8_t)((w >> 2) & 3u); s_ba[s] = (uint8_t)(w & 15u);
+			s_rf[s] = rf[win - 1]; s_af[s] = af[win - 1];
+		}
+	}
+}
+
+// the dictionaries' columns on the device: temporaries of the construction (freed when it is done)
+struct DevCols {
+	uint64_t n_ref = 0, n_ref_aux = 0, n_snp = 0, n_snp_aux = 0;
+	TempDev<uint64_t> ref_kmer, snp_kmer;
+	TempDev<uint32_t> ref_pos, snp_pos;
+	TempDev<uint8_t> ref_amb, snp_info, snp_amb, snp_rf, snp_af;
+	uint32_t *ref_aux = nullptr, *snp_aux_pos = nullptr; uint8_t *snp_aux_info = nullptr;     // final arrays, owned by the index
+	int alloc()
+	{
+		int rc;
+		if ((rc = ref_kmer.alloc(n_ref)) || (rc = ref_pos.alloc(n_ref)) || (rc = ref_amb.alloc(n_ref))) return rc;
+		if ((rc = snp_kmer.alloc(n_snp)) || (rc = snp_pos.alloc(n_snp)) || (rc = snp_info.alloc(n_snp)) || (rc = snp_amb.alloc(n_snp)) || (rc = snp_rf.alloc(n_snp)) || (rc = snp_af.alloc(n_snp))) return rc;
+		return VG_OK;
+	}
+};
+
+static int init_handle(vg_index *ix, int device)
+{
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VG_ENODEV, "no HIP device available (this library has no CPU fallback)");
 	if (device < 0 || device >= ndev) return fail(VG_EINVAL, "device index out of range");
@@ -766,123 +900,133 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	ix->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	ix->lane_grid_blocks = ix->cus * 8;                          // 2048 lanes per CU = every wave slot
-	int wpc = 16;                                                // waves per CU of the wave-tier grid: 102 VGPRs -> 4 waves per SIMD
+	int wpc = 16;                                                // waves per CU of the wave-tier grid: 128 VGPRs -> 4 waves per SIMD
 	if (const char *e = getenv("VG_WAVES_PER_CU")) wpc = std::max(1, atoi(e));
 	ix->wave_grid = ix->cus * wpc;
 	if (const char *e = getenv("VG_FORCE_GENERIC")) ix->force_generic = atoi(e) != 0;
 	if (const char *e = getenv("VG_WORK_CHUNK")) ix->work_chunk = (uint32_t)std::max(1, atoi(e));
 	if (const char *e = getenv("VG_W2_CHUNK")) ix->w2_chunk = (uint32_t)std::max(1, atoi(e));
 	if (const char *e = getenv("VG_W2_WPC")) ix->w2_wpc = (uint32_t)std::max(1, atoi(e));
+	return VG_OK;
+}
+
+// From the columns (device) + the two bit vectors (host words) to the resident index.
+static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const uint64_t *ref_bf_words, uint64_t snp_bf_bits, const uint64_t *snp_bf_words, PhaseClock &pc)
+{
+	if (c.n_ref >= 0xFFFFFFFFull || c.n_snp >= 0xFFFFFFFFull) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
+	if (ref_bf_bits == 0 || snp_bf_bits == 0) return fail(VG_EINVAL, "empty bit vector");
 	int rc;
 	DevIndex &d = ix->d;
-	d.n_ref = a->n_ref; d.n_snp = a->n_snp;
-
-	PhaseClock pc;
-	// ---- reference dictionary: jump table + 16-byte entries, built on the device from the file's columns
+	d.n_ref = c.n_ref; d.n_snp = c.n_snp;
+	d.ref_aux = c.ref_aux; d.snp_aux_pos = c.snp_aux_pos; d.snp_aux_info = c.snp_aux_info;
+	hipStream_t st = ix->stream;
+	// ---- largest position any entry names (needs columns that are released along the way)
+	unsigned long long maxp = 0;
 	{
-		TempDev<uint64_t> tk; TempDev<uint32_t> tp; TempDev<uint8_t> ta;
-		if ((rc = tk.upload(a->ref_kmer, a->n_ref))) return rc;
-		if ((rc = tp.upload(a->ref_pos, a->n_ref))) return rc;
-		if ((rc = ta.upload(a->ref_amb, a->n_ref))) return rc;
-		uint32_t *jg = nullptr; RefEnt *ent = nullptr; uint32_t *x = nullptr;
-		if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
-		if ((rc = dev_alloc(ix, &ent, a->n_ref))) return rc;
-		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, ix->stream>>>(tk.p, a->n_ref, jg, 1ull << 32, 32);
-		vg_make_ref_entries<<<2048, 256, 0, ix->stream>>>(tk.p, tp.p, ta.p, a->n_ref, ent);
+		TempDev<unsigned long long> dmax;
+		if ((rc = dmax.alloc(1))) return rc;
+		HIP_TRY(hipMemsetAsync(dmax.p, 0, 8, st));
+		if (c.n_ref) vg_max_pos<<<2048, 256, 0, st>>>(c.ref_pos.p, c.ref_amb.p, c.n_ref, dmax.p);
+		if (c.n_ref_aux) vg_max_pos<<<1024, 256, 0, st>>>(c.ref_aux, nullptr, c.n_ref_aux * AUX_COLS, dmax.p);
+		if (c.n_snp) vg_max_pos<<<2048, 256, 0, st>>>(c.snp_pos.p, c.snp_amb.p, c.n_snp, dmax.p);
+		if (c.n_snp_aux) vg_max_pos<<<1024, 256, 0, st>>>(c.snp_aux_pos, nullptr, c.n_snp_aux * AUX_COLS, dmax.p);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(ix->stream));
-		if ((rc = dev_upload(ix, &x, a->ref_aux, a->n_ref_aux * AUX_COLS))) return rc;
-		d.ref_jg = jg; d.ref = ent; d.ref_aux = x;
+		HIP_TRY(hipStreamSynchronize(st));
+		HIP_TRY(hipMemcpy(&maxp, dmax.p, 8, hipMemcpyDeviceToHost));
+	}
+	// ---- reference dictionary: jump table + 16-byte entries
+	{
+		uint32_t *jg = nullptr; RefEnt *ent = nullptr;
+		if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
+		if ((rc = dev_alloc(ix, &ent, c.n_ref))) return rc;
+		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.ref_kmer.p, c.n_ref, jg, 1ull << 32, 32);
+		vg_make_ref_entries<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, ent);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));
+		d.ref_jg = jg; d.ref = ent;
 		// secondary view ordered by (LO32, HI32): device radix sort of the swapped k-mers + a jump table over LO32's top bits
 		if (!getenv("VG_NO_SEC")) {
 			uint32_t bits = 14;
-			while (bits < 30 && (1ull << bits) < a->n_ref) bits++;          // ~1-2 entries per bucket
+			while (bits < 30 && (1ull << bits) < c.n_ref) bits++;          // ~1-3 entries per bucket
 			TempDev<uint64_t> kin; TempDev<uint32_t> vin;
-			if ((rc = kin.alloc(a->n_ref))) return rc;
-			if ((rc = vin.alloc(a->n_ref))) return rc;
+			if ((rc = kin.alloc(c.n_ref))) return rc;
+			if ((rc = vin.alloc(c.n_ref))) return rc;
 			uint64_t *skey = nullptr; uint32_t *sidx = nullptr, *sjg = nullptr;
-			if ((rc = dev_alloc(ix, &skey, a->n_ref))) return rc;
-			if ((rc = dev_alloc(ix, &sidx, a->n_ref))) return rc;
+			if ((rc = dev_alloc(ix, &skey, c.n_ref))) return rc;
+			if ((rc = dev_alloc(ix, &sidx, c.n_ref))) return rc;
 			if ((rc = dev_alloc(ix, &sjg, (1ull << bits) + 1))) return rc;
-			vg_make_sec_keys<<<2048, 256, 0, ix->stream>>>(tk.p, a->n_ref, kin.p, vin.p);
+			vg_make_sec_keys<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.n_ref, kin.p, vin.p);
 			HIP_TRY(hipGetLastError());
-			const int se = vg_dev_sort_pairs_u64_u32(kin.p, skey, vin.p, sidx, a->n_ref, ix->stream);
+			const int se = vg_dev_sort_pairs_u64_u32(kin.p, skey, vin.p, sidx, c.n_ref, st);
 			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
-			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, ix->stream>>>(skey, a->n_ref, sjg, 1ull << bits, (int)(64 - bits));
+			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, st>>>(skey, c.n_ref, sjg, 1ull << bits, (int)(64 - bits));
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(ix->stream));
+			HIP_TRY(hipStreamSynchronize(st));
 			d.sec_key = skey; d.sec_idx = sidx; d.sec_jg = sjg; d.sec_bits = bits;
 		}
 	}
 	pc.lap("reference dictionary + LO32-ordered view");
 	// ---- SNP dictionary
 	{
-		TempDev<uint64_t> tk; TempDev<uint32_t> tp; TempDev<uint8_t> ti, ta;
-		if ((rc = tk.upload(a->snp_kmer, a->n_snp))) return rc;
-		if ((rc = tp.upload(a->snp_pos, a->n_snp))) return rc;
-		if ((rc = ti.upload(a->snp_info, a->n_snp))) return rc;
-		if ((rc = ta.upload(a->snp_amb, a->n_snp))) return rc;
-		uint32_t *jg = nullptr; SnpEnt *ent = nullptr; uint32_t *xp = nullptr; uint8_t *xi = nullptr;
+		uint32_t *jg = nullptr; SnpEnt *ent = nullptr;
 		if ((rc = dev_alloc(ix, &jg, (1ull << 24) + 1))) return rc;
-		if ((rc = dev_alloc(ix, &ent, a->n_snp))) return rc;
-		vg_build_jumpgate<<<(unsigned)((1ull << 24) / JG_SPAN), 256, 0, ix->stream>>>(tk.p, a->n_snp, jg, 1ull << 24, 40);
-		vg_make_snp_entries<<<2048, 256, 0, ix->stream>>>(tk.p, tp.p, ti.p, ta.p, a->n_snp, ent);
+		if ((rc = dev_alloc(ix, &ent, c.n_snp))) return rc;
+		vg_build_jumpgate<<<(unsigned)((1ull << 24) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, jg, 1ull << 24, 40);
+		vg_make_snp_entries<<<2048, 256, 0, st>>>(c.snp_kmer.p, c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.n_snp, ent);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(ix->stream));
-		if ((rc = dev_upload(ix, &xp, a->snp_aux_pos, a->n_snp_aux * AUX_COLS))) return rc;
-		if ((rc = dev_upload(ix, &xi, a->snp_aux_info, a->n_snp_aux * AUX_COLS))) return rc;
-		d.snp_jg = jg; d.snp = ent; d.snp_aux_pos = xp; d.snp_aux_info = xi;
+		HIP_TRY(hipStreamSynchronize(st));
+		d.snp_jg = jg; d.snp = ent;
 		if (!getenv("VG_NO_PROBE_VIEW")) {
 			uint64_t *pv = nullptr;
-			if ((rc = dev_alloc(ix, &pv, a->n_snp + 1))) return rc;
-			vg_make_snp_probe<<<2048, 256, 0, ix->stream>>>(tk.p, jg, a->n_snp, pv);
+			if ((rc = dev_alloc(ix, &pv, c.n_snp + 1))) return rc;
+			vg_make_snp_probe<<<2048, 256, 0, st>>>(c.snp_kmer.p, jg, c.n_snp, pv);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(ix->stream));
+			HIP_TRY(hipStreamSynchronize(st));
 			d.snp_probe = pv;
 		}
-		// merged exact-match view (both dictionaries behind one HI32 jump table)
-		const uint64_t nm = a->n_ref + a->n_snp;
+		// merged exact-match view (both dictionaries behind one HI32 jump table); its indices are 32 bits wide
+		const uint64_t nm = c.n_ref + c.n_snp;
 		if (!getenv("VG_NO_MX") && nm < (1ull << 32)) {
-			TempDev<uint64_t> kin, kout; TempDev<uint32_t> vin, vout, rp; TempDev<uint8_t> ra;
-			if ((rc = rp.upload(a->ref_pos, a->n_ref))) return rc;
-			if ((rc = ra.upload(a->ref_amb, a->n_ref))) return rc;
+			TempDev<uint64_t> kin, kout; TempDev<uint32_t> vin, vout;
 			if ((rc = kin.alloc(nm)) || (rc = kout.alloc(nm)) || (rc = vin.alloc(nm)) || (rc = vout.alloc(nm))) return rc;
-			if (a->n_ref) HIP_TRY(hipMemcpy(kin.p, a->ref_kmer, (size_t)a->n_ref * 8, hipMemcpyHostToDevice));
-			if (a->n_snp) HIP_TRY(hipMemcpy(kin.p + a->n_ref, tk.p, (size_t)a->n_snp * 8, hipMemcpyDeviceToDevice));
-			vg_iota_u32<<<2048, 256, 0, ix->stream>>>(vin.p, nm);
+			if (c.n_ref) HIP_TRY(hipMemcpyAsync(kin.p, c.ref_kmer.p, (size_t)c.n_ref * 8, hipMemcpyDeviceToDevice, st));
+			if (c.n_snp) HIP_TRY(hipMemcpyAsync(kin.p + c.n_ref, c.snp_kmer.p, (size_t)c.n_snp * 8, hipMemcpyDeviceToDevice, st));
+			vg_iota_u32<<<2048, 256, 0, st>>>(vin.p, nm);
 			HIP_TRY(hipGetLastError());
-			const int se = vg_dev_sort_pairs_u64_u32(kin.p, kout.p, vin.p, vout.p, nm, ix->stream);     // stable: ref before snp on equal k-mers
+			HIP_TRY(hipStreamSynchronize(st));
+			c.ref_kmer.release();                                  // 23 GB at hg38 scale: the sort below needs the room
+			const int se = vg_dev_sort_pairs_u64_u32(kin.p, kout.p, vin.p, vout.p, nm, st);     // stable: ref before snp on equal k-mers
 			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
 			kin.release(); vin.release();                          // make room before the 16 GiB table
 			uint32_t *mjg = nullptr; uint4 *mx = nullptr;
 			if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
 			if ((rc = dev_alloc(ix, &mx, nm))) return rc;
-			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, ix->stream>>>(kout.p, nm, mjg, 1ull << 32, 32);
-			vg_make_mx_entries<<<2048, 256, 0, ix->stream>>>(kout.p, vout.p, nm, a->n_ref, rp.p, ra.p, tp.p, ta.p, mx);
+			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(kout.p, nm, mjg, 1ull << 32, 32);
+			vg_make_mx_entries<<<2048, 256, 0, st>>>(kout.p, vout.p, nm, c.n_ref, c.ref_pos.p, c.ref_amb.p, c.snp_pos.p, c.snp_amb.p, mx);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(ix->stream));
+			HIP_TRY(hipStreamSynchronize(st));
 			d.mx_jg = mjg; d.mx = mx;
 			// direct table (64 GiB) in place of the merged jump table (16 GiB) when the device has the room; no bucket may
 			// exceed the 24-bit count field (it would be a >16 M-fold repeated 16-mer)
 			if (!getenv("VG_NO_DIRECT")) {
-				kout.release(); vout.release(); rp.release(); ra.release();
+				kout.release(); vout.release(); c.ref_pos.release(); c.ref_amb.release();
 				size_t free_b = 0, total_b = 0;
 				uint4 *dx = nullptr;
 				TempDev<uint32_t> big;
 				if ((rc = big.alloc(1))) return rc;
-				HIP_TRY(hipMemsetAsync(big.p, 0, 4, ix->stream));
+				HIP_TRY(hipMemsetAsync(big.p, 0, 4, st));
 				uint32_t too_big = 0;
 				if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (80ull << 30) && hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) == hipSuccess) {
-					vg_make_direct<<<ix->cus * 32, 256, 0, ix->stream>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
+					vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
 					HIP_TRY(hipGetLastError());
-					HIP_TRY(hipStreamSynchronize(ix->stream));
+					HIP_TRY(hipStreamSynchronize(st));
 					HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
 				}
 				if (dx && too_big) { (void)hipFree(dx); dx = nullptr; }          // a bucket of more than 2^24 - 1 entries: jump-table form
 				if (dx) {
-					vg_inline_pairs<<<2048, 256, 0, ix->stream>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
+					vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
 					HIP_TRY(hipGetLastError());
-					HIP_TRY(hipStreamSynchronize(ix->stream));
+					HIP_TRY(hipStreamSynchronize(st));
 					ix->owned.push_back(dx); ix->dev_bytes += (uint64_t)(1ull << 32) * 16;
 					d.dx = dx;
 					// the merged jump table is not needed any more
@@ -895,94 +1039,61 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 			}
 		}
 	}
-	pc.lap("SNP dictionary, merged view, direct table");
+	pc.lap("SNP dictionary, probe view, merged view, direct table");
 	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first
 	//      2^32 bits of the 9.6 Gbit reference vector can ever be read (src/generate_bf.h:112-128)
 	{
-		const uint64_t rbits = std::min<uint64_t>(a->ref_bf_bits, 1ull << 32);
+		const uint64_t rbits = std::min<uint64_t>(ref_bf_bits, 1ull << 32);
 		uint64_t *r = nullptr, *s2 = nullptr;
-		if ((rc = dev_upload(ix, &r, a->ref_bf_words, (rbits + 63) / 64))) return rc;
-		if ((rc = dev_upload(ix, &s2, a->snp_bf_words, (a->snp_bf_bits + 63) / 64))) return rc;
-		d.ref_bf = r; d.ref_bf_bits = a->ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = a->snp_bf_bits;
+		if ((rc = dev_upload(ix, &r, ref_bf_words, (rbits + 63) / 64))) return rc;
+		if ((rc = dev_upload(ix, &s2, snp_bf_words, (snp_bf_bits + 63) / 64))) return rc;
+		d.ref_bf = r; d.ref_bf_bits = ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = snp_bf_bits;
 	}
-	pc.lap("bit vectors");
-	// ---- pile-up sites (src/qv.cc:602-603, 637-659).  The reference sizes its table max(raw pos field)+33,
-	//      i.e. 2^32+32 entries as soon as one k-mer is POS_AMBIGUOUS; only real positions are ever indexed.
+	// ---- pile-up sites (src/qv.cc:602-603, 637-659)
 	{
-		uint64_t maxp = 0;
+		const uint64_t plen = maxp + 64, nblk = plen / 64 + 1;
+		TempDev<uint32_t> winner; TempDev<uint64_t> blk; TempDev<uint8_t> tmp;
+		if ((rc = winner.alloc(plen)) || (rc = blk.alloc(nblk + 1))) return rc;
+		HIP_TRY(hipMemsetAsync(winner.p, 0, plen * 4, st));
+		uint8_t *dp = nullptr; ulonglong2 *dr = nullptr;
+		if ((rc = dev_alloc(ix, &dp, plen))) return rc;
+		if ((rc = dev_alloc(ix, &dr, nblk))) return rc;
+		if (c.n_snp) vg_site_winner<<<2048, 256, 0, st>>>(c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.n_snp, winner.p);
+		vg_site_blocks<<<ix->cus * 16, 256, 0, st>>>(winner.p, c.snp_kmer.p, c.snp_info.p, plen, dp, dr, blk.p);
+		HIP_TRY(hipMemsetAsync(blk.p + nblk, 0, 8, st));
+		HIP_TRY(hipGetLastError());
 		{
-			std::vector<uint64_t> mx(host_threads(), 0);
-			parallel_for(a->n_ref, [&](uint64_t lo, uint64_t hi, unsigned t) { uint64_t m = 0; for (uint64_t i = lo; i < hi; i++) if (a->ref_amb[i] == 0 && a->ref_pos[i] != POS_AMBIGUOUS && a->ref_pos[i] > m) m = a->ref_pos[i]; mx[t] = std::max(mx[t], m); });
-			parallel_for(a->n_ref_aux * AUX_COLS, [&](uint64_t lo, uint64_t hi, unsigned t) { uint64_t m = 0; for (uint64_t i = lo; i < hi; i++) if (a->ref_aux[i] > m) m = a->ref_aux[i]; mx[t] = std::max(mx[t], m); });
-			parallel_for(a->n_snp, [&](uint64_t lo, uint64_t hi, unsigned t) { uint64_t m = 0; for (uint64_t i = lo; i < hi; i++) if (a->snp_amb[i] == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_pos[i] > m) m = a->snp_pos[i]; mx[t] = std::max(mx[t], m); });
-			parallel_for(a->n_snp_aux * AUX_COLS, [&](uint64_t lo, uint64_t hi, unsigned t) { uint64_t m = 0; for (uint64_t i = lo; i < hi; i++) if (a->snp_aux_pos[i] > m) m = a->snp_aux_pos[i]; mx[t] = std::max(mx[t], m); });
-			for (uint64_t m : mx) maxp = std::max(maxp, m);
+			const size_t need = vg_dev_scan_temp_bytes(1, nblk + 1);
+			if ((rc = tmp.alloc(need))) return rc;
+			const int se = vg_dev_exclusive_scan_u64(blk.p, blk.p, nblk + 1, st, tmp.p, need);
+			if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
 		}
-		const uint64_t plen = maxp + 64;
-		// Seeding in FILE ORDER, last writer wins (qv.cc:637-659), done in parallel: first every position learns the index of
-		// the LAST dictionary entry that seeds it (atomic max), then each position applies that one entry.
-		std::unique_ptr<uint32_t[]> pile(new uint32_t[plen]);             // winner index + 1, then: low nibble ref|alt<<2, bits 16.. freqs (host only)
-		parallel_for(plen, [&](uint64_t lo, uint64_t hi, unsigned) { memset(pile.get() + lo, 0, (hi - lo) * 4); });
-		auto seeds = [&](uint64_t i) { const uint32_t info = a->snp_info[i]; return (info & 4u) == 0 && a->snp_pos[i] != POS_AMBIGUOUS && a->snp_amb[i] == 0; };
-		parallel_for(a->n_snp, [&](uint64_t lo, uint64_t hi, unsigned) {
-			for (uint64_t i = lo; i < hi; i++) if (seeds(i)) {
-				uint32_t *w = &pile[(uint64_t)a->snp_pos[i] + (a->snp_info[i] >> 3)];
-				const uint32_t mine = (uint32_t)(i + 1);                 // n_snp < 2^32 - 1
-				uint32_t cur = __atomic_load_n(w, __ATOMIC_RELAXED);
-				while (cur < mine && !__atomic_compare_exchange_n(w, &cur, mine, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
-			}
-		});
-		// per 64-position block: site bits; then site numbers by a prefix over the blocks; then everything that is per site
-		const uint64_t nblk = plen / 64 + 1;
-		std::vector<uint8_t> pile8(plen, 0);
-		std::vector<ulonglong2> rank(nblk, ulonglong2{0, 0});
-		parallel_for(plen, [&](uint64_t lo, uint64_t hi, unsigned) {
-			for (uint64_t p = lo; p < hi; p++) {
-				uint32_t w = pile[p];
-				if (w) {
-					const uint64_t i = w - 1;
-					const uint32_t info = a->snp_info[i];
-					const uint32_t alt = (uint32_t)(a->snp_kmer[i] >> (2 * (info >> 3))) & 3u;
-					w = (info & 3u) | (alt << 2) | ((uint32_t)a->snp_rf[i] << 16) | ((uint32_t)a->snp_af[i] << 24);
-					pile[p] = w;
-				}
-				const uint32_t r = w & 3u, al = (w >> 2) & 3u;
-				if (r != al) { pile8[p] = (uint8_t)((w & 15u) | 16u); rank[p >> 6].x |= 1ull << (p & 63); }
-				else pile8[p] = (uint8_t)(w & 15u);
-			}
-		});
+		HIP_TRY(hipStreamSynchronize(st));
 		uint64_t nsites = 0;
-		for (uint64_t bk = 0; bk < nblk; bk++) { rank[bk].y = nsites; nsites += (uint64_t)__builtin_popcountll(rank[bk].x); }
+		HIP_TRY(hipMemcpy(&nsites, blk.p + nblk, 8, hipMemcpyDeviceToHost));
+		if (nsites >= (1ull << 31)) return fail(VG_ETOOBIG, "more than 2^31 SNP sites");
+		ix->n_sites = nsites;
+		TempDev<uint32_t> s_pos; TempDev<uint8_t> s_ref, s_alt, s_rf, s_af;
+		uint8_t *dba = nullptr;
+		if ((rc = s_pos.alloc(nsites)) || (rc = s_ref.alloc(nsites)) || (rc = s_alt.alloc(nsites)) || (rc = s_rf.alloc(nsites)) || (rc = s_af.alloc(nsites))) return rc;
+		if ((rc = dev_alloc(ix, &dba, nsites + 1, true))) return rc;
+		vg_site_tables<<<ix->cus * 16, 256, 0, st>>>(winner.p, dp, c.snp_rf.p, c.snp_af.p, plen, dr, blk.p, s_pos.p, s_ref.p, s_alt.p, s_rf.p, s_af.p, dba);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));
 		ix->site_pos.resize(nsites); ix->site_ref.resize(nsites); ix->site_alt.resize(nsites); ix->site_rf.resize(nsites); ix->site_af.resize(nsites);
-		parallel_for(nblk * 64, [&](uint64_t lo, uint64_t hi, unsigned) {
-			for (uint64_t bk = lo / 64; bk < hi / 64 && bk < nblk; bk++) {
-				uint64_t m = rank[bk].x, sidx = rank[bk].y;
-				while (m) {
-					const uint64_t p = bk * 64 + (uint64_t)__builtin_ctzll(m);
-					m &= m - 1;
-					const uint32_t w = pile[p];
-					ix->site_pos[sidx] = (uint32_t)p; ix->site_ref[sidx] = (uint8_t)(w & 3u); ix->site_alt[sidx] = (uint8_t)((w >> 2) & 3u);
-					ix->site_rf[sidx] = (uint8_t)(w >> 16); ix->site_af[sidx] = (uint8_t)(w >> 24);
-					sidx++;
-				}
-			}
-		});
-		ix->n_sites = ix->site_pos.size();
-		if (ix->n_sites >= (1ull << 31)) return fail(VG_ETOOBIG, "more than 2^31 SNP sites");
-		uint8_t *dp = nullptr; ulonglong2 *dr = nullptr; uint32_t *dc = nullptr;
-		if ((rc = dev_upload(ix, &dp, pile8.data(), plen))) return rc;
-		if ((rc = dev_upload(ix, &dr, rank.data(), rank.size()))) return rc;
-		if ((rc = dev_alloc(ix, &dc, 2 * ix->n_sites + 2, true))) return rc;
-		d.srank = dr;
-		d.pile = dp; d.pile_len = plen; d.cnt = dc;
-		std::vector<uint8_t> ba(ix->n_sites + 1, 0);
-		for (uint64_t s2 = 0; s2 < ix->n_sites; s2++) ba[s2] = (uint8_t)(ix->site_ref[s2] | (ix->site_alt[s2] << 2));
-		uint8_t *dba = nullptr; uint32_t *dc4 = nullptr;
-		if ((rc = dev_upload(ix, &dba, ba.data(), ba.size()))) return rc;
-		if ((rc = dev_alloc(ix, &dc4, 4 * ix->n_sites + 4, true))) return rc;
-		d.site_ba = dba; d.cnt4 = dc4;
+		if (nsites) {
+			HIP_TRY(hipMemcpy(ix->site_pos.data(), s_pos.p, nsites * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ix->site_ref.data(), s_ref.p, nsites, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ix->site_alt.data(), s_alt.p, nsites, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ix->site_rf.data(), s_rf.p, nsites, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ix->site_af.data(), s_af.p, nsites, hipMemcpyDeviceToHost));
+		}
+		uint32_t *dc = nullptr, *dc4 = nullptr;
+		if ((rc = dev_alloc(ix, &dc, 2 * nsites + 2, true))) return rc;
+		if ((rc = dev_alloc(ix, &dc4, 4 * nsites + 4, true))) return rc;
+		d.srank = dr; d.pile = dp; d.pile_len = plen; d.cnt = dc; d.site_ba = dba; d.cnt4 = dc4;
 	}
-	pc.lap("pile-up sites (host threads) + upload");
+	pc.lap("bit vectors, pile-up sites");
 	// ---- scratch of the lane tier, overflow counters, stats
 	// VG_SCRATCH_CAP / VG_SCRATCH_KCAP shrink the per-lane scratch so tests can drive every tier
 	uint32_t cap = 64, kcap = 32;
@@ -990,12 +1101,29 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
-	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 8, true))) return rc;       // [0..2] spill counts, [4],[5] work counters of the two wave tiers
+	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 8, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
 	if ((rc = dev_alloc(ix, &ix->d_cum, 4, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
-	HIP_TRY(hipStreamSynchronize(ix->stream));
+	HIP_TRY(hipStreamSynchronize(st));
 	return VG_OK;
+}
+
+static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
+{
+	int rc = init_handle(ix, device);
+	if (rc) return rc;
+	PhaseClock pc;
+	DevCols c;
+	c.n_ref = a->n_ref; c.n_ref_aux = a->n_ref_aux; c.n_snp = a->n_snp; c.n_snp_aux = a->n_snp_aux;
+	if ((rc = c.ref_kmer.upload(a->ref_kmer, a->n_ref)) || (rc = c.ref_pos.upload(a->ref_pos, a->n_ref)) || (rc = c.ref_amb.upload(a->ref_amb, a->n_ref))) return rc;
+	if ((rc = c.snp_kmer.upload(a->snp_kmer, a->n_snp)) || (rc = c.snp_pos.upload(a->snp_pos, a->n_snp)) || (rc = c.snp_info.upload(a->snp_info, a->n_snp)) ||
+	    (rc = c.snp_amb.upload(a->snp_amb, a->n_snp)) || (rc = c.snp_rf.upload(a->snp_rf, a->n_snp)) || (rc = c.snp_af.upload(a->snp_af, a->n_snp))) return rc;
+	if ((rc = dev_upload(ix, &c.ref_aux, a->ref_aux, a->n_ref_aux * AUX_COLS))) return rc;
+	if ((rc = dev_upload(ix, &c.snp_aux_pos, a->snp_aux_pos, a->n_snp_aux * AUX_COLS))) return rc;
+	if ((rc = dev_upload(ix, &c.snp_aux_info, a->snp_aux_info, a->n_snp_aux * AUX_COLS))) return rc;
+	pc.lap("columns copied to the device");
+	return build_on_device(ix, c, a->ref_bf_bits, a->ref_bf_words, a->snp_bf_bits, a->snp_bf_words, pc);
 }
 
 extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **out)
@@ -1011,29 +1139,74 @@ extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **
 }
 
 // ---- index files (formats: SURVEY.md §8f-1; writers src/dictgen.c:63-275, sdsl int_vector.hpp:1563-1595)
-// whole file into an uninitialised buffer, its pieces pread() by several threads (the page cache / an NVMe array serve them
-// concurrently; one fread of the 43 GB hg38 dictionary is a single memcpy stream)
-struct RawFile { std::unique_ptr<uint8_t[]> p; size_t n = 0; const uint8_t *data() const { return p.get(); } size_t size() const { return n; } };
-static int read_file(const std::string &path, RawFile &buf)
+// A byte range of a file -> device memory: reader threads pread() pieces into a ring of pinned buffers, each piece is copied up
+// as soon as it is complete (the page cache / an NVMe array serve the threads concurrently; one fread of the 43 GB hg38
+// dictionary is a single memcpy stream, and a copy from pageable memory is staged a second time by the runtime).
+static int file_to_device(int fd, uint64_t off, uint64_t bytes, uint8_t *dst, const std::string &path)
 {
-	const int fd = open(path.c_str(), O_RDONLY);
-	if (fd < 0) return fail(VG_EIO, "cannot open %s", path.c_str());
-	struct stat st;
-	if (fstat(fd, &st) != 0) { close(fd); return fail(VG_EIO, "cannot stat %s", path.c_str()); }
-	buf.n = (size_t)st.st_size;
-	buf.p.reset(new uint8_t[buf.n + 1]);
-	std::vector<int> bad(host_threads(), 0);
-	parallel_for(buf.n, [&](uint64_t lo, uint64_t hi, unsigned t) {
-		while (lo < hi) {
-			const ssize_t g = pread(fd, buf.p.get() + lo, (size_t)std::min<uint64_t>(hi - lo, 1ull << 30), (off_t)lo);
-			if (g <= 0) { bad[t] = 1; return; }
-			lo += (uint64_t)g;
+	if (bytes == 0) return VG_OK;
+	const uint64_t PIECE = 64ull << 20;
+	const int NBUF = 8;
+	const uint64_t n_pieces = (bytes + PIECE - 1) / PIECE;
+	std::vector<uint8_t *> ring((size_t)NBUF, nullptr);
+	std::vector<hipEvent_t> copied((size_t)NBUF, nullptr);
+	hipStream_t cs = nullptr;
+	int rc = VG_OK;
+	auto cleanup = [&] { for (auto p : ring) if (p) (void)hipHostFree(p); for (auto e : copied) if (e) (void)hipEventDestroy(e); if (cs) (void)hipStreamDestroy(cs); };
+	for (int i = 0; i < NBUF && rc == VG_OK; i++) {
+		if (hipHostMalloc((void **)&ring[(size_t)i], PIECE, hipHostMallocDefault) != hipSuccess) rc = fail(VG_ENOMEM, "hipHostMalloc(staging) failed");
+		else if (hipEventCreateWithFlags(&copied[(size_t)i], hipEventDisableTiming) != hipSuccess) rc = fail(VG_ENODEV, "hipEventCreate failed");
+	}
+	if (rc == VG_OK && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) rc = fail(VG_ENODEV, "hipStreamCreate failed");
+	if (rc) { cleanup(); return rc; }
+	std::mutex mu; std::condition_variable cv;
+	std::vector<uint8_t> state(n_pieces, 0);                    // 1 = read into its ring slot
+	uint64_t issued = 0;                                        // pieces whose copy has been enqueued AND whose slot is free again once copied[slot] fires
+	uint64_t freed = 0;                                         // pieces known to have left their ring slot
+	std::atomic<uint64_t> next{0};
+	bool io_error = false;
+	const unsigned nt = std::min<unsigned>(host_threads(), 16u);
+	std::vector<std::thread> readers;
+	for (unsigned t = 0; t < nt; t++) readers.emplace_back([&] {
+		for (;;) {
+			const uint64_t p = next.fetch_add(1);
+			if (p >= n_pieces) return;
+			{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return p < freed + (uint64_t)NBUF || io_error; }); if (io_error) return; }
+			const uint64_t o = p * PIECE, n = std::min(PIECE, bytes - o);
+			uint64_t done = 0;
+			while (done < n) {
+				const ssize_t g = pread(fd, ring[(size_t)(p % NBUF)] + done, (size_t)(n - done), (off_t)(off + o + done));
+				if (g <= 0) break;
+				done += (uint64_t)g;
+			}
+			std::lock_guard<std::mutex> g(mu);
+			if (done < n) io_error = true;
+			state[p] = 1;
+			cv.notify_all();
 		}
 	});
-	close(fd);
-	for (int x : bad) if (x) return fail(VG_EIO, "short read on %s", path.c_str());
+	for (uint64_t p = 0; p < n_pieces; p++) {
+		{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return state[p] != 0 || io_error; }); if (io_error) break; }
+		const uint64_t o = p * PIECE, n = std::min(PIECE, bytes - o);
+		if (hipMemcpyAsync(dst + o, ring[(size_t)(p % NBUF)], n, hipMemcpyHostToDevice, cs) != hipSuccess || hipEventRecord(copied[(size_t)(p % NBUF)], cs) != hipSuccess) {
+			std::lock_guard<std::mutex> g(mu); io_error = true; rc = fail(VG_ENODEV, "host-to-device copy failed"); cv.notify_all(); break;
+		}
+		issued = p + 1;
+		// the slot of piece p - NBUF + 1 .. is reusable once its copy has finished: wait for the oldest outstanding one when the ring is full
+		if (issued - freed >= (uint64_t)NBUF - 1) {
+			(void)hipEventSynchronize(copied[(size_t)(freed % NBUF)]);
+			std::lock_guard<std::mutex> g(mu); freed++; cv.notify_all();
+		}
+	}
+	(void)hipStreamSynchronize(cs);
+	{ std::lock_guard<std::mutex> g(mu); freed = n_pieces + NBUF; cv.notify_all(); }
+	for (auto &t : readers) t.join();
+	cleanup();
+	if (rc) return rc;
+	if (io_error) return fail(VG_EIO, "short read on %s", path.c_str());
 	return VG_OK;
 }
+
 static int read_bf(const std::string &path, uint64_t cap_bits, uint64_t &bits, std::vector<uint64_t> &words)
 {
 	FILE *f = fopen(path.c_str(), "rb");
@@ -1047,68 +1220,73 @@ static int read_bf(const std::string &path, uint64_t cap_bits, uint64_t &bits, s
 	return VG_OK;
 }
 
-static int open_impl(const char *prefix, int device, vg_index **out);
-extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
-{
-	if (!prefix || !out) return fail(VG_EINVAL, "null argument");
-	*out = nullptr;
-	return guarded([&] { return open_impl(prefix, device, out); });
-}
-static int open_impl(const char *prefix, int device, vg_index **out)
+struct Fd { int fd = -1; ~Fd() { if (fd >= 0) close(fd); } };
+
+static int open_impl(const char *prefix, int device, vg_index *ix)
 {
 	const std::string pre(prefix);
-	RawFile rd, sd;
 	int rc;
-	PhaseClock pc;
-	if ((rc = read_file(pre + ".ref.dict", rd))) return rc;
-	if ((rc = read_file(pre + ".snp.dict", sd))) return rc;
-	pc.lap("dictionary files read");
-	if (rd.size() < 16 || sd.size() < 16) return fail(VG_EIO, "dictionary file too short: %s", prefix);
-	uint64_t n_ref, n_ref_aux, n_snp, n_snp_aux;
-	memcpy(&n_ref, rd.data(), 8); memcpy(&n_ref_aux, rd.data() + 8, 8);
-	memcpy(&n_snp, sd.data(), 8); memcpy(&n_snp_aux, sd.data() + 8, 8);
+	Fd rf, sf;
+	rf.fd = open((pre + ".ref.dict").c_str(), O_RDONLY);
+	if (rf.fd < 0) return fail(VG_EIO, "cannot open %s.ref.dict", prefix);
+	sf.fd = open((pre + ".snp.dict").c_str(), O_RDONLY);
+	if (sf.fd < 0) return fail(VG_EIO, "cannot open %s.snp.dict", prefix);
+	struct stat rs, ss;
+	if (fstat(rf.fd, &rs) != 0 || fstat(sf.fd, &ss) != 0) return fail(VG_EIO, "cannot stat the dictionary files of %s", prefix);
+	const uint64_t rsize = (uint64_t)rs.st_size, ssize = (uint64_t)ss.st_size;
+	if (rsize < 16 || ssize < 16) return fail(VG_EIO, "dictionary file too short: %s", prefix);
+	uint64_t rh[2], sh[2];
+	if (pread(rf.fd, rh, 16, 0) != 16 || pread(sf.fd, sh, 16, 0) != 16) return fail(VG_EIO, "short read on the dictionary files of %s", prefix);
+	const uint64_t n_ref = rh[0], n_ref_aux = rh[1], n_snp = sh[0], n_snp_aux = sh[1];
 	if (n_ref > (1ull << 32) || n_snp > (1ull << 32)) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
 	// every count is bounded by the file it came from before it is multiplied (a corrupt header must not wrap the size check)
-	if (n_ref > rd.size() / 13 || n_ref_aux > rd.size() / 40) return fail(VG_EIO, "%s.ref.dict: size does not match its header", prefix);
-	if (n_snp > sd.size() / 16 || n_snp_aux > sd.size() / 78) return fail(VG_EIO, "%s.snp.dict: size does not match its header", prefix);
-	if (rd.size() != 16 + 13 * n_ref + 40 * n_ref_aux) return fail(VG_EIO, "%s.ref.dict: size does not match its header", prefix);
-	if (sd.size() != 16 + 16 * n_snp + 78 * n_snp_aux) return fail(VG_EIO, "%s.snp.dict: size does not match its header", prefix);
-	// uninitialised: every element is written below, by the thread that first touches its page
-	std::unique_ptr<uint64_t[]> rk(new uint64_t[n_ref + 1]), sk(new uint64_t[n_snp + 1]);
-	std::unique_ptr<uint32_t[]> rp(new uint32_t[n_ref + 1]), sp(new uint32_t[n_snp + 1]);
-	std::unique_ptr<uint8_t[]> ra(new uint8_t[n_ref + 1]), si(new uint8_t[n_snp + 1]), sa(new uint8_t[n_snp + 1]), srf(new uint8_t[n_snp + 1]), saf(new uint8_t[n_snp + 1]);
-	std::vector<uint32_t> raux(n_ref_aux * 10), sxp(n_snp_aux * 10);
-	std::vector<uint8_t> sxi(n_snp_aux * 10);
-	parallel_for(n_ref, [&](uint64_t lo, uint64_t hi, unsigned) {
-		const uint8_t *q = rd.data() + 16 + 13 * lo;
-		for (uint64_t i = lo; i < hi; i++, q += 13) { memcpy(&rk[i], q, 8); memcpy(&rp[i], q + 8, 4); ra[i] = q[12]; }
-	});
-	if (n_ref_aux) memcpy(raux.data(), rd.data() + 16 + 13 * n_ref, n_ref_aux * 40);
-	parallel_for(n_snp, [&](uint64_t lo, uint64_t hi, unsigned) {
-		const uint8_t *q = sd.data() + 16 + 16 * lo;
-		for (uint64_t i = lo; i < hi; i++, q += 16) { memcpy(&sk[i], q, 8); memcpy(&sp[i], q + 8, 4); si[i] = q[12]; sa[i] = q[13]; srf[i] = q[14]; saf[i] = q[15]; }
-	});
-	{
-		const uint8_t *q = sd.data() + 16 + 16 * n_snp;
-		for (uint64_t i = 0; i < n_snp_aux; i++) {
-			q += 8;
-			for (int j = 0; j < 10; j++, q += 7) { memcpy(&sxp[i * 10 + j], q, 4); sxi[i * 10 + j] = q[4]; }
-		}
-	}
-	rd.p.reset(); sd.p.reset();
-	pc.lap("records unpacked");
+	if (n_ref > rsize / 13 || n_ref_aux > rsize / 40 || rsize != 16 + 13 * n_ref + 40 * n_ref_aux) return fail(VG_EIO, "%s.ref.dict: size does not match its header", prefix);
+	if (n_snp > ssize / 16 || n_snp_aux > ssize / 78 || ssize != 16 + 16 * n_snp + 78 * n_snp_aux) return fail(VG_EIO, "%s.snp.dict: size does not match its header", prefix);
 	uint64_t rbits = 0, sbits = 0;
 	std::vector<uint64_t> rw, sw;
 	if ((rc = read_bf(pre + ".ref.bf", 1ull << 32, rbits, rw))) return rc;
 	if ((rc = read_bf(pre + ".snp.bf", ~0ull, sbits, sw))) return rc;
-	pc.lap("bit-vector files read");
-	vg_index_arrays a{};
-	a.n_ref = n_ref; a.ref_kmer = rk.get(); a.ref_pos = rp.get(); a.ref_amb = ra.get();
-	a.n_ref_aux = n_ref_aux; a.ref_aux = raux.data();
-	a.n_snp = n_snp; a.snp_kmer = sk.get(); a.snp_pos = sp.get(); a.snp_info = si.get(); a.snp_amb = sa.get(); a.snp_rf = srf.get(); a.snp_af = saf.get();
-	a.n_snp_aux = n_snp_aux; a.snp_aux_pos = sxp.data(); a.snp_aux_info = sxi.data();
-	a.ref_bf_bits = rbits; a.ref_bf_words = rw.data(); a.snp_bf_bits = sbits; a.snp_bf_words = sw.data();
-	return vg_index_create(&a, device, out);
+	if ((rc = init_handle(ix, device))) return rc;
+	PhaseClock pc;
+	DevCols c;
+	c.n_ref = n_ref; c.n_ref_aux = n_ref_aux; c.n_snp = n_snp; c.n_snp_aux = n_snp_aux;
+	if ((rc = c.alloc())) return rc;
+	if ((rc = dev_alloc(ix, &c.ref_aux, n_ref_aux * AUX_COLS))) return rc;
+	if ((rc = dev_alloc(ix, &c.snp_aux_pos, n_snp_aux * AUX_COLS))) return rc;
+	if ((rc = dev_alloc(ix, &c.snp_aux_info, n_snp_aux * AUX_COLS))) return rc;
+	{
+		// the files' bytes, as they are, next to the columns they unpack into (the larger one first; freed right after)
+		TempDev<uint8_t> raw;
+		if ((rc = raw.alloc(rsize - 16 + 64))) return rc;
+		if ((rc = file_to_device(rf.fd, 16, rsize - 16, raw.p, pre + ".ref.dict"))) return rc;
+		vg_unpack_ref<<<4096, 256, 0, ix->stream>>>(raw.p, n_ref, c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p);
+		if (n_ref_aux) vg_unpack_ref_aux<<<1024, 256, 0, ix->stream>>>(raw.p + 13 * n_ref, n_ref_aux * AUX_COLS, c.ref_aux);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+	}
+	{
+		TempDev<uint8_t> raw;
+		if ((rc = raw.alloc(ssize - 16 + 64))) return rc;
+		if ((rc = file_to_device(sf.fd, 16, ssize - 16, raw.p, pre + ".snp.dict"))) return rc;
+		vg_unpack_snp<<<4096, 256, 0, ix->stream>>>(raw.p, n_snp, c.snp_kmer.p, c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.snp_rf.p, c.snp_af.p);
+		if (n_snp_aux) vg_unpack_snp_aux<<<1024, 256, 0, ix->stream>>>(raw.p + 16 * n_snp, n_snp_aux, c.snp_aux_pos, c.snp_aux_info);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(ix->stream));
+	}
+	pc.lap("dictionary files read, copied up, unpacked");
+	return build_on_device(ix, c, rbits, rw.data(), sbits, sw.data(), pc);
+}
+
+extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
+{
+	if (!prefix || !out) return fail(VG_EINVAL, "null argument");
+	*out = nullptr;
+	vg_index *ix = new (std::nothrow) vg_index();
+	if (!ix) return fail(VG_ENOMEM, "host allocation failed");
+	int rc = guarded([&] { return open_impl(prefix, device, ix); });
+	if (rc) { vg_index_close(ix); return rc; }
+	*out = ix;
+	return VG_OK;
 }
 
 extern "C" uint64_t vg_index_device_bytes(const vg_index *ix) { return ix ? ix->dev_bytes : 0; }
