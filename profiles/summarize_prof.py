@@ -53,7 +53,7 @@ if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
           "traffic_bytes_per_launch": int((means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024),
           "TCC_MISS_sum": means.get("TCC_MISS_sum"), "TCC_HIT_sum": means.get("TCC_HIT_sum"), "TCP_TCC_READ_REQ_sum": means.get("TCP_TCC_READ_REQ_sum"),
           "kernel_trace_avg_ns": kt_avg,
-          "source": "profiles/run_prof_%s.sh -> profiles/rocprof_summary_%s_final.txt; unit check in profiles/fetch_size_calibration_r01.txt" % (tag, tag)}
+          "source": "profiles/run_prof_r02.sh %s -> profiles/rocprof_summary_%s_final.txt; unit check in profiles/fetch_size_calibration_r01.txt" % (tag, tag)}
     open(os.path.join(src, "traffic_%s.json" % tag), "w").write(json.dumps(tj, indent=1) + "\n")
     out.append("== traffic_%s.json" % tag)
     out.append(json.dumps(tj))

@@ -31,9 +31,6 @@
 #ifndef VG_SCAN_W
 #define VG_SCAN_W 2        // further entries of a multi-entry bucket fetched together in stage A
 #endif
-#ifndef VG_SCAN_G
-#define VG_SCAN_G 2        // chunks whose further entries go out together (one wait per group)
-#endif
 #ifndef VG_WALK_BATCH
 #define VG_WALK_BATCH 1
 #endif
@@ -60,11 +57,8 @@ namespace vg {
 // resident; the second tier takes the reads that spill from it (repeat regions: aux rows, many keys)
 // with lists 6-8x deeper at 2 waves per CU -- still wave-parallel, so a heavy read costs a few dozen
 // dependent gathers instead of the thousands the sequential lane machine needs.
-#ifndef VG_PARK
-#define VG_PARK 1          // the k-mers of a read of up to four chunks (150 bp) are parked in LDS when the read is taken: every later
-#endif                     // use -- the exact look-ups of both passes, stage B's pair rows, the walk -- saves a dependent global load
 #ifndef VG_W1_ECAP
-#define VG_W1_ECAP (VG_PARK ? 10 : 14)     // exact contexts per lane in the main tier: what the other tables leave of a quarter of the CU's LDS
+#define VG_W1_ECAP 14     // exact contexts per lane in the main tier (the most that still leaves 4 workgroups per CU; vote keys live with them)
 #endif
 #ifndef VG_W1_WPB
 #define VG_W1_WPB 4
@@ -123,7 +117,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 	__shared__ uint32_t E_idx[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB];
 	__shared__ uint16_t N_meta[W_NCAP][64 * WPB], E_fm[W_ECAP][64 * WPB];
 	__shared__ uint8_t E_meta[W_ECAP][64 * WPB];
-	__shared__ uint64_t K_park[VG_PARK ? 4 : 1][VG_PARK ? 64 * WPB : 1];        // file-order chunk k-mers of each lane's read (n <= 4)
 	// stage B pair table: one row per gate-open (owner, chunk) pair of the wave, PCAP rows at a time
 	__shared__ uint32_t P_klo[PCAP][WPB], P_khi[PCAP][WPB], P_lo[PCAP][WPB], P_hi[PCAP][WPB], P_slo[PCAP][WPB], P_shi[PCAP][WPB];
 	__shared__ uint32_t P_meta[PCAP][WPB], P_cnt[PCAP][WPB], P_off[PCAP][WPB], P_hu[PCAP][WPB], P_hidx[HCAP][PCAP][WPB];
@@ -181,19 +174,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 	LaneStats<STATS> tot, cur;
 	tot.clear(); cur.clear();
 
-	const auto parked = [&]() -> bool { return VG_PARK && n <= 4u; };
 	auto chunk_kmer = [&](uint32_t c) -> uint64_t {
-		const uint32_t fi = pass ? n - 1 - c : c;
-		const uint64_t kf = parked() ? K_park[VG_PARK ? fi & 3u : 0][VG_PARK ? col : 0] : pk_kmer[(uint64_t)slot0 + fi];
+		const uint64_t kf = pk_kmer[(uint64_t)slot0 + (pass ? n - 1 - c : c)];
 		return pass ? revcomp64(kf) : kf;
 	};
 
 	// chunks c and c + 1 of the current strand sit side by side in pk_kmer whichever the strand: one 16-byte gather
 	auto chunk_kmer2 = [&](uint32_t c, uint64_t &k0, uint64_t &k1) {
-		const uint32_t fi = pass ? n - 2 - c : c;
 		ulonglong2 v;
-		if (parked()) { v.x = K_park[VG_PARK ? fi & 3u : 0][VG_PARK ? col : 0]; v.y = K_park[VG_PARK ? (fi + 1) & 3u : 0][VG_PARK ? col : 0]; }
-		else __builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + fi), 16);
+		__builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + (pass ? n - 2 - c : c)), 16);
 		k0 = pass ? revcomp64(v.y) : v.x;
 		k1 = pass ? revcomp64(v.x) : v.y;
 	};
@@ -270,12 +259,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						overflow_list[atomicAdd(overflow_count, 1u)] = rid;
 					} else {
 						active = true;
-						if constexpr (VG_PARK != 0) if (n <= 4u && n) {
-							ulonglong2 a = make_ulonglong2(0ull, 0ull), b = a;
-							if (n >= 2u) __builtin_memcpy(&a, pk_kmer + (uint64_t)slot0, 16); else a.x = pk_kmer[(uint64_t)slot0];
-							if (n == 4u) __builtin_memcpy(&b, pk_kmer + ((uint64_t)slot0 + 2), 16); else if (n == 3u) b.x = pk_kmer[(uint64_t)slot0 + 2];
-							K_park[0][col] = a.x; K_park[1][col] = a.y; K_park[2][col] = b.x; K_park[3][col] = b.y;
-						}
 					}
 				}
 			}
@@ -368,17 +351,17 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						// reference hit first, then SNP hit.  An ambiguous k-mer with exactly two positions carries both in its entry
 						// (flag PAIR, set by vg_inline_pairs), so only k-mers with 3-10 copies still read their auxiliary row.
 						#pragma unroll
-						for (uint32_t z0 = 0; z0 < 4; z0 += VG_SCAN_G) {
-							constexpr uint32_t SW = VG_SCAN_W, SG = VG_SCAN_G;
-							uint4 sv[SG][SW];
+						for (uint32_t z0 = 0; z0 < 4; z0 += 2) {
+							constexpr uint32_t SW = VG_SCAN_W;
+							uint4 sv[2][SW];
 							#pragma unroll
-							for (uint32_t y = 0; y < SG; y++) {
+							for (uint32_t y = 0; y < 2; y++) {
 								const uint32_t cnt = bq[z0 + y].z >> 8, lo = bq[z0 + y].w;
 								#pragma unroll
 								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = d.mx[lo + 1u + x]; }
 							}
 							#pragma unroll
-							for (uint32_t y = 0; y < SG; y++) {
+							for (uint32_t y = 0; y < 2; y++) {
 								const uint32_t z = z0 + y;
 								if (z >= m) continue;
 								cur.add(S_CHUNKS, 1);
@@ -507,8 +490,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 					const uint32_t o_n = __shfl(n, own), o_pass = __shfl(pass, own);
 					const uint64_t o_slot0 = __shfl(slot0, own);
 					if (mine) {
-						const uint32_t o_fi = o_pass ? o_n - 1 - c : c;
-						const uint64_t kf = (VG_PARK && o_n <= 4u) ? K_park[VG_PARK ? o_fi & 3u : 0][VG_PARK ? col0 + own : 0] : pk_kmer[o_slot0 + o_fi];
+						const uint64_t kf = pk_kmer[o_slot0 + (o_pass ? o_n - 1 - c : c)];
 						const uint64_t k = o_pass ? revcomp64(kf) : kf;
 						const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
 						uint32_t lo, hi, slo, shi, b0 = 0, b1 = 0, fl = 0;
@@ -923,8 +905,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 							const ulonglong2 r1 = blk0 + 1u <= blk_last ? d.srank[blk0 + 1u] : zz;
 							const ulonglong2 r2 = blk0 + 2u <= blk_last ? d.srank[blk0 + 2u] : zz;
 							uint64_t f0, f1, f2 = 0, f3 = 0;                     // the read's k-mers in file order
-							if constexpr (VG_PARK != 0) { f0 = K_park[0][col]; f1 = K_park[1][col]; f2 = K_park[2][col]; f3 = K_park[3][col]; }
-							else {
+							{
 								ulonglong2 v;
 								__builtin_memcpy(&v, pk_kmer + (uint64_t)slot0, 16); f0 = v.x; f1 = v.y;   // n >= 2: one chunk cannot win a vote
 								if (n == 4u) { __builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + 2), 16); f2 = v.x; f3 = v.y; }
