@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export VARGENO_VERBOSE=1 VG_VERBOSE=1
-CMD="python3 $R/bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-gather-probe"
+CMD="python3 $R/bench.py --steps 10 --warmup 2 --cpu-sample 0 --no-gather-probe --no-ingest"
 ( time python3 $R/bench.py --steps 20 --warmup 5 ) > $OUT/bench_default.json 2> $OUT/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $CMD > $OUT/kt.json 2> $OUT/kt.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
@@ -19,7 +19,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 python3 $R/profiles/summarize_prof.py $OUT $TAG > /dev/null
 # per-stage cycle shares and list-overflow reasons (development build with -DVG_STAGE_CLOCKS, if it came along)
 if [ -f $R/variants/clk.so ]; then
-	VARGENO_HIP_LIB=$R/variants/clk.so python3 $R/bench.py --cpu-sample 0 --no-gather-probe --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
+	VARGENO_HIP_LIB=$R/variants/clk.so python3 $R/bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
 fi
 # keep the merge small: the raw traces stay on the box
 rm -rf $OUT/kt/*/*_kernel_trace.csv $OUT/kt/*/*agent_info.csv

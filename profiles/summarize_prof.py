@@ -37,11 +37,12 @@ for grp in ("pmc_fetch", "pmc_write", "pmc_l2"):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, v in agg.items():
             means[c] = sum(v) / len(v)
-kt_avg = None
+kt_avg, kname = None, None
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     for row in csv.DictReader(open(f)):
         if "vg_wave_kernel<false, " in row["Name"] and ", 4>" in row["Name"]:
             kt_avg = float(row["AverageNs"])
+            kname = row["Name"].split("(")[0].replace("void ", "").replace("vg::", "").strip()
 if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
     wl = None
     try:
@@ -49,7 +50,7 @@ if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
         wl = {"genome": cfg["genome_bp"], "snps": cfg["snps_requested"], "reads": cfg["reads_per_step_per_gpu"]}
     except Exception:
         pass
-    tj = {"workload": wl, "kernel": "vg_wave_kernel<false, 12, 4, 4, 4>", "FETCH_SIZE_KB": means["FETCH_SIZE"], "WRITE_SIZE_KB": means["WRITE_SIZE"],
+    tj = {"workload": wl, "kernel": kname or "vg_wave_kernel (main tier)", "FETCH_SIZE_KB": means["FETCH_SIZE"], "WRITE_SIZE_KB": means["WRITE_SIZE"],
           "traffic_bytes_per_launch": int((means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024),
           "TCC_MISS_sum": means.get("TCC_MISS_sum"), "TCC_HIT_sum": means.get("TCC_HIT_sum"), "TCP_TCC_READ_REQ_sum": means.get("TCP_TCC_READ_REQ_sum"),
           "kernel_trace_avg_ns": kt_avg,
