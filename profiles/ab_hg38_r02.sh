@@ -22,20 +22,8 @@ PY
 }
 run base
 grep -E "vargeno index|\[vargeno index\]|FASTA|resident" $OUT/base.err | tee -a $OUT/summary.txt
-run wchunk64 VG_WORK_CHUNK=64
-# L2 misses per launch of the wave kernel (separate --pmc pass of the same command)
-( cd /tmp && TMPDIR=/tmp rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 $R/bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 10 --warmup 2 > $OUT/pmc_l2.json 2> $OUT/pmc_l2.err )
-python3 - $OUT <<'PY' | tee -a $OUT/summary.txt
-import csv, glob, collections, sys
-agg = collections.defaultdict(list)
-for f in glob.glob(sys.argv[1] + "/pmc_l2/*/*_counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        if "vg_wave_kernel<false" in r["Kernel_Name"] and ", 4>" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in sorted(agg.items()):
-    print("pmc base %-22s n=%d mean=%.6g" % (k, len(v), sum(v) / len(v)))
-PY
-rm -rf $OUT/pmc_l2
+run packbpc8 VG_PACK_BPC=8
+run packbpc32 VG_PACK_BPC=32
 for v in $R/variants/*.so; do
 	n=$(basename $v .so)
 	case $n in clk*) continue;; esac
@@ -45,5 +33,5 @@ if [ -f $R/variants/clk.so ]; then
 	VARGENO_HIP_LIB=$R/variants/clk.so python3 bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
 	grep "dbg" $OUT/clk.err | tail -1 | tee -a $OUT/summary.txt
 fi
-( time python3 -m pytest tests -x -q -m gpu -k "not reference_binary_at_hg38" ) > $OUT/pytest_all.log 2>&1
+( time python3 -m pytest tests -x -q -m gpu -k "not hg38" ) > $OUT/pytest_all.log 2>&1
 grep -E "passed|failed" $OUT/pytest_all.log | tail -2 | tee -a $OUT/summary.txt

@@ -274,21 +274,29 @@ __device__ inline int classify_bad(const uint8_t *p, uint32_t n)
 // A workgroup takes 256 consecutive reads: their bases are one contiguous span, copied to LDS with coalesced
 // 16-byte loads (lane-per-read loads at a 150-byte stride fetched every line ~2.5 times), then each lane packs
 // its own read out of LDS.  Only the first n quality characters of a read are ever looked at.
-#ifndef VG_PACK_T
-#define VG_PACK_T 64       // (128: 3.5 % fewer reads/s at hg38 scale -- smaller tiles keep more workgroups, i.e. more loads, in flight)
-#endif
-constexpr uint32_t PACK_T = VG_PACK_T;          // reads (= lanes) per tile
+constexpr uint32_t PACK_T = 64;                 // reads (= lanes) per tile: one wavefront per workgroup (128: 3.5 % fewer reads/s at hg38 scale --
+                                                // smaller tiles keep more workgroups, i.e. more loads, in flight)
 constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bases; longer reads take the direct path
-__global__ __launch_bounds__(PACK_T) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
+#ifndef VG_PACK_WPE
+#define VG_PACK_WPE 5
+#endif
+__global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_WPE))) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
                                                       uint64_t n_reads_arg, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta, uint32_t *__restrict__ invalid_reads,
                                                       const uint32_t *__restrict__ n_reads_dev)
 {
 	__shared__ __attribute__((aligned(16))) uint8_t sm[PACK_LDS + 64];
 	const uint64_t n_reads = n_reads_dev ? (uint64_t)*n_reads_dev : n_reads_arg;     // a batch framed on the device knows its size there
 	for (uint64_t r0 = (uint64_t)blockIdx.x * PACK_T; r0 < n_reads; r0 += (uint64_t)gridDim.x * PACK_T) {
+		// Two dependent waits per tile: (1) every lane's own offsets -- the tile's span comes out of them by shuffles --, (2) the
+		// tile's bases into LDS together with each read's first four quality characters (all a 150 bp read's gate can see).
 		const uint64_t r = r0 + threadIdx.x;
-		const uint64_t rl = r0 + PACK_T < n_reads ? r0 + PACK_T : n_reads;
-		const uint64_t base0 = offsets[r0], span = offsets[rl] - base0;
+		const uint32_t last = (uint32_t)((r0 + PACK_T < n_reads ? r0 + PACK_T : n_reads) - r0) - 1u;     // last live lane of the tile
+		uint64_t off = 0, off1 = 0;
+		if (r < n_reads) { off = offsets[r]; off1 = offsets[r + 1]; }
+		const uint64_t base0 = __shfl(off, 0), span = __shfl(off1, (int)last) - base0;
+		const uint32_t n = (uint32_t)((off1 - off) >> 5);
+		uint32_t q4 = 0;
+		if (n) __builtin_memcpy(&q4, quals + off, 4);                 // 4 <= n + 3 <= the read's own length: never past it
 		const bool staged = span <= PACK_LDS;
 		__syncthreads();                                              // previous tile fully consumed
 		if (staged) {
@@ -304,8 +312,6 @@ __global__ __launch_bounds__(PACK_T) void vg_pack_kernel(const uint8_t *__restri
 		}
 		__syncthreads();
 		if (r < n_reads) {
-			const uint64_t off = offsets[r];
-			const uint32_t n = (uint32_t)((offsets[r + 1] - off) >> 5);
 			const uint8_t *q = quals + off;
 			uint64_t meta = 0, bad = 0;
 			if (staged) {
@@ -325,10 +331,9 @@ __global__ __launch_bounds__(PACK_T) void vg_pack_kernel(const uint8_t *__restri
 			} else {
 				for (uint32_t c = 0; c < n; c++) pk_kmer[(off >> 5) + c] = encode32(bases + off + 32 * c, bad);
 			}
-			// quality gate bits (qv.cc:836): character c of the quality line, four characters per gather
+			// quality gate bits (qv.cc:836): character c of the quality line, four characters per gather (the first four are in hand)
 			for (uint32_t c0 = 0; c0 < n && c0 < 32; c0 += 4) {
-				uint32_t q4;                                              // c0 + 4 <= n + 3 <= the read's own length: never past it
-				__builtin_memcpy(&q4, q + c0, 4);
+				if (c0) __builtin_memcpy(&q4, q + c0, 4);                 // c0 + 4 <= n + 3 <= the read's own length
 				for (uint32_t j = 0; j < 4 && c0 + j < n && c0 + j < 32; j++) if ((int)(int8_t)(q4 >> (8 * j)) - '8' < 0) meta |= 1ull << (c0 + j);
 			}
 			if (bad) meta |= classify_bad(bases + off, n) == 1 ? PK_SKIP_N : PK_INVALID;
