@@ -126,3 +126,39 @@ def test_bench_starts_its_own_ranks(tmp_path):
     v = line["multi_gpu_verification"]
     assert v["sharded_equals_single_rank"] and v["increments"] > 0 and v["timed_region_increments"] > 0
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_allreduce_with_the_callers_own_communicator(ftiny_dir, ftiny_reads):
+    """vg_counts_allreduce(handle, ncclComm_t): a caller that owns its RCCL communicator (one process per GPU without torch).
+    One rank is all a one-GPU box can host: ncclCommInitRank(nranks = 1) through ctypes, the all-reduce is the identity."""
+    import ctypes as C
+
+    from vargeno_amd._lib import check, lib
+
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl not found")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    prefix = os.path.join(ftiny_dir, "idx")
+    with GenoIndex.open(prefix) as gx:
+        assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+        gx.submit(ftiny_reads.bases, ftiny_reads.quals, ftiny_reads.offsets)
+        before = gx.counts_tensor().clone()
+        assert int(before.sum()) > 0
+        check(lib().vg_counts_allreduce(gx._h, comm))
+        assert torch.equal(gx.counts_tensor(), before)
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
