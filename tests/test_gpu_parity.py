@@ -45,6 +45,23 @@ def test_ftiny_counts_sites_stats_equal_oracle(ftiny_dir, ftiny_reads):
         assert mine == O.parse_vcf_calls(os.path.join(GOLDEN, "ftiny.out.vcf.gz"))
 
 
+def test_index_from_memory_equals_index_from_files(ftiny_dir, ftiny_reads):
+    """vg_index_create (the dictionaries and bit vectors handed over as arrays, field by field as the files hold them) builds
+    the same resident index as vg_index_open (the files' bytes unpacked on the device): same sites, same counters."""
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    _, _, so = _oracle_counts(prefix, r)
+    arrays = index_io.read_index(prefix)
+    with GenoIndex.create(arrays) as gm, GenoIndex.open(prefix) as gf:
+        sm, sf = gm.sites(), gf.sites()
+        for k in ("pos", "ref_base", "alt_base", "ref_freq", "alt_freq"):
+            assert np.array_equal(sm[k], sf[k]) and np.array_equal(sm[k], so[k]), k
+        assert gm.device_bytes == gf.device_bytes
+        gm.submit(r.bases, r.quals, r.offsets)
+        rc, ac = gm.counts()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+
+
 def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
     prefix = os.path.join(ftiny_dir, "idx")
     r = ftiny_reads

@@ -7,7 +7,7 @@
 //   VARGENO_GPUS=n        shard read batches over n GPUs of this node (default 1), counters summed with RCCL
 //   VARGENO_BATCH=n       reads per batch of the host-framed path (default 4194304)
 //   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk sent to the device (default 64; 256 with several GPUs)
-//   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default 8)
+//   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default: an eighth of the hardware threads, 8 to 32)
 //   VARGENO_HOST_FASTQ=1  frame the FASTQ on the host (the reference's four fgets per record) instead of on the device
 //   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
 #include <fcntl.h>
@@ -108,7 +108,9 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		std::atomic<uint64_t> next_piece{0};
 		const uint64_t ppc = (chunk + piece - 1) / piece;           // pieces per (full) chunk
 		bool io_error = false;
-		const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", 8), 64));
+		// one thread copies ~2 GB/s out of the page cache: enough of them to keep a 50 GB/s link busy, if the host has the cores
+		const int hw = (int)std::thread::hardware_concurrency();
+		const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
 		std::vector<std::thread> readers;
 		for (int t = 0; t < n_readers; t++) readers.emplace_back([&] {
 			for (;;) {

@@ -724,7 +724,7 @@ struct PhaseClock {
 	}
 };
 
-// Host loops over billions of records (hg38: 2.9 G k-mers, 3.1 G positions) are spread over threads; fn(lo, hi, t).
+// reader threads of the index loader
 static unsigned host_threads()
 {
 	static const unsigned n = [] {
@@ -733,19 +733,6 @@ static unsigned host_threads()
 		return std::max(1u, std::min(h, 64u));
 	}();
 	return n;
-}
-template <class F>
-static void parallel_for(uint64_t n, F &&fn)
-{
-	const unsigned nt = n < (1ull << 20) ? 1u : host_threads();
-	if (nt == 1) { if (n) fn((uint64_t)0, n, 0u); return; }
-	const uint64_t per = ((n + nt - 1) / nt + 63) & ~63ull;          // 64-aligned shares (rank blocks never straddle two threads)
-	std::vector<std::thread> th;
-	for (unsigned t = 0; t < nt; t++) {
-		const uint64_t lo = (uint64_t)t * per, hi = std::min(n, lo + per);
-		if (lo < hi) th.emplace_back([&fn, lo, hi, t] { fn(lo, hi, t); });
-	}
-	for (auto &x : th) x.join();
 }
 
 // ------------------------------------------------------------------------------------------------
