@@ -22,8 +22,6 @@ PY
 }
 run base
 grep -E "vargeno index|\[vargeno index\]|FASTA|resident" $OUT/base.err | tee -a $OUT/summary.txt
-run packbpc8 VG_PACK_BPC=8
-run packbpc32 VG_PACK_BPC=32
 for v in $R/variants/*.so; do
 	n=$(basename $v .so)
 	case $n in clk*) continue;; esac
@@ -33,5 +31,5 @@ if [ -f $R/variants/clk.so ]; then
 	VARGENO_HIP_LIB=$R/variants/clk.so python3 bench.py --cpu-sample 0 --no-gather-probe --no-ingest --steps 1 --warmup 0 > $OUT/clk.txt 2> $OUT/clk.err
 	grep "dbg" $OUT/clk.err | tail -1 | tee -a $OUT/summary.txt
 fi
-( time python3 -m pytest tests -x -q -m gpu -k "not hg38" ) > $OUT/pytest_all.log 2>&1
+( time python3 -m pytest tests -x -q -m gpu ) > $OUT/pytest_all.log 2>&1
 grep -E "passed|failed" $OUT/pytest_all.log | tail -2 | tee -a $OUT/summary.txt
