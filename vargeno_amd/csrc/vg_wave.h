@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 	__shared__ uint8_t E_meta[W_ECAP][64 * WPB];
 	// stage B pair table: one row per gate-open (owner, chunk) pair of the wave, PCAP rows at a time
 	__shared__ uint32_t P_klo[PCAP][WPB], P_khi[PCAP][WPB], P_lo[PCAP][WPB], P_hi[PCAP][WPB], P_slo[PCAP][WPB], P_shi[PCAP][WPB];
-	__shared__ uint32_t P_meta[PCAP][WPB], P_cnt[PCAP][WPB], P_off[PCAP][WPB], P_off1[PCAP][WPB], P_hu[PCAP][WPB], P_hidx[HCAP][PCAP][WPB];
+	__shared__ uint32_t P_meta[PCAP][WPB], P_cnt[PCAP][WPB], P_off[PCAP][WPB], P_hu[PCAP][WPB], P_hidx[HCAP][PCAP][WPB];
 	__shared__ uint8_t P_ecnt[PCAP][WPB];
 	__shared__ uint16_t N_cnt[64 * WPB];
 	__shared__ uint8_t N_ovf[64 * WPB];
@@ -542,12 +542,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						const uint32_t L = large ? 48u : (hi - lo) + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
 						P_klo[p][wv] = klo; P_khi[p][wv] = khi; P_lo[p][wv] = lo; P_hi[p][wv] = hi; P_slo[p][wv] = slo; P_shi[p][wv] = shi;
 						P_meta[p][wv] = own | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
-						// Two phases of items (below): the strided-scan probes of all pairs first, then everything that needs dictionary
-						// queries or entry fetches.  The two counts share one word: 24 bits for the probes (a bucket beyond that sends its
-						// read to the next tier), 8 for the rest (at most 48 + 48).
-						const uint32_t c0 = large ? 0u : L, c1 = (large ? 48u : 0u) + nhigh;
-						if (c0 >= (1u << 24)) N_ovf[col0 + own] = 1;
-						P_cnt[p][wv] = (c0 < (1u << 24) ? c0 : 0u) | (c1 << 24);
+						P_cnt[p][wv] = L + nhigh;
 						P_hu[p][wv] = hu;
 					}
 				}
@@ -569,27 +564,20 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 				VG_WAVE_SYNC();
 				VG_CLK(2);
 				const uint32_t np = P - w0 < (uint32_t)PCAP ? P - w0 : (uint32_t)PCAP;
-				uint32_t T0, T1;
+				uint32_t T;
 				{
-					const uint32_t both = lane < np ? P_cnt[lane < (uint32_t)PCAP ? lane : 0][wv] : 0u;
-					const uint32_t n0 = both & 0xFFFFFFu, n1 = both >> 24;
-					uint32_t i0 = n0, i1 = n1;
-					for (int o = 1; o < 64; o <<= 1) { const uint32_t y0 = __shfl_up(i0, o), y1 = __shfl_up(i1, o); if ((int)lane >= o) { i0 += y0; i1 += y1; } }
-					if (lane < np) { P_off[lane][wv] = i0 - n0; P_off1[lane][wv] = i1 - n1; }
-					T0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
-					T1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+					const uint32_t cntp = lane < np ? P_cnt[lane < (uint32_t)PCAP ? lane : 0][wv] : 0u;
+					uint32_t ci = cntp;
+					for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(ci, o); if ((int)lane >= o) ci += y; }
+					if (lane < np) P_off[lane][wv] = ci - cntp;
+					T = (uint32_t)__builtin_amdgcn_readlane((int)ci, 63);
 				}
 				VG_WAVE_SYNC();
-				// ---- B1: rounds of 64 items, in two phases.  Phase 0: the strided-scan probes of all pairs (most items at hg38 scale,
-				// where a SNP bucket holds ~19 entries), each fetched one round ahead -- while a round is worked on, the next round's
-				// probes are in flight -- and nearly all of them settled by the probe alone.  Phase 1: the items that need dictionary
-				// queries or entry fetches (high-half slots and hits, the 48 + 48 queries of a large block).  A round pays the whole
-				// chain of dependent waits of its slowest item: laid out pair by pair, nearly every round held some pair's slow items;
-				// this way they share one or two rounds.  Kept contexts carry their phase, and an owner's list is put back into the
-				// reference's order (chunk by chunk, a chunk's scan hits before its high-half hits) once stage B is over.
+				// ---- B1: rounds of 64 items.  The strided-scan probe of an item (most items at hg38 scale, where a SNP bucket holds
+				// ~19 entries) is fetched one round ahead: while a round is worked on, the next round's probes are in flight.
 				auto scan_probe = [&](uint32_t g2) -> uint4 {
 					uint4 v = make_uint4(0u, 0u, 0u, 0u);
-					if (g2 < T0) {
+					if (g2 < T) {
 						uint32_t p = 0;
 						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g2) p += step;
 						const uint32_t t = g2 - P_off[p][wv];
@@ -607,23 +595,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 					}
 					return v;
 				};
-				for (uint32_t ph = 0; ph < 2u; ph++) {
-				const uint32_t T = ph ? T1 : T0;
-				uint4 scan_cur = make_uint4(0u, 0u, 0u, 0u);
-				if (ph == 0) scan_cur = scan_probe(lane);
+				uint4 scan_cur = scan_probe(lane);
 				for (uint32_t t0 = 0; t0 < T; t0 += 64) {
 					const uint32_t g = t0 + lane;
 					const bool valid = g < T;
-					uint4 scan_next = make_uint4(0u, 0u, 0u, 0u);
-					if (ph == 0) scan_next = scan_probe(g + 64u);
+					const uint4 scan_next = scan_probe(g + 64u);
 					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
 					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
 					LaneStats<STATS> hs;
 					hs.clear();
 					if (valid) {
-						uint32_t p = 0;                                                  // last row whose items start at or before g
-						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && (ph ? P_off1[p + step][wv] : P_off[p + step][wv]) <= g) p += step;
-						const uint32_t tph = g - (ph ? P_off1[p][wv] : P_off[p][wv]);  // item number inside the pair's share of this phase
+						uint32_t p = 0;                                                  // last row with P_off <= g
+						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g) p += step;
+						const uint32_t t = g - P_off[p][wv];
 						const uint32_t meta = P_meta[p][wv];
 						const uint32_t klo = P_klo[p][wv], khi = P_khi[p][wv], lo = P_lo[p][wv], hi = P_hi[p][wv], slo = P_slo[p][wv], shi = P_shi[p][wv];
 						const uint64_t k = ((uint64_t)khi << 32) | klo;
@@ -632,8 +616,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						const bool large = (meta >> 13) & 1u, sec_ok = (meta >> 15) & 1u;
 						const uint32_t Lsn = shi - slo;
 						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
-						// t: the item's number in the pair's canonical sequence [scan probes | 48 large-block slots][high-half items]
-						const uint32_t t = (ph && !large) ? tph + L : tph;
 						const uint32_t rsb = (fl & 1u) ? 64u : 32u, ssb = (fl & 2u) ? 64u : 40u;
 						o_ecnt = P_ecnt[p][wv];
 						bool q_r = false, q_s = false;                          // dictionary queries of the neighbour k-mer qk, issued together below
@@ -807,7 +789,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 							if (!fits) N_ovf[col0 + own] = 1;
 							else {
 								uint32_t at = curc + (incl - keep) - excl_ss;
-								const uint16_t mt = (uint16_t)(mk_meta(c, mod, true, nbase) | (ph << 13));
+								const uint16_t mt = (uint16_t)mk_meta(c, mod, true, nbase);
 								if (keepm & 0x3FFu) {
 									if (!r_aux) { N_kpos[at][col0 + own] = rpos; N_meta[at][col0 + own] = mt; at++; }
 									else {                                       // kept contexts out of a row are rare: re-read those columns
@@ -829,24 +811,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 					scan_cur = scan_next;
 					VG_WAVE_SYNC();
 				}
-				}
 				VG_CLK(3);
 			}
 			VG_WAVE_SYNC();
 			ncnt = N_cnt[col];
 			if (N_ovf[col]) { if (!ovf) VG_OVF(1); ovf = true; }
-			// The two phases (and, with several windows, the windows) appended an owner's kept contexts phase by phase; the vote
-			// wants them chunk by chunk, a chunk's scan hits before its high-half hits.  A stable insertion sort on (chunk, phase):
-			// lists of more than one kept context are rare and short.
-			if (ncnt > 1u && !ovf) {
-				auto key = [](uint32_t mt) -> uint32_t { return ((mt & 31u) << 1) | ((mt >> 13) & 1u); };
-				for (uint32_t i = 1; i < ncnt; i++) {
-					const uint32_t mi = N_meta[i][col], pi = N_kpos[i][col], ki = key(mi);
-					uint32_t j = i;
-					while (j > 0 && key(N_meta[j - 1][col]) > ki) { N_meta[j][col] = N_meta[j - 1][col]; N_kpos[j][col] = N_kpos[j - 1][col]; j--; }
-					if (j != i) { N_meta[j][col] = (uint16_t)mi; N_kpos[j][col] = pi; }
-				}
-			}
 			if constexpr (STATS) for (int i = 0; i < NSH; i++) cur.v[SH_IDS[i]] += S_own[i][col];
 		}
 		VG_WAVE_SYNC();
