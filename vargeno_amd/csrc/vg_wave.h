@@ -575,11 +575,10 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 				VG_WAVE_SYNC();
 				// ---- B1: rounds of 64 items.  The strided-scan probe of an item (most items at hg38 scale, where a SNP bucket holds
 				// ~19 entries) is fetched one round ahead: while a round is worked on, the next round's probes are in flight.
-				// (the row an item belongs to is looked up here, one round ahead, and handed to the round that works on the item)
-				auto scan_probe = [&](uint32_t g2, uint32_t &p) -> uint4 {
+				auto scan_probe = [&](uint32_t g2) -> uint4 {
 					uint4 v = make_uint4(0u, 0u, 0u, 0u);
-					p = 0;
 					if (g2 < T) {
+						uint32_t p = 0;
 						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g2) p += step;
 						const uint32_t t = g2 - P_off[p][wv];
 						if (!((P_meta[p][wv] >> 13) & 1u)) {                     // not a large block
@@ -596,18 +595,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 					}
 					return v;
 				};
-				uint32_t p_cur = 0, p_next = 0;
-				uint4 scan_cur = scan_probe(lane, p_cur);
+				uint4 scan_cur = scan_probe(lane);
 				for (uint32_t t0 = 0; t0 < T; t0 += 64) {
 					const uint32_t g = t0 + lane;
 					const bool valid = g < T;
-					const uint4 scan_next = scan_probe(g + 64u, p_next);
-					uint32_t own = 64, c = 0, mod = 0, nbase = 0;
+					const uint4 scan_next = scan_probe(g + 64u);
+					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
 					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
 					LaneStats<STATS> hs;
 					hs.clear();
 					if (valid) {
-						const uint32_t p = p_cur;                                        // last row with P_off <= g
+						uint32_t p = 0;                                                  // last row with P_off <= g
+						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g) p += step;
 						const uint32_t t = g - P_off[p][wv];
 						const uint32_t meta = P_meta[p][wv];
 						const uint32_t klo = P_klo[p][wv], khi = P_khi[p][wv], lo = P_lo[p][wv], hi = P_hi[p][wv], slo = P_slo[p][wv], shi = P_shi[p][wv];
@@ -618,6 +617,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						const uint32_t Lsn = shi - slo;
 						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
 						const uint32_t rsb = (fl & 1u) ? 64u : 32u, ssb = (fl & 2u) ? 64u : 40u;
+						o_ecnt = P_ecnt[p][wv];
 						bool q_r = false, q_s = false;                          // dictionary queries of the neighbour k-mer qk, issued together below
 						uint64_t qk = 0;
 						if (t < L) {
@@ -686,7 +686,6 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 					}
 					// is `position` the implied read position of one of the owner's exact hits?
 					auto in_keys = [&](uint32_t position) -> bool {
-						const uint32_t o_ecnt = P_ecnt[p_cur][wv];           // (only items with a hit get here)
 						bool f = false;
 						for (uint32_t e = 0; e < o_ecnt; e++) f |= E_idx[e][col0 + own] == position;
 						return f;
@@ -809,7 +808,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 						}
 						if (valid && fits && seg_total && (int)lane == se_l) N_cnt[col0 + own] = (uint16_t)(curc + seg_total);
 					}
-					scan_cur = scan_next; p_cur = p_next;
+					scan_cur = scan_next;
 					VG_WAVE_SYNC();
 				}
 				VG_CLK(3);
