@@ -72,14 +72,20 @@ static inline uint64_t hash40(uint64_t x) { x = (x ^ (x >> 30)) * 0xbf58476d1ce4
 
 struct Seq { std::string name, seq; };
 
-// src/fasta_parser.c:35-133
+// src/fasta_parser.c:35-133: a record starts at a '>' (wherever it stands); its name ends at '|', white space or 64 characters and
+// the rest of that line is skipped; its sequence is every character up to the next '>' except newlines, ACGT folded to upper
+// case, anything else mapped to N.  The bodies (3.1 GB for a human genome) are converted by all threads: newlines are counted
+// per 16 MiB piece first, so that every piece knows where its bases land.
 static std::vector<Seq> parse_fasta_dict(const std::string &buf)
 {
 	std::vector<Seq> out;
+	std::vector<std::pair<size_t, size_t>> body;                  // [begin, end) of every record's sequence text
 	const size_t n = buf.size();
 	size_t i = 0;
 	while (i < n) {
-		if (buf[i++] != '>') continue;
+		const char *gt = (const char *)memchr(buf.data() + i, '>', n - i);
+		if (!gt) break;
+		i = (size_t)(gt - buf.data()) + 1;
 		Seq s;
 		bool newline = false;
 		while (i < n) {
@@ -88,17 +94,45 @@ static std::vector<Seq> parse_fasta_dict(const std::string &buf)
 			s.name.push_back(c);
 		}
 		if (!newline) while (i < n && buf[i++] != '\n') {}
-		size_t j = i, cnt = 0;
-		while (j < n && buf[j] != '>') { cnt += buf[j] != '\n'; j++; }
-		s.seq.resize(cnt);
-		size_t k = 0;
-		for (; i < j; i++) {
-			const char c = buf[i];
+		const char *nx = i < n ? (const char *)memchr(buf.data() + i, '>', n - i) : nullptr;
+		const size_t j = nx ? (size_t)(nx - buf.data()) : n;
+		body.push_back({i, j});
+		out.push_back(std::move(s));
+		i = j;
+	}
+	struct Piece { size_t rec, lo, hi, bases, at; };
+	std::vector<Piece> pieces;
+	for (size_t r = 0; r < body.size(); r++)
+		for (size_t lo = body[r].first; lo < body[r].second || lo == body[r].first; lo += (size_t)16 << 20) {
+			pieces.push_back(Piece{r, lo, std::min(body[r].second, lo + ((size_t)16 << 20)), 0, 0});
+			if (lo >= body[r].second) break;
+		}
+	#pragma omp parallel for schedule(dynamic, 1)
+	for (long p = 0; p < (long)pieces.size(); p++) {
+		Piece &pc = pieces[(size_t)p];
+		size_t nl = 0;
+		for (const char *q = buf.data() + pc.lo, *e = buf.data() + pc.hi; q < e;) {
+			const char *f = (const char *)memchr(q, '\n', (size_t)(e - q));
+			if (!f) break;
+			nl++; q = f + 1;
+		}
+		pc.bases = (pc.hi - pc.lo) - nl;
+	}
+	{
+		size_t r = (size_t)-1, at = 0;
+		for (Piece &pc : pieces) { if (pc.rec != r) { if (r != (size_t)-1) out[r].seq.resize(at); r = pc.rec; at = 0; } pc.at = at; at += pc.bases; }
+		if (r != (size_t)-1) out[r].seq.resize(at);
+	}
+	#pragma omp parallel for schedule(dynamic, 1)
+	for (long p = 0; p < (long)pieces.size(); p++) {
+		const Piece &pc = pieces[(size_t)p];
+		char *dst = &out[pc.rec].seq[0] + pc.at;
+		for (size_t k = pc.lo; k < pc.hi; k++) {
+			const char c = buf[k];
 			if (c == '\n') continue;
 			const int code = base_code((unsigned char)c);
-			s.seq[k++] = code < 4 ? "ACGT"[code] : 'N';
+			*dst++ = code < 4 ? "ACGT"[code] : 'N';
 		}
-		out.push_back(std::move(s));
 	}
 	return out;
 }
