@@ -32,7 +32,10 @@ sys.path.insert(0, ROOT)
 BIN = os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno")
 
 PRESETS = {"chr22": dict(genome=40_000_000, snps=1_000_000, chroms=1, reads=1_000_000, cpu_sample=1_000_000),
-           "hg38": dict(genome=3_100_000_000, snps=10_000_000, chroms=24, reads=8_000_000, cpu_sample=2_000_000)}
+           "hg38": dict(genome=3_100_000_000, snps=10_000_000, chroms=24, reads=8_000_000, cpu_sample=2_000_000),
+           # the index of BASELINE.json configs[4] (hg38 + full dbSNP, ~100 M SNPs) on ONE replica: ~100 GB of index files (point
+           # VG_BENCH_DIR at a file system with the room, e.g. /dev/shm), ~195 GB of HBM, no merged view / direct table
+           "hg38f": dict(genome=3_100_000_000, snps=100_000_000, chroms=24, reads=8_000_000, cpu_sample=500_000)}
 
 
 def log(*a):
@@ -46,7 +49,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(PRESETS), default="hg38",
                     help="hg38 = BASELINE.json configs[2] (default: 3.1 Gbp in 24 sequences, 10 M SNPs, 8 M-read steps of its 30x reads; ~240 GB of HBM); "
-                         "chr22 = configs[1] (40 Mbp, 1 M SNPs, 1 M-read steps)")
+                         "chr22 = configs[1] (40 Mbp, 1 M SNPs, 1 M-read steps); hg38f = the index of configs[4] (100 M SNPs) on one replica")
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step")
     ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps rotate over")
     ap.add_argument("--genome", type=int, default=None)
@@ -175,7 +178,7 @@ def main():
     d = os.path.join(args.workdir, tag)
     prefix = os.path.join(d, "idx")
     t0 = time.time()
-    g, s, _ = synth.genome_and_snps(genome_len=args.genome, n_snps=args.snps, n_chroms=args.chroms)
+    g, s, _ = synth.genome_and_snps(genome_len=args.genome, n_snps=args.snps, n_chroms=args.chroms, genotypes="hwe" if args.workload == "hg38f" else "uniform")
     if rank == 0:
         log("[bench] synthetic genome + SNP list: %.1fs (%d bp, %d SNPs)" % (time.time() - t0, g.total_len, len(s.pos)))
         build_index_files(args, g, s, d, prefix)
@@ -404,6 +407,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %d bp synthetic genome in %d sequence(s), %d SNPs requested, %d x 150 bp reads per GPU per step rotating over %d "
                                    "distinct resident batches of the read stream, 0.5%% error, %g%% low-quality chars, seed 20261002" % (
+                                       "hg38 + full-dbSNP-scale index (BASELINE.json configs[4], one replica)" if args.snps >= 5 * 10 ** 7 else
                                        "hg38-scale (BASELINE.json configs[2])" if args.genome >= 10 ** 9 else "chr22-scale (BASELINE.json configs[1])",
                                        args.genome, args.chroms, args.snps, args.reads, args.batches, 100 * args.lowq),
                        "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps,

@@ -957,6 +957,10 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			d.sec_key = skey; d.sec_idx = sidx; d.sec_jg = sjg; d.sec_bits = bits;
 		}
 	}
+	// the merged view is the last user of the reference dictionary's columns: without it (2^32 or more k-mers in the two
+	// dictionaries together -- hg38 + full dbSNP --, or VG_NO_MX) they go now, 37 GB at hg38 scale
+	const bool want_mx = !getenv("VG_NO_MX") && c.n_ref + c.n_snp < (1ull << 32);
+	if (!want_mx) { c.ref_kmer.release(); c.ref_pos.release(); c.ref_amb.release(); }
 	pc.lap("reference dictionary + LO32-ordered view");
 	// ---- SNP dictionary
 	{
@@ -978,7 +982,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		}
 		// merged exact-match view (both dictionaries behind one HI32 jump table); its indices are 32 bits wide
 		const uint64_t nm = c.n_ref + c.n_snp;
-		if (!getenv("VG_NO_MX") && nm < (1ull << 32)) {
+		if (want_mx) {
 			TempDev<uint64_t> kin, kout; TempDev<uint32_t> vin, vout;
 			if ((rc = kin.alloc(nm)) || (rc = kout.alloc(nm)) || (rc = vin.alloc(nm)) || (rc = vout.alloc(nm))) return rc;
 			if (c.n_ref) HIP_TRY(hipMemcpyAsync(kin.p, c.ref_kmer.p, (size_t)c.n_ref * 8, hipMemcpyDeviceToDevice, st));

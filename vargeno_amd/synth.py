@@ -148,8 +148,10 @@ def make_genome(rng, lengths, names, *, repeats_per_mbp=50.0, repeat_len=(200, 2
     return Genome(list(names), seqs)
 
 
-def make_snps(rng, genome, n, *, with_caf=True):
-    """Uniform positions (not N, not within 32 of a chromosome end), one alt != ref, CAF ~ Beta(5,1)."""
+def make_snps(rng, genome, n, *, with_caf=True, genotypes="uniform"):
+    """Uniform positions (not N, not within 32 of a chromosome end), one alt != ref, CAF ~ Beta(5,1).
+    Donor genotypes: "uniform" over {0/0, 0/1, 1/1}, or "hwe": each haplotype carries the alt allele with
+    the SNP's alt frequency -- the dense lists (100 M SNPs, one per 31 bp) need that to keep k-mers with a single alt common."""
     lens = np.array([len(s) for s in genome.seqs], dtype=np.int64)
     total = int(lens.sum())
     n = min(n, total // 3)
@@ -170,7 +172,11 @@ def make_snps(rng, genome, n, *, with_caf=True):
     altc = (refc + rng.integers(1, 4, size=len(refc), dtype=np.uint8)) % 4
     p = 0.01 + 0.98 * rng.beta(5.0, 1.0, size=len(refc))
     s = SnpSet(chrom, pos0 + 1, ref, ACGT[altc], p, 1.0 - p)
-    s.genotype = rng.integers(0, 3, size=len(refc)).astype(np.uint8)
+    if genotypes == "hwe":
+        q = 1.0 - p
+        s.genotype = (rng.random(len(refc)) < q).astype(np.uint8) + (rng.random(len(refc)) < q).astype(np.uint8)    # 0 = 0/0, 1 = 0/1, 2 = 1/1
+    else:
+        s.genotype = rng.integers(0, 3, size=len(refc)).astype(np.uint8)
     s._with_caf = with_caf
     return s
 
@@ -384,7 +390,7 @@ def f_tiny(seed=7):
     return g, s, r
 
 
-def genome_and_snps(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_chroms=1):
+def genome_and_snps(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_chroms=1, genotypes="uniform"):
     """Genome + SNP list of the bench workloads (F-mid recipe scaled by length): BASELINE.json configs[1] by default; with
     genome_len = 3.1e9, n_chroms = 24, n_snps = 1e7 the hg38-scale configs[2].  Returns (genome, snps, rng): the generator is
     left where make_reads() continues from."""
@@ -397,7 +403,7 @@ def genome_and_snps(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_ch
         names = ["chr%d" % (i + 1) for i in range(n_chroms)]
     g = make_genome(rng, lens, names, repeats_per_mbp=50.0, repeat_len=(200, 2000),
                     repeat_div=0.02, microsat_per_mbp=12.5)
-    s = make_snps(rng, g, n_snps)
+    s = make_snps(rng, g, n_snps, genotypes=genotypes)
     return g, s, rng
 
 
