@@ -980,6 +980,19 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			HIP_TRY(hipStreamSynchronize(st));
 			d.snp_probe = pv;
 		}
+		// an index too large for the merged view gets a HI32 jump table of the SNP dictionary instead (17 GB): its HI24 buckets hold
+		// ~190 entries there, 8 dependent bisection probes per look-up
+		if (!want_mx && !getenv("VG_NO_SNP_JG32")) {
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (40ull << 30)) {
+				uint32_t *j32 = nullptr;
+				if ((rc = dev_alloc(ix, &j32, (1ull << 32) + 1))) return rc;
+				vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, j32, 1ull << 32, 32);
+				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipStreamSynchronize(st));
+				d.snp_jg32 = j32;
+			}
+		}
 		// merged exact-match view (both dictionaries behind one HI32 jump table); its indices are 32 bits wide
 		const uint64_t nm = c.n_ref + c.n_snp;
 		if (want_mx) {
@@ -1353,14 +1366,17 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));               // the wave kernel's own start
 		ix->cnt4_dirty = true;
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 64 * W1_WPB - 1) / (64 * W1_WPB), (uint64_t)ix->wave_grid / W1_WPB);
-		vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
+		const bool big = !STATS && ix->d.mx == nullptr;                // an index without the merged view: the kernel built for it
+		if (big) vg_wave_kernel_big<W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
+		else vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		// tail stream, second tier: the same kernel with deep lists over the spill list (2 waves per CU)
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		// (its workgroups hold 42 KB of LDS each while they live, in the way of the next batch's main tier: a wave takes at least
 		// w2_chunk reads at a time, so a few hundred spilled reads wake few of them)
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
-		vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats);
+		if (big) vg_wave_kernel_big<W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats);
+		else vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream

@@ -61,6 +61,11 @@ struct DevIndex {
 	// (0 where that index lies beyond the array) -- exactly the values iterate_snp_dict's scan (bug B1, qv.cc:447-455) tests for a
 	// bucket, laid side by side: at hg38 scale a bucket holds ~19 entries, i.e. 19 lines 176 bytes apart become 3 adjacent ones.
 	const uint64_t *snp_probe;     // [n_snp] (timed build only; nullptr: the probes read `snp` itself)
+	// jump table of the SNP dictionary over HI32 (2^32 + 1 words, like ref_jg): built only for an index too large for the merged view
+	// (2^32 or more k-mers in the two dictionaries together: hg38 + full dbSNP), where a HI24 bucket holds ~190 entries and the
+	// reference's bsearch would be 8 dependent probes; a HI32 bucket holds one or two.  Same entries found: the dictionary is
+	// sorted by the whole k-mer, so a HI32 bucket is a contiguous piece of its HI24 bucket.
+	const uint32_t *snp_jg32;
 	// bit vectors (src/generate_bf.h:112-142)
 	const uint64_t *ref_bf; uint64_t ref_bf_bits;
 	const uint64_t *snp_bf; uint64_t snp_bf_bits;
@@ -86,10 +91,12 @@ enum StatId {
 
 template <bool STATS> struct LaneStats;
 template <> struct LaneStats<false> {
+	static constexpr bool counting = false;
 	__device__ inline void add(int, uint32_t) {}
 	__device__ inline void clear() {}
 };
 template <> struct LaneStats<true> {
+	static constexpr bool counting = true;
 	uint32_t v[S_COUNT];
 	__device__ inline void add(int id, uint32_t x) { v[id] += x; }
 	__device__ inline void clear() { for (int i = 0; i < S_COUNT; i++) v[i] = 0; }
@@ -196,7 +203,11 @@ __device__ inline void dual_query(const DevIndex &d, ST &st, uint64_t k, bool wa
 {
 	uint32_t ra = 0, rb = 0, sa = 0, sb = 0;
 	if (want_r) { jg_pair(d.ref_jg, k >> 32, ra, rb); st.add(S_REF_QUERY, 1); }
-	if (want_s) { jg_pair(d.snp_jg, k >> 40, sa, sb); st.add(S_SNP_QUERY, 1); }
+	if (want_s) {
+		// (the counting build prices the walk through the HI24 table; the HI32 table, when the index has one, bounds the same entries)
+		if (!ST::counting && d.snp_jg32) jg_pair(d.snp_jg32, k >> 32, sa, sb); else jg_pair(d.snp_jg, k >> 40, sa, sb);
+		st.add(S_SNP_QUERY, 1);
+	}
 	if (ra < rb) st.add(S_REF_PROBE, ceil_log2_p1(rb - ra));
 	if (sa < sb) st.add(S_SNP_PROBE, ceil_log2_p1(sb - sa));
 	const uint32_t rkey = (uint32_t)k;
@@ -210,6 +221,47 @@ __device__ inline void dual_query(const DevIndex &d, ST &st, uint64_t k, bool wa
 		if (ps) sk = d.snp[sm].key & LO40_MASK;
 		if (pr) { if (rlo == rkey) { ri = rm; ra = rb; } else if (rlo < rkey) ra = rm + 1; else rb = rm; }
 		if (ps) { if (sk == skey) { si = sm; sa = sb; } else if (sk < skey) sa = sm + 1; else sb = sm; }
+	}
+}
+
+// The exact look-ups of TWO chunks in both dictionaries in lock step, for an index without the merged view: four bucket-bound
+// gathers go out together, then every bisection step probes all four buckets at once -- 1 + max depth waits for what four
+// separate queries would spend ~12 on.  SNP buckets come from the HI32 jump table when the index has one.  The entries found
+// are returned whole (every probe fetches 16 bytes).  Not for the counting build: no events are booked.
+__device__ inline void exact_pair_nomx(const DevIndex &d, const uint64_t (&k)[2], const bool (&want)[2], bool (&rhit)[2], RefEnt (&re)[2], bool (&shit)[2], SnpEnt (&se)[2])
+{
+	uint32_t ra[2] = {0, 0}, rb[2] = {0, 0}, sa[2] = {0, 0}, sb[2] = {0, 0};
+	#pragma unroll
+	for (int z = 0; z < 2; z++) {
+		rhit[z] = shit[z] = false;
+		if (!want[z]) continue;
+		jg_pair(d.ref_jg, k[z] >> 32, ra[z], rb[z]);
+		if (d.snp_jg32) jg_pair(d.snp_jg32, k[z] >> 32, sa[z], sb[z]); else jg_pair(d.snp_jg, k[z] >> 40, sa[z], sb[z]);
+	}
+	for (;;) {
+		bool pr[2], ps[2], any = false;
+		uint32_t rm[2], sm[2];
+		RefEnt er[2]; SnpEnt es[2];
+		#pragma unroll
+		for (int z = 0; z < 2; z++) {
+			pr[z] = ra[z] < rb[z]; ps[z] = sa[z] < sb[z];
+			any = any || pr[z] || ps[z];
+			rm[z] = ra[z] + ((rb[z] - ra[z]) >> 1); sm[z] = sa[z] + ((sb[z] - sa[z]) >> 1);
+			if (pr[z]) er[z] = d.ref[rm[z]];
+			if (ps[z]) es[z] = d.snp[sm[z]];
+		}
+		if (!any) break;
+		#pragma unroll
+		for (int z = 0; z < 2; z++) {
+			if (pr[z]) {
+				const uint32_t key = (uint32_t)k[z];
+				if (er[z].lo == key) { rhit[z] = true; re[z] = er[z]; ra[z] = rb[z]; } else if (er[z].lo < key) ra[z] = rm[z] + 1; else rb[z] = rm[z];
+			}
+			if (ps[z]) {
+				const uint64_t key = k[z] & LO40_MASK, ek = es[z].key & LO40_MASK;
+				if (ek == key) { shit[z] = true; se[z] = es[z]; sa[z] = sb[z]; } else if (ek < key) sa[z] = sm[z] + 1; else sb[z] = sm[z];
+			}
+		}
 	}
 }
 

@@ -101,11 +101,14 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 
 // WORK_CHUNK: reads a wave pulls from the launch's work counter at a time (large for the main tier, a handful for the
 // spill tier, whose few hundred heavy reads must spread over all its waves)
-template <bool STATS, int W_ECAP, int W_NCAP, int WPB>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
-                                                     const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
-                                                     const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
-                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
+// NOMX: the instantiation for an index without the merged view / direct table (2^32 or more k-mers in the two dictionaries
+// together, or VG_NO_MX).  A kernel of its own (vg_wave_kernel_big) rather than a branch: the two exact-look-up stages would
+// otherwise share one register allocation, and the kernel has no register to spare.
+template <bool STATS, int W_ECAP, int W_NCAP, int WPB, bool NOMX>
+__device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
+                                             const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
+                                             const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
+                                             uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
 {
 	// narrow element types: an exact context only needs its chunk number next to the position, a neighbour context 13 bits.
 	// A vote key (qv.cc:132-178) is always created by an exact context -- neighbour contexts never open one, :134-139 -- so its
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 	// The secondary (LO32-ordered) view answers the 48 high-half reference queries with one bucket read.  The counting
 	// build keeps the 48 individual queries because the event counters price each of them.
 	const bool use_sec = !STATS && d.sec_key != nullptr;
-	const bool use_mx = !STATS && d.mx != nullptr;
+	const bool use_mx = !STATS && !NOMX && d.mx != nullptr;
 	const bool use_probe = !STATS && d.snp_probe != nullptr;
 	// two SNP-scan probes per stage-B item, in the main tier only: an item with two hits sends its read to the next tier, and the
 	// deep-list tier must be able to finish such a read itself (the lane tier behind it takes milliseconds per read)
@@ -310,7 +313,21 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 					else { cur.add(S_AUX_SNP, 1); push_row(d.snp_aux_pos + (uint64_t)spos * AUX_COLS, c); }
 				}
 			};
-			if (use_mx) {
+			if constexpr (NOMX) {
+				// An index without the merged view: both dictionaries of two chunks at a time, bisected in lock step
+				for (uint32_t c = 0; c < n; c += 2) {
+					uint64_t kq[2] = {0, 0};
+					const bool want[2] = {true, c + 1 < n};
+					if (want[1]) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
+					bool rhit[2], shit[2]; RefEnt re[2]; SnpEnt se[2];
+					exact_pair_nomx(d, kq, want, rhit, re, shit, se);
+					#pragma unroll
+					for (uint32_t z = 0; z < 2; z++) if (want[z]) {
+						cur.add(S_CHUNKS, 1);
+						emit_exact(c + z, rhit[z], rhit[z] ? re[z].pos : 0u, rhit[z] ? re[z].amb : 0u, shit[z], shit[z] ? se[z].pos : 0u, shit[z] ? (uint32_t)((se[z].key >> 48) & 0xFFu) : 0u);
+					}
+				}
+			} else if (use_mx) {
 				// The timed build reads the merged view: one jump-table gather + one bucket line answers both dictionaries.
 				// Two chunks are in flight at a time (their gathers are issued back to back before either is consumed).
 				auto scan_bucket = [&](uint64_t k, uint32_t lo, uint32_t hi, uint4 first, bool &rhit, uint32_t &rpos, uint32_t &ramb, bool &shit, uint32_t &spos, uint32_t &samb) {
@@ -996,6 +1013,25 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 
 	if constexpr (STATS) {
 		for (int i = 0; i < S_COUNT; i++) if (tot.v[i]) atomicAdd(&stats[i], (unsigned long long)tot.v[i]);
 	}
+}
+
+template <bool STATS, int W_ECAP, int W_NCAP, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
+                                                     const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
+                                                     const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
+                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
+{
+	vg_wave_body<STATS, W_ECAP, W_NCAP, WPB, false>(d, pk_kmer, pk_meta, offsets, n_reads_arg, read_ids, n_ids, overflow_list, overflow_count, work_next, WORK_CHUNK_ARG, stats);
+}
+
+// the timed build for an index without the merged view (see vg_wave_body)
+template <int W_ECAP, int W_NCAP, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel_big(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
+                                                     const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
+                                                     const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
+                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
+{
+	vg_wave_body<false, W_ECAP, W_NCAP, WPB, true>(d, pk_kmer, pk_meta, offsets, n_reads_arg, read_ids, n_ids, overflow_list, overflow_count, work_next, WORK_CHUNK_ARG, stats);
 }
 
 }  // namespace vg
