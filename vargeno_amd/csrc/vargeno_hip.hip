@@ -280,6 +280,9 @@ constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bas
 #ifndef VG_PACK_WPE
 #define VG_PACK_WPE 5
 #endif
+#ifndef VG_PACK_NT
+#define VG_PACK_NT 0                            // `nt` on the pack kernel's loads of the base text, read once
+#endif
 __global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_WPE))) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
                                                       uint64_t n_reads_arg, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta, uint32_t *__restrict__ invalid_reads,
                                                       const uint32_t *__restrict__ n_reads_dev)
@@ -302,8 +305,7 @@ __global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_
 		if (staged) {
 			for (uint64_t i = (uint64_t)threadIdx.x * 16; i < span; i += PACK_T * 16) {
 				if (i + 16 <= span) {
-					uint4 v;
-					__builtin_memcpy(&v, bases + base0 + i, 16);
+					const uint4 v = load_policy<VG_PACK_NT != 0, uint4, 1>(bases + base0 + i);     // (a batch may start at any byte)
 					*reinterpret_cast<uint4 *>(sm + i) = v;
 				} else {
 					for (uint64_t j = i; j < span; j++) sm[j] = bases[base0 + j];

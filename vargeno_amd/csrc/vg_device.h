@@ -124,11 +124,50 @@ __device__ inline uint64_t revcomp64(uint64_t k)
 	return ~k;
 }
 
+// Loads with the `nt` bit of gfx950's memory instructions ("nothing will touch this line again soon").  A probe of bare random
+// gathers from a table far larger than L2 (tools/gather_policy_probe, profiles/gather_policy_probe_r02.jsonl) runs at 55.0 G/s
+// with it and 50.9 G/s without, whatever the width (sc0 / sc1 change nothing; an L2-resident table: 250 G/s) -- but the read
+// loop is not that probe.  Measured on the hg38-scale workload (profiles/ab_hg38_r02_a12.txt, _a13.txt; run-to-run spread
+// +-1.5 %): the bit on the dictionary / view gathers changes nothing, on the rank blocks under a read it costs ~3 % (their
+// neighbours are wanted a moment later), on the two bit-vector probes of a gate-open chunk it is worth 1 % at most.  Hence
+// three switches, by what is loaded.  ALIGN: what the address is known to be aligned to.
+#ifndef VG_NT_TAB
+#define VG_NT_TAB 0
+#endif
+#ifndef VG_NT_BF
+#define VG_NT_BF 1
+#endif
+#ifndef VG_NT_WALK
+#define VG_NT_WALK 0
+#endif
+typedef uint32_t nt_v4a16 __attribute__((ext_vector_type(4), aligned(16)));
+typedef uint32_t nt_v4a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef uint32_t nt_v2a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef uint32_t nt_v2a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t nt_v4a1 __attribute__((ext_vector_type(4), aligned(1)));
+template <bool NT, typename T, int ALIGN>
+__device__ __forceinline__ T load_policy(const void *p)
+{
+	static_assert(sizeof(T) == 4 || sizeof(T) == 8 || sizeof(T) == 16, "4, 8 or 16 bytes");
+	static_assert(ALIGN == 1 || ALIGN == 4 || ALIGN == 8 || ALIGN == 16, "alignment 1, 4, 8 or 16");
+	T r;
+	if constexpr (!NT) __builtin_memcpy(&r, __builtin_assume_aligned(p, ALIGN), sizeof(T));
+	else if constexpr (sizeof(T) == 16 && ALIGN >= 16) { const nt_v4a16 v = __builtin_nontemporal_load((const nt_v4a16 *)p); __builtin_memcpy(&r, &v, 16); }
+	else if constexpr (sizeof(T) == 16 && ALIGN == 8) { const nt_v4a8 v = __builtin_nontemporal_load((const nt_v4a8 *)p); __builtin_memcpy(&r, &v, 16); }
+	else if constexpr (sizeof(T) == 16) { static_assert(ALIGN == 1, "16 bytes: aligned to 16, 8 or not at all"); const nt_v4a1 v = __builtin_nontemporal_load((const nt_v4a1 *)p); __builtin_memcpy(&r, &v, 16); }
+	else if constexpr (sizeof(T) == 8 && ALIGN >= 8) { const nt_v2a8 v = __builtin_nontemporal_load((const nt_v2a8 *)p); __builtin_memcpy(&r, &v, 8); }
+	else if constexpr (sizeof(T) == 8) { static_assert(ALIGN == 4, "8 bytes: aligned to 8 or 4"); const nt_v2a4 v = __builtin_nontemporal_load((const nt_v2a4 *)p); __builtin_memcpy(&r, &v, 8); }
+	else { const uint32_t v = __builtin_nontemporal_load((const uint32_t *)p); __builtin_memcpy(&r, &v, 4); }
+	return r;
+}
+template <typename T, int ALIGN = alignof(T)> __device__ __forceinline__ T gather(const void *p) { return load_policy<VG_NT_TAB != 0, T, ALIGN>(p); }        // dictionaries, views, jump tables
+template <typename T> __device__ __forceinline__ T gather_bf(const T *p) { return load_policy<VG_NT_BF != 0, T, alignof(T)>(p); }                           // bit vectors
+template <typename T> __device__ __forceinline__ T gather_walk(const T *p) { return load_policy<VG_NT_WALK != 0, T, alignof(T)>(p); }                       // rank blocks
+
 // bucket bounds: one 8-byte gather (two adjacent jump-table words)
 __device__ inline void jg_pair(const uint32_t *jg, uint64_t h, uint32_t &lo, uint32_t &hi)
 {
-	uint64_t v;
-	__builtin_memcpy(&v, jg + h, 8);
+	const uint64_t v = gather<uint64_t, 4>(jg + h);
 	lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
 }
 
@@ -217,8 +256,8 @@ __device__ inline void dual_query(const DevIndex &d, ST &st, uint64_t k, bool wa
 		const uint32_t rm = ra + ((rb - ra) >> 1), sm = sa + ((sb - sa) >> 1);
 		uint32_t rlo = 0;
 		uint64_t sk = 0;
-		if (pr) rlo = d.ref[rm].lo;
-		if (ps) sk = d.snp[sm].key & LO40_MASK;
+		if (pr) rlo = gather<uint32_t>(&d.ref[rm].lo);
+		if (ps) sk = gather<uint64_t>(&d.snp[sm].key) & LO40_MASK;
 		if (pr) { if (rlo == rkey) { ri = rm; ra = rb; } else if (rlo < rkey) ra = rm + 1; else rb = rm; }
 		if (ps) { if (sk == skey) { si = sm; sa = sb; } else if (sk < skey) sa = sm + 1; else sb = sm; }
 	}

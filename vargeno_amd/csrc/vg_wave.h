@@ -356,7 +356,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						VG_CLKW(9);
 						uint4 bq[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = d.dx[kq[z] >> 32]; }
+						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = gather<uint4>(d.dx + (kq[z] >> 32)); }
 						VG_CLKW(10);
 						// `more`: the bucket has further entries that may hold the key (entries are sorted by lo: nothing below the first; a
 						// match on the first entry is final unless the table says its successor has the same k-mer -- flag TIE)
@@ -375,7 +375,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							for (uint32_t y = 0; y < 2; y++) {
 								const uint32_t cnt = bq[z0 + y].z >> 8, lo = bq[z0 + y].w;
 								#pragma unroll
-								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = d.mx[lo + 1u + x]; }
+								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = gather<uint4>(d.mx + (lo + 1u + x)); }
 							}
 							#pragma unroll
 							for (uint32_t y = 0; y < 2; y++) {
@@ -516,8 +516,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						if (use_sec) jg_pair(d.sec_jg, klo >> (32 - d.sec_bits), b0, b1);
 						const uint64_t rp = (uint64_t)hash32(klo) % d.ref_bf_bits;   // qv.cc:946-956
 						const uint64_t sp = hash40(k & LO40_MASK) % d.snp_bf_bits;
-						if ((d.ref_bf[rp >> 6] >> (rp & 63)) & 1u) fl |= 1u;
-						if ((d.snp_bf[sp >> 6] >> (sp & 63)) & 1u) fl |= 2u;
+						if ((gather_bf<uint64_t>(d.ref_bf + (rp >> 6)) >> (rp & 63)) & 1u) fl |= 1u;
+						if ((gather_bf<uint64_t>(d.snp_bf + (sp >> 6)) >> (sp & 63)) & 1u) fl |= 2u;
 						const bool large = hi - lo >= BLOCK_THRESHOLD;
 						// high-half SNP queries are live for a contiguous range of slots u = 3 * (pair - 16) + sel  (qv.cc:1303-1306)
 						uint32_t s_lo = 0, s_hi = 0;
@@ -540,7 +540,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								// the usual bucket: its (at most SEC_W) keys and dictionary indices in one go, no search
 								uint64_t key[SEC_W]; uint32_t idx[SEC_W];
 								#pragma unroll
-								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; key[z] = d.sec_key[e]; idx[z] = d.sec_idx[e]; }
+								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; key[z] = gather<uint64_t>(d.sec_key + e); idx[z] = gather<uint32_t>(d.sec_idx + e); }
 								#pragma unroll
 								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) if (b0 + z < b1 && (uint32_t)(key[z] >> 32) == klo) sec_entry(key[z], idx[z]);
 							}
@@ -604,9 +604,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							if (t < L) {
 								const bool isr = t < Lr;
 								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)t * REF_STRIDE : (uint64_t)slo + (uint64_t)(t - Lr) * SNP_STRIDE;
-								if (!isr && probe2) __builtin_memcpy(&v, d.snp_probe + ((uint64_t)slo + 2u * (t - Lr)), 16);   // two probed LO40 values, side by side
-								else if (!isr && use_probe) { uint2 q; __builtin_memcpy(&q, d.snp_probe + ((uint64_t)slo + (t - Lr)), 8); v.x = q.x; v.y = q.y; }
-								else if (tt < (isr ? d.n_ref : d.n_snp)) v = *(isr ? (const uint4 *)(d.ref + tt) : (const uint4 *)(d.snp + tt));
+								if (!isr && probe2) v = gather<uint4, 8>(d.snp_probe + ((uint64_t)slo + 2u * (t - Lr)));   // two probed LO40 values, side by side
+								else if (!isr && use_probe) { const uint2 q = gather<uint2, 8>(d.snp_probe + ((uint64_t)slo + (t - Lr))); v.x = q.x; v.y = q.y; }
+								else if (tt < (isr ? d.n_ref : d.n_snp)) v = gather<uint4>(isr ? (const void *)(d.ref + tt) : (const void *)(d.snp + tt));
 							}
 						}
 					}
@@ -715,8 +715,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					{
 						RefEnt re; SnpEnt se;
 						re.pos = POS_AMBIGUOUS; re.amb = 0; se.pos = POS_AMBIGUOUS; se.key = 0;
-						if (ri != NOHIT) re = d.ref[ri];
-						if (si != NOHIT) se = d.snp[si];
+						if (ri != NOHIT) re = gather<RefEnt>(d.ref + ri);
+						if (si != NOHIT) se = gather<SnpEnt>(d.snp + si);
 						const bool r_ok = re.pos != POS_AMBIGUOUS, s_ok = se.pos != POS_AMBIGUOUS;
 						r_aux = r_ok && re.amb != 0; s_aux = s_ok && ((se.key >> 48) & 0xFFu) != 0;
 						rpos = re.pos; spos = se.pos;
@@ -918,9 +918,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							const uint32_t blk0 = target >> 6, blk_last = (target + 32u * n - 1u) >> 6;
 							// named scalars, not arrays: an array the compiler cannot keep in registers ends up in scratch memory
 							const ulonglong2 zz = make_ulonglong2(0ull, 0ull);
-							const ulonglong2 r0 = d.srank[blk0];
-							const ulonglong2 r1 = blk0 + 1u <= blk_last ? d.srank[blk0 + 1u] : zz;
-							const ulonglong2 r2 = blk0 + 2u <= blk_last ? d.srank[blk0 + 2u] : zz;
+							const ulonglong2 r0 = gather_walk<ulonglong2>(d.srank + blk0);
+							const ulonglong2 r1 = blk0 + 1u <= blk_last ? gather_walk<ulonglong2>(d.srank + (blk0 + 1u)) : zz;
+							const ulonglong2 r2 = blk0 + 2u <= blk_last ? gather_walk<ulonglong2>(d.srank + (blk0 + 2u)) : zz;
 							uint64_t f0, f1, f2 = 0, f3 = 0;                     // the read's k-mers in file order
 							{
 								ulonglong2 v;
