@@ -336,3 +336,62 @@ def test_device_resident_batches_and_very_long_reads(ftiny_dir, ftiny_reads):
         want = ox.stats.as_dict()
         for k in CMP_STATS:
             assert st[k] == want[k], k
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_randomly_damaged_ragged_reads_both_builds(ftiny_dir, seed):
+    """Seeded fuzz: reads of every length from 0 to 400 cut from the genome (both strands), with substitutions, lower case, N
+    runs, the odd non-ACGTN character, and quality lines from all-low to all-high, in batches of odd sizes -- every event
+    counter and every site counter of both builds against the oracle."""
+    from vargeno_amd import synth
+
+    prefix = os.path.join(ftiny_dir, "idx")
+    g = synth.f_tiny()[0]
+    cat = np.concatenate(g.seqs)
+    rng = np.random.default_rng(seed)
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+        comp[a] = b
+    reads, quals = [], []
+    for _ in range(6000):
+        L = int(rng.integers(0, 401)) if rng.random() < 0.5 else int(rng.choice([31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 150, 151, 160, 161, 250]))
+        st = int(rng.integers(0, len(cat) - L))
+        s = cat[st:st + L].copy()
+        if rng.random() < 0.5:
+            s = comp[s[::-1]]
+        k = rng.random()
+        if L and k < 0.6:                                       # a few substitutions
+            for p in rng.integers(0, L, size=int(rng.integers(0, 4))):
+                s[p] = rng.choice(np.frombuffer(b"ACGT", np.uint8))
+        if L and rng.random() < 0.15:
+            s[rng.random(L) < 0.3] |= 0x20                      # lower case is accepted (util.c:89-111)
+        if L and rng.random() < 0.05:
+            p = int(rng.integers(0, L)); s[p:p + int(rng.integers(1, 5))] = ord("N")
+        if L and rng.random() < 0.01:
+            s[int(rng.integers(0, L))] = rng.choice(np.frombuffer(b"XR-.*", np.uint8))
+        lowq = rng.choice([0.0, 0.08, 0.5, 1.0])
+        q = np.where(rng.random(L) < lowq, rng.integers(ord("#"), ord("8"), size=L), rng.integers(ord("8"), ord("J"), size=L)).astype(np.uint8)
+        reads.append(s); quals.append(q)
+    bases = np.concatenate(reads); qs = np.concatenate(quals)
+    offs = np.concatenate([[0], np.cumsum([len(x) for x in reads])]).astype(np.uint64)
+    keep = np.diff(offs.astype(np.int64)) <= 1022              # the reference's line buffer (qv.cc:700); longer reads are refused at submit
+    assert keep.all()
+    ox = O.OracleIndex.load(prefix)
+    ox.process(bases, qs, offs)
+    so, want = ox.sites(), ox.stats.as_dict()
+    assert want["reads_invalid"] > 0 and want["reads_n"] > 0 and want["incr"] > 0
+    cuts = [0, 1, 2, 65, 66, 1000, 1003, 4097, len(reads)]
+    with GenoIndex.open(prefix) as gx:
+        for stats in (True, False):
+            gx.reset()
+            gx.set_stats(stats)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                lo, hi = int(offs[a]), int(offs[b])
+                gx.submit(bases[lo:hi], qs[lo:hi], offs[a:b + 1] - offs[a])
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), "stats=%s" % stats
+            st = gx.stats()
+            if stats:
+                for k in CMP_STATS:
+                    assert st[k] == want[k], k
+            assert st["reads_invalid"] == want["reads_invalid"]
