@@ -280,9 +280,22 @@ def main():
             ox.process(sub.bases, sub.quals, sub.offsets, nthreads=1)
             t_cpu += time.time() - t0
             passes += 1
+        # the many-thread figure: 64 threads above (the parity run), and every hardware thread of the host when it has more;
+        # the faster of the two is the one reported, both are listed
+        tried = {str(nt): r0.n / t_all}
+        best_nt, best_t = nt, t_all
+        if ncores > nt:
+            ox.reset()
+            t0 = time.time()
+            ox.process(r0.bases, r0.quals, r0.offsets, nthreads=ncores)
+            t_more = time.time() - t0
+            tried[str(ncores)] = r0.n / t_more
+            if t_more < best_t:
+                best_nt, best_t = ncores, t_more
         cpu = {"value": passes * ns / t_cpu, "unit": "reads/s", "cores": 1, "kind": "port",
                "sample": "%d pass(es) over the first %d reads of batch 0, oracle/vg_oracle.c, 1 thread, %.1f s" % (passes, ns, t_cpu),
-               "all_cores": {"value": r0.n / t_all, "threads": nt, "host_cores": ncores, "sample": "batch 0 (%d reads), %.1f s" % (r0.n, t_all)}}
+               "all_cores": {"value": r0.n / best_t, "threads": best_nt, "host_cores": ncores, "reads_per_s_by_threads": tried,
+                             "sample": "batch 0 (%d reads), %.1f s" % (r0.n, best_t)}}
         ox.close()
         # the reference itself, when its binary came along (oracle/_ref/vargeno, built from /root/reference by oracle/Makefile in
         # the build container): `geno` wall time on the sample minus wall time on an empty FASTQ = its read loop, one thread
