@@ -13,6 +13,9 @@ Produces
                reference's output VCF are committed.
   fdense.*     dense-bucket fixture (synth.f_dense: ~150 SNP k-mers per HI24 bucket, the bucket shape of hg38 + full dbSNP):
                sha256 list + the reference's output VCF.
+  fquirk.*     irregular FASTA / VCF inputs (synth.f_quirk: IUPAC codes, blanks and carriage returns in sequence lines, long
+               names, multi-allelic / indel / out-of-order / repeated records, odd INFO fields ...): sha256 list + the
+               reference's output VCF.
 Fixtures are data (inputs and reference outputs); no reference source text is stored here.
 """
 import gzip
@@ -62,10 +65,13 @@ def bf_setbits(path):
 def run(name, gen, work, commit_all):
     d = os.path.join(work, name)
     os.makedirs(d, exist_ok=True)
-    g, s, r = gen()
-    synth.write_fasta(os.path.join(d, "ref.fa"), g)
-    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
-    synth.write_fastq(os.path.join(d, "reads.fq"), r)
+    if name == "fquirk":
+        synth.write_quirk(d, gen())
+    else:
+        g, s, r = gen()
+        synth.write_fasta(os.path.join(d, "ref.fa"), g)
+        synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+        synth.write_fastq(os.path.join(d, "reads.fq"), r)
     subprocess.check_call([REF_BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, stdout=subprocess.DEVNULL)
     subprocess.check_call([REF_BIN, "geno", "idx", "reads.fq", "snps.vcf", "out.vcf"], cwd=d, stdout=subprocess.DEVNULL)
     files = ["ref.fa", "snps.vcf", "reads.fq", "idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf",
@@ -97,13 +103,15 @@ if __name__ == "__main__":
     work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/vg_golden"
     if not os.path.exists(REF_BIN):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall", "fdense"]
+    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall", "fdense", "fquirk"]
     if "ftiny" in which:
         run("ftiny", synth.f_tiny, work, True)
     if "fsmall" in which:
         run("fsmall", synth.f_small, work, False)
     if "fdense" in which:
         run("fdense", synth.f_dense, work, False)
+    if "fquirk" in which:
+        run("fquirk", synth.f_quirk, work, False)
     # the reference's own test data (test/snp.vcf, test/expected_output): data files, copied verbatim
     if os.path.isdir("/root/reference/test"):
         shutil.copy("/root/reference/test/snp.vcf", os.path.join(OUT, "reftest.snp.vcf"))

@@ -12,13 +12,16 @@ from vargeno_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,gen", [("ftiny", synth.f_tiny), ("fsmall", synth.f_small)])
+@pytest.mark.parametrize("name,gen", [("ftiny", synth.f_tiny), ("fsmall", synth.f_small), ("fquirk", synth.f_quirk)])
 def test_cli_vcf_is_byte_identical_to_the_reference(name, gen, tmp_path):
-    g, s, r = gen()
     d = str(tmp_path)
-    synth.write_fasta(os.path.join(d, "ref.fa"), g)
-    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
-    synth.write_fastq(os.path.join(d, "reads.fq"), r)
+    if name == "fquirk":                                                  # irregular FASTA / SNP-list inputs (synth.f_quirk)
+        synth.write_quirk(d, gen())
+    else:
+        g, s, r = gen()
+        synth.write_fasta(os.path.join(d, "ref.fa"), g)
+        synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+        synth.write_fastq(os.path.join(d, "reads.fq"), r)
     env = dict(os.environ, VARGENO_NO_LITE="1", VARGENO_BATCH="7000")     # several batches
     subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=env, stdout=subprocess.DEVNULL)
     p = subprocess.run([BIN, "geno", "idx", "reads.fq", "snps.vcf", "out.vcf"], cwd=d, env=env, capture_output=True, text=True)

@@ -200,3 +200,29 @@ def test_vcf_writer_refuses_what_the_reference_asserts_on(ftiny_dir, tmp_path):
     g, _, gq = O.call(5, 4, 127, 127)
     assert g == 3
     assert body == ["chr1\t1000\tb\tA\tC\t.\t.\t.\tGT:GQ\t0/1:%d" % gq, "1\t1000\tGT:GQ\t0/1:%d" % gq]
+
+
+def test_irregular_inputs_index_and_vcf_are_byte_identical_to_the_reference(tmp_path):
+    """synth.f_quirk: a FASTA with soft-masked runs, N/n runs, '|' and over-long names, uneven and empty lines, no final newline;
+    a SNP list with out-of-order, multi-allelic, indel, lower-case, repeated, margin and unknown-chromosome records and CAF
+    anywhere in INFO.  `vargeno index` must write the five files the reference wrote for it (sha256 captured from the
+    reference binary by tests/golden/make_golden.py), and from the pinned oracle's counters on that index the caller / VCF pass
+    must write the reference's output VCF byte for byte."""
+    import gzip
+
+    d = str(tmp_path)
+    q = synth.f_quirk()
+    synth.write_quirk(d, q)
+    want = read_sha256_list("fquirk")
+    for fn in ("ref.fa", "snps.vcf", "reads.fq"):
+        assert _sha(os.path.join(d, fn)) == want[fn], fn
+    _index(d)
+    for fn in ("idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf", "idx.snp.bf"):
+        assert _sha(os.path.join(d, fn)) == want[fn], fn
+    counts = os.path.join(d, "counts.txt")
+    _oracle_counts_file(os.path.join(d, "idx"), q["reads"], counts)
+    out = os.path.join(d, "out.vcf")
+    subprocess.check_call([BIN, "callvcf", os.path.join(d, "idx.chrlens"), counts, os.path.join(d, "snps.vcf"), out])
+    gold = gzip.open(os.path.join(GOLDEN, "fquirk.out.vcf.gz"), "rb").read()
+    assert gold.count(b"\n") > 1500
+    assert open(out, "rb").read() == gold

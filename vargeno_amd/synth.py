@@ -10,6 +10,7 @@ Conventions follow the reference's file formats (README.md:61-72 of the referenc
 from __future__ import annotations
 
 import io
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -388,6 +389,158 @@ def f_tiny(seed=7):
     r = make_reads(rng, g, s, 4_000, lengths=(150, 150, 101, 64, 31, 250), err=0.01, lowq=0.40,
                    lower_frac=0.05)
     return g, s, r
+
+
+def _fasta_norm(stream):
+    """What the reference's FASTA reader makes of a sequence's characters (fasta_parser.c:7-25): ACGT in either case -> upper
+    case, ANY other character that is not a newline -> 'N' (IUPAC codes, blanks, carriage returns all count as a base)."""
+    out = np.full(len(stream), ord("N"), np.uint8)
+    code = _CODE[stream]
+    ok = code < 4
+    out[ok] = ACGT[code[ok]]
+    return out
+
+
+def f_quirk(seed=99):
+    """Inputs with the irregularities real FASTA / dbSNP files have, for the producer of the index (`vargeno index`,
+    src/dictgen.c:561-794, src/fasta_parser.c) and the VCF pass of `geno`: a pure function of the seed.  Returns a dict:
+    fasta (bytes), vcf (str), reads (Reads), genome (Genome as the reference reads it: short names, normalised bases).
+
+    FASTA: names with '|' and descriptions, a name longer than 64 characters, lower-case (soft-masked) runs -- what the
+    bit-vector pass compares case-sensitively (generate_bf.cc:230) and the dictionary pass does not --, N and n runs, lines
+    of uneven width, empty lines, no newline at the end of the file.
+    VCF: records out of order, multi-allelic and indel records, lower-case alleles, ALT equal to REF, REF 'N',
+    chromosomes the FASTA does not have (one of them the 64-character name, which the 50-byte name buffer of dictgen.c:575
+    cannot hold), names with and without "chr", positions at and beyond the 32-base margins, SNPs next to N runs,
+    repeated positions, empty and comment lines in the body, CAF anywhere in INFO, a later INFO key that merely starts with
+    "CAF" (dictgen.c:718-724 takes the last such key), '.' and exponent notation in CAF, extra columns.
+    Left out because the reference aborts on them or its behaviour is undefined: characters other than ACGTN in the FASTA
+    (IUPAC codes, blanks, carriage returns: generate_bf.cc:132 -> util.c:122 assert), a one-character ALT that is not a base
+    ('.', 'N': generate_bf.cc:257, same assert), a sequence shorter than 32 bases, a processed record without CAF after one
+    with it, a record beyond its chromosome's end or whose REF disagrees with the FASTA (fatal, dictgen.c:666-672)."""
+    rng = np.random.default_rng(seed)
+    long_name = "chr" + "L" * 80
+    names = ["chr1|gi|555|ref|NC_1.1| Homo quirkus chromosome 1", "chrUn_gl000220 unplaced scaffold", "contig7", long_name + " too long"]
+    g0 = make_genome(rng, [30_000, 14_000, 9_000, 5_000], names, repeats_per_mbp=300.0, repeat_len=(100, 500),
+                     microsat_per_mbp=80.0, plant_block16=40, plant_hi24=40, plant_t16=20)
+    streams = []
+    for s in g0.seqs:
+        s = s.copy()
+        for _ in range(8):                                   # soft-masked runs
+            a = int(rng.integers(0, len(s) - 600)); s[a:a + int(rng.integers(30, 500))] |= 0x20
+        for _ in range(5):                                   # short N runs inside the sequence, some of them lower case
+            a = int(rng.integers(1000, len(s) - 1000)); s[a:a + int(rng.integers(1, 40))] = ord("N") if rng.random() < 0.6 else ord("n")
+        streams.append(s)
+    norm = [_fasta_norm(s) for s in streams]
+    g = Genome(names, norm)
+    short = g.short_names
+    # ---- FASTA text
+    fa = []
+    for name, s in zip(names, streams):
+        fa.append(b">" + name.encode() + b"\n")
+        i = 0
+        while i < len(s):
+            w = int(rng.choice([60, 60, 60, 70, 61, 1, 120]))
+            fa.append(s[i:i + w].tobytes() + b"\n")
+            if rng.random() < 0.02:
+                fa.append(b"\n")
+            i += w
+    fasta = b"".join(fa)[:-1]                                # the file ends without a newline
+    # ---- the regular SNPs (on the first three sequences; none can be addressed on the fourth)
+    g3 = Genome(names[:3], norm[:3])
+    s = make_snps(rng, g3, 2_400)
+    vnames = ["1", "Un_gl000220", "contig7"]                 # "chr" is prepended to a name that does not start with 'c'
+    recs = []                                                # (sort key, line)
+    for i in range(len(s.pos)):
+        c, ps = int(s.chrom[i]), int(s.pos[i])
+        caf = "CAF=%.4f,%.4f" % (s.caf_ref[i], s.caf_alt[i])
+        k = i % 7
+        info = ("RS=%d;%s;COMMON=1" % (i + 1, caf), "%s;RS=%d" % (caf, i + 1), "RS=%d;PM;%s" % (i + 1, caf), "RS=%d;dbSNPBuildID=132;VP=0x05;%s;G5" % (i + 1, caf),
+                "%s" % caf, "RS=%d;%s;COMMON=0" % (i + 1, caf), "RSPOS=%d;%s" % (ps, caf))[k]
+        ref, alt = chr(s.ref[i]), chr(s.alt[i])
+        if i % 11 == 3:
+            ref, alt = ref.lower(), alt.lower()              # alleles are upper-cased (dictgen.c:634, 687)
+        name = vnames[c] if i % 13 else ("chr" + vnames[c] if c < 2 else vnames[c])
+        pos_txt = "%d" % ps if i % 17 else "%05d" % ps
+        tail = "" if i % 19 else "\tGT:DP\t0/1:%d" % (i % 50)
+        recs.append(((c, ps, 0), "%s\t%s\trs%d\t%s\t%s\t.\t.\t%s%s\n" % (name, pos_txt, i + 1, ref, alt, info, tail)))
+    # ---- irregular records
+    def base(c, p1):                                         # normalised base at 1-based position p1 of sequence c
+        return chr(norm[c][p1 - 1])
+    def other(b, k=1):
+        return "ACGT"[("ACGT".index(b) + k) % 4]
+    taken = set((int(c), int(q)) for c, q in zip(s.chrom, s.pos))
+    def free_pos(c):
+        while True:
+            q = int(rng.integers(100, len(norm[c]) - 100))
+            if (c, q) not in taken and all(base(c, q + d) in "ACGT" for d in range(-40, 41)):
+                taken.add((c, q)); return q
+    odd_recs = []
+    for j in range(40):
+        c = j % 3
+        q = free_pos(c); b = base(c, q); caf = "CAF=0.7,0.3"
+        kind = j % 10
+        if kind == 0: ref, alt = b, other(b) + "," + other(b, 2)                 # multi-allelic
+        elif kind == 1: ref, alt = b + base(c, q + 1), b                          # deletion
+        elif kind == 2: ref, alt = b, b + "T"                                     # insertion
+        elif kind == 3: ref, alt = b, b                                           # ALT equal to REF: marks the site, no k-mers
+        elif kind == 4: ref, alt = b.lower(), other(b)                            # REF in lower case only
+        elif kind == 5: ref, alt = b, "<DEL>"
+        elif kind == 6: ref, alt = b, other(b, 2).lower()                         # ALT in lower case only
+        elif kind == 7: ref, alt, caf = b, other(b), "CAF=.,0.4"                   # atof(".") = 0
+        elif kind == 8: ref, alt, caf = b, other(b, 3), "CAF=9.5e-1,5e-2;CAFX=0.25,0.75"   # the last key starting with CAF wins
+        else: ref, alt, caf = b, other(b, 2), "CAF=0.5,0.5;"
+        odd_recs.append(((c, q, 1), "%s\t%d\tq%d\t%s\t%s\t50\tPASS\tRS=%d;%s\n" % (vnames[c], q, j, ref, alt, 900000 + j, caf)))
+    for j in range(6):                                       # the same position twice: another ALT, and the very same record
+        c = j % 3
+        q = free_pos(c); b = base(c, q)
+        odd_recs.append(((c, q, 1), "%s\t%d\td%da\t%s\t%s\t.\t.\tCAF=0.6,0.4\n" % (vnames[c], q, j, b, other(b))))
+        odd_recs.append(((c, q, 2), "%s\t%d\td%db\t%s\t%s\t.\t.\tCAF=0.8,0.2\n" % (vnames[c], q, j, b, other(b, 2) if j % 2 else other(b))))
+    for c in range(3):                                       # the 32-base margins (dictgen.c:675): index 31 out, 32 in, size - 32 in, size - 31 out
+        L = len(norm[c])
+        for q in (5, 32, 33, L - 32, L - 31, L - 30, L):
+            b = base(c, q)
+            if b == "N":
+                odd_recs.append(((c, q, 1), "%s\t%d\tm%d\tN\tA\t.\t.\tCAF=0.5,0.5\n" % (vnames[c], q, q)))      # REF 'N' is skipped before anything is checked
+            else:
+                odd_recs.append(((c, q, 1), "%s\t%d\tm%d\t%s\t%s\t.\t.\tCAF=0.5,0.5\n" % (vnames[c], q, q, b, other(b))))
+    for c in range(3):                                       # next to an N: the window of 32-mers runs into it (dictgen.c:760-770)
+        npos = np.nonzero(norm[c] == ord("N"))[0]
+        npos = npos[(npos > 200) & (npos < len(norm[c]) - 200)]
+        for z in npos[:: max(1, len(npos) // 6)][:6]:
+            for d in (-20, 7):
+                q = int(z) + 1 + d
+                b = base(c, q)
+                if b != "N" and (c, q) not in taken:
+                    taken.add((c, q))
+                    odd_recs.append(((c, q, 1), "%s\t%d\tn%d\t%s\t%s\t.\t.\tCAF=0.9,0.1\n" % (vnames[c], q, q, b, other(b))))
+    for j in range(5):
+        odd_recs.append(((3, 100 + j, 1), "%s\t%d\tl%d\tA\tC\t.\t.\tCAF=0.5,0.5\n" % (short[3], 100 + j, j)))          # 64-character name: not found
+        odd_recs.append(((4, 100 + j, 1), "MT\t%d\tmt%d\tA\tC\t.\t.\tCAF=0.5,0.5\n" % (100 + j, j)))                     # no such chromosome
+    allr = recs + odd_recs
+    allr.sort(key=lambda x: x[0])
+    lines = [ln for _, ln in allr]
+    blocks = [lines[i:i + 97] for i in range(0, len(lines), 97)]          # out of order: blocks of 97 lines shuffled
+    order = rng.permutation(len(blocks))
+    body = []
+    for bi in order:
+        body.extend(blocks[bi])
+        if bi % 3 == 0:
+            body.append("\n")
+        if bi % 5 == 0:
+            body.append("# a comment line in the body\n")
+    vcf = VCF_HEADER + "".join(body)
+    r = make_reads(rng, g3, s, 3_000, lengths=(150, 150, 101, 64, 250), err=0.01, lowq=0.30, lower_frac=0.03)
+    return {"fasta": fasta, "vcf": vcf, "reads": r, "genome": g, "snps": s}
+
+
+def write_quirk(d, q):
+    """The files of f_quirk() in directory d: ref.fa, snps.vcf, reads.fq."""
+    with open(os.path.join(d, "ref.fa"), "wb") as f:
+        f.write(q["fasta"])
+    with open(os.path.join(d, "snps.vcf"), "w") as f:
+        f.write(q["vcf"])
+    write_fastq(os.path.join(d, "reads.fq"), q["reads"])
 
 
 def genome_and_snps(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_chroms=1, genotypes="uniform"):
