@@ -42,6 +42,7 @@ def test_index_rejects_what_the_reference_rejects(tmp_path):
     g, s, _ = synth.f_tiny()
     synth.write_fasta(os.path.join(d, "ref.fa"), g)
     synth.write_vcf(os.path.join(d, "snps.txt"), g, s)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
     # qv.cc:2244,2315: the SNP list must be named *.vcf
     p = subprocess.run([BIN, "index", "ref.fa", "snps.txt", "idx"], cwd=d, capture_output=True, text=True)
     assert p.returncode == 1 and "Unrecongized SNP list file format." in p.stdout
@@ -53,6 +54,19 @@ def test_index_rejects_what_the_reference_rejects(tmp_path):
         f.write("1\t1000\trs1\t%s\tT\t.\t.\tCAF=0.5,0.5\n" % wrong)
     p = subprocess.run([BIN, "index", "ref.fa", "bad.vcf", "idx2"], cwd=d, capture_output=True, text=True)
     assert p.returncode == 1 and "Mismatch found between reference sequence and SNP file at 0-based index 999 in chr1." in p.stderr
+    # a base other than ACGTN in the FASTA, or a one-character ALT that is not a base on an otherwise good record: the
+    # reference dies on an assert while filling its bit vectors (generate_bf.cc:132, 257 -> util.c:122); the product says why
+    g.seqs[0][5000] = ord("R")
+    synth.write_fasta(os.path.join(d, "iupac.fa"), g)
+    p = subprocess.run([BIN, "index", "iupac.fa", "snps.vcf", "idx3"], cwd=d, capture_output=True, text=True, env=dict(os.environ, VARGENO_NO_LITE="1"))
+    assert p.returncode == 1 and "invalid base 'R'" in p.stderr
+    lines = open(os.path.join(d, "snps.vcf")).read().splitlines(keepends=True)
+    k = [i for i, ln in enumerate(lines) if ln[0] != "#"][50]
+    c = lines[k].split("\t"); c[4] = "."; lines[k] = "\t".join(c)
+    with open(os.path.join(d, "dot.vcf"), "w") as f:
+        f.write("".join(lines))
+    p = subprocess.run([BIN, "index", "ref.fa", "dot.vcf", "idx4"], cwd=d, capture_output=True, text=True, env=dict(os.environ, VARGENO_NO_LITE="1"))
+    assert p.returncode == 1 and "invalid base" in p.stderr
     # wrong argument count prints the usage and fails (qv.cc:1875-1881)
     p = subprocess.run([BIN, "index", "ref.fa"], cwd=d, capture_output=True, text=True)
     assert p.returncode == 1 and "Usage: vargeno <option>" in p.stderr
