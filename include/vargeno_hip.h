@@ -149,7 +149,8 @@ int  vg_counts_allreduce(vg_index *ix, void *nccl_comm);
 
 /* The same exchange for ONE process that drives n devices (one handle each, all replicas of one index): builds an RCCL
  * communicator over the handles' devices, all-reduces every replica's counters in place, tears the communicator down.
- * This is what `vargeno geno` calls with VARGENO_GPUS=n.  n = 1 is the identity (and still goes through RCCL). */
+ * This is what `vargeno geno` calls with VARGENO_GPUS=n.  n = 1 is the identity (and still goes through RCCL).
+ * Replicas that share a device are summed on that device first; one of them joins the all-reduce, all get the result. */
 int  vg_counts_allreduce_devices(vg_index **handles, int n);
 
 #ifdef __cplusplus

@@ -42,9 +42,39 @@ def test_rccl_allreduce_over_one_device_is_the_identity(ftiny_dir, ftiny_reads):
     assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
 
 
-def test_cli_counters_through_rccl_give_the_golden_vcf(ftiny_dir, tmp_path):
-    ngpu = min(2, torch.cuda.device_count())
-    env = dict(os.environ, VARGENO_GPUS=str(ngpu), VARGENO_FORCE_RCCL="1", VARGENO_BATCH="500", VARGENO_CHUNK_MB="1")
+def test_replicas_sharing_a_device_sum_like_one(ftiny_dir, ftiny_reads):
+    """Two replicas of the index (each holds the 80 GiB of jump + direct tables whatever the genome's size, so two is what a
+    288 GB device takes), uneven shards of the reads, seven passes each (the exact sums pass 63): after
+    vg_counts_allreduce_devices every replica holds the counters of one replica on all reads.  With one GPU the two share it
+    (summed on the device, the first goes through RCCL alone); with two they sit on both (RCCL proper)."""
+    prefix = os.path.join(ftiny_dir, "idx")
+    so = _oracle(prefix, ftiny_reads, times=7)
+    ndev = torch.cuda.device_count()
+    r = ftiny_reads
+    cuts = [0, r.n // 3, r.n]
+    gxs = [GenoIndex.open(prefix, device=k % ndev) for k in range(2)]
+    try:
+        for k, gx in enumerate(gxs):
+            sub = r.slice(cuts[k], cuts[k + 1])
+            for _ in range(7):
+                gx.submit(sub.bases, sub.quals, sub.offsets)
+        all_reduce_devices(gxs)
+        raw0 = gxs[0].counts_tensor().clone().cpu()
+        assert int(raw0.max()) > 63
+        for gx in gxs:
+            assert torch.equal(gx.counts_tensor().cpu(), raw0)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+    finally:
+        for gx in gxs:
+            gx.close()
+
+
+@pytest.mark.parametrize("replicas", [1, 2])
+def test_cli_counters_through_rccl_give_the_golden_vcf(ftiny_dir, tmp_path, replicas):
+    """`vargeno geno` with VARGENO_GPUS replicas: chunks of the FASTQ go round robin, the counters meet in one all-reduce.  On a
+    one-GPU box the replicas share the device (VARGENO_SHARE_DEVICES), with more they sit on distinct ones."""
+    env = dict(os.environ, VARGENO_GPUS=str(replicas), VARGENO_SHARE_DEVICES="1", VARGENO_FORCE_RCCL="1", VARGENO_BATCH="500", VARGENO_CHUNK_MB="1")
     p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), os.path.join(ftiny_dir, "reads.fq"), os.path.join(ftiny_dir, "snps.vcf"), str(tmp_path / "out.vcf")],
                        env=env, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr

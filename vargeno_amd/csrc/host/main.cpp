@@ -5,6 +5,7 @@
 // HIP library through the C-ABI of include/vargeno_hip.h only.  Extra knobs come from the
 // environment so that the argument list stays the reference's:
 //   VARGENO_GPUS=n        shard read batches over n GPUs of this node (default 1), counters summed with RCCL
+//   VARGENO_SHARE_DEVICES=1  allow more replicas than GPUs (replica g on device g % GPUs): small indexes, one-GPU test boxes
 //   VARGENO_BATCH=n       reads per batch of the host-framed path (default 4194304)
 //   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk sent to the device (default 64; 256 with several GPUs)
 //   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default: an eighth of the hardware threads, 8 to 32)
@@ -57,7 +58,8 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	int ngpu = env_int("VARGENO_GPUS", 1);
 	const int have = vg_device_count();
 	if (have <= 0) { fprintf(stderr, "vargeno: no HIP device found (this build has no CPU path)\n"); return EXIT_FAILURE; }
-	if (ngpu > have) ngpu = have;
+	const bool share = env_int("VARGENO_SHARE_DEVICES", 0) != 0;     // more replicas than devices: replica g sits on device g % have
+	if (ngpu > have && !share) ngpu = have;
 	if (ngpu < 1) ngpu = 1;
 	const uint64_t batch = (uint64_t)env_int("VARGENO_BATCH", 1 << 22);
 
@@ -67,7 +69,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		std::vector<std::thread> th;
 		std::vector<int> rcs((size_t)ngpu, 0);
 		std::vector<std::string> errs((size_t)ngpu);
-		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_index_open(prefix.c_str(), g, &ix[(size_t)g]); if (rcs[(size_t)g]) errs[(size_t)g] = vg_last_error(); });
+		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_index_open(prefix.c_str(), g % have, &ix[(size_t)g]); if (rcs[(size_t)g]) errs[(size_t)g] = vg_last_error(); });
 		for (auto &t : th) t.join();
 		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) { fprintf(stderr, "vargeno: cannot load index %s on GPU %d (%d): %s\n", prefix.c_str(), g, rcs[(size_t)g], errs[(size_t)g].c_str()); return EXIT_FAILURE; }
 	}

@@ -1784,37 +1784,65 @@ extern "C" int vg_counts_allreduce(vg_index *ix, void *nccl_comm)
 	return VG_OK;
 }
 
-// One process driving n devices (the CLI with VARGENO_GPUS=n): communicator over the handles' devices, one grouped in-place
-// all-reduce of every replica's counters, communicator torn down.  n = 1 is the identity and still goes through RCCL.
+__global__ void vg_add_counters(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+// One process driving n replicas (the CLI with VARGENO_GPUS=n): communicator over the replicas' devices, one grouped in-place
+// all-reduce of the counters, communicator torn down.  n = 1 is the identity and still goes through RCCL.  Replicas that share
+// a device (small indexes; the one-GPU test boxes) are summed on that device first -- RCCL wants one rank per device --, the
+// first of them takes part in the all-reduce, and the others get its result.
 extern "C" int vg_counts_allreduce_devices(vg_index **handles, int n)
 {
 	if (!handles || n <= 0) return fail(VG_EINVAL, "null argument");
 	for (int i = 0; i < n; i++) {
 		if (!handles[i]) return fail(VG_EINVAL, "null handle");
 		if (handles[i]->n_sites != handles[0]->n_sites) return fail(VG_EINVAL, "the handles do not hold replicas of one index");
-		for (int j = 0; j < i; j++) if (handles[j]->device == handles[i]->device) return fail(VG_EINVAL, "two handles on one device");
+		for (int j = 0; j < i; j++) if (handles[j] == handles[i]) return fail(VG_EINVAL, "the same handle twice");
 	}
 	const Rccl &R = rccl();
 	if (!R.ok) return fail(VG_ENODEV, "cannot load librccl (or it lacks the collective entry points)");
 	for (int i = 0; i < n; i++) { int rc = finish_pending(handles[i]); if (rc) return rc; }
 	if (handles[0]->n_sites == 0) return VG_OK;
 	return guarded([&]() -> int {
-		std::vector<int> devs((size_t)n);
-		for (int i = 0; i < n; i++) devs[(size_t)i] = handles[i]->device;
-		std::vector<ncclComm_t> comms((size_t)n, nullptr);
-		ncclResult_t rc = R.comm_init_all(comms.data(), n, devs.data());
+		const uint64_t words = 2 * handles[0]->n_sites;
+		std::vector<vg_index *> reps;                               // the first replica on each device
+		std::vector<int> rep_of((size_t)n, -1);
+		for (int i = 0; i < n; i++) {
+			for (size_t k = 0; k < reps.size(); k++) if (reps[k]->device == handles[i]->device) rep_of[(size_t)i] = (int)k;
+			if (rep_of[(size_t)i] < 0) { rep_of[(size_t)i] = (int)reps.size(); reps.push_back(handles[i]); }
+		}
+		for (int i = 0; i < n; i++) {                               // every replica is idle (finish_pending): fold the guests into their device's first
+			vg_index *rep = reps[(size_t)rep_of[(size_t)i]];
+			if (rep == handles[i]) continue;
+			HIP_TRY(hipSetDevice(rep->device));
+			vg_add_counters<<<(unsigned)std::min<uint64_t>((words + 255) / 256, 4096), 256, 0, rep->stream>>>(rep->d.cnt, handles[i]->d.cnt, words);
+			HIP_TRY(hipGetLastError());
+		}
+		const int nr = (int)reps.size();
+		std::vector<int> devs((size_t)nr);
+		for (int i = 0; i < nr; i++) devs[(size_t)i] = reps[(size_t)i]->device;
+		std::vector<ncclComm_t> comms((size_t)nr, nullptr);
+		ncclResult_t rc = R.comm_init_all(comms.data(), nr, devs.data());
 		if (rc != ncclSuccess) return fail(VG_ENODEV, "ncclCommInitAll: %s", R.error_string(rc));
 		rc = R.group_start();
-		for (int i = 0; i < n && rc == ncclSuccess; i++) {
-			vg_index *ix = handles[i];
+		for (int i = 0; i < nr && rc == ncclSuccess; i++) {
+			vg_index *ix = reps[(size_t)i];
 			if (hipSetDevice(ix->device) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
-			rc = R.all_reduce(ix->d.cnt, ix->d.cnt, (size_t)(2 * ix->n_sites), ncclUint32, ncclSum, comms[(size_t)i], ix->stream);
+			rc = R.all_reduce(ix->d.cnt, ix->d.cnt, (size_t)words, ncclUint32, ncclSum, comms[(size_t)i], ix->stream);
 		}
 		const ncclResult_t rc2 = R.group_end();
 		int out = VG_OK;
 		if (rc != ncclSuccess || rc2 != ncclSuccess) out = fail(VG_ENODEV, "RCCL all-reduce of the site counters: %s", R.error_string(rc != ncclSuccess ? rc : rc2));
-		for (int i = 0; i < n; i++) {
-			if (hipSetDevice(handles[i]->device) == hipSuccess && hipStreamSynchronize(handles[i]->stream) != hipSuccess && out == VG_OK)
+		for (int i = 0; i < n && out == VG_OK; i++) {               // the guests take their device's result (same stream: after the all-reduce)
+			vg_index *rep = reps[(size_t)rep_of[(size_t)i]];
+			if (rep == handles[i]) continue;
+			if (hipSetDevice(rep->device) != hipSuccess || hipMemcpyAsync(handles[i]->d.cnt, rep->d.cnt, words * 4, hipMemcpyDeviceToDevice, rep->stream) != hipSuccess)
+				out = fail(VG_ENODEV, "copy of the reduced counters to a replica on the same device failed");
+		}
+		for (int i = 0; i < nr; i++) {
+			if (hipSetDevice(reps[(size_t)i]->device) == hipSuccess && hipStreamSynchronize(reps[(size_t)i]->stream) != hipSuccess && out == VG_OK)
 				out = fail(VG_ENODEV, "stream synchronisation after the all-reduce failed");
 		}
 		for (ncclComm_t c : comms) if (c) (void)R.comm_destroy(c);
