@@ -66,8 +66,8 @@ def test_incomplete_tail_is_left_to_the_caller_and_long_lines_are_refused(ftiny_
         assert n == 1 and used == len(ok_rec)
 
 
-@pytest.mark.parametrize("host_framing", ["0", "1"])
-def test_cli_truncated_final_record_matches_the_reference(ftiny_dir, tmp_path, host_framing):
+@pytest.mark.parametrize("host_framing,replicas", [("0", "1"), ("1", "1"), ("0", "2")])
+def test_cli_truncated_final_record_matches_the_reference(ftiny_dir, tmp_path, host_framing, replicas):
     """The reference's fgets() returns NULL on the missing quality line and keeps the previous record's
     buffer (qv.cc:761-763): the gate of the truncated read is the PREVIOUS read's quality string."""
     want_path = os.path.join(GOLDEN, "ftiny.trunc.out.vcf.gz")
@@ -75,7 +75,8 @@ def test_cli_truncated_final_record_matches_the_reference(ftiny_dir, tmp_path, h
     k = int(open(os.path.join(GOLDEN, "ftiny.trunc.k")).read())
     fq = tmp_path / "reads_trunc.fq"
     fq.write_bytes(b"\n".join(lines[:4 * k + 3]))
-    env = dict(os.environ, VARGENO_HOST_FASTQ=host_framing, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900")
+    # (two replicas: each streams its own record-aligned half of the file; on a one-GPU box they share the device)
+    env = dict(os.environ, VARGENO_HOST_FASTQ=host_framing, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1")
     p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(tmp_path / "out.vcf")],
                        env=env, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
@@ -134,19 +135,25 @@ def test_cli_long_line_in_the_middle_of_the_file_falls_back_to_host_framing(ftin
     reference would abort otherwise -- and the file is back in step afterwards: 8 fgets lines).  The device refuses from that
     chunk on and the host reader takes over there; the VCF must equal the one from framing the whole file on the host."""
     lines = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read().split(b"\n")[:-1]
-    k = 4 * 1500
     odd = [b"@" + b"ACGT" * 300,            # 1201 characters: fgets pieces of 1023 and 178 (+ newline); the second is read as a READ
            b"ACGT" * 20,                    # lands in separator position
            b"+",                            # lands in quality position: a 1-character quality line, the gate sees stale buffer contents
            b"ACGT" * 800]                   # 3200 characters: four pieces = id / read (1023 characters, 31 chunks) / separator / quality
-    fq = tmp_path / "reads_long.fq"
-    fq.write_bytes(b"\n".join(lines[:k] + odd + lines[k:]) + b"\n")
-    outs = []
-    for host in ("1", "0"):
-        out = tmp_path / ("out%s.vcf" % host)
-        env = dict(os.environ, VARGENO_HOST_FASTQ=host, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_READERS="3", VARGENO_VERBOSE="1")
-        p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(out)], env=env, capture_output=True, text=True)
-        assert p.returncode == 0, p.stderr
-        assert "reads: %d " % (len(lines) // 4 + 2) in p.stderr, p.stderr       # the odd record counts as two
-        outs.append(out.read_bytes())
-    assert outs[0] == outs[1] and outs[0].count(b"\n") > 2000
+    # The odd record in the first half and in the second half of the file.  Device framing with one replica: the refused chunk
+    # onwards goes to the host reader.  With two replicas (each streams its own record-aligned half; they share the device on a
+    # one-GPU box): in the second = last range the same hand-over happens; in the first range everything is reset and framed on
+    # the host, because the range after it would be out of step with the reference.
+    for at in (1500, 2500):
+        k = 4 * at
+        fq = tmp_path / ("reads_long_%d.fq" % at)
+        fq.write_bytes(b"\n".join(lines[:k] + odd + lines[k:]) + b"\n")
+        outs = []
+        for host, replicas in (("1", "1"), ("0", "1"), ("0", "2")):
+            out = tmp_path / ("out%d_%s_%s.vcf" % (at, host, replicas))
+            env = dict(os.environ, VARGENO_HOST_FASTQ=host, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_READERS="3", VARGENO_VERBOSE="1",
+                       VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1")
+            p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(out)], env=env, capture_output=True, text=True)
+            assert p.returncode == 0, p.stderr
+            assert "reads: %d " % (len(lines) // 4 + 2) in p.stderr, p.stderr       # the odd record counts as two
+            outs.append(out.read_bytes())
+        assert all(o == outs[0] for o in outs) and outs[0].count(b"\n") > 2000

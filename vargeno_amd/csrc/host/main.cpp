@@ -4,10 +4,11 @@
 // Same positional arguments, file names, messages and exit codes as upstream.  `geno` drives the
 // HIP library through the C-ABI of include/vargeno_hip.h only.  Extra knobs come from the
 // environment so that the argument list stays the reference's:
-//   VARGENO_GPUS=n        shard read batches over n GPUs of this node (default 1), counters summed with RCCL
+//   VARGENO_GPUS=n        n index replicas, one per GPU of this node (default 1): each streams its own record-aligned range of
+//                         the FASTQ file, counters summed with RCCL
 //   VARGENO_SHARE_DEVICES=1  allow more replicas than GPUs (replica g on device g % GPUs): small indexes, one-GPU test boxes
 //   VARGENO_BATCH=n       reads per batch of the host-framed path (default 4194304)
-//   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk sent to the device (default 64; 256 with several GPUs)
+//   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk sent to the device (default 64)
 //   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default: an eighth of the hardware threads, 8 to 32)
 //   VARGENO_HOST_FASTQ=1  frame the FASTQ on the host (the reference's four fgets per record) instead of on the device
 //   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
@@ -50,6 +51,94 @@ static int env_int(const char *name, int dflt) { const char *e = getenv(name); r
 		if (rc_ != VG_OK) { fprintf(stderr, "vargeno: %s failed (%d): %s\n", #call, rc_, vg_last_error()); exit(EXIT_FAILURE); } \
 	} while (0)
 
+// Bytes [lo, hi) of the FASTQ file as a stream to one replica: reader threads pread() the range piecewise into a ring of pinned
+// chunk buffers; this thread pushes the chunks in order (vg_fastq_stream_push returns as soon as a chunk is on the device) and
+// learns what was framed only at the end.  Offsets in the result are relative to lo.
+struct StreamResult {
+	uint64_t nrec = 0, used = 0, last = 0;
+	int refused = 0;
+	std::string error;                                               // empty: fine
+};
+static StreamResult stream_range(vg_index *ix, int fd, uint64_t lo, uint64_t hi, uint64_t chunk, int n_readers)
+{
+	StreamResult res;
+	const uint64_t fsize = hi - lo;                                  // the stream's length
+	const uint64_t piece = std::min<uint64_t>(chunk, 8ull << 20);
+	const uint64_t n_chunks = (fsize + chunk - 1) / chunk;
+	const int NBUF = 4;
+	std::vector<uint8_t *> ring((size_t)NBUF, nullptr);
+	std::vector<std::vector<uint8_t>> pageable((size_t)NBUF);
+	for (int i = 0; i < NBUF; i++) {
+		ring[(size_t)i] = (uint8_t *)vg_host_alloc_pinned((size_t)chunk);
+		if (!ring[(size_t)i]) { pageable[(size_t)i].resize((size_t)chunk); ring[(size_t)i] = pageable[(size_t)i].data(); }
+	}
+	std::mutex mu; std::condition_variable cv;
+	std::vector<uint32_t> left((size_t)n_chunks);                   // pieces of chunk i still to be read
+	for (uint64_t i = 0; i < n_chunks; i++) { const uint64_t len = std::min(chunk, fsize - i * chunk); left[(size_t)i] = (uint32_t)((len + piece - 1) / piece); }
+	uint64_t pushed = 0;                                            // chunks handed to the device (their buffers are free again)
+	std::atomic<uint64_t> next_piece{0};
+	const uint64_t ppc = (chunk + piece - 1) / piece;               // pieces per (full) chunk
+	bool io_error = false;
+	std::vector<std::thread> readers;
+	for (int t = 0; t < n_readers; t++) readers.emplace_back([&] {
+		for (;;) {
+			const uint64_t p = next_piece.fetch_add(1);
+			const uint64_t ci = p / ppc, off = ci * chunk + (p % ppc) * piece;
+			if (ci >= n_chunks) return;
+			if (off >= std::min(fsize, (ci + 1) * chunk)) continue;
+			{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ci < pushed + (uint64_t)NBUF || io_error; }); if (io_error) return; }
+			uint64_t n = std::min(piece, std::min(fsize, (ci + 1) * chunk) - off), done = 0;
+			uint8_t *dst = ring[(size_t)(ci % NBUF)] + (off - ci * chunk);
+			while (done < n) {
+				const ssize_t g = pread(fd, dst + done, (size_t)(n - done), (off_t)(lo + off + done));
+				if (g <= 0) break;
+				done += (uint64_t)g;
+			}
+			std::lock_guard<std::mutex> g(mu);
+			if (done < n) io_error = true;
+			left[(size_t)ci]--;
+			cv.notify_all();
+		}
+	});
+	int rc = vg_fastq_stream_begin(ix);
+	for (uint64_t i = 0; i < n_chunks && rc == VG_OK; i++) {
+		{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return left[(size_t)i] == 0 || io_error; }); if (io_error) break; }
+		rc = vg_fastq_stream_push(ix, ring[(size_t)(i % NBUF)], std::min(chunk, fsize - i * chunk));
+		{ std::lock_guard<std::mutex> g(mu); pushed = i + 1; }
+		cv.notify_all();
+	}
+	{ std::lock_guard<std::mutex> g(mu); if (rc != VG_OK) io_error = true; pushed = n_chunks; }
+	cv.notify_all();
+	for (auto &t : readers) t.join();
+	if (rc != VG_OK) res.error = std::string("FASTQ stream failed: ") + vg_last_error();
+	else if (io_error) res.error = "error reading the FASTQ file";
+	else {
+		rc = vg_fastq_stream_end(ix, &res.nrec, &res.used, &res.last, &res.refused);
+		if (rc != VG_OK) res.error = std::string("vg_fastq_stream_end failed: ") + vg_last_error();
+	}
+	for (int i = 0; i < NBUF; i++) if (pageable[(size_t)i].empty()) vg_host_free_pinned(ring[(size_t)i]);
+	return res;
+}
+
+// The first record start at or after `from`: the start of a line that begins with '@' whose next-but-one line begins with '+'
+// (a quality line may begin with '@', but then the line two below it is a sequence line, and no sequence begins with '+').
+// Returns fsize when there is none; UINT64_MAX on a line too long to be a FASTQ line of this tool (the caller falls back).
+static uint64_t find_record_start(int fd, uint64_t from, uint64_t fsize)
+{
+	if (from == 0) return 0;
+	const uint64_t WIN = 1 << 20;
+	std::vector<char> buf((size_t)WIN);
+	uint64_t base = from - 1;                                        // one byte back: is `from` itself the start of a line?
+	const uint64_t n = std::min(WIN, fsize - base);
+	uint64_t got = 0;
+	while (got < n) { const ssize_t g = pread(fd, buf.data() + got, (size_t)(n - got), (off_t)(base + got)); if (g <= 0) break; got += (uint64_t)g; }
+	std::vector<uint64_t> starts;                                    // line starts inside the window
+	for (uint64_t i = 0; i + 1 < got; i++) if (buf[(size_t)i] == '\n') starts.push_back(i + 1);
+	for (size_t k = 0; k + 2 < starts.size(); k++)
+		if (buf[(size_t)starts[k]] == '@' && buf[(size_t)starts[k + 2]] == '+') return base + starts[k];
+	return base + got >= fsize && starts.size() < 3 ? fsize : UINT64_MAX;
+}
+
 static int run_geno(const std::string &prefix, const std::string &fastq, const std::string &vcf_in, const std::string &vcf_out)
 {
 	const clock_t begin = clock();
@@ -84,103 +173,52 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	const bool host_framing = env_int("VARGENO_HOST_FASTQ", 0) != 0;
 	uint64_t host_from = 0;                    // file offset the host reader takes over from
 	uint64_t prime_from = UINT64_MAX;          // start of the last record the device framed (to prime the stale buffers)
-	if (!host_framing && ngpu == 1) {
-		// One GPU: the file is a byte stream to the device.  Reader threads pread() it piecewise into a ring of pinned chunk
-		// buffers; this thread pushes the chunks in file order (vg_fastq_stream_push returns as soon as a chunk is on the
-		// device) and learns what was framed only at the end.
+	if (!host_framing) {
+		// The file is a byte stream to the device(s).  One replica takes all of it; several take one contiguous range each, cut at
+		// record starts, all at once.  What the device refuses (a line beyond fgets' 1023 characters) and the tail of the file go
+		// through the host reader below; with several replicas a refusal anywhere but in the last range means the ranges after it
+		// were framed out of step with the reference, so everything is reset and framed on the host.
 		const int fd = open(fastq.c_str(), O_RDONLY);
 		if (fd < 0) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
 		struct stat sb;
 		if (fstat(fd, &sb) != 0) { close(fd); fprintf(stderr, "vargeno: cannot stat %s\n", fastq.c_str()); return EXIT_FAILURE; }
 		const uint64_t fsize = (uint64_t)sb.st_size;
 		const uint64_t chunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", 64)) << 20;
-		const uint64_t piece = std::min<uint64_t>(chunk, 8ull << 20);
-		const uint64_t n_chunks = (fsize + chunk - 1) / chunk;
-		const int NBUF = 4;
-		std::vector<uint8_t *> ring((size_t)NBUF, nullptr);
-		std::vector<std::vector<uint8_t>> pageable((size_t)NBUF);
-		for (int i = 0; i < NBUF; i++) {
-			ring[(size_t)i] = (uint8_t *)vg_host_alloc_pinned((size_t)chunk);
-			if (!ring[(size_t)i]) { pageable[(size_t)i].resize((size_t)chunk); ring[(size_t)i] = pageable[(size_t)i].data(); }
-		}
-		std::mutex mu; std::condition_variable cv;
-		std::vector<uint32_t> left((size_t)n_chunks);               // pieces of chunk i still to be read
-		for (uint64_t i = 0; i < n_chunks; i++) { const uint64_t len = std::min(chunk, fsize - i * chunk); left[(size_t)i] = (uint32_t)((len + piece - 1) / piece); }
-		uint64_t pushed = 0;                                        // chunks handed to the device (their buffers are free again)
-		std::atomic<uint64_t> next_piece{0};
-		const uint64_t ppc = (chunk + piece - 1) / piece;           // pieces per (full) chunk
-		bool io_error = false;
 		// one thread copies ~2 GB/s out of the page cache: enough of them to keep a 50 GB/s link busy, if the host has the cores
 		const int hw = (int)std::thread::hardware_concurrency();
 		const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
-		std::vector<std::thread> readers;
-		for (int t = 0; t < n_readers; t++) readers.emplace_back([&] {
-			for (;;) {
-				const uint64_t p = next_piece.fetch_add(1);
-				const uint64_t ci = p / ppc, off = ci * chunk + (p % ppc) * piece;
-				if (ci >= n_chunks) return;
-				if (off >= std::min(fsize, (ci + 1) * chunk)) continue;
-				{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ci < pushed + (uint64_t)NBUF || io_error; }); if (io_error) return; }
-				uint64_t n = std::min(piece, std::min(fsize, (ci + 1) * chunk) - off), done = 0;
-				uint8_t *dst = ring[(size_t)(ci % NBUF)] + (off - ci * chunk);
-				while (done < n) {
-					const ssize_t g = pread(fd, dst + done, (size_t)(n - done), (off_t)(off + done));
-					if (g <= 0) break;
-					done += (uint64_t)g;
-				}
-				std::lock_guard<std::mutex> g(mu);
-				if (done < n) io_error = true;
-				left[(size_t)ci]--;
-				cv.notify_all();
+		std::vector<uint64_t> cut((size_t)ngpu + 1, fsize);
+		cut[0] = 0;
+		bool cuts_ok = true;
+		for (int g = 1; g < ngpu && cuts_ok; g++) {
+			const uint64_t at = find_record_start(fd, std::max(cut[(size_t)g - 1], fsize / (uint64_t)ngpu * (uint64_t)g), fsize);
+			if (at == UINT64_MAX) cuts_ok = false; else cut[(size_t)g] = at;
+		}
+		if (!cuts_ok) {
+			host_from = 0;                                              // no record start found where one should be: the host reader takes the file
+		} else {
+			std::vector<StreamResult> res((size_t)ngpu);
+			std::vector<std::thread> th;
+			for (int g = 0; g < ngpu; g++)
+				if (cut[(size_t)g] < cut[(size_t)g + 1] || g == 0)
+					th.emplace_back([&, g] { res[(size_t)g] = stream_range(ix[(size_t)g], fd, cut[(size_t)g], cut[(size_t)g + 1], chunk, std::max(2, n_readers / ngpu)); });
+			for (auto &t : th) t.join();
+			for (int g = 0; g < ngpu; g++) if (!res[(size_t)g].error.empty()) { fprintf(stderr, "vargeno: %s\n", res[(size_t)g].error.c_str()); exit(EXIT_FAILURE); }
+			int last_range = 0;                                         // the last range that holds bytes
+			for (int g = 0; g < ngpu; g++) if (cut[(size_t)g] < cut[(size_t)g + 1]) last_range = g;
+			bool in_step = true;
+			for (int g = 0; g < last_range; g++) if (res[(size_t)g].used != cut[(size_t)g + 1] - cut[(size_t)g]) in_step = false;
+			if (in_step) {
+				for (int g = 0; g <= last_range; g++) total += res[(size_t)g].nrec;
+				for (int g = last_range; g >= 0; g--) if (res[(size_t)g].nrec) { prime_from = cut[(size_t)g] + res[(size_t)g].last; break; }
+				host_from = cut[(size_t)last_range] + res[(size_t)last_range].used;    // the incomplete tail, or everything from a refused chunk on
+				next_gpu = last_range;
+			} else {
+				for (auto *h : ix) VG_CHECK(vg_counts_reset(h));
+				host_from = 0;
 			}
-		});
-		int rc = vg_fastq_stream_begin(ix[0]);
-		for (uint64_t i = 0; i < n_chunks && rc == VG_OK; i++) {
-			{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return left[(size_t)i] == 0 || io_error; }); if (io_error) break; }
-			rc = vg_fastq_stream_push(ix[0], ring[(size_t)(i % NBUF)], std::min(chunk, fsize - i * chunk));
-			{ std::lock_guard<std::mutex> g(mu); pushed = i + 1; }
-			cv.notify_all();
 		}
-		{ std::lock_guard<std::mutex> g(mu); if (rc != VG_OK) io_error = true; pushed = n_chunks; }
-		cv.notify_all();
-		for (auto &t : readers) t.join();
 		close(fd);
-		if (rc != VG_OK) { fprintf(stderr, "vargeno: FASTQ stream failed (%d): %s\n", rc, vg_last_error()); exit(EXIT_FAILURE); }
-		if (io_error) { fprintf(stderr, "vargeno: error reading %s\n", fastq.c_str()); exit(EXIT_FAILURE); }
-		uint64_t nrec = 0, used = 0, last = 0; int refused = 0;
-		VG_CHECK(vg_fastq_stream_end(ix[0], &nrec, &used, &last, &refused));
-		for (int i = 0; i < NBUF; i++) if (pageable[(size_t)i].empty()) vg_host_free_pinned(ring[(size_t)i]);
-		total += nrec;
-		if (nrec) prime_from = last;
-		host_from = used;                                           // the incomplete tail, or everything from a refused chunk on
-	} else if (!host_framing) {
-		// Several GPUs: chunks go round robin and each is framed on its own (the carry-over of a stream lives on one device), so
-		// the host learns what a chunk consumed before it reads the next.
-		FILE *f = fopen(fastq.c_str(), "rb");
-		if (!f) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
-		const size_t chunk = (size_t)env_int("VARGENO_CHUNK_MB", 256) << 20;
-		uint8_t *pinned = (uint8_t *)vg_host_alloc_pinned(chunk);
-		std::vector<uint8_t> pageable;
-		if (!pinned) pageable.resize(chunk);
-		struct Buf { uint8_t *p; uint8_t *data() const { return p; } } buf{pinned ? pinned : pageable.data()};
-		size_t have = 0; uint64_t file_off = 0;       // buf[0] is byte file_off of the file
-		for (;;) {
-			const size_t got = fread(buf.data() + have, 1, chunk - have, f);
-			have += got;
-			if (have == 0) break;
-			uint64_t nrec = 0, used = 0, last = 0;
-			const int rc = vg_fastq_submit(ix[(size_t)next_gpu], buf.data(), have, &nrec, &used, &last);
-			if (rc == VG_EBADREAD) break;              // an over-long line: the host reader takes the rest
-			if (rc != VG_OK) { fprintf(stderr, "vargeno: vg_fastq_submit failed (%d): %s\n", rc, vg_last_error()); exit(EXIT_FAILURE); }
-			if (nrec) { total += nrec; prime_from = file_off + last; next_gpu = (next_gpu + 1) % ngpu; }
-			memmove(buf.data(), buf.data() + used, have - used);
-			have -= (size_t)used; file_off += used;
-			if (got == 0 && used == 0) break;          // end of file: what is left is an incomplete record
-			if (have == chunk) break;                  // a single record larger than the chunk: host reader
-		}
-		fclose(f);
-		vg_host_free_pinned(pinned);
-		host_from = file_off;
 	}
 	{
 		vgh::FastqReader rd(fastq);
