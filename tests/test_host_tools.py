@@ -240,3 +240,37 @@ def test_irregular_inputs_index_and_vcf_are_byte_identical_to_the_reference(tmp_
     gold = gzip.open(os.path.join(GOLDEN, "fquirk.out.vcf.gz"), "rb").read()
     assert gold.count(b"\n") > 1500
     assert open(out, "rb").read() == gold
+
+
+def test_fastq_range_cuts_fall_on_record_starts(tmp_path):
+    """`geno` with n replicas cuts the FASTQ file into n ranges at record starts: a line that begins with '@' whose next-but-one
+    line begins with '+'.  Quality lines that begin with '@' (and '+' lines that repeat the name) must not fool it; a file
+    whose lines near a cut are too long to hold three line starts in the search window gives "none" (host framing)."""
+    import random
+
+    rnd = random.Random(5)
+    recs, starts, off = [], [], 0
+    for i in range(3000):
+        L = rnd.choice([31, 64, 101, 150, 150, 250])
+        seq = "".join(rnd.choice("ACGT") for _ in range(L))
+        q = "".join(rnd.choice("@@@+#5I") for _ in range(L))             # many quality lines begin with '@' or '+'
+        plus = "+" if i % 3 else "+r%d" % i
+        rec = "@r%d\n%s\n%s\n%s\n" % (i, seq, plus, q)
+        starts.append(off); off += len(rec); recs.append(rec)
+    f = tmp_path / "r.fq"
+    f.write_text("".join(recs))
+    for n in (1, 2, 3, 7, 64):
+        out = subprocess.run([BIN, "fqcuts", str(f), str(n)], capture_output=True, text=True, check=True).stdout.split()
+        cuts = [int(x) for x in out]
+        assert len(cuts) == n + 1 and cuts[0] == 0 and cuts[-1] == off and cuts == sorted(cuts)
+        assert all(c in set(starts) or c == off for c in cuts[1:-1]), n
+        if n <= 7:
+            assert all(abs(cuts[g] - off * g // n) < 2000 for g in range(1, n))        # and close to the even split
+    # a 3 MB line where the second range should start: no record start within the window
+    g = tmp_path / "long.fq"
+    g.write_text("@a\nACGT\n+\nIIII\n@b\n" + "A" * 3_000_000 + "\n+\n" + "I" * 3_000_000 + "\n")
+    assert subprocess.run([BIN, "fqcuts", str(g), "2"], capture_output=True, text=True, check=True).stdout.split() == ["none"]
+    # fewer than three lines left after the cut point: the range is empty, the last replica gets nothing
+    h = tmp_path / "short.fq"
+    h.write_text("@a\nACGT\n+\nIIII\n")
+    assert subprocess.run([BIN, "fqcuts", str(h), "2"], capture_output=True, text=True, check=True).stdout.split() == ["0", "15", "15"]

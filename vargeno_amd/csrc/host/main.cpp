@@ -139,6 +139,20 @@ static uint64_t find_record_start(int fd, uint64_t from, uint64_t fsize)
 	return base + got >= fsize && starts.size() < 3 ? fsize : UINT64_MAX;
 }
 
+// Where n replicas split the file: cut[0] = 0 <= cut[1] <= ... <= cut[n] = fsize, every inner cut a record start.  false: no
+// record start where one should be (the caller frames the whole file on the host).
+static bool range_cuts(int fd, uint64_t fsize, int n, std::vector<uint64_t> &cut)
+{
+	cut.assign((size_t)n + 1, fsize);
+	cut[0] = 0;
+	for (int g = 1; g < n; g++) {
+		const uint64_t at = find_record_start(fd, std::max(cut[(size_t)g - 1], fsize / (uint64_t)n * (uint64_t)g), fsize);
+		if (at == UINT64_MAX) return false;
+		cut[(size_t)g] = at;
+	}
+	return true;
+}
+
 static int run_geno(const std::string &prefix, const std::string &fastq, const std::string &vcf_in, const std::string &vcf_out)
 {
 	const clock_t begin = clock();
@@ -187,13 +201,8 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		// one thread copies ~2 GB/s out of the page cache: enough of them to keep a 50 GB/s link busy, if the host has the cores
 		const int hw = (int)std::thread::hardware_concurrency();
 		const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
-		std::vector<uint64_t> cut((size_t)ngpu + 1, fsize);
-		cut[0] = 0;
-		bool cuts_ok = true;
-		for (int g = 1; g < ngpu && cuts_ok; g++) {
-			const uint64_t at = find_record_start(fd, std::max(cut[(size_t)g - 1], fsize / (uint64_t)ngpu * (uint64_t)g), fsize);
-			if (at == UINT64_MAX) cuts_ok = false; else cut[(size_t)g] = at;
-		}
+		std::vector<uint64_t> cut;
+		const bool cuts_ok = range_cuts(fd, fsize, ngpu, cut);
 		if (!cuts_ok) {
 			host_from = 0;                                              // no record start found where one should be: the host reader takes the file
 		} else {
@@ -302,6 +311,18 @@ int main(int argc, const char *argv[])
 					printf("\n");
 				}
 			}
+			return EXIT_SUCCESS;
+		} else if (opt == "fqcuts") {
+			// hidden: where `geno` with n replicas would cut the FASTQ file (no device needed; tests/test_host_tools.py)
+			arg_check(argc, 2);
+			const int fd = open(argv[2], O_RDONLY);
+			struct stat sb;
+			if (fd < 0 || fstat(fd, &sb) != 0) throw vgh::Error{std::string("cannot open ") + argv[2]};
+			std::vector<uint64_t> cut;
+			const bool ok = range_cuts(fd, (uint64_t)sb.st_size, std::max(1, atoi(argv[3])), cut);
+			close(fd);
+			if (!ok) { printf("none\n"); return EXIT_SUCCESS; }
+			for (uint64_t c : cut) printf("%lu\n", (unsigned long)c);
 			return EXIT_SUCCESS;
 		} else if (opt == "callvcf") {
 			// hidden (like the reference's vcfd/ucscd/filt): caller + VCF writer alone, from a counts table
