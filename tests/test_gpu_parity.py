@@ -75,12 +75,14 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
         assert tm["ms_main"] > 0 and tm["batches"] == 1
 
 
-@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_SEC", "VG_PACK_OVERLAP", "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW"])
+@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_MX+VG_NO_SNP_JG32", "VG_NO_MX+VG_NO_SEC+VG_NO_PROBE_VIEW", "VG_NO_SEC", "VG_PACK_OVERLAP",
+                                  "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW"])
 def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
     """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view, strided-probe
     view); the pack kernel can run on the ingest stream.  Each has a fallback / alternative; all must give the reference's bits.
     Several batches, so that slots, streams and the base-indexed counters' fold are exercised too."""
-    monkeypatch.setenv(knob, "1")
+    for k in knob.split("+"):                      # (VG_NO_MX: the kernel of an index too big for the merged view; with
+        monkeypatch.setenv(k, "1")                 # VG_NO_SNP_JG32 it bisects HI24 buckets of the SNP dictionary)
     prefix = os.path.join(ftiny_dir, "idx")
     r = ftiny_reads
     _, _, so = _oracle_counts(prefix, r)
@@ -240,7 +242,8 @@ def test_dense_snp_buckets_parity_all_layouts(tmp_path, monkeypatch):
     want = ox.stats.as_dict()
     assert want["scan_snp"] > 100 * want["gate_open"]
     rows = []
-    for label, env in (("all views", {}), ("no merged view (the > 2^32-entry fallback)", {"VG_NO_MX": "1"})):
+    for label, env in (("all views", {}), ("no merged view (the > 2^32-entry fallback)", {"VG_NO_MX": "1"}),
+                       ("no merged view, no HI32 jump table of the SNP dictionary", {"VG_NO_MX": "1", "VG_NO_SNP_JG32": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with GenoIndex.open(prefix) as gx:
