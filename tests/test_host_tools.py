@@ -274,3 +274,35 @@ def test_fastq_range_cuts_fall_on_record_starts(tmp_path):
     h = tmp_path / "short.fq"
     h.write_text("@a\nACGT\n+\nIIII\n")
     assert subprocess.run([BIN, "fqcuts", str(h), "2"], capture_output=True, text=True, check=True).stdout.split() == ["0", "15", "15"]
+
+
+def test_caller_equals_the_reference_function_over_its_whole_domain(tmp_path):
+    """The product's caller + VCF pass against tests/golden/caller_table.npz (the reference's own choose_best_genotype for every
+    count pair in [0, 63]^2 and 16 allele-frequency pairs, GQ as qv.cc:1681 derives it): one site per table entry, every
+    genotyped entry must come out with the reference's GT and GQ, every other entry not at all."""
+    import numpy as np
+
+    z = np.load(os.path.join(GOLDEN, "caller_table.npz"))
+    t = {k: z[k] for k in z.files}                     # (an NpzFile decompresses a member on every access)
+    n = len(t["genotype"])
+    with open(tmp_path / "chrlens", "w") as f:
+        f.write("chr1 %d\n" % (n + 100))
+    with open(tmp_path / "counts.txt", "w") as f:
+        for i in range(n):
+            f.write("%d %d %d %d %d\n" % (i + 1, t["ref_freq"][i], t["alt_freq"][i], t["ref_cnt"][i], t["alt_cnt"][i]))
+    with open(tmp_path / "in.vcf", "w") as f:
+        f.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n")
+        for i in range(n):
+            f.write("1\t%d\t.\tA\tC\t.\t.\t.\n" % (i + 1))
+    subprocess.check_call([BIN, "callvcf", str(tmp_path / "chrlens"), str(tmp_path / "counts.txt"), str(tmp_path / "in.vcf"), str(tmp_path / "out.vcf")])
+    got = {}
+    for ln in open(tmp_path / "out.vcf"):
+        if ln[0] == "#":
+            continue
+        c = ln.rstrip("\n").split("\t")
+        assert c[8] == "GT:GQ"
+        gt, gq = c[9].split(":")
+        got[int(c[1]) - 1] = (gt, int(gq))
+    names = {1: "0/0", 2: "1/1", 3: "0/1"}
+    want = {i: (names[int(t["genotype"][i])], int(t["gq"][i])) for i in range(n) if t["genotype"][i] != 0}
+    assert len(want) > 65000 and got == want

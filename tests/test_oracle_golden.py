@@ -155,3 +155,20 @@ def test_oracle_reproduces_reference_vcf_on_fdense(tmp_path):
     st = ix.stats.as_dict()
     assert st["scan_snp"] > 100 * st["gate_open"]              # the scans are two orders of magnitude longer than on F-tiny
     assert st["large_block"] > 0 and st["aux_snp"] > 0
+
+
+def test_oracle_caller_equals_the_reference_function_over_its_whole_domain():
+    """tests/golden/caller_table.npz holds the REFERENCE's own choose_best_genotype (qv.cc:1789-1848; evaluated by
+    oracle/ref_caller_table.cc, which #includes qv.cc) for every (ref_cnt, alt_cnt) in [0, 63]^2 and 16 allele-frequency
+    pairs, with the GQ of qv.cc:1681: the oracle's caller must return the same genotype, the same GQ and the same confidence
+    bits for all 65 536 of them."""
+    z = np.load(os.path.join(GOLDEN, "caller_table.npz"))
+    t = {k: z[k] for k in z.files}                     # (an NpzFile decompresses a member on every access)
+    n = len(t["genotype"])
+    assert n == 16 * 64 * 64
+    bad = 0
+    for i in range(n):
+        g, conf, gq = O.call(t["ref_cnt"][i], t["alt_cnt"][i], t["ref_freq"][i], t["alt_freq"][i])
+        ok = g == t["genotype"][i] and (g == 0 or (gq == t["gq"][i] and conf == t["conf"][i]))
+        bad += not ok
+    assert bad == 0
