@@ -61,6 +61,7 @@ def lib():
         L.vgo_call.restype = C.c_int
         L.vgo_call.argtypes = [C.c_int, C.c_int, C.c_uint8, C.c_uint8, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.vgo_trace_read.argtypes = [C.c_void_p, u8p, u8p, C.c_uint64, u32p]
+        L.vgo_vote_replay.argtypes = [u32p, u32p, u32p, C.c_uint64, u32p]
         L.vgo_alg_bytes.restype = C.c_uint64
         L.vgo_alg_bytes.argtypes = [C.POINTER(Stats)]
         _lib = L
@@ -139,6 +140,14 @@ class OracleIndex:
 
     def alg_bytes(self):
         return int(lib().vgo_alg_bytes(C.byref(self.stats)))
+
+
+def vote_replay(index, kpos, neigh):
+    """The oracle's vote state machine alone on a sequence of adds -> (has_best, best index, best freq, ambiguous)."""
+    index = np.ascontiguousarray(index, dtype=np.uint32); kpos = np.ascontiguousarray(kpos, dtype=np.uint32); neigh = np.ascontiguousarray(neigh, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().vgo_vote_replay(_p(index, C.c_uint32), _p(kpos, C.c_uint32), _p(neigh, C.c_uint32), len(index), _p(out, C.c_uint32))
+    return tuple(int(x) for x in out)
 
 
 def call(ref_cnt, alt_cnt, ref_freq, alt_freq):

@@ -146,6 +146,18 @@ static void vote(pass_state *ps, uint32_t index, uint32_t kpos, int neigh)
 	else if (k->freq > ps->keys[ps->best].freq) { ps->best = e; ps->amb = 0; }
 }
 
+/* Test hook: the vote alone, replayed on a sequence of (index, kmer_pos, is_neighbour) -- what tests/golden/vote_table.npz holds
+ * from the reference's own improved_index_table_add.  out = {has_best, best index, best freq, ambiguous}. */
+void vgo_vote_replay(const uint32_t *index, const uint32_t *kpos, const uint32_t *neigh, uint64_t n, uint32_t out[4])
+{
+	pass_state ps;
+	memset(&ps, 0, sizeof ps);
+	ps.best = -1;
+	for (uint64_t i = 0; i < n; i++) vote(&ps, index[i], kpos[i], neigh[i] != 0);
+	out[0] = ps.best >= 0; out[1] = ps.best >= 0 ? ps.keys[ps.best].index : 0u; out[2] = ps.best >= 0 ? ps.keys[ps.best].freq : 0u; out[3] = (uint32_t)ps.amb;
+	free(ps.keys);
+}
+
 static inline int is_site_loose(const vgo_index *ix, uint32_t p)   /* !(ref==0 && alt==0), qv.cc:990-991 */
 {
 	return p < ix->pile_len && (ix->pile[p] & 15u) != 0;

@@ -74,6 +74,9 @@ int vgo_call(int ref_cnt, int alt_cnt, uint8_t ref_freq, uint8_t alt_freq, doubl
  * out[3]=#ref ctx, out[4]=#snp ctx of the LAST pass. */
 void vgo_trace_read(vgo_index *ix, const uint8_t *bases, const uint8_t *quals, uint64_t len, uint32_t out[5]);
 
+/* test hook: the vote state machine alone (qv.cc:132-178) on a sequence of adds; out = {has_best, best index, best freq, ambiguous} */
+void vgo_vote_replay(const uint32_t *index, const uint32_t *kpos, const uint32_t *neigh, uint64_t n, uint32_t out[4]);
+
 uint64_t vgo_alg_bytes(const vgo_stats *s);
 
 #ifdef __cplusplus

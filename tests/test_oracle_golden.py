@@ -172,3 +172,24 @@ def test_oracle_caller_equals_the_reference_function_over_its_whole_domain():
         ok = g == t["genotype"][i] and (g == 0 or (gq == t["gq"][i] and conf == t["conf"][i]))
         bad += not ok
     assert bad == 0
+
+
+def test_oracle_vote_equals_the_reference_state_machine():
+    """tests/golden/vote_table.npz: 2 400 seeded sequences of votes (ties, ambiguity flips, positions sharing a slot of the
+    reference's table, refused neighbour votes, repeated k-mer positions, runs past 255 votes) and what the REFERENCE's own
+    improved_index_table_add (qv.cc:132-178, driven by oracle/ref_vote_replay.cc) holds after each.  The oracle's vote must
+    end every sequence with the same best position, the same uint8_t frequency and the same ambiguity flag."""
+    z = np.load(os.path.join(GOLDEN, "vote_table.npz"))
+    lens, index, kpos, neigh, want = (z[k] for k in ("lens", "index", "kpos", "neigh", "result"))
+    ends = np.cumsum(lens.astype(np.int64))
+    wrapped = 0
+    for s in range(len(lens)):
+        a, b = int(ends[s] - lens[s]), int(ends[s])
+        got = O.vote_replay(index[a:b], kpos[a:b], neigh[a:b])
+        w = tuple(int(x) for x in want[s])
+        assert got[0] == w[0] and got[3] == w[3] and (not w[0] or got[1:3] == w[1:3]), (s, got, w)
+        if w[0]:
+            opened = np.nonzero((index[a:b] == w[1]) & (neigh[a:b] == 0))[0]
+            votes = int((index[a + int(opened[0]):b] == w[1]).sum())
+            wrapped += votes > 255 and w[2] == votes % 256
+    assert int(want[:, 0].sum()) > 2000 and int(want[:, 3].sum()) > 100 and wrapped > 50
