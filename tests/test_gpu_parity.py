@@ -398,3 +398,36 @@ def test_randomly_damaged_ragged_reads_both_builds(ftiny_dir, seed):
                 for k in CMP_STATS:
                     assert st[k] == want[k], k
             assert st["reads_invalid"] == want["reads_invalid"]
+
+
+def test_corrupt_dictionaries_are_refused_not_read(ftiny_dir, tmp_path):
+    """An index whose files have the right sizes but the wrong contents -- k-mers out of order, an entry naming an auxiliary row
+    beyond the table -- must come back as an error code from vg_index_open, not as a wild read on the device."""
+    import shutil
+
+    from vargeno_amd._lib import VgError
+
+    def copy_index(dst):
+        os.makedirs(dst, exist_ok=True)
+        for fn in ("idx.ref.dict", "idx.snp.dict", "idx.ref.bf", "idx.snp.bf", "idx.chrlens"):
+            shutil.copy(os.path.join(ftiny_dir, fn), os.path.join(dst, fn))
+        return os.path.join(dst, "idx")
+
+    # reference dictionary: u64 n, u64 n_aux, then n x {u64 kmer, u32 pos, u8 ambig} (13 bytes)
+    p = copy_index(str(tmp_path / "swapped"))
+    raw = bytearray(open(p + ".ref.dict", "rb").read())
+    a, b = 16 + 13 * 100, 16 + 13 * 101
+    raw[a:a + 8], raw[b:b + 8] = raw[b:b + 8], raw[a:a + 8]
+    open(p + ".ref.dict", "wb").write(raw)
+    with pytest.raises(VgError) as e:
+        GenoIndex.open(p)
+    assert e.value.code == -2 and "out of order" in str(e.value)
+    p = copy_index(str(tmp_path / "wild"))
+    raw = bytearray(open(p + ".ref.dict", "rb").read())
+    n = int.from_bytes(raw[0:8], "little")
+    k = next(i for i in range(n) if raw[16 + 13 * i + 12] != 0 and raw[16 + 13 * i + 8:16 + 13 * i + 12] != b"\xff\xff\xff\xff")
+    raw[16 + 13 * k + 8:16 + 13 * k + 12] = (0x7FFFFFF0).to_bytes(4, "little")
+    open(p + ".ref.dict", "wb").write(raw)
+    with pytest.raises(VgError) as e:
+        GenoIndex.open(p)
+    assert e.value.code == -2 and "auxiliary rows" in str(e.value)

@@ -805,6 +805,20 @@ __global__ void vg_max_pos(const uint32_t *__restrict__ pos, const uint8_t *__re
 	for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(m, o); m = y > m ? y : m; }
 	if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
+// What the kernels take for granted about a dictionary and a corrupt file could violate: k-mers strictly increasing (the jump
+// tables and every bisection), and an entry flagged "several positions" naming a row the auxiliary table has.  bad[0] / bad[1]
+// count the violations; the caller refuses the index (a wild row index would be a wild read on the device).
+__global__ void vg_check_columns(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ pos, const uint8_t *__restrict__ amb, uint64_t n, uint64_t n_aux,
+                                 unsigned long long *bad)
+{
+	unsigned long long unsorted = 0, wild = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		if (i + 1 < n && kmer[i] >= kmer[i + 1]) unsorted++;
+		if (amb[i] != 0 && pos[i] != POS_AMBIGUOUS && pos[i] >= n_aux) wild++;
+	}
+	if (unsorted) atomicAdd(&bad[0], unsorted);
+	if (wild) atomicAdd(&bad[1], wild);
+}
 // Pile-up seeding in FILE ORDER, last writer wins (qv.cc:637-659): every position first learns the index of the LAST SNP-dictionary
 // entry that seeds it ...
 __global__ void vg_site_winner(const uint32_t *__restrict__ pos, const uint8_t *__restrict__ info, const uint8_t *__restrict__ amb, uint64_t n, uint32_t *__restrict__ winner)
@@ -927,6 +941,21 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(st));
 		HIP_TRY(hipMemcpy(&maxp, dmax.p, 8, hipMemcpyDeviceToHost));
+		// ---- and what a file that `vargeno index` did not write could get wrong
+		TempDev<unsigned long long> dbad;
+		if ((rc = dbad.alloc(2))) return rc;
+		HIP_TRY(hipMemsetAsync(dbad.p, 0, 16, st));
+		if (c.n_ref) vg_check_columns<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, c.n_ref_aux, dbad.p);
+		if (c.n_snp) vg_check_columns<<<2048, 256, 0, st>>>(c.snp_kmer.p, c.snp_pos.p, c.snp_amb.p, c.n_snp, c.n_snp_aux, dbad.p);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));
+		unsigned long long bad[2] = {0, 0};
+		HIP_TRY(hipMemcpy(bad, dbad.p, 16, hipMemcpyDeviceToHost));
+		if (bad[0] || bad[1]) {
+			char msg[200];
+			snprintf(msg, sizeof msg, "k-mers out of order in %llu places, %llu entries naming auxiliary rows the file does not have", bad[0], bad[1]);
+			return fail(VG_EIO, "not an index `vargeno index` wrote: %s", msg);
+		}
 	}
 	// ---- reference dictionary: jump table + 16-byte entries
 	{
