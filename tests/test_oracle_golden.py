@@ -193,3 +193,16 @@ def test_oracle_vote_equals_the_reference_state_machine():
             votes = int((index[a + int(opened[0]):b] == w[1]).sum())
             wrapped += votes > 255 and w[2] == votes % 256
     assert int(want[:, 0].sum()) > 2000 and int(want[:, 3].sum()) > 100 and wrapped > 50
+
+
+def test_reference_written_dictionaries_satisfy_what_the_loader_checks(ftiny_dir):
+    """vg_index_open refuses dictionaries whose k-mers are not strictly increasing or whose "several positions" entries name
+    auxiliary rows beyond the table.  The files the REFERENCE wrote (committed F-tiny index) satisfy both, so the check
+    cannot turn away an index it should take."""
+    rd = index_io.read_ref_dict(os.path.join(ftiny_dir, "idx.ref.dict"))
+    sd = index_io.read_snp_dict(os.path.join(ftiny_dir, "idx.snp.dict"))
+    for kmer, pos, amb, n_aux in ((rd["ref_kmer"], rd["ref_pos"], rd["ref_amb"], len(rd["ref_aux"])),
+                                  (sd["snp_kmer"], sd["snp_pos"], sd["snp_amb"], len(sd["snp_aux_pos"]))):
+        assert np.all(kmer[1:] > kmer[:-1])
+        multi = (amb != 0) & (pos != 0xFFFFFFFF)
+        assert multi.sum() > 0 and np.all(pos[multi] < n_aux)
