@@ -55,12 +55,14 @@ def parse_args():
     ap.add_argument("--genome", type=int, default=None)
     ap.add_argument("--snps", type=int, default=None)
     ap.add_argument("--chroms", type=int, default=None, help="number of sequences the genome is split into")
+    ap.add_argument("--repeats", type=float, default=0.0, help="fraction of the genome in planted exact repeats (2-10 copies and > 10 copies) -- the repeat-rich stress genome; 0 = the default genome (2 %% diverged repeats)")
     ap.add_argument("--lowq", type=float, default=0.08, help="fraction of low-quality (gate-open) characters; 0.5 = the stress profile of SURVEY.md §8d")
     ap.add_argument("--cpu-sample", type=int, default=None, help="reads timed on one host thread of the CPU oracle (0 = skip the CPU legs and the parity check)")
     ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench"))
     ap.add_argument("--no-check", action="store_true", help="skip the parity check against the oracle")
     ap.add_argument("--cpu-reference", choices=["auto", "yes", "no"], default="auto",
-                    help="also time the reference binary (oracle/_ref/vargeno) on the host: auto = chr22 workload only (at hg38 scale its start-up alone takes minutes)")
+                    help="time the reference binary (oracle/_ref/vargeno) on the host, beside the GPU legs, as the cpu_baseline of record: auto = yes unless the "
+                         "workload is hg38f (the reference cannot run it: int index into a > 2^31-entry SNP dictionary, qv.cc:447) or the host is short of memory")
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the secondary end-to-end number (FASTQ text in pinned host memory -> counters)")
     args = ap.parse_args()
@@ -97,6 +99,67 @@ def build_index_files(args, g, s, d, prefix):
     subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
     log("[bench] vargeno index: %.1fs" % (time.time() - t0))
     open(prefix + ".done", "w").close()
+
+
+class ReferenceTimer:
+    """The reference itself (oracle/_ref/vargeno, built from the reference sources by oracle/Makefile in the build container) on the
+    GPU box's host, one thread -- it has no other mode -- next to the GPU legs: two `geno` child processes, one over the
+    sample's FASTQ and one over an empty FASTQ, started as soon as the index files exist and left alone until the GPU legs
+    are done.  The reference prints "Processing..." right before its read loop (qv.cc:753) and creates the output VCF right
+    after the calling scan that follows the loop (qv.cc:1573-1637), so
+        read loop = (sample: VCF created - "Processing...") - (empty: VCF created - "Processing...")
+    whatever its minutes of start-up (16 GiB jump table) took on a host that is busy with the rest of the bench."""
+
+    def __init__(self, ref_bin, d, sample_fq, n_reads):
+        import threading
+
+        self.n = n_reads
+        self.res = {}
+        self.threads = []
+        for name, fq in (("empty", os.path.join(d, "cpu_empty.fq")), ("sample", sample_fq)):
+            if name == "empty":
+                open(fq, "w").close()
+            out_vcf = os.path.join(d, "cpu_%s.vcf" % name)
+            if os.path.exists(out_vcf):
+                os.remove(out_vcf)
+            t = threading.Thread(target=self._run, args=(name, [ref_bin, "geno", "idx", os.path.basename(fq), "snps.vcf", os.path.basename(out_vcf)], d, out_vcf), daemon=True)
+            t.start()
+            self.threads.append(t)
+
+    def _run(self, name, cmd, cwd, out_vcf):
+        try:
+            t_start = time.time()
+            p = subprocess.Popen(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            t_proc = None
+            for line in p.stderr:                        # stderr is unbuffered on the reference's side
+                if line.startswith(b"Processing"):
+                    t_proc = time.time()
+                    break
+            t_vcf = None
+            while p.poll() is None:
+                if t_vcf is None and os.path.exists(out_vcf):
+                    t_vcf = time.time()
+                time.sleep(0.02)
+            t_end = time.time()
+            if p.returncode == 0 and t_proc is not None:
+                self.res[name] = {"startup": t_proc - t_start, "loop_and_scan": (t_vcf or t_end) - t_proc, "wall": t_end - t_start}
+        except Exception as e:
+            log("[bench] reference binary (%s FASTQ) not timed: %r" % (name, e))
+
+    def result(self, timeout=1500):
+        t0 = time.time()
+        for t in self.threads:
+            t.join(max(1.0, timeout - (time.time() - t0)))
+        if "sample" not in self.res or "empty" not in self.res:
+            return None
+        a, b = self.res["sample"], self.res["empty"]
+        loop = a["loop_and_scan"] - b["loop_and_scan"]
+        if loop <= 0:
+            return None
+        return {"value": self.n / loop, "unit": "reads/s", "cores": 1, "kind": "reference",
+                "sample": "oracle/_ref/vargeno geno (the reference's own binary, its only mode: one thread) on the first %d reads of batch 0: %.1f s from \"Processing...\" to the "
+                          "output VCF's creation, minus %.1f s of the same span on an empty FASTQ (the calling scan); start-up %.0f s, not counted; "
+                          "ran beside the GPU legs of this bench" % (self.n, a["loop_and_scan"], b["loop_and_scan"], a["startup"])}
 
 
 def gather_ceiling():
@@ -174,11 +237,11 @@ def main():
     from vargeno_amd import synth
 
     # ---- data set + index files: host only (rank 0 builds, the others wait for its marker file) ----------------------------
-    tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms)
+    tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms) + ("_r%g" % args.repeats if args.repeats else "")
     d = os.path.join(args.workdir, tag)
     prefix = os.path.join(d, "idx")
     t0 = time.time()
-    g, s, _ = synth.genome_and_snps(genome_len=args.genome, n_snps=args.snps, n_chroms=args.chroms, genotypes="hwe" if args.workload == "hg38f" else "uniform")
+    g, s, _ = synth.genome_and_snps(genome_len=args.genome, n_snps=args.snps, n_chroms=args.chroms, genotypes="hwe" if args.workload == "hg38f" else "uniform", repeats=args.repeats)
     if rank == 0:
         log("[bench] synthetic genome + SNP list: %.1fs (%d bp, %d SNPs)" % (time.time() - t0, g.total_len, len(s.pos)))
         build_index_files(args, g, s, d, prefix)
@@ -226,6 +289,28 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0:
         log("[bench] %d batches of %d reads generated on the device: %.1fs" % (args.batches, args.reads, time.time() - t0))
+
+    # ---- the reference binary on the host, beside everything that follows (N = 1 only) ------------------------------------------
+    ref_timer = None
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "vargeno")
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and os.path.exists(ref_bin) and (args.cpu_reference == "yes" or (args.cpu_reference == "auto" and args.workload != "hg38f")):
+        avail_gb = 0.0
+        try:
+            avail_gb = [int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0] / 1e6
+        except Exception:
+            pass
+        # two reference processes (each: 16 GiB jump table + both dictionaries + a pile-up table of up to 17 GB) next to the oracle's copy
+        need_gb = 40.0 if args.genome < 10 ** 9 else 260.0
+        if avail_gb >= need_gb or args.cpu_reference == "yes":
+            t0 = time.time()
+            sub = synth.reads_to_host(*batches[0]).slice(0, args.cpu_sample)
+            fq = os.path.join(d, "cpu_sample.fq")
+            synth.write_fastq(fq, sub)
+            del sub
+            ref_timer = ReferenceTimer(ref_bin, d, fq, args.cpu_sample)
+            log("[bench] reference binary started on the host (sample FASTQ of %d reads written in %.1fs; %.0f GB of host memory available)" % (args.cpu_sample, time.time() - t0, avail_gb))
+        else:
+            log("[bench] reference binary NOT timed: %.0f GB of host memory available, %.0f wanted" % (avail_gb, need_gb))
 
     t0 = time.time()
     gx = GenoIndex.open(prefix, device=dev_index)
@@ -297,26 +382,6 @@ def main():
                "all_cores": {"value": r0.n / best_t, "threads": best_nt, "host_cores": ncores, "reads_per_s_by_threads": tried,
                              "sample": "batch 0 (%d reads), %.1f s" % (r0.n, best_t)}}
         ox.close()
-        # the reference itself, when its binary came along (oracle/_ref/vargeno, built from /root/reference by oracle/Makefile in
-        # the build container): `geno` wall time on the sample minus wall time on an empty FASTQ = its read loop, one thread
-        ref_bin = os.path.join(ROOT, "oracle", "_ref", "vargeno")
-        want_ref = args.cpu_reference == "yes" or (args.cpu_reference == "auto" and args.workload == "chr22")
-        if os.path.exists(ref_bin) and want_ref:
-            try:
-                synth.write_fastq(os.path.join(d, "cpu_sample.fq"), sub)
-                open(os.path.join(d, "cpu_empty.fq"), "w").close()
-                wall = {}
-                for name in ("cpu_empty", "cpu_sample"):
-                    t0 = time.time()
-                    subprocess.run([ref_bin, "geno", "idx", name + ".fq", "snps.vcf", name + ".vcf"], cwd=d, check=True, timeout=1500,
-                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                    wall[name] = time.time() - t0
-                loop = wall["cpu_sample"] - wall["cpu_empty"]
-                if loop > 0:
-                    cpu["reference_binary"] = {"value": ns / loop, "unit": "reads/s", "cores": 1, "kind": "reference",
-                                               "sample": "oracle/_ref/vargeno geno on the same %d reads: %.1f s wall, minus %.1f s wall on an empty FASTQ (its start-up)" % (ns, wall["cpu_sample"], wall["cpu_empty"])}
-            except Exception as e:                                  # the baseline of record is the port above
-                log("[bench] reference binary not timed: %r" % (e,))
         del r0, sub
 
     # ---- secondary number (N = 1): end to end from FASTQ text in pinned HOST memory -- H2D over PCIe, framing on the device, the
@@ -371,11 +436,12 @@ def main():
         gx.sync()
         local_sum = gx.counts_tensor().sum(dtype=torch.int64).reshape(1).to(coll_dev)      # this rank's increments, before the exchange (checked below)
         all_reduce_counts(gx)                           # one RCCL all-reduce of the per-site counters over xGMI
-    gx.sync()
+    fetched = gx.counts()                               # "first submit -> counters reduced and fetched": fold, clamp at 63, device -> host
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    del fetched
     tm = gx.timing()                                    # HIP events on the library's own streams, averaged over the K batches
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
@@ -388,18 +454,41 @@ def main():
         if rank == 0:
             verification["timed_region_increments"] = total_after
 
+    if rank == 0 and ref_timer is not None:
+        # the reference's own binary is the baseline of record; the port (oracle) stays beside it
+        t0 = time.time()
+        refres = ref_timer.result()
+        log("[bench] waited %.0fs more for the reference binary: %s" % (time.time() - t0, refres and "%.4g reads/s" % refres["value"]))
+        if refres is not None:
+            port = cpu or {}
+            cpu = dict(refres)
+            if port:
+                cpu["port"] = {k: port[k] for k in ("value", "unit", "cores", "kind", "sample")}
+                cpu["all_cores"] = port.get("all_cores")
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         k_ms = tm["ms_main"]
         achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
         # HBM traffic and L2 misses of the dominant kernel cannot be counted inside a timed run: they come from the separate
         # rocprofv3 --pmc passes of this same command, committed under profiles/ (null for any other workload)
-        traffic, misses = None, None
-        for name in ("traffic_r02.json",):
+        # -- and only of THIS build of the library: a traffic file is stamped with the vg_build_id() it was measured on
+        from vargeno_amd._lib import lib as _vg_lib
+
+        build_id = _vg_lib().vg_build_id().decode()
+        traffic, misses, traffic_note = None, None, "no profiles/traffic_*.json for this workload"
+        import glob
+
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                if tj["workload"] == {"genome": args.genome, "snps": args.snps, "reads": args.reads} and args.lowq == 0.08:
-                    traffic, misses = tj["traffic_bytes_per_launch"], tj.get("TCC_MISS_sum")
+                tj = json.load(open(path))
+                if tj["workload"] != {"genome": args.genome, "snps": args.snps, "reads": args.reads} or args.lowq != 0.08 or args.repeats != 0.0:
+                    continue
+                if tj.get("build_id") != build_id:
+                    traffic_note = "%s was measured on build %s, this is build %s: not quoted" % (os.path.basename(path), tj.get("build_id"), build_id)
+                    continue
+                traffic, misses = tj["traffic_bytes_per_launch"], tj.get("TCC_MISS_sum")
+                traffic_note = "%s (separate rocprofv3 --pmc passes of this command on this build; %s)" % (os.path.basename(path), tj.get("traffic_formula", "FETCH_SIZE + WRITE_SIZE"))
+                break
             except Exception:
                 pass
         gc = None
@@ -419,19 +508,20 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "%s: %d bp synthetic genome in %d sequence(s), %d SNPs requested, %d x 150 bp reads per GPU per step rotating over %d "
-                                   "distinct resident batches of the read stream, 0.5%% error, %g%% low-quality chars, seed 20261002" % (
+                                   "distinct resident batches of the read stream, 0.5%% error, %g%% low-quality chars, seed 20261002%s" % (
                                        "hg38 + full-dbSNP-scale index (BASELINE.json configs[4], one replica)" if args.snps >= 5 * 10 ** 7 else
                                        "hg38-scale (BASELINE.json configs[2])" if args.genome >= 10 ** 9 else "chr22-scale (BASELINE.json configs[1])",
-                                       args.genome, args.chroms, args.snps, args.reads, args.batches, 100 * args.lowq),
+                                       args.genome, args.chroms, args.snps, args.reads, args.batches, 100 * args.lowq,
+                                       "" if not args.repeats else "; REPEAT-RICH genome: %g%% of it in planted families of near-identical copies (2-10 and 11-200 copies), 50 microsatellites per Mbp" % (100 * args.repeats)),
                        "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps,
-                       "index_bytes_hbm": gx.device_bytes,
+                       "index_bytes_hbm": gx.device_bytes, "index_views": gx.views, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "vg_wave_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "algorithmic_bytes_per_read": alg_bytes_per_launch / args.reads, "gather_ceiling": gc},
             "cpu_baseline": cpu,
             "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "spill_tiers_overlapped": tm["ms_tail"], "of_which_deep_list_wave_tier": tm["ms_deep_lists"], "batches": tm["batches"]},
-            "reads_per_step_spilled_to_lane_tier": st["overflow_reads"], "reads_per_step_deep_scratch": st["overflow_deep"],
+            "reads_per_step_redone_by_deep_list_tier": st["overflow_reads"], "reads_per_step_sent_on_to_lane_tier": st["overflow_deep"],
             "events_per_read": {k: st[k] / args.reads for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
             "ingest_end_to_end": ingest,
             "multi_gpu_verification": verification,

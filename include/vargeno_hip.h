@@ -48,8 +48,10 @@ typedef struct {
 	         refbf_pos, snpbf_pos, large_block, ref_query, snp_query, ref_probe, snp_probe,
 	         scan_ref, scan_snp, scan_oob, aux_ref, aux_snp, site_test, ctx, walks, incr,
 	         ingest_bytes;
-	uint64_t overflow_reads;     /* reads the wave tier handed to the generic lane tier       */
-	uint64_t overflow_deep;      /* of those, reads that needed the deep scratch              */
+	uint64_t overflow_reads;     /* reads that outgrew the main wave tier's LDS lists and were redone by
+	                                the deep-list wave tier (same kernel, lists 3-12x deeper)  */
+	uint64_t overflow_deep;      /* of those, reads that outgrew the deep lists too and went to the
+	                                generic lane tier (one read per lane, lists in HBM scratch)   */
 	uint64_t alg_bytes;          /* sum of unit cost x event count                            */
 } vg_stats;
 
@@ -86,6 +88,17 @@ void vg_index_close(vg_index *ix);               /* qv.cc:1775-1786 */
 
 /* Device bytes held by the index (tables + pile-up + scratch). */
 uint64_t vg_index_device_bytes(const vg_index *ix);
+
+/* Which optional re-laid-out views of the dictionaries the handle holds (bit mask).  They change speed, never results: a
+ * view is left out when the index is too large for it or the device had too little free memory while the handle was
+ * built (or a VG_NO_* development switch said so) -- a caller that cares about throughput should look. */
+#define VG_VIEW_SEC        1u   /* LO32-ordered view of the reference dictionary (high-half neighbours, qv.cc:1213-1296)   */
+#define VG_VIEW_MX         2u   /* merged exact-match view of both dictionaries (qv.cc:840-841)                            */
+#define VG_VIEW_DX         4u   /* direct table over HI32 in front of the merged view                                      */
+#define VG_VIEW_SNP_PROBE  8u   /* strided-probe view of the SNP dictionary (iterate_snp_dict, qv.cc:413-464)              */
+#define VG_VIEW_SNP_JG32  16u   /* HI32 jump table of the SNP dictionary (indexes too large for the merged view)           */
+#define VG_VIEW_HX        32u   /* paired HI32 table of both dictionaries (indexes too large for the merged view)          */
+uint32_t vg_index_views(const vg_index *ix);
 
 /* Replaces the FASTQ loop body, qv.cc:760-1558, for a batch of reads: flat ASCII bases and quality
  * characters (same offsets; offsets[n_reads] = total length) in HOST memory.  Copies to the

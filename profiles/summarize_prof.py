@@ -8,6 +8,14 @@ import os
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+# which kernel the traffic file is about: the main tier of the read loop ("vg_wave_kernel<false, " ... ", 4>"), or e.g. "vg_wave_kernel_big<"
+ksel = sys.argv[3] if len(sys.argv) > 3 else "vg_wave_kernel<false, "
+
+
+def is_main(name):
+    return ksel in name and ", 4>" in name
+
+
 out = []
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     out.append("== rocprofv3 --kernel-trace --stats (%s)" % os.path.relpath(f, src))
@@ -33,28 +41,29 @@ for grp in ("pmc_fetch", "pmc_write", "pmc_l2"):
     for f in glob.glob(os.path.join(src, grp, "*", "*_counter_collection.csv")):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "vg_wave_kernel<false, " in r["Kernel_Name"] and ", 4>" in r["Kernel_Name"]:
+            if is_main(r["Kernel_Name"]):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, v in agg.items():
             means[c] = sum(v) / len(v)
 kt_avg, kname = None, None
 for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
     for row in csv.DictReader(open(f)):
-        if "vg_wave_kernel<false, " in row["Name"] and ", 4>" in row["Name"]:
+        if is_main(row["Name"]):
             kt_avg = float(row["AverageNs"])
             kname = row["Name"].split("(")[0].replace("void ", "").replace("vg::", "").strip()
 if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
-    wl = None
+    wl, build_id = None, None
     try:
         cfg = json.loads(open(os.path.join(src, "kt.json")).read().strip().splitlines()[-1])["config"]
         wl = {"genome": cfg["genome_bp"], "snps": cfg["snps_requested"], "reads": cfg["reads_per_step_per_gpu"]}
+        build_id = cfg.get("lib_build_id")
     except Exception:
         pass
-    tj = {"workload": wl, "kernel": kname or "vg_wave_kernel (main tier)", "FETCH_SIZE_KB": means["FETCH_SIZE"], "WRITE_SIZE_KB": means["WRITE_SIZE"],
+    tj = {"workload": wl, "build_id": build_id, "kernel": kname or "vg_wave_kernel (main tier)", "FETCH_SIZE_KB": means["FETCH_SIZE"], "WRITE_SIZE_KB": means["WRITE_SIZE"],
           "traffic_bytes_per_launch": int((means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024),
           "TCC_MISS_sum": means.get("TCC_MISS_sum"), "TCC_HIT_sum": means.get("TCC_HIT_sum"), "TCP_TCC_READ_REQ_sum": means.get("TCP_TCC_READ_REQ_sum"),
           "kernel_trace_avg_ns": kt_avg,
-          "source": "profiles/run_prof_r02.sh %s -> profiles/rocprof_summary_%s_final.txt; unit check in profiles/fetch_size_calibration_r01.txt" % (tag, tag)}
+          "source": "profiles/run_prof_r03.sh %s -> profiles/rocprof_summary_%s.txt; what one L2 miss moves: profiles/line_probe_r03.*" % (tag, tag)}
     open(os.path.join(src, "traffic_%s.json" % tag), "w").write(json.dumps(tj, indent=1) + "\n")
     out.append("== traffic_%s.json" % tag)
     out.append(json.dumps(tj))

@@ -90,3 +90,39 @@ def test_product_never_references_the_oracle():
         for line in txt.splitlines():
             if "/root/reference" in line:
                 assert "isdir" in line or "make" in line or line.strip().startswith("#"), (fn, line)
+
+
+def test_bit_vector_file_whose_size_does_not_match_its_header_is_refused(ftiny_dir, tmp_path):
+    """A corrupt .bf header (the bit count the kernels take the hash modulo of) must be refused by the loader before anything is
+    sized from it -- on the host, so this needs no GPU."""
+    import shutil
+
+    from vargeno_amd._lib import VgError
+    from vargeno_amd.api import GenoIndex
+
+    for which, bits in (("snp", (1 << 64) - 5), ("snp", 0), ("ref", 1 << 40), ("snp", 1_120_000_064)):
+        d = tmp_path / ("%s_%d" % (which, bits % 1000))
+        d.mkdir()
+        for fn in ("idx.ref.dict", "idx.snp.dict", "idx.chrlens"):
+            shutil.copy(os.path.join(ftiny_dir, fn), d / fn)
+        for w in ("ref", "snp"):
+            src, dst = os.path.join(ftiny_dir, "idx.%s.bf" % w), d / ("idx.%s.bf" % w)
+            os.link(src, dst) if w != which else None
+        # a sparse copy of the right size with a wrong header
+        size = os.path.getsize(os.path.join(ftiny_dir, "idx.%s.bf" % which))
+        with open(d / ("idx.%s.bf" % which), "wb") as f:
+            f.write(int(bits).to_bytes(8, "little"))
+            f.truncate(size)
+        with pytest.raises(VgError) as e:
+            GenoIndex.open(str(d / "idx"))
+        assert e.value.code == -2 and "size does not match its header" in str(e.value), (which, bits, str(e.value))
+
+
+def test_python_binding_refuses_a_stale_library(monkeypatch):
+    """_lib.lib() compares vg_build_id() with the hash of the sources next to the library."""
+    assert _lib.lib().vg_build_id().decode() == _lib.source_build_id()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "source_build_id", lambda: "0123456789abcdef")
+    with pytest.raises(RuntimeError, match="stale"):
+        _lib.lib()
+    monkeypatch.setattr(_lib, "_lib", None)

@@ -157,3 +157,15 @@ def test_cli_long_line_in_the_middle_of_the_file_falls_back_to_host_framing(ftin
             assert "reads: %d " % (len(lines) // 4 + 2) in p.stderr, p.stderr       # the odd record counts as two
             outs.append(out.read_bytes())
         assert all(o == outs[0] for o in outs) and outs[0].count(b"\n") > 2000
+
+
+def test_an_empty_stream_on_a_used_handle_reports_nothing(ftiny_dir):
+    """vg_fastq_stream_begin resets the stream state on the ingest stream; with no push in between, vg_fastq_stream_end must
+    still see that reset (not the previous stream's record count)."""
+    prefix = os.path.join(ftiny_dir, "idx")
+    text = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read()
+    with GenoIndex.open(prefix) as gx:
+        first = gx.fastq_stream([text[:1_000_003], text[1_000_003:]])
+        assert first[0] > 0 and first[1] == len(text) and not first[3]
+        for _ in range(3):
+            assert gx.fastq_stream([]) == (0, 0, 0, False)

@@ -18,7 +18,7 @@ STAT_FIELDS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chun
 
 # every symbol include/vargeno_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = ["vg_last_error", "vg_build_id", "vg_device_count", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_create", "vg_index_close",
-           "vg_index_device_bytes", "vg_reads_submit", "vg_reads_process_device", "vg_fastq_submit", "vg_fastq_stream_begin", "vg_fastq_stream_push", "vg_fastq_stream_end", "vg_sync", "vg_stats_get",
+           "vg_index_device_bytes", "vg_index_views", "vg_reads_submit", "vg_reads_process_device", "vg_fastq_submit", "vg_fastq_stream_begin", "vg_fastq_stream_push", "vg_fastq_stream_end", "vg_sync", "vg_stats_get",
            "vg_set_stats", "vg_timing_get", "vg_num_sites", "vg_sites_fetch", "vg_counts_fetch", "vg_counts_reset",
            "vg_counts_device_ptr", "vg_counts_allreduce", "vg_counts_allreduce_devices"]
 
@@ -74,6 +74,8 @@ def lib():
         L.vg_index_close.restype = None
         L.vg_index_device_bytes.argtypes = [vp]
         L.vg_index_device_bytes.restype = C.c_uint64
+        L.vg_index_views.argtypes = [vp]
+        L.vg_index_views.restype = C.c_uint32
         L.vg_reads_submit.argtypes = [vp, vp, vp, vp, C.c_uint64]
         L.vg_reads_process_device.argtypes = [vp, vp, vp, vp, C.c_uint64]
         L.vg_fastq_submit.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -96,8 +98,34 @@ def lib():
         L.vg_counts_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.vg_counts_allreduce.argtypes = [vp, vp]
         L.vg_counts_allreduce_devices.argtypes = [C.POINTER(vp), C.c_int]
+        # The library is a build product that travels next to its sources (not in git): refuse a stale one.  Its build id is the
+        # sha256 of the sources it was compiled from (csrc/Makefile); VARGENO_HIP_LIB (A/B variants) opts out.
+        if not os.environ.get("VARGENO_HIP_LIB"):
+            want = source_build_id()
+            got = L.vg_build_id().decode()
+            if want is not None and got != want:
+                raise RuntimeError("stale %s: built from sources with id %s, the sources next to it have id %s -- rebuild with "
+                                   "`python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, got, want))
         _lib = L
     return _lib
+
+
+# the files (in this order) whose sha256 csrc/Makefile compiles into the library as vg_build_id()
+LIB_SOURCES = [os.path.join(HERE, "..", "include", "vargeno_hip.h")] + [os.path.join(HERE, "csrc", f) for f in ("vg_device.h", "vg_wave.h", "vargeno_hip.hip", "vg_sort.hip")]
+
+
+def source_build_id():
+    """Build id the library would have if compiled from the sources as they are now; None when they are not there."""
+    import hashlib
+
+    h = hashlib.sha256()
+    try:
+        for f in LIB_SOURCES:
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
 
 
 def check(rc):

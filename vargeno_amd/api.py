@@ -149,6 +149,14 @@ class GenoIndex:
     def device_bytes(self):
         return int(lib().vg_index_device_bytes(self._h))
 
+    VIEW_NAMES = {1: "sec", 2: "mx", 4: "dx", 8: "snp_probe", 16: "snp_jg32", 32: "hx"}
+
+    @property
+    def views(self):
+        """Names of the optional re-laid-out views this handle holds (vg_index_views): they change speed, never results."""
+        m = int(lib().vg_index_views(self._h))
+        return [n for b, n in sorted(self.VIEW_NAMES.items()) if m & b]
+
     def sites(self):
         n = self.num_sites
         pos = np.empty(n, np.uint32)

@@ -136,7 +136,10 @@ static uint64_t find_record_start(int fd, uint64_t from, uint64_t fsize)
 	for (uint64_t i = 0; i + 1 < got; i++) if (buf[(size_t)i] == '\n') starts.push_back(i + 1);
 	for (size_t k = 0; k + 2 < starts.size(); k++)
 		if (buf[(size_t)starts[k]] == '@' && buf[(size_t)starts[k + 2]] == '+') return base + starts[k];
-	return base + got >= fsize && starts.size() < 3 ? fsize : UINT64_MAX;
+	// the window reaches the end of the file and holds no record start: the split point fell inside the last record (its header
+	// line included) -- what is left belongs to the range before
+	if (base + got >= fsize) return fsize;
+	return UINT64_MAX;
 }
 
 // Where n replicas split the file: cut[0] = 0 <= cut[1] <= ... <= cut[n] = fsize, every inner cut a record start.  false: no
@@ -205,6 +208,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		const bool cuts_ok = range_cuts(fd, fsize, ngpu, cut);
 		if (!cuts_ok) {
 			host_from = 0;                                              // no record start found where one should be: the host reader takes the file
+			fprintf(stderr, "vargeno: no FASTQ record start within 1 MiB of a range boundary: the whole file is framed on the host (slower)\n");
 		} else {
 			std::vector<StreamResult> res((size_t)ngpu);
 			std::vector<std::thread> th;
@@ -223,6 +227,9 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 				host_from = cut[(size_t)last_range] + res[(size_t)last_range].used;    // the incomplete tail, or everything from a refused chunk on
 				next_gpu = last_range;
 			} else {
+				// (the file has been streamed once already: a 2x or larger slowdown that must not pass silently)
+				fprintf(stderr, "vargeno: a FASTQ range before the last one was refused by the device framing (a line beyond 1023 characters?): "
+				                "counters reset, the whole file is framed on the host\n");
 				for (auto *h : ix) VG_CHECK(vg_counts_reset(h));
 				host_from = 0;
 			}

@@ -360,6 +360,16 @@ __global__ void vg_fold_counters(uint32_t *__restrict__ cnt4, const uint8_t *__r
 	}
 }
 
+// MAX_COV saturation (src/vartype.h:27, qv.cc:1411, 1419) of the exact sums, on the way to the host: 2 bytes per site cross the link instead of 8
+__global__ void vg_clamp_counters(const uint32_t *__restrict__ cnt, uint64_t n_sites, uint8_t *__restrict__ ref_cnt, uint8_t *__restrict__ alt_cnt)
+{
+	for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_sites; s += (uint64_t)gridDim.x * blockDim.x) {
+		const uint2 v = ((const uint2 *)cnt)[s];
+		ref_cnt[s] = (uint8_t)(v.x < 63u ? v.x : 63u);
+		alt_cnt[s] = (uint8_t)(v.y < 63u ? v.y : 63u);
+	}
+}
+
 __global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 {
 	cum[0] += ctr[0]; cum[1] += ctr[1]; cum[2] += ctr[2]; cum[3] += ctr[3];     // wave-tier overflow, lane-tier overflow, lost, reads with a non-ACGTN character
@@ -623,6 +633,7 @@ struct vg_index {
 	Slot slot[NSLOT];
 	int next_slot = 0;
 	uint32_t *d_cum = nullptr;            // since reset: [0] wave-tier overflow, [1] lane-tier overflow, [2] lost
+	uint8_t *d_clamped = nullptr;         // [2 * n_sites] staging of vg_counts_fetch: min(63, sum), ref counts then alt counts
 	unsigned long long *d_stats = nullptr;
 	bool stats_enabled = true;
 	bool force_generic = false;           // VG_FORCE_GENERIC=1: skip the wave tier (tests compare the tiers)
@@ -1143,6 +1154,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
 	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 8, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
 	if ((rc = dev_alloc(ix, &ix->d_cum, 4, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_clamped, 2 * ix->n_sites + 2))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
 	HIP_TRY(hipStreamSynchronize(st));
@@ -1252,7 +1264,18 @@ static int read_bf(const std::string &path, uint64_t cap_bits, uint64_t &bits, s
 	FILE *f = fopen(path.c_str(), "rb");
 	if (!f) return fail(VG_EIO, "cannot open %s", path.c_str());
 	if (fread(&bits, 8, 1, f) != 1) { fclose(f); return fail(VG_EIO, "short read on %s", path.c_str()); }
-	const uint64_t nw = (std::min(bits, cap_bits) + 63) / 64;
+	// sdsl int_vector<1> (int_vector.hpp:1563-1595): u64 bit count, then ceil(bits / 64) words.  A header that does not match the
+	// file's size is a corrupt file: the kernels index the words with (hash % bits) >> 6
+	{
+		struct stat sb;
+		const uint64_t words_all = bits / 64 + (bits % 64 != 0);
+		if (fstat(fileno(f), &sb) != 0 || bits == 0 || words_all > ((uint64_t)sb.st_size - 8) / 8 || (uint64_t)sb.st_size != 8 + 8 * words_all) {
+			fclose(f);
+			return fail(VG_EIO, "%s: size does not match its header", path.c_str());
+		}
+	}
+	const uint64_t capped = std::min(bits, cap_bits);
+	const uint64_t nw = capped / 64 + (capped % 64 != 0);
 	words.resize(nw);
 	const size_t got = nw ? fread(words.data(), 8, nw, f) : 0;
 	fclose(f);
@@ -1331,6 +1354,12 @@ extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
 
 extern "C" uint64_t vg_index_device_bytes(const vg_index *ix) { return ix ? ix->dev_bytes : 0; }
 extern "C" uint64_t vg_num_sites(const vg_index *ix) { return ix ? ix->n_sites : 0; }
+extern "C" uint32_t vg_index_views(const vg_index *ix)
+{
+	if (!ix) return 0;
+	const DevIndex &d = ix->d;
+	return (d.sec_key ? VG_VIEW_SEC : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.dx ? VG_VIEW_DX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u);
+}
 
 // ------------------------------------------------------------------------------------------------
 // read batches
@@ -1354,6 +1383,9 @@ static int finish_pending(vg_index *ix)
 	HIP_TRY(hipSetDevice(ix->device));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	HIP_TRY(hipStreamSynchronize(ix->tail));
+	// (the FASTQ stream's own work -- vg_fastq_stream_begin's reset of the stream state included -- is otherwise only ordered
+	// before the batches it produced: an empty stream has none)
+	if (ix->ingest) HIP_TRY(hipStreamSynchronize(ix->ingest));
 	for (Slot &sl : ix->slot) { int rc = harvest(ix, sl); if (rc) return rc; }
 	if (ix->cnt4_dirty && ix->n_sites) {
 		vg_fold_counters<<<(unsigned)std::min<uint64_t>((ix->n_sites + 255) / 256, 4096), 256, 0, ix->stream>>>(ix->d.cnt4, ix->d.site_ba, ix->d.cnt, ix->n_sites);
@@ -1737,15 +1769,13 @@ extern "C" int vg_counts_fetch(vg_index *ix, uint8_t *ref_cnt, uint8_t *alt_cnt)
 	if (!ix || !ref_cnt || !alt_cnt) return fail(VG_EINVAL, "null argument");
 	int rc = vg_sync(ix);
 	if (rc) return rc;
-	return guarded([&] {
-		std::vector<uint32_t> h(2 * ix->n_sites);
-		if (ix->n_sites) HIP_TRY(hipMemcpy(h.data(), ix->d.cnt, h.size() * 4, hipMemcpyDeviceToHost));
-		for (uint64_t s = 0; s < ix->n_sites; s++) {       // MAX_COV saturation, src/vartype.h:27, qv.cc:1411, 1419
-			ref_cnt[s] = (uint8_t)std::min<uint32_t>(63u, h[2 * s]);
-			alt_cnt[s] = (uint8_t)std::min<uint32_t>(63u, h[2 * s + 1]);
-		}
-		return (int)VG_OK;
-	});
+	if (ix->n_sites == 0) return VG_OK;
+	vg_clamp_counters<<<(unsigned)std::min<uint64_t>((ix->n_sites + 255) / 256, 4096), 256, 0, ix->stream>>>(ix->d.cnt, ix->n_sites, ix->d_clamped, ix->d_clamped + ix->n_sites);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(ref_cnt, ix->d_clamped, ix->n_sites, hipMemcpyDeviceToHost, ix->stream));
+	HIP_TRY(hipMemcpyAsync(alt_cnt, ix->d_clamped + ix->n_sites, ix->n_sites, hipMemcpyDeviceToHost, ix->stream));
+	HIP_TRY(hipStreamSynchronize(ix->stream));
+	return VG_OK;
 }
 
 extern "C" int vg_counts_reset(vg_index *ix)

@@ -82,7 +82,7 @@ def random_bases(rng, n):
 
 def make_genome(rng, lengths, names, *, repeats_per_mbp=50.0, repeat_len=(200, 2000), repeat_div=0.03,
                 microsat_per_mbp=12.5, n_gaps=True, plant_block16=0, plant_hi24=0, plant_copy14=False,
-                plant_ac_run=False, plant_t16=0):
+                plant_ac_run=False, plant_t16=0, exact_repeat_frac=0.0):
     """i.i.d. uniform ACGT with planted structure (SURVEY.md §8c F-small / F-mid recipes).
 
     plant_block16: number of copies of one 16-mer, each preceded by 16 random bases, i.e. that many
@@ -93,6 +93,11 @@ def make_genome(rng, lengths, names, *, repeats_per_mbp=50.0, repeat_len=(200, 2
     plant_t16:     number of [16 random bases][T x 16] segments: 32-mers in the LAST ref-dict bucket
                    (HI32 = 0xFFFFFFFF) and SNP k-mers in the last SNP bucket, so the strided scan (B1)
                    runs past the end of the arrays (SURVEY.md §8a "out-of-range t").
+    exact_repeat_frac: fraction of every sequence covered by planted repeat FAMILIES whose copies are (nearly) identical --
+                   what drives the reference's auxiliary rows (2-10 occurrences of a 32-mer, dictgen.c:63-154) and
+                   POS_AMBIGUOUS (> 10): 70 % of those bases in families of 2-10 copies of 300-3000 bp (segmental-
+                   duplication-like: a third of the copies identical, the others 0.5 % or 2 % diverged), 30 % in families of
+                   11-200 copies of 250-350 bp (young-interspersed-repeat-like, 0-5 % diverged).
     """
     seqs = []
     for L in lengths:
@@ -109,6 +114,25 @@ def make_genome(rng, lengths, names, *, repeats_per_mbp=50.0, repeat_len=(200, 2
             m = rng.random(rl) < repeat_div
             seg[m] = random_bases(rng, int(m.sum()))
             s[dst:dst + rl] = seg
+        # repeat families of (nearly) identical copies
+        if exact_repeat_frac > 0:
+            for share, clo, chi, llo, lhi, divs in ((0.7, 2, 10, 300, 3000, (0.0, 0.005, 0.02)), (0.3, 11, 200, 250, 350, (0.0, 0.01, 0.05))):
+                budget = int(exact_repeat_frac * share * L)
+                while budget > 0:
+                    rl = int(rng.integers(llo, lhi + 1))
+                    copies = int(rng.integers(clo, chi + 1))
+                    if rl * 2 + 200 >= L:
+                        break
+                    unit = s[int(rng.integers(0, L - rl)):][:rl].copy()
+                    for dst in rng.integers(0, L - rl, size=copies):
+                        seg = unit
+                        dv = divs[int(rng.integers(0, len(divs)))]
+                        if dv > 0:
+                            seg = unit.copy()
+                            m = rng.random(rl) < dv
+                            seg[m] = random_bases(rng, int(m.sum()))
+                        s[int(dst):int(dst) + rl] = seg
+                    budget -= rl * copies
         # microsatellites
         for _ in range(int(round(microsat_per_mbp * mbp))):
             unit = random_bases(rng, int(rng.integers(1, 5)))
@@ -543,7 +567,7 @@ def write_quirk(d, q):
     write_fastq(os.path.join(d, "reads.fq"), q["reads"])
 
 
-def genome_and_snps(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_chroms=1, genotypes="uniform"):
+def genome_and_snps(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_chroms=1, genotypes="uniform", repeats=0.0):
     """Genome + SNP list of the bench workloads (F-mid recipe scaled by length): BASELINE.json configs[1] by default; with
     genome_len = 3.1e9, n_chroms = 24, n_snps = 1e7 the hg38-scale configs[2].  Returns (genome, snps, rng): the generator is
     left where make_reads() continues from."""
@@ -554,8 +578,9 @@ def genome_and_snps(seed=20261002, genome_len=40_000_000, n_snps=1_000_000, n_ch
         w = np.linspace(2.0, 0.6, n_chroms)
         lens = [int(x) for x in np.floor(w / w.sum() * genome_len)]
         names = ["chr%d" % (i + 1) for i in range(n_chroms)]
+    # repeats > 0: the repeat-rich stress genome (that fraction of it in families of near-identical copies, four times the microsatellites)
     g = make_genome(rng, lens, names, repeats_per_mbp=50.0, repeat_len=(200, 2000),
-                    repeat_div=0.02, microsat_per_mbp=12.5)
+                    repeat_div=0.02, microsat_per_mbp=12.5 if repeats <= 0 else 50.0, exact_repeat_frac=repeats)
     s = make_snps(rng, g, n_snps, genotypes=genotypes)
     return g, s, rng
 
