@@ -58,11 +58,12 @@ def parse_args():
     ap.add_argument("--repeats", type=float, default=0.0, help="fraction of the genome in planted exact repeats (2-10 copies and > 10 copies) -- the repeat-rich stress genome; 0 = the default genome (2 %% diverged repeats)")
     ap.add_argument("--lowq", type=float, default=0.08, help="fraction of low-quality (gate-open) characters; 0.5 = the stress profile of SURVEY.md §8d")
     ap.add_argument("--cpu-sample", type=int, default=None, help="reads timed on one host thread of the CPU oracle (0 = skip the CPU legs and the parity check)")
-    ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench"))
+    ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR"), help="where the index files go (default: $VG_BENCH_DIR, else /tmp/vg_bench, else -- when /tmp lacks the room -- /dev/shm/vg_bench)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity check against the oracle")
     ap.add_argument("--cpu-reference", choices=["auto", "yes", "no"], default="auto",
                     help="time the reference binary (oracle/_ref/vargeno) on the host, beside the GPU legs, as the cpu_baseline of record: auto = yes unless the "
                          "workload is hg38f (the reference cannot run it: int index into a > 2^31-entry SNP dictionary, qv.cc:447) or the host is short of memory")
+    ap.add_argument("--ascii-quals", action="store_true", help="hand the read loop the quality STRINGS (vg_reads_process_device) instead of one gate word per read")
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the secondary end-to-end number (FASTQ text in pinned host memory -> counters)")
     args = ap.parse_args()
@@ -70,6 +71,19 @@ def parse_args():
         if getattr(args, k) is None:
             setattr(args, k, v)
     args.cpu_sample = min(args.cpu_sample, args.reads)
+    if args.workdir is None:
+        # index files: ~16 bytes per base of the genome + ~550 bytes per SNP (hg38 + 10 M SNPs: 48 GB; + 100 M SNPs: 104 GB)
+        need = 1.25 * (16.0 * args.genome + 550.0 * args.snps)
+
+        def free(path):
+            try:
+                st = os.statvfs(path)
+                return st.f_bavail * st.f_frsize
+            except OSError:
+                return 0
+        args.workdir = "/tmp/vg_bench"
+        if not os.path.isdir(args.workdir) and free("/tmp") < need and free("/dev/shm") >= need:
+            args.workdir = "/dev/shm/vg_bench"
     return args
 
 
@@ -186,7 +200,7 @@ def measure_ingest(gx, batch, log, chunk_mb=64, reps=3):
     from vargeno_amd import synth
     from vargeno_amd.api import pinned_buffer
 
-    tb, tq, to = batch
+    tb, tq, to = batch[:3]
     n = len(to) - 1
     L = int(to[1].item())
     gx.set_stats(False)
@@ -303,7 +317,7 @@ def main():
         need_gb = 40.0 if args.genome < 10 ** 9 else 260.0
         if avail_gb >= need_gb or args.cpu_reference == "yes":
             t0 = time.time()
-            sub = synth.reads_to_host(*batches[0]).slice(0, args.cpu_sample)
+            sub = synth.reads_to_host(*batches[0][:3]).slice(0, args.cpu_sample)
             fq = os.path.join(d, "cpu_sample.fq")
             synth.write_fastq(fq, sub)
             del sub
@@ -317,8 +331,19 @@ def main():
     if rank == 0:
         log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (time.time() - t0, gx.device_bytes / 1e9, gx.num_sites))
 
-    def run(b):
-        gx.process_device(b[0], b[1], b[2], len(b[2]) - 1)
+    # The resident batches: ASCII bases + offsets + one gate word per read (bit c = quality character c < '8': all the path reads of
+    # a quality string, qv.cc:836, 943; vg_reads_process_device_gated -- the form the device-side FASTQ framing hands the read loop too).
+    # --ascii-quals hands over the quality strings themselves instead (vg_reads_process_device); both forms are timed, see below.
+    from vargeno_amd.api import gate_words
+
+    batches = [tuple(b) + (gate_words(b[1], b[2]),) for b in batches]
+    torch.cuda.synchronize(dev)
+
+    def run(b, strings=args.ascii_quals):
+        if strings:
+            gx.process_device(b[0], b[1], b[2], len(b[2]) - 1)
+        else:
+            gx.process_device_gated(b[0], b[3], b[2], len(b[2]) - 1)
 
     # ---- one counted pass over batch 0: event counts -> algorithmic bytes; parity against the oracle ------------------------
     gx.set_stats(True)
@@ -333,7 +358,7 @@ def main():
         t0 = time.time()
         ox = O.OracleIndex.load(prefix)
         log("[bench] oracle index load: %.1fs" % (time.time() - t0))
-        r0 = synth.reads_to_host(*batches[0])
+        r0 = synth.reads_to_host(*batches[0][:3])
         ncores = os.cpu_count() or 1
         nt = min(ncores, 64)
         # every host core first: the whole batch, which is also what the parity check compares
@@ -454,6 +479,22 @@ def main():
         if rank == 0:
             verification["timed_region_increments"] = total_after
 
+    # ---- the other input form, for the record (N = 1): the same K steps with the quality strings handed over (or, under --ascii-quals, the gate words)
+    other_form = None
+    if rank == 0 and world == 1:
+        gx.reset()
+        for i in range(min(args.warmup, 2)):
+            run(batches[i % args.batches], strings=not args.ascii_quals)
+        gx.sync()
+        gx.timing()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            run(batches[i % args.batches], strings=not args.ascii_quals)
+        gx.counts()
+        dt = time.perf_counter() - t0
+        tm2 = gx.timing()
+        other_form = {"input": "quality strings (vg_reads_process_device)" if not args.ascii_quals else "gate words (vg_reads_process_device_gated)",
+                      "value": args.reads * args.steps / dt, "unit": "reads/s", "ms_per_step": 1e3 * dt / args.steps, "pack_ms": tm2["ms_pack"], "wave_ms": tm2["ms_main"]}
     if rank == 0 and ref_timer is not None:
         # the reference's own binary is the baseline of record; the port (oracle) stays beside it
         t0 = time.time()
@@ -523,6 +564,8 @@ def main():
             "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "spill_tiers_overlapped": tm["ms_tail"], "of_which_deep_list_wave_tier": tm["ms_deep_lists"], "batches": tm["batches"]},
             "reads_per_step_redone_by_deep_list_tier": st["overflow_reads"], "reads_per_step_sent_on_to_lane_tier": st["overflow_deep"],
             "events_per_read": {k: st[k] / args.reads for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
+            "input_form": "ASCII bases + offsets + " + ("quality strings" if args.ascii_quals else "one gate word per read (bit c = quality character c < '8')") + ", resident in HBM",
+            "other_input_form": other_form,
             "ingest_end_to_end": ingest,
             "multi_gpu_verification": verification,
         }

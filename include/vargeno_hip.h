@@ -112,6 +112,15 @@ int  vg_reads_submit(vg_index *ix, const uint8_t *bases, const uint8_t *quals,
 int  vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals,
                              const uint64_t *d_offsets, uint64_t n_reads);
 
+/* The same batch with the quality strings reduced to what the path reads of them: ONE GATE WORD per read, bit c set iff quality
+ * character c of the read is below '8' -- the only question qv.cc:836, 943 asks, with c the CHUNK number (a read of at most
+ * 1022 bases has at most 31 chunks).  The reference's loop never looks at the other characters; handing the strings over makes
+ * the device fetch every line of them for four characters per 150 bp read, as much traffic again as the bases.  This is the form
+ * the device-side FASTQ framing (vg_fastq_stream_push) produces for itself, and what bench.py's resident batches use.
+ * A read of more than 32 chunks (1055 bases: no FASTQ line the reference can read holds one) is counted in reads_invalid. */
+int  vg_reads_process_device_gated(vg_index *ix, const uint8_t *d_bases, const uint32_t *d_gate_words,
+                                   const uint64_t *d_offsets, uint64_t n_reads);
+
 /* Same again, starting from raw FASTQ text (host memory): replaces the four fgets() + strlen of qv.cc:760-784.
  *
  * Stream form -- the caller only moves bytes.  vg_fastq_stream_push takes the next chunk of the file, cut anywhere; the device

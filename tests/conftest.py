@@ -118,3 +118,22 @@ def read_sha256_list(name):
             h, fn = line.split()
             out[fn] = h
     return out
+
+
+def bench_dir(need_gb=0):
+    """Directory for index files shared with bench.py (built once per box): $VG_BENCH_DIR, else /tmp/vg_bench -- unless it
+    lacks the room a big index needs (hg38 + full dbSNP: ~110 GB of files) and /dev/shm (memory-backed) has it."""
+    d = os.environ.get("VG_BENCH_DIR")
+    if d:
+        return d
+    d = "/tmp/vg_bench"
+    if need_gb:
+        def free_gb(path):
+            try:
+                st = os.statvfs(path)
+                return st.f_bavail * st.f_frsize / 1e9
+            except OSError:
+                return 0.0
+        if free_gb("/tmp") < need_gb and free_gb("/dev/shm") >= need_gb:
+            d = "/dev/shm/vg_bench"
+    return d

@@ -54,3 +54,45 @@ def test_two_rank_shard_and_reduce_equals_one_rank(ftiny_dir, tmp_path):
     s = ox.sites()
     assert np.array_equal(got[:, 0], s["ref_cnt"]) and np.array_equal(got[:, 1], s["alt_cnt"])
     assert got.max() == 63                          # saturation really happened somewhere
+
+
+def test_shard_arithmetic_at_eight_ranks_with_fewer_items_than_ranks():
+    """The target is 8 GPUs: contiguous shards must tile [0, n) exactly for every n, including n < 8 (empty shards)."""
+    from vargeno_amd.api import shard_range
+
+    for n in (0, 1, 5, 7, 8, 9, 63, 64, 65, 1_000_003):
+        cuts = [shard_range(n, r, 8) for r in range(8)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:]))
+        sizes = [hi - lo for lo, hi in cuts]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 0
+
+
+def test_cli_range_cuts_at_eight_replicas(tmp_path):
+    """`vargeno fqcuts <fastq> <n>` prints the byte offsets at which n replicas split a FASTQ file (every inner cut a record
+    start, a line beginning with '@' whose next-but-one line begins with '+'): 8 ranges over files with more, as many and
+    fewer records than ranges, quality lines that begin with '@', and a split point inside the last record."""
+    import subprocess
+
+    from conftest import BIN
+
+    def cuts_of(text, n):
+        f = tmp_path / "x.fq"
+        f.write_bytes(text)
+        out = subprocess.run([BIN, "fqcuts", str(f), str(n)], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        return [int(x) for x in out.stdout.split()]
+
+    rec = lambda i, q=b"I": b"@r%d\n" % i + b"ACGT" * 10 + b"\n+\n" + q * 40 + b"\n"
+    for nrec in (100, 8, 3, 1, 0):
+        text = b"".join(rec(i, b"@" if i % 3 == 0 else b"I") for i in range(nrec))
+        c = cuts_of(text, 8)
+        assert len(c) == 9 and c[0] == 0 and c[-1] == len(text) and c == sorted(c)
+        starts = {0, len(text)}
+        off = 0
+        for i in range(nrec):
+            starts.add(off)
+            off += len(rec(i, b"@" if i % 3 == 0 else b"I"))
+        assert all(x in starts for x in c), (nrec, c)
+        if nrec >= 16:
+            assert len(set(c)) == 9                                # every replica got a range

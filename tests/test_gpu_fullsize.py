@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import BIN, ROOT
+from conftest import BIN, ROOT, bench_dir
 from oracle import oracle as O
 from vargeno_amd import synth
 from vargeno_amd.api import GenoIndex
@@ -130,6 +130,81 @@ def test_hg38_sample_against_oracle_and_linearity_at_full_batch(hg38):
         assert whole.sum() > n // 4                                  # ~0.34 increments per read: one SNP per 310 bp here
         gx.reset()
         cuts = [0, 1, 3_000_001, 3_000_002, 7_654_321, n]
+        for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
+            c0, c1 = int(to[lo].item()), int(to[hi].item())
+            gx.process_device(tb[c0:c1], tq[c0:c1], (to[lo:hi + 1] - to[lo]).contiguous(), hi - lo)
+            gx.sync()
+        assert np.array_equal(_raw(gx), whole)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, np.minimum(whole[0::2], 63)) and np.array_equal(ac, np.minimum(whole[1::2], 63))
+
+
+# ---- BASELINE.json configs[4]: the index of hg38 + full dbSNP (3.1 Gbp, ~100 M SNPs: 3.2 G SNP k-mers, 6.1 G k-mers in the two
+#      dictionaries together -- too many for the merged view's 32-bit indices), one replica ------------------------------------------
+
+@pytest.fixture(scope="module")
+def hg38f():
+    """~104 GB of index files (about three minutes of host work), shared with `bench.py --workload hg38f` through the work
+    directory; ~245 GB of HBM once open."""
+    d = bench_dir(need_gb=130) + "/g3100000000_s100000000_c24"
+    g, s, _ = synth.genome_and_snps(genome_len=3_100_000_000, n_snps=100_000_000, n_chroms=24, genotypes="hwe")
+    if not os.path.exists(d + "/idx.done"):
+        os.makedirs(d, exist_ok=True)
+        synth.write_fasta(d + "/ref.fa", g)
+        synth.write_vcf(d + "/snps.vcf", g, s)
+        subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+        open(d + "/idx.done", "w").close()
+    dev = torch.device("cuda", 0)
+    src = synth.DeviceReadSource(g, s, dev)
+    del g, s
+    big = src.batch(4243, 2_000_000)
+    src.release()
+    del src
+    torch.cuda.empty_cache()
+    yield d, big
+    if d.startswith("/dev/shm/"):                                   # memory-backed: give the 104 GB back
+        import shutil
+
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_hg38f_sample_against_oracle_and_linearity(hg38f):
+    """configs[4]'s layout at its own size: vg_wave_kernel_big (no merged view / direct table), ~190-entry HI24 buckets in the
+    SNP dictionary (iterate_snp_dict, qv.cc:413-464, whose `int i` overflows on this dictionary in the reference itself, :447 --
+    so parity here is against the oracle).  60 000 reads against the oracle: all site counters for both builds of the kernel,
+    all event counters; then 2 M reads in uneven shards against the whole."""
+    d, (tb, tq, to) = hg38f
+    prefix = d + "/idx"
+    n = len(to) - 1
+    lo_s, hi_s = 500_000, 560_000
+    sample = synth.reads_to_host(tb, tq, to, lo_s, hi_s)
+    ox = O.OracleIndex.load(prefix)
+    ox.process(sample.bases, sample.quals, sample.offsets, nthreads=min(32, os.cpu_count() or 1))
+    so, want = ox.sites(), ox.stats.as_dict()
+    ox.close()
+    assert want["scan_snp"] > 100 * want["gate_open"]                # the dense-bucket regime: > 100 SNP-bucket entries per gate-open chunk
+    with GenoIndex.open(prefix) as gx:
+        assert "mx" not in gx.views and "dx" not in gx.views         # 2^32 or more k-mers: the layout of vg_wave_kernel_big
+        assert gx.num_sites > 90_000_000
+        b0, b1 = int(to[lo_s].item()), int(to[hi_s].item())
+        so_dev = (to[lo_s:hi_s + 1] - to[lo_s]).contiguous()
+        for stats in (True, False):                                  # counting build, then the timed build
+            gx.reset()
+            gx.set_stats(stats)
+            gx.process_device(tb[b0:b1], tq[b0:b1], so_dev, hi_s - lo_s)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), "stats=%s" % stats
+            if stats:
+                st = gx.stats()
+                for k, v in want.items():
+                    assert st[k] == v, k
+        gx.reset()
+        gx.set_stats(False)
+        gx.process_device(tb, tq, to, n)
+        whole = _raw(gx)
+        assert whole.sum() > 2 * n                                   # ~3.3 increments per read: one SNP per 31 bp
+        gx.reset()
+        cuts = [0, 1, 700_001, 700_002, 1_654_321, n]
         for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):
             c0, c1 = int(to[lo].item()), int(to[hi].item())
             gx.process_device(tb[c0:c1], tq[c0:c1], (to[lo:hi + 1] - to[lo]).contiguous(), hi - lo)

@@ -192,3 +192,37 @@ def test_allreduce_with_the_callers_own_communicator(ftiny_dir, ftiny_reads):
         assert torch.equal(gx.counts_tensor(), before)
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+# ---- rehearsal of the target's rank count on whatever the box has -------------------------------------------------------------------
+# Eight replicas of an index fit one 288 GB device once the optional views are off (what stays is the 16 GiB jump table of the
+# reference dictionary + scratch, ~20 GB per replica): the 8-way shard arithmetic, rank 0's index build with the others waiting
+# for its marker, eight vg_index_open of the same files at once and the CLI's eight-range cut of the FASTQ file all run.
+# With 8 GPUs visible the same tests take RCCL (one rank / replica per device) without a change.
+LEAN = {"VG_NO_MX": "1", "VG_NO_SNP_JG32": "1", "VG_NO_SEC": "1", "VG_NO_PROBE_VIEW": "1"}
+
+
+def test_bench_with_eight_ranks(tmp_path):
+    backend = "nccl" if torch.cuda.device_count() >= 8 else "gloo"
+    env = dict(os.environ, VG_BENCH_BACKEND=backend, VG_BENCH_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", **LEAN)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "chr22", "--genome", "3000000", "--snps", "30000",
+                        "--reads", "20000", "--batches", "2", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--no-gather-probe"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-4000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 3
+    v = line["multi_gpu_verification"]
+    assert v["sharded_equals_single_rank"] and v["increments"] > 0 and v["timed_region_increments"] > 0
+    assert line["value"] > 0
+
+
+def test_cli_with_eight_replicas_gives_the_golden_vcf(ftiny_dir, tmp_path):
+    """Eight contiguous record-aligned ranges of the FASTQ file, one per replica, all streamed at once; one all-reduce."""
+    env = dict(os.environ, VARGENO_GPUS="8", VARGENO_SHARE_DEVICES="1", VARGENO_CHUNK_MB="1", **LEAN)
+    p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), os.path.join(ftiny_dir, "reads.fq"), os.path.join(ftiny_dir, "snps.vcf"), str(tmp_path / "out.vcf")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr
+    assert "framed on the host" not in p.stderr, p.stderr            # the eight ranges went through the device-side framing
+    assert open(tmp_path / "out.vcf", "rb").read() == gzip.open(os.path.join(GOLDEN, "ftiny.out.vcf.gz"), "rb").read()

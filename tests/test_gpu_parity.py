@@ -75,7 +75,7 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
         assert tm["ms_main"] > 0 and tm["batches"] == 1
 
 
-@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_MX+VG_NO_SNP_JG32", "VG_NO_MX+VG_NO_SEC+VG_NO_PROBE_VIEW", "VG_NO_SEC", "VG_PACK_OVERLAP",
+@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_MX+VG_NO_HX", "VG_NO_MX+VG_NO_SNP_JG32", "VG_NO_MX+VG_NO_SEC+VG_NO_PROBE_VIEW", "VG_NO_SEC", "VG_PACK_OVERLAP",
                                   "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW"])
 def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
     """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view, strided-probe
@@ -217,6 +217,33 @@ def test_fsmall_full_parity_through_all_tiers(tmp_path):
             assert st[k] == want[k], k
         assert st["overflow_reads"] > 0 and st["large_block"] > 0 and st["scan_oob"] > 0
         print("fsmall tiers: spilled %d of %d reads, %d to the lane tier" % (st["overflow_reads"], r.n, st["overflow_deep"]))
+        # the same batch with its quality strings reduced to one gate word per read (vg_reads_process_device_gated): reads of
+        # 31-250 bases, 40 % gate-open chunks, every tier -- both builds of the kernel
+        import torch
+        from vargeno_amd.api import gate_words
+
+        dev = torch.device("cuda", 0)
+        tb, tq = torch.from_numpy(r.bases).to(dev), torch.from_numpy(r.quals).to(dev)
+        to = torch.from_numpy(r.offsets.astype(np.int64)).to(dev)
+        gw = gate_words(tq, to)
+        lens = (r.offsets[1:] - r.offsets[:-1]).astype(np.int64)
+        o = r.offsets.astype(np.int64)
+        expect = np.zeros(r.n, np.int64)
+        for c in range(int(lens.max()) // 32):
+            live = lens // 32 > c
+            expect[live] |= (r.quals[o[:-1][live] + c] < ord("8")).astype(np.int64) << c
+        assert np.array_equal(gw.cpu().numpy().view(np.uint32).astype(np.int64), expect)
+        del tq
+        for stats in (True, False):
+            gx.reset()
+            gx.set_stats(stats)
+            gx.process_device_gated(tb, gw, to, r.n)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), "gate words, stats=%s" % stats
+            if stats:
+                st = gx.stats()
+                for k in CMP_STATS:
+                    assert st[k] == want[k], k
 
 
 def test_dense_snp_buckets_parity_all_layouts(tmp_path, monkeypatch):
@@ -242,11 +269,13 @@ def test_dense_snp_buckets_parity_all_layouts(tmp_path, monkeypatch):
     want = ox.stats.as_dict()
     assert want["scan_snp"] > 100 * want["gate_open"]
     rows = []
-    for label, env in (("all views", {}), ("no merged view (the > 2^32-entry fallback)", {"VG_NO_MX": "1"}),
-                       ("no merged view, no HI32 jump table of the SNP dictionary", {"VG_NO_MX": "1", "VG_NO_SNP_JG32": "1"})):
+    for label, env, views in (("all views", {}, ("mx", "dx")), ("no merged view (the > 2^32-entry fallback): paired HI32 table", {"VG_NO_MX": "1"}, ("hx",)),
+                              ("no merged view, HI32 jump tables instead of the paired table", {"VG_NO_MX": "1", "VG_NO_HX": "1"}, ("snp_jg32",)),
+                              ("no merged view, no HI32 table of the SNP dictionary at all", {"VG_NO_MX": "1", "VG_NO_HX": "1", "VG_NO_SNP_JG32": "1"}, ())):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with GenoIndex.open(prefix) as gx:
+            assert all(v in gx.views for v in views) and ("mx" in gx.views) == ("mx" in views), (label, gx.views)
             gx.submit(r.bases, r.quals, r.offsets)                   # counting build
             rc, ac = gx.counts()
             st = gx.stats()

@@ -18,7 +18,7 @@ STAT_FIELDS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chun
 
 # every symbol include/vargeno_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = ["vg_last_error", "vg_build_id", "vg_device_count", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_create", "vg_index_close",
-           "vg_index_device_bytes", "vg_index_views", "vg_reads_submit", "vg_reads_process_device", "vg_fastq_submit", "vg_fastq_stream_begin", "vg_fastq_stream_push", "vg_fastq_stream_end", "vg_sync", "vg_stats_get",
+           "vg_index_device_bytes", "vg_index_views", "vg_reads_submit", "vg_reads_process_device", "vg_reads_process_device_gated", "vg_fastq_submit", "vg_fastq_stream_begin", "vg_fastq_stream_push", "vg_fastq_stream_end", "vg_sync", "vg_stats_get",
            "vg_set_stats", "vg_timing_get", "vg_num_sites", "vg_sites_fetch", "vg_counts_fetch", "vg_counts_reset",
            "vg_counts_device_ptr", "vg_counts_allreduce", "vg_counts_allreduce_devices"]
 
@@ -78,6 +78,7 @@ def lib():
         L.vg_index_views.restype = C.c_uint32
         L.vg_reads_submit.argtypes = [vp, vp, vp, vp, C.c_uint64]
         L.vg_reads_process_device.argtypes = [vp, vp, vp, vp, C.c_uint64]
+        L.vg_reads_process_device_gated.argtypes = [vp, vp, vp, vp, C.c_uint64]
         L.vg_fastq_submit.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.vg_fastq_stream_begin.argtypes = [vp]
         L.vg_fastq_stream_push.argtypes = [vp, vp, C.c_uint64]

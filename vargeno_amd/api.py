@@ -124,6 +124,12 @@ class GenoIndex:
         check(lib().vg_reads_process_device(self._h, C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_quals.data_ptr()),
                                             C.c_void_p(d_offsets.data_ptr()), int(n_reads)))
 
+    def process_device_gated(self, d_bases, d_gate_words, d_offsets, n_reads):
+        """Device-resident batch whose quality strings are reduced to one gate word per read (int32/uint32 tensor; bit c = quality
+        character c < '8', see gate_words())."""
+        check(lib().vg_reads_process_device_gated(self._h, C.c_void_p(d_bases.data_ptr()), C.c_void_p(d_gate_words.data_ptr()),
+                                                  C.c_void_p(d_offsets.data_ptr()), int(n_reads)))
+
     def sync(self):
         check(lib().vg_sync(self._h))
 
@@ -259,3 +265,19 @@ def shard_range(n_items, rank, world):
     base, rem = divmod(int(n_items), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gate_words(d_quals, d_offsets):
+    """Gate words of a device-resident batch (torch tensors: uint8 quality characters, int64 offsets[n+1]): bit c of word r is set
+    iff quality character c of read r is below '8' (qv.cc:836, 943), for the read's chunk numbers c < len // 32."""
+    import torch
+
+    off = d_offsets.to(torch.int64)
+    n_chunks = ((off[1:] - off[:-1]) >> 5).clamp(max=32)
+    out = torch.zeros(len(off) - 1, dtype=torch.int64, device=d_quals.device)
+    for c in range(int(n_chunks.max().item()) if len(n_chunks) else 0):
+        live = n_chunks > c
+        idx = torch.where(live, off[:-1] + c, torch.zeros_like(off[:-1]))
+        low = (d_quals[idx].to(torch.int16) < 56) & live
+        out |= low.to(torch.int64) << c
+    return out.to(torch.int32) if out.numel() == 0 else (out & 0xFFFFFFFF).to(torch.int64).view(torch.int32)[::2].contiguous()

@@ -211,6 +211,33 @@ __global__ void vg_make_snp_probe(const uint64_t *__restrict__ kmer, const uint3
 		out[i] = t < n ? (kmer[t] & LO40_MASK) : 0ull;
 	}
 }
+// paired HI32 table (DevIndex::hx) in two passes, so that only one 16 GiB jump table is alive at a time: the reference side
+// writes whole records, the SNP side completes them.  A filter is computed over at most 64 entries; a longer bucket gets the
+// mask that lets everything through.
+__global__ void vg_hx_fill_ref(const uint32_t *__restrict__ jg, const RefEnt *__restrict__ ref, uint4 *__restrict__ hx)
+{
+	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h <= (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t lo = jg[h], hi = h < (1ull << 32) ? jg[h + 1] : lo, cnt = hi - lo;
+		uint32_t f = 0;
+		if (cnt == 1u) f = hx_fp16(ref[lo].lo);
+		else if (cnt > 64u) f = 0xFFFFu;
+		else for (uint32_t e = lo; e < hi; e++) f |= hx_bit(ref[e].lo);
+		hx[h] = make_uint4(lo, 0u, cnt < 0xFFFFu ? cnt : 0xFFFFu, f);
+	}
+}
+__global__ void vg_hx_fill_snp(const uint32_t *__restrict__ jg, const uint64_t *__restrict__ kmer, uint4 *__restrict__ hx)
+{
+	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h <= (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t lo = jg[h], hi = h < (1ull << 32) ? jg[h + 1] : lo, cnt = hi - lo;
+		uint32_t f = 0;
+		if (cnt == 1u) f = hx_fp16((uint32_t)kmer[lo]);
+		else if (cnt > 64u) f = 0xFFFFu;
+		else for (uint32_t e = lo; e < hi; e++) f |= hx_bit((uint32_t)kmer[e]);
+		uint4 r = hx[h];
+		r.y = lo; r.z |= (cnt < 0xFFFFu ? cnt : 0xFFFFu) << 16; r.w |= f << 16;
+		hx[h] = r;
+	}
+}
 __global__ void vg_iota_u32(uint32_t *v, uint64_t n) { for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i; }
 
 // SoA as the dictionary file has it -> one 16-byte entry per k-mer (a hit then costs one line)
@@ -285,8 +312,11 @@ constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bas
 #endif
 __global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_WPE))) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
                                                       uint64_t n_reads_arg, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta, uint32_t *__restrict__ invalid_reads,
-                                                      const uint32_t *__restrict__ n_reads_dev)
+                                                      const uint32_t *__restrict__ n_reads_dev, const uint32_t *__restrict__ gate)
 {
+	// gate != nullptr: the batch comes with one gate word per read (bit c = quality character c < '8') instead of quality strings --
+	// the kernel then streams the bases only.  (With strings it fetches one line per read for the <= 4 characters a 150 bp read's
+	// gate can see: at a 150-byte stride that is every line of the quality array, as much traffic again as the bases.)
 	__shared__ __attribute__((aligned(16))) uint8_t sm[PACK_LDS + 64];
 	const uint64_t n_reads = n_reads_dev ? (uint64_t)*n_reads_dev : n_reads_arg;     // a batch framed on the device knows its size there
 	for (uint64_t r0 = (uint64_t)blockIdx.x * PACK_T; r0 < n_reads; r0 += (uint64_t)gridDim.x * PACK_T) {
@@ -299,7 +329,8 @@ __global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_
 		const uint64_t base0 = __shfl(off, 0), span = __shfl(off1, (int)last) - base0;
 		const uint32_t n = (uint32_t)((off1 - off) >> 5);
 		uint32_t q4 = 0;
-		if (n) __builtin_memcpy(&q4, quals + off, 4);                 // 4 <= n + 3 <= the read's own length: never past it
+		if (gate) { if (r < n_reads) q4 = gate[r]; }
+		else if (n) __builtin_memcpy(&q4, quals + off, 4);            // 4 <= n + 3 <= the read's own length: never past it
 		const bool staged = span <= PACK_LDS;
 		__syncthreads();                                              // previous tile fully consumed
 		if (staged) {
@@ -314,7 +345,6 @@ __global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_
 		}
 		__syncthreads();
 		if (r < n_reads) {
-			const uint8_t *q = quals + off;
 			uint64_t meta = 0, bad = 0;
 			if (staged) {
 				const uint8_t *p = sm + (off - base0);
@@ -334,13 +364,14 @@ __global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_
 				for (uint32_t c = 0; c < n; c++) pk_kmer[(off >> 5) + c] = encode32(bases + off + 32 * c, bad);
 			}
 			// quality gate bits (qv.cc:836): character c of the quality line, four characters per gather (the first four are in hand)
-			for (uint32_t c0 = 0; c0 < n && c0 < 32; c0 += 4) {
-				if (c0) __builtin_memcpy(&q4, q + c0, 4);                 // c0 + 4 <= n + 3 <= the read's own length
+			if (gate) meta = n >= 32 ? q4 : (q4 & ((1u << n) - 1u));
+			else for (uint32_t c0 = 0; c0 < n && c0 < 32; c0 += 4) {
+				if (c0) __builtin_memcpy(&q4, quals + off + c0, 4);       // c0 + 4 <= n + 3 <= the read's own length
 				for (uint32_t j = 0; j < 4 && c0 + j < n && c0 + j < 32; j++) if ((int)(int8_t)(q4 >> (8 * j)) - '8' < 0) meta |= 1ull << (c0 + j);
 			}
 			if (bad) meta |= classify_bad(bases + off, n) == 1 ? PK_SKIP_N : PK_INVALID;
+			if (n > 32) meta |= gate ? PK_INVALID : PK_LONG;            // (a gate word has 32 bits; the reference's line buffer admits 31 chunks)
 			if (meta & PK_INVALID) atomicAdd(invalid_reads, 1u);       // the reference aborts on such a read (util.c:103): the caller is told
-			if (n > 32) meta |= PK_LONG;
 			pk_meta[r] = meta;
 		}
 	}
@@ -381,7 +412,8 @@ __global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 template <bool STATS>
 __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
                                                       const uint64_t *__restrict__ offsets, uint64_t n_reads_arg, const uint32_t *__restrict__ read_ids,
-                                                      const uint32_t *__restrict__ n_ids, uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats, uint32_t *invalid_reads)
+                                                      const uint32_t *__restrict__ n_ids, uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats, uint32_t *invalid_reads,
+                                                      const uint32_t *__restrict__ gate)
 {
 	const uint64_t n_reads = n_ids ? (uint64_t)*n_ids : n_reads_arg;          // a list launch (or a device-framed batch) is sized on the device: no host round trip
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,7 +430,10 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 		const uint64_t off = offsets[rid];
 		const uint32_t n = (uint32_t)((offsets[rid + 1] - off) >> 5);            // src/qv.cc:778-779: len = (read_len/32)*32
 		const uint8_t *p = bases + off;
-		const uint8_t *q = quals + off;
+		// src/qv.cc:836, 943: the chunk NUMBER indexes the quality string (which is NOT reversed for the second pass, qv.cc:786-806);
+		// a batch may bring the comparison's results as one word per read instead of the strings (a read has at most 31 chunks)
+		const uint32_t gw = gate ? gate[rid] : 0u;
+		auto gate_open = [&](uint32_t c) -> bool { return gate ? ((gw >> (c & 31u)) & 1u) != 0u : (int)(int8_t)quals[off + c] - '8' < 0; };
 		if constexpr (STATS) { for (int i = 0; i < S_COUNT; i++) L.st.v[i] = 0; }
 		L.st.add(S_READS, 1);
 		L.st.add(S_INGEST, 9 * n);
@@ -416,7 +451,7 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 			for (uint32_t c = 0; c < n && !L.overflow; c++) {
 				uint64_t b2 = 0;
 				const uint64_t k = encode32(p + 32 * c, b2);
-				L.do_chunk(k, c, (int)(int8_t)q[c] - '8' < 0);                    // src/qv.cc:836, 943: chunk NUMBER indexes the quality string
+				L.do_chunk(k, c, gate_open(c));
 			}
 			if (!L.overflow) ok = L.finish_pass();
 			if (!L.overflow && !ok) {
@@ -424,7 +459,7 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 				for (uint32_t c = 0; c < n && !L.overflow; c++) {
 					uint64_t b2 = 0;
 					const uint64_t k = revcomp64(encode32(p + 32 * (n - 1 - c), b2));
-					L.do_chunk(k, c, (int)(int8_t)q[c] - '8' < 0);                // quality string is NOT reversed (qv.cc:786-806)
+					L.do_chunk(k, c, gate_open(c));
 				}
 				if (!L.overflow) (void)L.finish_pass();
 			}
@@ -569,8 +604,10 @@ __global__ void vg_fqs_finish(FqStream *__restrict__ st, FqChunk *__restrict__ c
 
 // gather bases and quality characters of every record into the flat batch layout; a quality line shorter than the
 // read keeps what the reference's buffer would hold there: its newline, then NULs (qv.cc:763, 836)
+// The quality line is looked at here and nowhere else: all the path ever asks of it is whether character c is below '8' for the
+// read's chunk numbers c (qv.cc:836, 943), so the batch carries one GATE WORD per read (bit c) instead of the strings.
 __global__ __launch_bounds__(256) void vg_fq_gather(const uint8_t *__restrict__ text, const uint32_t *__restrict__ line_start, const uint64_t *__restrict__ offsets,
-                                                    const FqChunk *__restrict__ ck, uint8_t *__restrict__ bases, uint8_t *__restrict__ quals)
+                                                    const FqChunk *__restrict__ ck, uint8_t *__restrict__ bases, uint32_t *__restrict__ gate)
 {
 	const uint64_t n_rec = ck->n_reads;
 	const uint32_t lane = threadIdx.x & 63;
@@ -579,10 +616,14 @@ __global__ __launch_bounds__(256) void vg_fq_gather(const uint8_t *__restrict__ 
 		const uint64_t o = offsets[r], len = offsets[r + 1] - o;
 		const uint32_t s1 = line_start[4 * r + 1], s3 = line_start[4 * r + 3];
 		const uint32_t qlen = line_start[4 * r + 4] - s3;                       // quality line incl. its newline
-		for (uint64_t j = lane; j < len; j += 64) {
-			bases[o + j] = text[s1 + j];
-			quals[o + j] = j < qlen ? text[s3 + j] : (uint8_t)0;
-		}
+		for (uint64_t j = lane; j < len; j += 64) bases[o + j] = text[s1 + j];
+		// (a record is only framed here when its quality line has a character for every chunk, vg_fq_record_lengths; a lane past
+		// the line reads what the reference's buffer would hold there: its newline, then NULs)
+		const uint32_t n = (uint32_t)(len >> 5);
+		bool open = false;
+		if (lane < n && lane < 32u) { const uint8_t q = lane < qlen ? text[s3 + lane] : (uint8_t)0; open = (int)(int8_t)q - '8' < 0; }
+		const uint64_t m = __ballot(open);
+		if (lane == 0) gate[r] = (uint32_t)m;
 	}
 }
 
@@ -602,13 +643,14 @@ struct Slot {
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
+	uint32_t *st_gate = nullptr; uint64_t st_gate_cap = 0;                              // gate words of a batch framed on the device
 	uint8_t *fq_text = nullptr; uint32_t *fq_lines = nullptr, *fq_tiles = nullptr; uint64_t fq_text_cap = 0, fq_lines_cap = 0, fq_tiles_cap = 0;   // FASTQ framing
 	void *fq_tmp = nullptr; uint64_t fq_tmp_cap = 0;                 // scan scratch (grow-only: no allocation per chunk)
 	FqChunk *fq_chunk = nullptr;                                     // this chunk's framing results, device resident
 	uint64_t fq_text_len = 0;                                        // bytes of text copied into fq_text (after the FQ_CARRY gap)
 	hipEvent_t e_in = nullptr;                                       // the batch's buffers are complete (when another stream produced them)
 	hipEvent_t e_fq = nullptr; bool fq_tail_wanted = false;          // the NEXT chunk's prepare kernel reads this text's tail: recorded after it
-	uint64_t stage_bytes = 0, stage_reads = 0;
+	uint64_t stage_bytes = 0, stage_quals_bytes = 0, stage_reads = 0;      // capacities of st_bases, st_quals, st_offsets
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
 	bool busy = false;
 };
@@ -712,7 +754,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (ix->ingest) (void)hipStreamSynchronize(ix->ingest);
 	for (void *p : ix->owned) (void)hipFree(p);
 	for (Slot &sl : ix->slot) {
-		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
+		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_gate, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
 		for (void *p : extra) if (p) (void)hipFree(p);
 		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5, sl.e_fq, sl.e_in};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -968,6 +1010,59 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			return fail(VG_EIO, "not an index `vargeno index` wrote: %s", msg);
 		}
 	}
+	// The merged view's indices are 32 bits wide: an index of 2^32 or more k-mers (hg38 + full dbSNP), or VG_NO_MX, runs on the
+	// layout without it -- and, its own peak being the tighter one (the paired HI32 table), with another order of construction:
+	// pile-up sites first, columns released as soon as their last reader is done.
+	const bool want_mx = !getenv("VG_NO_MX") && c.n_ref + c.n_snp < (1ull << 32);
+	auto build_sites = [&]() -> int {
+		// ---- pile-up sites (src/qv.cc:602-603, 637-659)
+		{
+			const uint64_t plen = maxp + 64, nblk = plen / 64 + 1;
+			TempDev<uint32_t> winner; TempDev<uint64_t> blk; TempDev<uint8_t> tmp;
+			if ((rc = winner.alloc(plen)) || (rc = blk.alloc(nblk + 1))) return rc;
+			HIP_TRY(hipMemsetAsync(winner.p, 0, plen * 4, st));
+			uint8_t *dp = nullptr; ulonglong2 *dr = nullptr;
+			if ((rc = dev_alloc(ix, &dp, plen))) return rc;
+			if ((rc = dev_alloc(ix, &dr, nblk))) return rc;
+			if (c.n_snp) vg_site_winner<<<2048, 256, 0, st>>>(c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.n_snp, winner.p);
+			vg_site_blocks<<<ix->cus * 16, 256, 0, st>>>(winner.p, c.snp_kmer.p, c.snp_info.p, plen, dp, dr, blk.p);
+			HIP_TRY(hipMemsetAsync(blk.p + nblk, 0, 8, st));
+			HIP_TRY(hipGetLastError());
+			{
+				const size_t need = vg_dev_scan_temp_bytes(1, nblk + 1);
+				if ((rc = tmp.alloc(need))) return rc;
+				const int se = vg_dev_exclusive_scan_u64(blk.p, blk.p, nblk + 1, st, tmp.p, need);
+				if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
+			}
+			HIP_TRY(hipStreamSynchronize(st));
+			uint64_t nsites = 0;
+			HIP_TRY(hipMemcpy(&nsites, blk.p + nblk, 8, hipMemcpyDeviceToHost));
+			if (nsites >= (1ull << 31)) return fail(VG_ETOOBIG, "more than 2^31 SNP sites");
+			ix->n_sites = nsites;
+			TempDev<uint32_t> s_pos; TempDev<uint8_t> s_ref, s_alt, s_rf, s_af;
+			uint8_t *dba = nullptr;
+			if ((rc = s_pos.alloc(nsites)) || (rc = s_ref.alloc(nsites)) || (rc = s_alt.alloc(nsites)) || (rc = s_rf.alloc(nsites)) || (rc = s_af.alloc(nsites))) return rc;
+			if ((rc = dev_alloc(ix, &dba, nsites + 1, true))) return rc;
+			vg_site_tables<<<ix->cus * 16, 256, 0, st>>>(winner.p, dp, c.snp_rf.p, c.snp_af.p, plen, dr, blk.p, s_pos.p, s_ref.p, s_alt.p, s_rf.p, s_af.p, dba);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(st));
+			ix->site_pos.resize(nsites); ix->site_ref.resize(nsites); ix->site_alt.resize(nsites); ix->site_rf.resize(nsites); ix->site_af.resize(nsites);
+			if (nsites) {
+				HIP_TRY(hipMemcpy(ix->site_pos.data(), s_pos.p, nsites * 4, hipMemcpyDeviceToHost));
+				HIP_TRY(hipMemcpy(ix->site_ref.data(), s_ref.p, nsites, hipMemcpyDeviceToHost));
+				HIP_TRY(hipMemcpy(ix->site_alt.data(), s_alt.p, nsites, hipMemcpyDeviceToHost));
+				HIP_TRY(hipMemcpy(ix->site_rf.data(), s_rf.p, nsites, hipMemcpyDeviceToHost));
+				HIP_TRY(hipMemcpy(ix->site_af.data(), s_af.p, nsites, hipMemcpyDeviceToHost));
+			}
+			uint32_t *dc = nullptr, *dc4 = nullptr;
+			if ((rc = dev_alloc(ix, &dc, 2 * nsites + 2, true))) return rc;
+			if ((rc = dev_alloc(ix, &dc4, 4 * nsites + 4, true))) return rc;
+			d.srank = dr; d.pile = dp; d.pile_len = plen; d.cnt = dc; d.site_ba = dba; d.cnt4 = dc4;
+			c.snp_rf.release(); c.snp_af.release();
+		}
+		return VG_OK;
+	};
+	if (!want_mx) { if ((rc = build_sites())) return rc; pc.lap("pile-up sites"); }
 	// ---- reference dictionary: jump table + 16-byte entries
 	{
 		uint32_t *jg = nullptr; RefEnt *ent = nullptr;
@@ -1001,9 +1096,36 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	}
 	// the merged view is the last user of the reference dictionary's columns: without it (2^32 or more k-mers in the two
 	// dictionaries together -- hg38 + full dbSNP --, or VG_NO_MX) they go now, 37 GB at hg38 scale
-	const bool want_mx = !getenv("VG_NO_MX") && c.n_ref + c.n_snp < (1ull << 32);
 	if (!want_mx) { c.ref_kmer.release(); c.ref_pos.release(); c.ref_amb.release(); }
 	pc.lap("reference dictionary + LO32-ordered view");
+	// ---- paired HI32 table in place of the two HI32 jump tables (an index without merged view): built in two passes so that only
+	// one 16 GiB jump table is alive next to it; without the room (or with VG_NO_HX) the jump tables stay
+	uint4 *hx = nullptr;
+	if (!want_mx && !getenv("VG_NO_HX") && !getenv("VG_NO_SNP_JG32")) {
+		size_t free_b = 0, total_b = 0;
+		const uint64_t later = (c.n_snp + 1) * 16ull + (getenv("VG_NO_PROBE_VIEW") ? 0ull : (c.n_snp + 1) * 8ull) + (6ull << 30);     // SNP entries + probe view + scratch, still to come
+		const uint64_t hx_bytes = ((1ull << 32) + 1) * 16ull;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b + ((1ull << 32) + 1) * 4ull > hx_bytes + later && hipMalloc((void **)&hx, hx_bytes) == hipSuccess) {
+			uint32_t *rjg = const_cast<uint32_t *>(d.ref_jg);
+			vg_hx_fill_ref<<<ix->cus * 32, 256, 0, st>>>(rjg, d.ref, hx);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(st));
+			for (size_t z = 0; z < ix->owned.size(); z++) if (ix->owned[z] == (void *)rjg) { ix->owned.erase(ix->owned.begin() + (long)z); break; }
+			(void)hipFree(rjg); ix->dev_bytes -= ((1ull << 32) + 1) * 4;
+			d.ref_jg = nullptr;
+			TempDev<uint32_t> j32;
+			if ((rc = j32.alloc((1ull << 32) + 1))) { (void)hipFree(hx); return rc; }
+			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, j32.p, 1ull << 32, 32);
+			vg_hx_fill_snp<<<ix->cus * 32, 256, 0, st>>>(j32.p, c.snp_kmer.p, hx);
+			if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(hx); return fail(VG_ENODEV, "building the paired HI32 table failed"); }
+			ix->owned.push_back(hx); ix->dev_bytes += hx_bytes;
+			d.hx = hx;
+		} else {
+			(void)hipGetLastError();
+			hx = nullptr;
+		}
+		pc.lap("paired HI32 table");
+	}
 	// ---- SNP dictionary
 	{
 		uint32_t *jg = nullptr; SnpEnt *ent = nullptr;
@@ -1014,6 +1136,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(st));
 		d.snp_jg = jg; d.snp = ent;
+		if (!want_mx) { c.snp_pos.release(); c.snp_info.release(); c.snp_amb.release(); }     // (the sites are built: the entries were their last reader)
 		if (!getenv("VG_NO_PROBE_VIEW")) {
 			uint64_t *pv = nullptr;
 			if ((rc = dev_alloc(ix, &pv, c.n_snp + 1))) return rc;
@@ -1024,7 +1147,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		}
 		// an index too large for the merged view gets a HI32 jump table of the SNP dictionary instead (17 GB): its HI24 buckets hold
 		// ~190 entries there, 8 dependent bisection probes per look-up
-		if (!want_mx && !getenv("VG_NO_SNP_JG32")) {
+		if (!want_mx && !d.hx && !getenv("VG_NO_SNP_JG32")) {
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (40ull << 30)) {
 				uint32_t *j32 = nullptr;
@@ -1035,6 +1158,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 				d.snp_jg32 = j32;
 			}
 		}
+		if (!want_mx) c.snp_kmer.release();                        // its last readers (probe view, HI32 tables) are done
 		// merged exact-match view (both dictionaries behind one HI32 jump table); its indices are 32 bits wide
 		const uint64_t nm = c.n_ref + c.n_snp;
 		if (want_mx) {
@@ -1100,50 +1224,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		if ((rc = dev_upload(ix, &s2, snp_bf_words, (snp_bf_bits + 63) / 64))) return rc;
 		d.ref_bf = r; d.ref_bf_bits = ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = snp_bf_bits;
 	}
-	// ---- pile-up sites (src/qv.cc:602-603, 637-659)
-	{
-		const uint64_t plen = maxp + 64, nblk = plen / 64 + 1;
-		TempDev<uint32_t> winner; TempDev<uint64_t> blk; TempDev<uint8_t> tmp;
-		if ((rc = winner.alloc(plen)) || (rc = blk.alloc(nblk + 1))) return rc;
-		HIP_TRY(hipMemsetAsync(winner.p, 0, plen * 4, st));
-		uint8_t *dp = nullptr; ulonglong2 *dr = nullptr;
-		if ((rc = dev_alloc(ix, &dp, plen))) return rc;
-		if ((rc = dev_alloc(ix, &dr, nblk))) return rc;
-		if (c.n_snp) vg_site_winner<<<2048, 256, 0, st>>>(c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.n_snp, winner.p);
-		vg_site_blocks<<<ix->cus * 16, 256, 0, st>>>(winner.p, c.snp_kmer.p, c.snp_info.p, plen, dp, dr, blk.p);
-		HIP_TRY(hipMemsetAsync(blk.p + nblk, 0, 8, st));
-		HIP_TRY(hipGetLastError());
-		{
-			const size_t need = vg_dev_scan_temp_bytes(1, nblk + 1);
-			if ((rc = tmp.alloc(need))) return rc;
-			const int se = vg_dev_exclusive_scan_u64(blk.p, blk.p, nblk + 1, st, tmp.p, need);
-			if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
-		}
-		HIP_TRY(hipStreamSynchronize(st));
-		uint64_t nsites = 0;
-		HIP_TRY(hipMemcpy(&nsites, blk.p + nblk, 8, hipMemcpyDeviceToHost));
-		if (nsites >= (1ull << 31)) return fail(VG_ETOOBIG, "more than 2^31 SNP sites");
-		ix->n_sites = nsites;
-		TempDev<uint32_t> s_pos; TempDev<uint8_t> s_ref, s_alt, s_rf, s_af;
-		uint8_t *dba = nullptr;
-		if ((rc = s_pos.alloc(nsites)) || (rc = s_ref.alloc(nsites)) || (rc = s_alt.alloc(nsites)) || (rc = s_rf.alloc(nsites)) || (rc = s_af.alloc(nsites))) return rc;
-		if ((rc = dev_alloc(ix, &dba, nsites + 1, true))) return rc;
-		vg_site_tables<<<ix->cus * 16, 256, 0, st>>>(winner.p, dp, c.snp_rf.p, c.snp_af.p, plen, dr, blk.p, s_pos.p, s_ref.p, s_alt.p, s_rf.p, s_af.p, dba);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(st));
-		ix->site_pos.resize(nsites); ix->site_ref.resize(nsites); ix->site_alt.resize(nsites); ix->site_rf.resize(nsites); ix->site_af.resize(nsites);
-		if (nsites) {
-			HIP_TRY(hipMemcpy(ix->site_pos.data(), s_pos.p, nsites * 4, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(ix->site_ref.data(), s_ref.p, nsites, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(ix->site_alt.data(), s_alt.p, nsites, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(ix->site_rf.data(), s_rf.p, nsites, hipMemcpyDeviceToHost));
-			HIP_TRY(hipMemcpy(ix->site_af.data(), s_af.p, nsites, hipMemcpyDeviceToHost));
-		}
-		uint32_t *dc = nullptr, *dc4 = nullptr;
-		if ((rc = dev_alloc(ix, &dc, 2 * nsites + 2, true))) return rc;
-		if ((rc = dev_alloc(ix, &dc4, 4 * nsites + 4, true))) return rc;
-		d.srank = dr; d.pile = dp; d.pile_len = plen; d.cnt = dc; d.site_ba = dba; d.cnt4 = dc4;
-	}
+	if (want_mx && (rc = build_sites())) return rc;
 	pc.lap("bit vectors, pile-up sites");
 	// ---- scratch of the lane tier, overflow counters, stats
 	// VG_SCRATCH_CAP / VG_SCRATCH_KCAP shrink the per-lane scratch so tests can drive every tier
@@ -1358,7 +1439,7 @@ extern "C" uint32_t vg_index_views(const vg_index *ix)
 {
 	if (!ix) return 0;
 	const DevIndex &d = ix->d;
-	return (d.sec_key ? VG_VIEW_SEC : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.dx ? VG_VIEW_DX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u);
+	return (d.sec_key ? VG_VIEW_SEC : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.dx ? VG_VIEW_DX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u) | (d.hx ? VG_VIEW_HX : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1403,7 +1484,7 @@ static int finish_pending(vg_index *ix)
 // on the tail stream; the list launches size themselves from device counters, so nothing waits for the host.
 // n_reads: the batch's size, or (d_n_reads given) an upper bound of the size the device holds at d_n_reads
 template <bool STATS>
-static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on, const uint32_t *d_n_reads)
+static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint32_t *d_gate, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on, const uint32_t *d_n_reads)
 {
 	uint32_t *ctr = sl.ctr;
 	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
@@ -1420,7 +1501,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T - 1) / PACK_T, (uint64_t)ix->cus * pack_bpc * (256 / PACK_T));
-		vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads);
+		vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate);
 		HIP_TRY(hipEventRecord(sl.e1, ps));
 		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
@@ -1450,13 +1531,13 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
-		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, &ctr[3]);
+		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, &ctr[3], d_gate);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	}
 	// ... then the generic lane machine with the deep HBM scratch for whatever is left
-	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr);
+	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate);
 	vg_accumulate_counters<<<1, 1, 0, ix->tail>>>(ctr, ix->d_cum);
 	HIP_TRY(hipEventRecord(sl.e3, ix->tail));
 	HIP_TRY(hipGetLastError());
@@ -1477,7 +1558,7 @@ static int acquire_slot(vg_index *ix, Slot **out)
 // produced_on: the stream whose earlier work fills the batch buffers (nullptr: they are complete already).
 // d_n_reads: the batch was framed on the device and only the device knows its size; n_reads and total_bases are then upper bounds.
 static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on = nullptr,
-                        const uint32_t *d_n_reads = nullptr, uint64_t total_bases = 0)
+                        const uint32_t *d_n_reads = nullptr, uint64_t total_bases = 0, const uint32_t *d_gate = nullptr)
 {
 	if (n_reads >= (1ull << 32) - (1ull << 24)) return fail(VG_EINVAL, "more than 2^32 - 2^24 reads in one batch");
 	// packed-read buffers are sized from the batch's total length (8 bytes from the device; the handle's streams are
@@ -1496,8 +1577,8 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));
 		sl.list_cap = n_reads;
 	}
-	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_offsets, n_reads, produced_on, d_n_reads)
-	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_offsets, n_reads, produced_on, d_n_reads);
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads)
+	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads);
 }
 
 extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
@@ -1509,6 +1590,17 @@ extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, con
 	int rc = acquire_slot(ix, &sl);
 	if (rc) return rc;
 	return launch_batch(ix, *sl, d_bases, d_quals, d_offsets, n_reads);
+}
+
+extern "C" int vg_reads_process_device_gated(vg_index *ix, const uint8_t *d_bases, const uint32_t *d_gate_words, const uint64_t *d_offsets, uint64_t n_reads)
+{
+	if (!ix || ((!d_offsets || !d_gate_words) && n_reads)) return fail(VG_EINVAL, "null argument");
+	if (n_reads == 0) return VG_OK;
+	HIP_TRY(hipSetDevice(ix->device));
+	Slot *sl = nullptr;
+	int rc = acquire_slot(ix, &sl);
+	if (rc) return rc;
+	return launch_batch(ix, *sl, d_bases, nullptr, d_offsets, n_reads, nullptr, nullptr, 0, d_gate_words);
 }
 
 static int submit_impl(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads);
@@ -1533,11 +1625,15 @@ static int submit_impl(vg_index *ix, const uint8_t *bases, const uint8_t *quals,
 	Slot &sl = *slp;
 	if (total + 64 > sl.stage_bytes) {
 		if (sl.st_bases) (void)hipFree(sl.st_bases);
-		if (sl.st_quals) (void)hipFree(sl.st_quals);
-		sl.st_bases = sl.st_quals = nullptr; sl.stage_bytes = 0;
+		sl.st_bases = nullptr; sl.stage_bytes = 0;
 		HIP_TRY(hipMalloc((void **)&sl.st_bases, total + 64));
-		HIP_TRY(hipMalloc((void **)&sl.st_quals, total + 64));
 		sl.stage_bytes = total + 64;
+	}
+	if (total + 64 > sl.stage_quals_bytes) {
+		if (sl.st_quals) (void)hipFree(sl.st_quals);
+		sl.st_quals = nullptr; sl.stage_quals_bytes = 0;
+		HIP_TRY(hipMalloc((void **)&sl.st_quals, total + 64));
+		sl.stage_quals_bytes = total + 64;
 	}
 	if (n_reads + 1 > sl.stage_reads) {
 		if (sl.st_offsets) (void)hipFree(sl.st_offsets);
@@ -1610,14 +1706,13 @@ extern "C" int vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t 
 		HIP_TRY(hipMalloc((void **)&sl.st_offsets, (cap_rec + 2) * 8));
 		sl.stage_reads = cap_rec + 2;
 	}
-	if (span + 64 > sl.stage_bytes) {                               // bases and quality characters of a chunk are each shorter than its text
+	if (span + 64 > sl.stage_bytes) {                               // the bases of a chunk are shorter than its text
 		if (sl.st_bases) (void)hipFree(sl.st_bases);
-		if (sl.st_quals) (void)hipFree(sl.st_quals);
-		sl.st_bases = sl.st_quals = nullptr; sl.stage_bytes = 0;
+		sl.st_bases = nullptr; sl.stage_bytes = 0;
 		HIP_TRY(hipMalloc((void **)&sl.st_bases, span + 64));
-		HIP_TRY(hipMalloc((void **)&sl.st_quals, span + 64));
 		sl.stage_bytes = span + 64;
 	}
+	if ((rc = grow_dev(&sl.st_gate, sl.st_gate_cap, cap_rec + 2))) return rc;
 	{
 		uint8_t *tmp = (uint8_t *)sl.fq_tmp;
 		const uint64_t need = vg_dev_scan_temp_bytes(n_tiles + 1, cap_rec + 1);
@@ -1642,10 +1737,10 @@ extern "C" int vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t 
 	se = vg_dev_exclusive_scan_u64(sl.st_offsets, sl.st_offsets, cap_rec + 1, is, sl.fq_tmp, sl.fq_tmp_cap);
 	if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
 	vg_fqs_finish<<<1, 1, 0, is>>>(ix->d_fq, sl.fq_chunk, d_n_lines, sl.fq_lines, sl.st_offsets, (uint32_t)cap_rec);
-	vg_fq_gather<<<(unsigned)std::min<uint64_t>((cap_rec + 3) / 4, (uint64_t)ix->cus * 32), 256, 0, is>>>(sl.fq_text, sl.fq_lines, sl.st_offsets, sl.fq_chunk, sl.st_bases, sl.st_quals);
+	vg_fq_gather<<<(unsigned)std::min<uint64_t>((cap_rec + 3) / 4, (uint64_t)ix->cus * 32), 256, 0, is>>>(sl.fq_text, sl.fq_lines, sl.st_offsets, sl.fq_chunk, sl.st_bases, sl.st_gate);
 	HIP_TRY(hipGetLastError());
 	ix->fq_prev_slot = slot_no;
-	return launch_batch(ix, sl, sl.st_bases, sl.st_quals, sl.st_offsets, cap_rec, is, &sl.fq_chunk->n_reads, span);
+	return launch_batch(ix, sl, sl.st_bases, nullptr, sl.st_offsets, cap_rec, is, &sl.fq_chunk->n_reads, span, sl.st_gate);
 }
 
 static int fq_collect(vg_index *ix, bool drain, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start, int *refused)

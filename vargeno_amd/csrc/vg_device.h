@@ -66,6 +66,14 @@ struct DevIndex {
 	// reference's bsearch would be 8 dependent probes; a HI32 bucket holds one or two.  Same entries found: the dictionary is
 	// sorted by the whole k-mer, so a HI32 bucket is a contiguous piece of its HI24 bucket.
 	const uint32_t *snp_jg32;
+	// paired HI32 table (an index too large for the merged view): ONE 16-byte record per HI32 value in place of the two jump tables
+	// ref_jg / snp_jg32 -- {first reference entry, first SNP entry, reference count | SNP count << 16, reference filter | SNP
+	// filter << 16}; record 2^32 is the sentinel {n_ref, n_snp, 0, 0}.  Counts saturate at 0xFFFF (then the next record's start is
+	// the bucket's end).  A filter says which low halves a bucket can hold, so that a look-up of a k-mer the dictionary does not
+	// have -- every look-up of a reverse-strand read's forward pass, the SNP side of nearly every look-up, nearly every neighbour
+	// query -- ends at this record instead of fetching a bucket entry to find that out: 16-bit fingerprint of the only entry
+	// (count 1), 16-bit presence mask over a 4-bit hash of the entries (count > 1).  ref_jg == snp_jg32 == nullptr when hx is built.
+	const uint4 *hx;
 	// bit vectors (src/generate_bf.h:112-142)
 	const uint64_t *ref_bf; uint64_t ref_bf_bits;
 	const uint64_t *snp_bf; uint64_t snp_bf_bits;
@@ -164,11 +172,31 @@ template <typename T, int ALIGN = alignof(T)> __device__ __forceinline__ T gathe
 template <typename T> __device__ __forceinline__ T gather_bf(const T *p) { return load_policy<VG_NT_BF != 0, T, alignof(T)>(p); }                           // bit vectors
 template <typename T> __device__ __forceinline__ T gather_walk(const T *p) { return load_policy<VG_NT_WALK != 0, T, alignof(T)>(p); }                       // rank blocks
 
+// filters of the paired HI32 table (DevIndex::hx), over the low 32 bits of a k-mer
+__device__ __host__ inline uint32_t hx_fp16(uint32_t lo) { return (lo ^ (lo >> 16)) & 0xFFFFu; }
+__device__ __host__ inline uint32_t hx_bit(uint32_t lo) { return 1u << ((lo * 0x9E3779B1u) >> 28); }
+// can a bucket with `cnt` entries and filter word `f` hold low half `lo`?  (never a false "no")
+__device__ inline bool hx_may_hold(uint32_t cnt, uint32_t f, uint32_t lo)
+{
+	return cnt > 1u ? (f & hx_bit(lo)) != 0u : (cnt == 1u && f == hx_fp16(lo));
+}
+
 // bucket bounds: one 8-byte gather (two adjacent jump-table words)
 __device__ inline void jg_pair(const uint32_t *jg, uint64_t h, uint32_t &lo, uint32_t &hi)
 {
 	const uint64_t v = gather<uint64_t, 4>(jg + h);
 	lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+}
+
+// bounds of the HI32 bucket of the reference dictionary, from whichever table the index has
+__device__ inline void ref_bounds(const DevIndex &d, uint64_t h, uint32_t &lo, uint32_t &hi)
+{
+	if (d.hx) {
+		const uint4 r = gather<uint4>(d.hx + h);
+		const uint32_t c = r.z & 0xFFFFu;
+		lo = r.x;
+		hi = c == 0xFFFFu ? gather<uint32_t>(&d.hx[h + 1].x) : lo + c;
+	} else jg_pair(d.ref_jg, h, lo, hi);
 }
 
 // columns [j0, j0 + 4) of an auxiliary-table row (AUX_COLS = 10 positions, rows 8-byte aligned) as two independent 8-byte
@@ -188,7 +216,7 @@ __device__ inline void load_row4(const uint32_t *row, int j0, uint32_t (&v)[4])
 template <class ST>
 __device__ inline int64_t ref_query(const DevIndex &d, ST &st, uint64_t k, uint32_t &lo, uint32_t &hi, RefEnt &ent)
 {
-	jg_pair(d.ref_jg, k >> 32, lo, hi);
+	ref_bounds(d, k >> 32, lo, hi);
 	st.add(S_REF_QUERY, 1);
 	if (lo == hi) return -1;                          // also covers lo == n_ref (then hi == n_ref)
 	st.add(S_REF_PROBE, ceil_log2_p1(hi - lo));
@@ -234,6 +262,17 @@ __device__ inline int64_t snp_query(const DevIndex &d, ST &st, uint64_t k, uint3
 	return snp_query(d, st, k, lo, hi, e);
 }
 
+// both HI32 buckets of k-mer k from the paired table, already narrowed by its filters: an empty range = "cannot be there"
+__device__ inline void hx_bounds(const DevIndex &d, uint64_t k, bool want_r, bool want_s, uint32_t &ra, uint32_t &rb, uint32_t &sa, uint32_t &sb)
+{
+	const uint64_t h = k >> 32;
+	const uint4 r = gather<uint4>(d.hx + h);
+	const uint32_t rc = r.z & 0xFFFFu, sc = r.z >> 16, lo = (uint32_t)k;
+	ra = rb = sa = sb = 0;
+	if (want_r && hx_may_hold(rc, r.w & 0xFFFFu, lo)) { ra = r.x; rb = rc == 0xFFFFu ? gather<uint32_t>(&d.hx[h + 1].x) : r.x + rc; }
+	if (want_s && hx_may_hold(sc, r.w >> 16, lo)) { sa = r.y; sb = sc == 0xFFFFu ? gather<uint32_t>(&d.hx[h + 1].y) : r.y + sc; }
+}
+
 // Both dictionary queries of one neighbour k-mer in lock step: the two jump-table gathers go out together and so do the two
 // probes of every bisection step, so the pair costs 1 + max(depth) waits instead of 2 + the sum.  Same results and the same
 // event counts as ref_query + snp_query.  ri / si are left untouched on a miss.
@@ -241,11 +280,16 @@ template <class ST>
 __device__ inline void dual_query(const DevIndex &d, ST &st, uint64_t k, bool want_r, bool want_s, uint32_t &ri, uint32_t &si)
 {
 	uint32_t ra = 0, rb = 0, sa = 0, sb = 0;
-	if (want_r) { jg_pair(d.ref_jg, k >> 32, ra, rb); st.add(S_REF_QUERY, 1); }
-	if (want_s) {
-		// (the counting build prices the walk through the HI24 table; the HI32 table, when the index has one, bounds the same entries)
-		if (!ST::counting && d.snp_jg32) jg_pair(d.snp_jg32, k >> 32, sa, sb); else jg_pair(d.snp_jg, k >> 40, sa, sb);
-		st.add(S_SNP_QUERY, 1);
+	if (!ST::counting && d.hx) {
+		// paired HI32 table: both buckets in one record, and a bucket that cannot hold the k-mer is not looked at
+		hx_bounds(d, k, want_r, want_s, ra, rb, sa, sb);
+	} else {
+		if (want_r) { ref_bounds(d, k >> 32, ra, rb); st.add(S_REF_QUERY, 1); }
+		if (want_s) {
+			// (the counting build prices the walk through the HI24 table; the HI32 table, when the index has one, bounds the same entries)
+			if (!ST::counting && d.snp_jg32) jg_pair(d.snp_jg32, k >> 32, sa, sb); else jg_pair(d.snp_jg, k >> 40, sa, sb);
+			st.add(S_SNP_QUERY, 1);
+		}
 	}
 	if (ra < rb) st.add(S_REF_PROBE, ceil_log2_p1(rb - ra));
 	if (sa < sb) st.add(S_SNP_PROBE, ceil_log2_p1(sb - sa));
@@ -274,6 +318,7 @@ __device__ inline void exact_pair_nomx(const DevIndex &d, const uint64_t (&k)[2]
 	for (int z = 0; z < 2; z++) {
 		rhit[z] = shit[z] = false;
 		if (!want[z]) continue;
+		if (d.hx) { hx_bounds(d, k[z], true, true, ra[z], rb[z], sa[z], sb[z]); continue; }
 		jg_pair(d.ref_jg, k[z] >> 32, ra[z], rb[z]);
 		if (d.snp_jg32) jg_pair(d.snp_jg32, k[z] >> 32, sa[z], sb[z]); else jg_pair(d.snp_jg, k[z] >> 40, sa[z], sb[z]);
 	}

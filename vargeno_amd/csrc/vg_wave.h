@@ -511,7 +511,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						const uint64_t k = o_pass ? revcomp64(kf) : kf;
 						const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
 						uint32_t lo, hi, slo, shi, b0 = 0, b1 = 0, fl = 0;
-						jg_pair(d.ref_jg, k >> 32, lo, hi);                      // check_block_size, qv.cc:242-264
+						ref_bounds(d, k >> 32, lo, hi);                          // check_block_size, qv.cc:242-264
 						jg_pair(d.snp_jg, k >> 40, slo, shi);
 						if (use_sec) jg_pair(d.sec_jg, klo >> (32 - d.sec_bits), b0, b1);
 						const uint64_t rp = (uint64_t)hash32(klo) % d.ref_bf_bits;   // qv.cc:946-956
