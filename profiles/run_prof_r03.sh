@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profiling recipe for the DEFAULT bench (hg38-scale, BASELINE.json configs[2]); run on the MI355X box from the repo
+# Round-3 profiling recipe for the DEFAULT bench (hg38-scale, BASELINE.json configs[2]); run on the MI355X box from the repo
 # root: `bash profiles/run_prof_r03.sh [tag] [bench args...]`.  Kernel-trace/--stats and each --pmc group are separate rocprofv3 runs of the
 # SAME bench.py command (program directly after `--`).  Raw output -> gpurun_out/prof_<tag>/ (scratch);
 # profiles/summarize_prof.py condenses it into summary_<tag>.txt / traffic_<tag>.json, which are copied into profiles/.
@@ -15,6 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $CMD > $OUT/k
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- $CMD > $OUT/pmc_l2.json 2> $OUT/pmc_l2.err
+rocprofv3 --pmc TCC_EA0_RDREQ_128B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_DRAM_32B --output-format csv -d $OUT/pmc_ea -- $CMD > $OUT/pmc_ea.json 2> $OUT/pmc_ea.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
 python3 $R/profiles/summarize_prof.py $OUT $TAG > /dev/null
 # per-stage cycle shares and list-overflow reasons (development build with -DVG_STAGE_CLOCKS, if it came along)

@@ -42,15 +42,20 @@ struct DevIndex {
 	// merged exact-match view: the reference and SNP dictionaries sorted together by k-mer (reference entry first on
 	// ties) behind ONE jump table over HI32, so the two exact look-ups of a chunk (qv.cc:840-841) cost one
 	// jump-table gather + at most one bucket line instead of two of each.  mx entry: {lo32, pos, flags, pos2} with
-	// flags bit 0 = SNP-dictionary entry, bit 1 = ambig_flag, bit 2 = PAIR (set once the direct table exists: the k-mer's
-	// auxiliary row holds exactly two positions and they are pos, pos2 -- no row gather in stage A).
-	const uint32_t *mx_jg;         // [2^32 + 1]   (dropped when the direct table below could be allocated)
+	// flags bit 0 = SNP-dictionary entry, bit 1 = ambig_flag, bit 2 = PAIR (the k-mer's auxiliary row holds exactly two
+	// positions and they are pos, pos2 -- no row gather in stage A).  Construction material of the group table below, and
+	// what the kernel reads when that table could not be allocated.
+	const uint32_t *mx_jg;         // [2^32 + 1]   (both released once the group table exists)
 	const uint4 *mx;               // [n_ref + n_snp]
-	// direct table over HI32: one 16-byte record per bucket = the bucket's FIRST merged entry inline {lo32, pos, flags,
-	// index of that entry in mx}, flags bit 0 = bucket non-empty, bit 1 = SNP entry, bit 2 = ambig_flag, bit 4 = TIE (the second
-	// entry has the same k-mer), bit 3 = PAIR (single-
-	// entry buckets only: then the last word is the second position), bits 8.. = entries in the bucket.  A bucket with one entry -- the common case -- is settled, hit or miss, by ONE gather.  64 GiB.
-	const uint4 *dx;
+	// group table over HI29 (64 GiB): one 128-byte line -- what an L2 miss moves -- per group of eight HI32 buckets, holding EVERY
+	// merged entry of the group: header {x: eight 4-bit slot counts, cumulative (bits 4j..4j+3 = slots used by buckets 0..j), y | z
+	// bits 0-11: 3 bits per slot (SNP entry, ambiguous, continuation), z bit 31: overflow, w: -} + 14 slots {low half, position}.  An
+	// ambiguous k-mer whose auxiliary row holds exactly two positions takes two slots (the second flagged "continuation"); other
+	// ambiguous k-mers keep their row index.  A group that needs more than 14 slots (low-complexity HI29) is flagged overflow:
+	// x = number of entries, w = index of the first in gx_ovf ({low half, position, flags 1 SNP 2 ambiguous 4 PAIR | bucket << 8,
+	// second position}, sorted).  With the table in place the merged view itself is released (51 GB at hg38 scale).
+	const uint4 *gx;
+	const uint4 *gx_ovf;
 	// SNP dictionary (src/qv.cc:606-695)
 	const uint32_t *snp_jg;        // [2^24 + 1]
 	const SnpEnt   *snp;           // [n_snp]
@@ -61,6 +66,13 @@ struct DevIndex {
 	// (0 where that index lies beyond the array) -- exactly the values iterate_snp_dict's scan (bug B1, qv.cc:447-455) tests for a
 	// bucket, laid side by side: at hg38 scale a bucket holds ~19 entries, i.e. 19 lines 176 bytes apart become 3 adjacent ones.
 	const uint64_t *snp_probe;     // [n_snp] (timed build only; nullptr: the probes read `snp` itself)
+	// signature form of the same view (the default): snp_sig[i] = the 40 bits of snp_probe[i] folded to 16 (sig16 below).  Two 40-bit
+	// values that differ in exactly one base have signatures that differ in exactly one base (the fold is linear and keeps a base's
+	// two bits together), so the signatures say which entries of a bucket the strided scan can possibly keep -- 24 of 65 536 patterns
+	// pass by chance -- and only those have their full value fetched (entry slo + 11 (i - slo) of `snp` itself).  2 bytes per entry
+	// where the probe view holds 8: the ~190-entry buckets of hg38 + full dbSNP are 3 lines instead of 12, and one 16-byte load
+	// covers eight entries of the scan.
+	const uint16_t *snp_sig;       // [n_snp + 16]
 	// jump table of the SNP dictionary over HI32 (2^32 + 1 words, like ref_jg): built only for an index too large for the merged view
 	// (2^32 or more k-mers in the two dictionaries together: hg38 + full dbSNP), where a HI24 bucket holds ~190 entries and the
 	// reference's bsearch would be 8 dependent probes; a HI32 bucket holds one or two.  Same entries found: the dictionary is
@@ -114,6 +126,11 @@ __device__ inline uint32_t hash32(uint32_t x) { x = ((x >> 16) ^ x) * 0x45d9f3bu
 __device__ inline uint64_t hash40(uint64_t x) { x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull; x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; return x ^ (x >> 31); }
 
 __device__ inline uint32_t ceil_log2_p1(uint32_t b) { return 32u - (uint32_t)__clz((int)b); }   // ceil(log2(b+1)) for b >= 1
+
+// 40 bits -> 16, linear over xor, bases stay whole (bit pairs map to bit pairs)
+__device__ __host__ inline uint32_t sig16(uint64_t lo40) { return (uint32_t)((lo40 ^ (lo40 >> 16) ^ (lo40 >> 32)) & 0xFFFFull); }
+// is x (16 bits) non-zero and confined to one base?
+__device__ inline bool onebase16(uint32_t x) { return x != 0u && (x & ~(3u << ((uint32_t)(__ffs((int)x) - 1) & ~1u))) == 0u; }
 
 // one_hamming_distance_32/64 (src/qv.cc:267-312): x != 0 and confined to one base -> base index, else -1
 __device__ inline int onebase(uint64_t x)

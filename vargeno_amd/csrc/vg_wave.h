@@ -135,14 +135,19 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	// The secondary (LO32-ordered) view answers the 48 high-half reference queries with one bucket read.  The counting
 	// build keeps the 48 individual queries because the event counters price each of them.
 	const bool use_sec = !STATS && d.sec_key != nullptr;
-	const bool use_mx = !STATS && !NOMX && d.mx != nullptr;
-	const bool use_probe = !STATS && d.snp_probe != nullptr;
-	// two SNP-scan probes per stage-B item, in the main tier only: an item with two hits sends its read to the next tier, and the
-	// deep-list tier must be able to finish such a read itself (the lane tier behind it takes milliseconds per read)
-	const bool probe2 = use_probe && WPB > 1;
-	const uint32_t lane = threadIdx.x & 63u;             // lane in the wave
-	const uint32_t col = threadIdx.x;                    // this lane's LDS column
+	const bool use_mx = !STATS && !NOMX && (d.gx != nullptr || d.mx != nullptr);
+	const bool use_sig = !STATS && d.snp_sig != nullptr;
+	const bool use_probe = !STATS && !use_sig && d.snp_probe != nullptr;
+	// eight entries of the SNP bucket (their signatures) per stage-B item, in the main tier only: an item with two candidates sends
+	// its read to the next tier, and the deep-list tier must be able to finish such a read itself (the lane tier behind it takes
+	// milliseconds per read)
+	const uint32_t sw_log = WPB > 1 && use_sig ? 3u : 0u;                             // log2 of the entries per item (wave-uniform)
+	const uint32_t sw_m1 = (1u << sw_log) - 1u;
 	const uint32_t col0 = wv << 6;                       // first column of this wave (scalar)
+	// lane in the wave / this lane's LDS column: recomputed where they are used (two ALU operations) instead of held in a register
+	// from the first line of the kernel to its last -- the main tier sits exactly at its register budget
+#define lane (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#define col (col0 + lane)
 	const uint64_t n_reads = n_ids ? (uint64_t)*n_ids : n_reads_arg;     // (n_ids without read_ids: a batch framed on the device, which alone knows its size)
 	// A list-driven launch (the spill tier) does not know its size on the host: its chunk grows with the list, from the
 	// WORK_CHUNK_ARG reads that spread a few hundred heavy reads over all waves up to 16 when there are tens of thousands
@@ -345,68 +350,72 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
 					}
 				};
-				if (d.dx) {
-					// direct table: the bucket's first entry arrives with the bucket itself.  Up to four chunks -- a whole 150 bp
-					// read -- are in flight at a time: their k-mers come as 16-byte pairs, their buckets go out back to back.
+				if (d.gx) {
+					// group table: every merged entry of the eight HI32 buckets that share HI29 sits in ONE 128-byte line -- header + up to 14
+					// {low half, position} slots -- which is what an L2 miss moves anyway (profiles/line_probe_r03_counters.txt): a look-up
+					// is one miss whatever the bucket holds (the direct table it replaces sent a third of them to a second line).  Up to
+					// four chunks -- a whole 150 bp read -- are in flight: their headers go out back to back (the misses), then the slots
+					// of each chunk's own bucket are read out of the lines that have just arrived (cache hits), two chunks per wait.
 					for (uint32_t c = 0; c < n; c += 4) {
 						const uint32_t m = n - c < 4u ? n - c : 4u;
 						uint64_t kq[4] = {0, 0, 0, 0};
 						if (m >= 2) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
 						if (m >= 4) chunk_kmer2(c + 2, kq[2], kq[3]); else if (m == 3) kq[2] = chunk_kmer(c + 2);
 						VG_CLKW(9);
-						uint4 bq[4];
+						uint4 hq[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = gather<uint4>(d.dx + (kq[z] >> 32)); }
+						for (uint32_t z = 0; z < 4; z++) { hq[z] = make_uint4(0, 0, 0, 0); if (z < m) hq[z] = gather<uint4>(d.gx + ((kq[z] >> 35) << 3)); }
 						VG_CLKW(10);
-						// `more`: the bucket has further entries that may hold the key (entries are sorted by lo: nothing below the first; a
-						// match on the first entry is final unless the table says its successor has the same k-mer -- flag TIE)
-						bool more[4];
+						// one chunk at a time from here on (the lines are in the cache: these waits are short, and a second chunk's slots held
+						// in registers across this one's rare paths cost the kernel its last free registers)
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && (bq[z].z >> 8) > 1u && (bq[z].x < (uint32_t)kq[z] || (bq[z].x == (uint32_t)kq[z] && (bq[z].z & 16u)));
-						// Two chunks at a time: the rest of a small bucket -- up to VG_SCAN_W more entries -- arrives together (one wait;
-						// anything deeper is rare and goes one by one); then each chunk's exact contexts are appended (qv.cc:850-937),
-						// reference hit first, then SNP hit.  An ambiguous k-mer with exactly two positions carries both in its entry
-						// (flag PAIR, set by vg_inline_pairs), so only k-mers with 3-10 copies still read their auxiliary row.
-						#pragma unroll
-						for (uint32_t z0 = 0; z0 < 4; z0 += 2) {
-							constexpr uint32_t SW = VG_SCAN_W;
-							uint4 sv[2][SW];
-							#pragma unroll
-							for (uint32_t y = 0; y < 2; y++) {
-								const uint32_t cnt = bq[z0 + y].z >> 8, lo = bq[z0 + y].w;
-								#pragma unroll
-								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = gather<uint4>(d.mx + (lo + 1u + x)); }
-							}
-							#pragma unroll
-							for (uint32_t y = 0; y < 2; y++) {
-								const uint32_t z = z0 + y;
+						for (uint32_t z = 0; z < 4; z++) {
+							{
 								if (z >= m) continue;
+								// slots [a, b) of the line belong to the chunk's HI32 bucket
+								const uint32_t jb = (uint32_t)(kq[z] >> 32) & 7u;
+								const bool ovfl = (hq[z].z >> 31) != 0u;
+								uint32_t a = (jb && !ovfl) ? (hq[z].x >> (4u * (jb - 1u))) & 15u : 0u;
+								uint32_t bend = !ovfl ? (hq[z].x >> (4u * jb)) & 15u : 0u;
+								if (bend < a) bend = a;
 								cur.add(S_CHUNKS, 1);
-								const uint4 b = bq[z];
 								const uint32_t key = (uint32_t)kq[z];
 								// hit state: position (or row index), second position of a PAIR, flags 1 hit, 2 ambiguous, 4 PAIR
 								uint32_t rp = 0, rp2 = 0, rf = 0, sp = 0, sp2 = 0, sf = 0;
-								if ((b.z & 1u) && b.x == key) {                        // the inline first entry (dx flags: 2 SNP, 4 ambiguous, 8 PAIR)
-									const uint32_t f = 1u | (((b.z >> 2) & 1u) << 1) | (((b.z >> 3) & 1u) << 2);
-									if (b.z & 2u) { sp = b.y; sp2 = b.w; sf = f; } else { rp = b.y; rp2 = b.w; rf = f; }
-								}
-								if (more[z]) {
-									const uint32_t cnt = b.z >> 8, lo = b.w, hi = lo + cnt;
-									auto take = [&](const uint4 v) {                     // mx flags: 1 SNP, 2 ambiguous, 4 PAIR
+								if (ovfl) {
+									// a group of more than 14 slots (low-complexity HI29): its entries {low half, position, flags | bucket << 8, second
+									// position} lie in gx_ovf, sorted; bisect to the first entry of the bucket with the key, take what matches
+									const uint32_t cnt = hq[z].x, j = jb;
+									const uint4 *e0 = d.gx_ovf + hq[z].w;
+									uint32_t ea = 0, eb = cnt;
+									while (ea < eb) { const uint32_t mm = ea + ((eb - ea) >> 1); const uint4 v = e0[mm]; if ((v.z >> 8) < j || ((v.z >> 8) == j && v.x < key)) ea = mm + 1; else eb = mm; }
+									for (; ea < cnt; ea++) {
+										const uint4 v = e0[ea];
+										if ((v.z >> 8) != j || v.x != key) break;
 										const uint32_t f = 1u | (v.z & 2u) | (v.z & 4u);
 										if (v.z & 1u) { sp = v.y; sp2 = v.w; sf = f; } else { rp = v.y; rp2 = v.w; rf = f; }
+									}
+								} else {
+									// 3 bits per slot: SNP entry, ambiguous, continuation (a PAIR's second position sits in the slot behind it)
+									auto mt3 = [&](uint32_t s) -> uint32_t { return (s < 10u ? hq[z].y >> (3u * s) : hq[z].z >> (3u * (s - 10u))) & 7u; };
+									auto take = [&](uint32_t s, uint32_t lo, uint32_t pos, uint32_t nxt_pos) {
+										if (s >= bend || lo != key) return;
+										const uint32_t mt = mt3(s);
+										if (mt & 4u) return;
+										const bool pair = s + 1u < bend && (mt3(s + 1u) & 4u);
+										const uint32_t f = 1u | (mt & 2u) | (pair ? 4u : 0u);
+										if (mt & 1u) { sp = pos; sp2 = nxt_pos; sf = f; } else { rp = pos; rp2 = nxt_pos; rf = f; }
 									};
-									#pragma unroll
-									for (uint32_t x = 0; x < SW; x++) if (x + 1u < cnt && sv[y][x].x == key) take(sv[y][x]);
-									if (cnt > SW + 1u && sv[y][SW - 1].x <= key) {      // the bucket goes on and may still hold the key
-										uint32_t e = lo + SW + 1u;
-										if (cnt > 8u) { uint32_t eb = hi; while (e < eb) { const uint32_t mm = e + ((eb - e) >> 1); if (d.mx[mm].x < key) e = mm + 1; else eb = mm; } }
-										for (; e < hi; e++) {
-											const uint4 v = d.mx[e];
-											if (v.x < key) continue;
-											if (v.x > key) break;
-											take(v);
-										}
+									// four slots arrive together (cache hits); three are consumed per round -- the fourth is the "slot behind" of the
+									// third -- and a bucket rarely has more (the slot beyond the line's last reads as zeros: the table is padded)
+									const uint2 *line = (const uint2 *)d.gx + ((kq[z] >> 35) << 4) + 2u;
+									for (; a < bend; a += 3u) {
+										const uint4 s01 = gather<uint4, 8>(line + a);
+										uint4 s23 = make_uint4(0, 0, 0, 0);
+										if (bend > a + 2u) s23 = gather<uint4, 8>(line + a + 2u);
+										take(a, s01.x, s01.y, s01.w);
+										take(a + 1u, s01.z, s01.w, s23.y);
+										take(a + 2u, s23.x, s23.y, s23.w);
 									}
 								}
 								const bool r_ok = (rf & 1u) && ((rf & 4u) || rp != POS_AMBIGUOUS), s_ok = (sf & 1u) && ((sf & 4u) || sp != POS_AMBIGUOUS);
@@ -556,7 +565,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						// lie side by side (strided-probe view): the SNP scan is most of stage B's items at hg38 scale, and every round of 64
 						// items pays the full chain of dependent waits of the few items in it that do have something to look up
 						const uint32_t Lsn = shi - slo;
-						const uint32_t L = large ? 48u : (hi - lo) + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
+						const uint32_t L = large ? 48u : (hi - lo) + ((Lsn + sw_m1) >> sw_log);
 						P_klo[p][wv] = klo; P_khi[p][wv] = khi; P_lo[p][wv] = lo; P_hi[p][wv] = hi; P_slo[p][wv] = slo; P_shi[p][wv] = shi;
 						P_meta[p][wv] = own | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
 						P_cnt[p][wv] = L + nhigh;
@@ -600,11 +609,14 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						const uint32_t t = g2 - P_off[p][wv];
 						if (!((P_meta[p][wv] >> 13) & 1u)) {                     // not a large block
 							const uint32_t lo = P_lo[p][wv], slo = P_slo[p][wv], Lr = P_hi[p][wv] - lo, Lsn = P_shi[p][wv] - slo;
-							const uint32_t L = Lr + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
+							const uint32_t L = Lr + ((Lsn + sw_m1) >> sw_log);
 							if (t < L) {
 								const bool isr = t < Lr;
 								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)t * REF_STRIDE : (uint64_t)slo + (uint64_t)(t - Lr) * SNP_STRIDE;
-								if (!isr && probe2) v = gather<uint4, 8>(d.snp_probe + ((uint64_t)slo + 2u * (t - Lr)));   // two probed LO40 values, side by side
+								if (!isr && use_sig) {
+									if (WPB > 1) v = gather<uint4, 1>(d.snp_sig + ((uint64_t)slo + 8u * (t - Lr)));          // eight signatures
+									else v.x = d.snp_sig[(uint64_t)slo + (t - Lr)];
+								}
 								else if (!isr && use_probe) { const uint2 q = gather<uint2, 8>(d.snp_probe + ((uint64_t)slo + (t - Lr))); v.x = q.x; v.y = q.y; }
 								else if (tt < (isr ? d.n_ref : d.n_snp)) v = gather<uint4>(isr ? (const void *)(d.ref + tt) : (const void *)(d.snp + tt));
 							}
@@ -632,7 +644,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						const uint32_t fl = (meta >> 11) & 3u, mode = (meta >> 14) & 1u, nh = (meta >> 16) & 7u, u_lo = (meta >> 19) & 63u;
 						const bool large = (meta >> 13) & 1u, sec_ok = (meta >> 15) & 1u;
 						const uint32_t Lsn = shi - slo;
-						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + (probe2 ? (Lsn + 1u) >> 1 : Lsn);
+						const uint32_t Lr = large ? 48u : hi - lo, L = large ? 48u : (hi - lo) + ((Lsn + sw_m1) >> sw_log);
 						const uint32_t rsb = (fl & 1u) ? 64u : 32u, ssb = (fl & 2u) ? 64u : 40u;
 						o_ecnt = P_ecnt[p][wv];
 						bool q_r = false, q_s = false;                          // dictionary queries of the neighbour k-mer qk, issued together below
@@ -649,14 +661,27 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								// tested, entry lo + u (slo + u) recorded.  Both dictionaries hold 16-byte entries: one gather site.
 								const bool isr = t < Lr;
 								const uint4 v = scan_cur;                                 // zeros when the probe fell off the array
-								if (!isr && probe2) {
-									// two consecutive entries of the SNP bucket per item (timed build only: no event counts here)
-									const uint32_t u0 = 2u * (t - Lr);
-									const uint64_t t0 = (((uint64_t)v.y << 32) | v.x) & LO40_MASK, t1 = (((uint64_t)v.w << 32) | v.z) & LO40_MASK;
-									const int d0 = onebase((k & LO40_MASK) ^ t0), d1 = u0 + 1u < Lsn ? onebase((k & LO40_MASK) ^ t1) : -1;
-									if (d0 >= 0 && d1 >= 0) N_ovf[col0 + own] = 1;        // two hits in one item (repeats): the read goes to the next tier
-									else if (d0 >= 0) { si = slo + u0; mod = (uint32_t)d0; nbase = (uint32_t)(t0 >> (2 * d0)) & 3u; }
-									else if (d1 >= 0) { si = slo + u0 + 1u; mod = (uint32_t)d1; nbase = (uint32_t)(t1 >> (2 * d1)) & 3u; }
+								if (!isr && use_sig) {
+									// signatures of up to eight consecutive entries of the SNP bucket: which of them can the scan keep at all?
+									const uint32_t u0 = (t - Lr) << sw_log, ks = sig16(k & LO40_MASK);
+									// per 32-bit word two signatures: y = one bit per base in which a signature differs from the k-mer's
+									const uint32_t kk2 = ks | (ks << 16), live = Lsn - u0;   // entries of the bucket from u0 on (>= 1)
+									uint32_t cand = 0;
+									auto two = [&](uint32_t w, uint32_t z) {
+										const uint32_t x = w ^ kk2, y = (x | (x >> 1)) & 0x55555555u, yl = y & 0xFFFFu, yh = y >> 16;
+										if (z < live && z <= sw_m1 && yl && !(yl & (yl - 1u))) cand |= 1u << z;
+										if (z + 1u < live && z + 1u <= sw_m1 && yh && !(yh & (yh - 1u))) cand |= 2u << z;
+									};
+									two(v.x, 0u); two(v.y, 2u); two(v.z, 4u); two(v.w, 6u);
+									if (cand & (cand - 1u)) N_ovf[col0 + own] = 1;        // two candidates in one item: the read goes to the next tier
+									else if (cand) {
+										// the candidate's probed value itself: entry slo + 11 u of the dictionary (zero beyond its end)
+										const uint32_t u = u0 + (uint32_t)__ffs((int)cand) - 1u;
+										const uint64_t tt = (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
+										const uint64_t full = tt < d.n_snp ? gather<uint64_t>(&d.snp[tt].key) & LO40_MASK : 0ull;
+										const int dd = onebase((k & LO40_MASK) ^ full);
+										if (dd >= 0) { si = slo + u; mod = (uint32_t)dd; nbase = (uint32_t)(full >> (2 * dd)) & 3u; }
+									}
 								} else {
 								const uint32_t u = isr ? t : t - Lr;
 								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)u * REF_STRIDE : (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
@@ -1014,6 +1039,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 		for (int i = 0; i < S_COUNT; i++) if (tot.v[i]) atomicAdd(&stats[i], (unsigned long long)tot.v[i]);
 	}
 }
+
+#undef lane
+#undef col
 
 template <bool STATS, int W_ECAP, int W_NCAP, int WPB>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
