@@ -71,19 +71,6 @@ def parse_args():
         if getattr(args, k) is None:
             setattr(args, k, v)
     args.cpu_sample = min(args.cpu_sample, args.reads)
-    if args.workdir is None:
-        # index files: ~16 bytes per base of the genome + ~550 bytes per SNP (hg38 + 10 M SNPs: 48 GB; + 100 M SNPs: 104 GB)
-        need = 1.25 * (16.0 * args.genome + 550.0 * args.snps)
-
-        def free(path):
-            try:
-                st = os.statvfs(path)
-                return st.f_bavail * st.f_frsize
-            except OSError:
-                return 0
-        args.workdir = "/tmp/vg_bench"
-        if not os.path.isdir(args.workdir) and free("/tmp") < need and free("/dev/shm") >= need:
-            args.workdir = "/dev/shm/vg_bench"
     return args
 
 
@@ -252,6 +239,20 @@ def main():
 
     # ---- data set + index files: host only (rank 0 builds, the others wait for its marker file) ----------------------------
     tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms) + ("_r%g" % args.repeats if args.repeats else "")
+    if args.workdir is None:
+        # index files: ~16 bytes per base of the genome + ~550 bytes per SNP (hg38 + 10 M SNPs: 48 GB; + 100 M SNPs: 104 GB).
+        # /tmp unless it lacks the room for an index that is not there yet and /dev/shm (memory-backed) has it
+        need = 1.25 * (16.0 * args.genome + 550.0 * args.snps)
+
+        def free(path):
+            try:
+                st = os.statvfs(path)
+                return st.f_bavail * st.f_frsize
+            except OSError:
+                return 0
+        args.workdir = "/tmp/vg_bench"
+        if not os.path.exists(os.path.join(args.workdir, tag, "idx.done")) and free("/tmp") < need and free("/dev/shm") >= need:
+            args.workdir = "/dev/shm/vg_bench"
     d = os.path.join(args.workdir, tag)
     prefix = os.path.join(d, "idx")
     t0 = time.time()

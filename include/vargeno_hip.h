@@ -94,8 +94,7 @@ uint64_t vg_index_device_bytes(const vg_index *ix);
  * built (or a VG_NO_* development switch said so) -- a caller that cares about throughput should look. */
 #define VG_VIEW_SEC        1u   /* LO32-ordered view of the reference dictionary (high-half neighbours, qv.cc:1213-1296)   */
 #define VG_VIEW_MX         2u   /* merged exact-match view of both dictionaries (qv.cc:840-841)                            */
-#define VG_VIEW_GX         4u   /* group table over HI29: every merged entry of eight HI32 buckets in one 128-byte line;
-                                   it replaces the merged view (VG_VIEW_MX is then clear)                               */
+#define VG_VIEW_DX         4u   /* direct table over HI32 in front of the merged view                                      */
 #define VG_VIEW_SNP_PROBE  8u   /* strided-probe view of the SNP dictionary (iterate_snp_dict, qv.cc:413-464)              */
 #define VG_VIEW_SNP_JG32  16u   /* HI32 jump table of the SNP dictionary (indexes too large for the merged view)           */
 #define VG_VIEW_SNP_SIG   64u   /* ... its 16-bit signature form (the default; the probe view is built under VG_NO_SIG_VIEW)    */

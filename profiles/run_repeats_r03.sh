@@ -8,6 +8,7 @@ OUT=$R/gpurun_out/repeats_r03
 mkdir -p $OUT
 cd $R
 export VARGENO_VERBOSE=1 VG_VERBOSE=1
+rm -rf /tmp/vg_bench   # (an earlier run's 48 GB index: /tmp holds one of them)
 A="--repeats $F --cpu-reference no --no-ingest --no-gather-probe --steps 10 --warmup 2"
 ( time timeout 1500 python3 bench.py $A --cpu-sample 1000000 "$@" ) > $OUT/bench_F$F.json 2> $OUT/bench_F$F.err
 tail -6 $OUT/bench_F$F.err

@@ -184,7 +184,7 @@ def test_hg38f_sample_against_oracle_and_linearity(hg38f):
     ox.close()
     assert want["scan_snp"] > 100 * want["gate_open"]                # the dense-bucket regime: > 100 SNP-bucket entries per gate-open chunk
     with GenoIndex.open(prefix) as gx:
-        assert "mx" not in gx.views and "gx" not in gx.views and "hx" in gx.views     # 2^32 or more k-mers: the layout of vg_wave_kernel_big
+        assert "mx" not in gx.views and "dx" not in gx.views and "hx" in gx.views     # 2^32 or more k-mers: the layout of vg_wave_kernel_big
         assert gx.num_sites > 90_000_000
         b0, b1 = int(to[lo_s].item()), int(to[hi_s].item())
         so_dev = (to[lo_s:hi_s + 1] - to[lo_s]).contiguous()

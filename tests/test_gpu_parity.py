@@ -75,7 +75,7 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
         assert tm["ms_main"] > 0 and tm["batches"] == 1
 
 
-@pytest.mark.parametrize("knob", ["VG_NO_GROUPS", "VG_NO_MX", "VG_NO_MX+VG_NO_HX", "VG_NO_MX+VG_NO_SNP_JG32", "VG_NO_MX+VG_NO_SEC+VG_NO_PROBE_VIEW", "VG_NO_SEC", "VG_PACK_OVERLAP",
+@pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_MX+VG_NO_HX", "VG_NO_MX+VG_NO_SNP_JG32", "VG_NO_MX+VG_NO_SEC+VG_NO_PROBE_VIEW", "VG_NO_SEC", "VG_PACK_OVERLAP",
                                   "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW"])
 def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
     """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view, strided-probe
@@ -269,13 +269,13 @@ def test_dense_snp_buckets_parity_all_layouts(tmp_path, monkeypatch):
     want = ox.stats.as_dict()
     assert want["scan_snp"] > 100 * want["gate_open"]
     rows = []
-    for label, env, views in (("all views", {}, ("gx",)), ("no merged view (the > 2^32-entry fallback): paired HI32 table", {"VG_NO_MX": "1"}, ("hx",)),
+    for label, env, views in (("all views", {}, ("mx", "dx")), ("no merged view (the > 2^32-entry fallback): paired HI32 table", {"VG_NO_MX": "1"}, ("hx",)),
                               ("no merged view, HI32 jump tables instead of the paired table", {"VG_NO_MX": "1", "VG_NO_HX": "1"}, ("snp_jg32",)),
                               ("no merged view, no HI32 table of the SNP dictionary at all", {"VG_NO_MX": "1", "VG_NO_HX": "1", "VG_NO_SNP_JG32": "1"}, ())):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with GenoIndex.open(prefix) as gx:
-            assert all(v in gx.views for v in views) and ("gx" in gx.views) == ("gx" in views) and "mx" not in gx.views, (label, gx.views)
+            assert all(v in gx.views for v in views) and ("mx" in gx.views) == ("mx" in views), (label, gx.views)
             gx.submit(r.bases, r.quals, r.offsets)                   # counting build
             rc, ac = gx.counts()
             st = gx.stats()

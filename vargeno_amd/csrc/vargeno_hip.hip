@@ -171,62 +171,25 @@ __device__ inline bool aux_pair(const uint32_t *__restrict__ aux, uint32_t row, 
 	p0 = r[0]; p1 = r[1];
 	return p1 != 0 && r[2] == 0;
 }
-// group table (DevIndex::gx): pass 1 -- how many slots does each HI29 group need (an entry takes one, a PAIR two), and how many
-// entries go to the overflow array because their group needs more than 14
-constexpr uint32_t GX_SLOTS = 14;
-// (runs on the merged view in its row form -- PAIRs are inlined only once the table's memory is secured, because the fallback reads rows)
-__global__ void vg_gx_count(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos,
-                            unsigned long long *__restrict__ ovf_entries)
+// direct table: the first entry of every HI32 bucket of the merged view, inline.  flags: 1 non-empty, 2 SNP entry, 4 ambiguous,
+// 8 PAIR (single-entry buckets only: a longer bucket needs w for the index of its entries), 16 TIE (the second entry has the
+// first one's k-mer: a query that matches the first entry of a bucket without it needs no further entry), bits 8.. = entries
+__global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ dx,
+                               const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos, uint32_t *__restrict__ too_big)
 {
-	unsigned long long mine = 0;
-	for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < (1ull << 29); g += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t lo = jg[8 * g], hi = jg[8 * g + 8];
-		uint32_t slots = hi - lo;
-		if (slots <= GX_SLOTS) for (uint32_t e = lo; e < hi; e++) {
-			const uint4 v = mx[e];
+	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t lo = jg[h], hi = jg[h + 1];
+		uint4 r = make_uint4(0, 0, 0, 0);
+		if (hi > lo) {
+			const uint4 e = mx[lo];
+			const uint32_t cnt = hi - lo > 0xFFFFFFu ? 0xFFFFFFu : hi - lo;
+			if (hi - lo > 0xFFFFFFu) atomicOr(too_big, 1u);          // the count field is 24 bits wide: the host keeps the jump-table form
+			r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (cnt << 8), lo);
+			if (cnt > 1u && mx[lo + 1].x == e.x) r.z |= 16u;            // TIE: the second entry carries the same k-mer (reference + SNP dictionary)
 			uint32_t p0, p1;
-			if ((v.z & 2u) && aux_pair((v.z & 1u) ? snp_aux_pos : ref_aux, v.y, p0, p1)) slots++;
+			if (cnt == 1u && (e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { r.y = p0; r.w = p1; r.z |= 8u; }
 		}
-		if (slots > GX_SLOTS) mine += hi - lo;
-	}
-	for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(ovf_entries, mine);
-}
-// pass 2 -- one thread writes one 128-byte line (and, for an overflow group, its run of the overflow array, claimed with one atomic)
-__global__ void vg_make_gx(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ gx, uint4 *__restrict__ ovf, unsigned long long *__restrict__ ovf_next)
-{
-	for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < (1ull << 29); g += (uint64_t)gridDim.x * blockDim.x) {
-		uint32_t b[9];
-		for (int j = 0; j < 9; j++) b[j] = jg[8 * g + j];
-		const uint32_t lo = b[0], hi = b[8];
-		uint32_t slots = hi - lo;
-		if (slots <= GX_SLOTS) for (uint32_t e = lo; e < hi; e++) slots += (mx[e].z >> 2) & 1u;
-		uint2 sl[GX_SLOTS];
-		for (uint32_t s = 0; s < GX_SLOTS; s++) sl[s] = make_uint2(0u, 0u);
-		uint4 hdr = make_uint4(0u, 0u, 0u, 0u);
-		if (slots > GX_SLOTS) {
-			const uint64_t at = atomicAdd(ovf_next, (unsigned long long)(hi - lo));
-			for (int j = 0; j < 8; j++) for (uint32_t e = b[j]; e < b[j + 1]; e++) { const uint4 v = mx[e]; ovf[at + (e - lo)] = make_uint4(v.x, v.y, (v.z & 7u) | ((uint32_t)j << 8), v.w); }
-			hdr = make_uint4(hi - lo, 0u, 1u << 31, (uint32_t)at);
-		} else {
-			uint32_t s = 0;
-			uint64_t meta = 0;
-			for (int j = 0; j < 8; j++) {
-				for (uint32_t e = b[j]; e < b[j + 1]; e++) {
-					const uint4 v = mx[e];                             // flags: 1 SNP, 2 ambiguous, 4 PAIR (then y, w = the two positions)
-					sl[s] = make_uint2(v.x, v.y);
-					meta |= (uint64_t)(v.z & 3u) << (3 * s);
-					s++;
-					if (v.z & 4u) { sl[s] = make_uint2(v.x, v.w); meta |= (uint64_t)((v.z & 3u) | 4u) << (3 * s); s++; }
-				}
-				hdr.x |= s << (4 * j);
-			}
-			hdr.y = (uint32_t)(meta & 0x3FFFFFFFull);
-			hdr.z = (uint32_t)(meta >> 30) & 0xFFFu;
-		}
-		uint4 *line = gx + 8 * g;
-		line[0] = hdr;
-		for (uint32_t q = 0; q < 7; q++) line[1 + q] = make_uint4(sl[2 * q].x, sl[2 * q].y, sl[2 * q + 1].x, sl[2 * q + 1].y);
+		dx[h] = r;
 	}
 }
 // the same for the entries of the merged view themselves (read for buckets of several entries); mx flags: 1 SNP, 2 ambiguous, 4 PAIR
@@ -352,7 +315,7 @@ constexpr uint32_t PACK_T = 64;                 // reads (= lanes) per tile: one
                                                 // smaller tiles keep more workgroups, i.e. more loads, in flight)
 constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bases; longer reads take the direct path
 #ifndef VG_PACK_WPE
-#define VG_PACK_WPE 5
+#define VG_PACK_WPE 3
 #endif
 #ifndef VG_PACK_NT
 #define VG_PACK_NT 0                            // `nt` on the pack kernel's loads of the base text, read once
@@ -381,13 +344,21 @@ __global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_
 		const bool staged = span <= PACK_LDS;
 		__syncthreads();                                              // previous tile fully consumed
 		if (staged) {
-			for (uint64_t i = (uint64_t)threadIdx.x * 16; i < span; i += PACK_T * 16) {
-				if (i + 16 <= span) {
-					const uint4 v = load_policy<VG_PACK_NT != 0, uint4, 1>(bases + base0 + i);     // (a batch may start at any byte)
-					*reinterpret_cast<uint4 *>(sm + i) = v;
-				} else {
-					for (uint64_t j = i; j < span; j++) sm[j] = bases[base0 + j];
-				}
+			// every 16-byte piece of the tile this lane is responsible for goes out before the first is stored to LDS: with one load
+			// in flight per lane (1 KB per wave) the kernel was bound by latency, not by the memory system (0.50 ms per 8 M reads
+			// for 1.5 GB; the quality strings it used to fetch as well had hidden that)
+			constexpr uint32_t NP = PACK_LDS / (PACK_T * 16);              // pieces per lane: 10
+			uint4 v[NP];
+			#pragma unroll
+			for (uint32_t q = 0; q < NP; q++) {
+				const uint64_t i = (uint64_t)threadIdx.x * 16 + (uint64_t)q * PACK_T * 16;
+				if (i + 16 <= span) v[q] = load_policy<VG_PACK_NT != 0, uint4, 1>(bases + base0 + i);     // (a batch may start at any byte)
+			}
+			#pragma unroll
+			for (uint32_t q = 0; q < NP; q++) {
+				const uint64_t i = (uint64_t)threadIdx.x * 16 + (uint64_t)q * PACK_T * 16;
+				if (i + 16 <= span) *reinterpret_cast<uint4 *>(sm + i) = v[q];
+				else if (i < span) for (uint64_t j = i; j < span; j++) sm[j] = bases[base0 + j];
 			}
 		}
 		__syncthreads();
@@ -722,7 +693,6 @@ struct vg_index {
 	Slot slot[NSLOT];
 	int next_slot = 0;
 	uint32_t *d_cum = nullptr;            // since reset: [0] wave-tier overflow, [1] lane-tier overflow, [2] lost
-	uint64_t gx_overflow_entries = 0;     // entries of groups that did not fit their 128-byte line (VG_VERBOSE reports them)
 	uint8_t *d_clamped = nullptr;         // [2 * n_sites] staging of vg_counts_fetch: min(63, sum), ref counts then alt counts
 	unsigned long long *d_stats = nullptr;
 	bool stats_enabled = true;
@@ -1238,46 +1208,40 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(st));
 			d.mx_jg = mjg; d.mx = mx;
-			// group table (64 GiB) in place of the merged view AND its jump table (51 + 17 GB at hg38 scale) when the device has the
-			// room to hold all three while it is built
-			if (!getenv("VG_NO_GROUPS")) {
+			// direct table (64 GiB) in place of the merged jump table (16 GiB) when the device has the room; no bucket may
+			// exceed the 24-bit count field (it would be a >16 M-fold repeated 16-mer)
+			if (!getenv("VG_NO_DIRECT")) {
 				kout.release(); vout.release(); c.ref_pos.release(); c.ref_amb.release();
 				size_t free_b = 0, total_b = 0;
-				uint4 *gx = nullptr, *ovf = nullptr;
-				TempDev<unsigned long long> ctr;
-				if ((rc = ctr.alloc(2))) return rc;
-				HIP_TRY(hipMemsetAsync(ctr.p, 0, 16, st));
-				vg_gx_count<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, d.ref_aux, d.snp_aux_pos, ctr.p);
-				HIP_TRY(hipGetLastError());
-				HIP_TRY(hipStreamSynchronize(st));
-				unsigned long long n_ovf = 0;
-				HIP_TRY(hipMemcpy(&n_ovf, ctr.p, 8, hipMemcpyDeviceToHost));
-				const size_t gx_bytes = ((size_t)1 << 29) * 128 + 64, ovf_bytes = ((size_t)n_ovf + 1) * 16;
-				if (n_ovf < (1ull << 32) && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > gx_bytes + ovf_bytes + (8ull << 30) &&
-				    hipMalloc((void **)&gx, gx_bytes) == hipSuccess && hipMalloc((void **)&ovf, ovf_bytes) == hipSuccess) {
-					vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // two-position k-mers carry both positions from here on
-					vg_make_gx<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, gx, ovf, ctr.p + 1);
-					HIP_TRY(hipMemsetAsync((uint8_t *)gx + gx_bytes - 64, 0, 64, st));              // (a look-up may read one slot past the last line)
+				uint4 *dx = nullptr;
+				TempDev<uint32_t> big;
+				if ((rc = big.alloc(1))) return rc;
+				HIP_TRY(hipMemsetAsync(big.p, 0, 4, st));
+				uint32_t too_big = 0;
+				if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (80ull << 30) && hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) == hipSuccess) {
+					vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
 					HIP_TRY(hipGetLastError());
 					HIP_TRY(hipStreamSynchronize(st));
-					ix->owned.push_back(gx); ix->owned.push_back(ovf); ix->dev_bytes += gx_bytes + ovf_bytes;
-					d.gx = gx; d.gx_ovf = ovf;
-					ix->gx_overflow_entries = n_ovf;
-					// the merged view and its jump table have served
-					for (void *dead : {(void *)mjg, (void *)mx})
-						for (size_t z = 0; z < ix->owned.size(); z++) if (ix->owned[z] == dead) { ix->owned.erase(ix->owned.begin() + (long)z); break; }
-					(void)hipFree(mjg); (void)hipFree(mx);
-					ix->dev_bytes -= ((1ull << 32) + 1) * 4 + nm * 16;
-					d.mx_jg = nullptr; d.mx = nullptr;
+					HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
+				}
+				if (dx && too_big) { (void)hipFree(dx); dx = nullptr; }          // a bucket of more than 2^24 - 1 entries: jump-table form
+				if (dx) {
+					vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
+					HIP_TRY(hipGetLastError());
+					HIP_TRY(hipStreamSynchronize(st));
+					ix->owned.push_back(dx); ix->dev_bytes += (uint64_t)(1ull << 32) * 16;
+					d.dx = dx;
+					// the merged jump table is not needed any more
+					for (size_t z = 0; z < ix->owned.size(); z++) if (ix->owned[z] == (void *)mjg) { ix->owned.erase(ix->owned.begin() + (long)z); break; }
+					(void)hipFree(mjg); ix->dev_bytes -= ((1ull << 32) + 1) * 4;
+					d.mx_jg = nullptr;
 				} else {
-					if (gx) (void)hipFree(gx);
-					if (ovf) (void)hipFree(ovf);
-					(void)hipGetLastError();                     // not enough memory: the kernel reads the merged view through its jump table
+					(void)hipGetLastError();                     // not enough memory: keep the jump-table form
 				}
 			}
 		}
 	}
-	pc.lap("SNP dictionary, scan view, merged view, group table");
+	pc.lap("SNP dictionary, scan view, merged view, direct table");
 	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first
 	//      2^32 bits of the 9.6 Gbit reference vector can ever be read (src/generate_bf.h:112-128)
 	{
@@ -1502,7 +1466,7 @@ extern "C" uint32_t vg_index_views(const vg_index *ix)
 {
 	if (!ix) return 0;
 	const DevIndex &d = ix->d;
-	return (d.sec_key ? VG_VIEW_SEC : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.gx ? VG_VIEW_GX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u) | (d.hx ? VG_VIEW_HX : 0u) | (d.snp_sig ? VG_VIEW_SNP_SIG : 0u);
+	return (d.sec_key ? VG_VIEW_SEC : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.dx ? VG_VIEW_DX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u) | (d.hx ? VG_VIEW_HX : 0u) | (d.snp_sig ? VG_VIEW_SNP_SIG : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1573,7 +1537,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));               // the wave kernel's own start
 		ix->cnt4_dirty = true;
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 64 * W1_WPB - 1) / (64 * W1_WPB), (uint64_t)ix->wave_grid / W1_WPB);
-		const bool big = !STATS && ix->d.mx == nullptr && ix->d.gx == nullptr;     // an index without the merged view / group table: the kernel built for it
+		const bool big = !STATS && ix->d.mx == nullptr;                // an index without the merged view: the kernel built for it
 		if (big) vg_wave_kernel_big<W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		else vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));

@@ -42,20 +42,15 @@ struct DevIndex {
 	// merged exact-match view: the reference and SNP dictionaries sorted together by k-mer (reference entry first on
 	// ties) behind ONE jump table over HI32, so the two exact look-ups of a chunk (qv.cc:840-841) cost one
 	// jump-table gather + at most one bucket line instead of two of each.  mx entry: {lo32, pos, flags, pos2} with
-	// flags bit 0 = SNP-dictionary entry, bit 1 = ambig_flag, bit 2 = PAIR (the k-mer's auxiliary row holds exactly two
-	// positions and they are pos, pos2 -- no row gather in stage A).  Construction material of the group table below, and
-	// what the kernel reads when that table could not be allocated.
-	const uint32_t *mx_jg;         // [2^32 + 1]   (both released once the group table exists)
+	// flags bit 0 = SNP-dictionary entry, bit 1 = ambig_flag, bit 2 = PAIR (set once the direct table exists: the k-mer's
+	// auxiliary row holds exactly two positions and they are pos, pos2 -- no row gather in stage A).
+	const uint32_t *mx_jg;         // [2^32 + 1]   (dropped when the direct table below could be allocated)
 	const uint4 *mx;               // [n_ref + n_snp]
-	// group table over HI29 (64 GiB): one 128-byte line -- what an L2 miss moves -- per group of eight HI32 buckets, holding EVERY
-	// merged entry of the group: header {x: eight 4-bit slot counts, cumulative (bits 4j..4j+3 = slots used by buckets 0..j), y | z
-	// bits 0-11: 3 bits per slot (SNP entry, ambiguous, continuation), z bit 31: overflow, w: -} + 14 slots {low half, position}.  An
-	// ambiguous k-mer whose auxiliary row holds exactly two positions takes two slots (the second flagged "continuation"); other
-	// ambiguous k-mers keep their row index.  A group that needs more than 14 slots (low-complexity HI29) is flagged overflow:
-	// x = number of entries, w = index of the first in gx_ovf ({low half, position, flags 1 SNP 2 ambiguous 4 PAIR | bucket << 8,
-	// second position}, sorted).  With the table in place the merged view itself is released (51 GB at hg38 scale).
-	const uint4 *gx;
-	const uint4 *gx_ovf;
+	// direct table over HI32: one 16-byte record per bucket = the bucket's FIRST merged entry inline {lo32, pos, flags,
+	// index of that entry in mx}, flags bit 0 = bucket non-empty, bit 1 = SNP entry, bit 2 = ambig_flag, bit 4 = TIE (the second
+	// entry has the same k-mer), bit 3 = PAIR (single-
+	// entry buckets only: then the last word is the second position), bits 8.. = entries in the bucket.  A bucket with one entry -- the common case -- is settled, hit or miss, by ONE gather.  64 GiB.
+	const uint4 *dx;
 	// SNP dictionary (src/qv.cc:606-695)
 	const uint32_t *snp_jg;        // [2^24 + 1]
 	const SnpEnt   *snp;           // [n_snp]

@@ -135,7 +135,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	// The secondary (LO32-ordered) view answers the 48 high-half reference queries with one bucket read.  The counting
 	// build keeps the 48 individual queries because the event counters price each of them.
 	const bool use_sec = !STATS && d.sec_key != nullptr;
-	const bool use_mx = !STATS && !NOMX && (d.gx != nullptr || d.mx != nullptr);
+	const bool use_mx = !STATS && !NOMX && d.mx != nullptr;
 	const bool use_sig = !STATS && d.snp_sig != nullptr;
 	const bool use_probe = !STATS && !use_sig && d.snp_probe != nullptr;
 	// eight entries of the SNP bucket (their signatures) per stage-B item, in the main tier only: an item with two candidates sends
@@ -350,72 +350,68 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
 					}
 				};
-				if (d.gx) {
-					// group table: every merged entry of the eight HI32 buckets that share HI29 sits in ONE 128-byte line -- header + up to 14
-					// {low half, position} slots -- which is what an L2 miss moves anyway (profiles/line_probe_r03_counters.txt): a look-up
-					// is one miss whatever the bucket holds (the direct table it replaces sent a third of them to a second line).  Up to
-					// four chunks -- a whole 150 bp read -- are in flight: their headers go out back to back (the misses), then the slots
-					// of each chunk's own bucket are read out of the lines that have just arrived (cache hits), two chunks per wait.
+				if (d.dx) {
+					// direct table: the bucket's first entry arrives with the bucket itself.  Up to four chunks -- a whole 150 bp
+					// read -- are in flight at a time: their k-mers come as 16-byte pairs, their buckets go out back to back.
 					for (uint32_t c = 0; c < n; c += 4) {
 						const uint32_t m = n - c < 4u ? n - c : 4u;
 						uint64_t kq[4] = {0, 0, 0, 0};
 						if (m >= 2) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
 						if (m >= 4) chunk_kmer2(c + 2, kq[2], kq[3]); else if (m == 3) kq[2] = chunk_kmer(c + 2);
 						VG_CLKW(9);
-						uint4 hq[4];
+						uint4 bq[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) { hq[z] = make_uint4(0, 0, 0, 0); if (z < m) hq[z] = gather<uint4>(d.gx + ((kq[z] >> 35) << 3)); }
+						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = gather<uint4>(d.dx + (kq[z] >> 32)); }
 						VG_CLKW(10);
-						// one chunk at a time from here on (the lines are in the cache: these waits are short, and a second chunk's slots held
-						// in registers across this one's rare paths cost the kernel its last free registers)
+						// `more`: the bucket has further entries that may hold the key (entries are sorted by lo: nothing below the first; a
+						// match on the first entry is final unless the table says its successor has the same k-mer -- flag TIE)
+						bool more[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) {
-							{
+						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && (bq[z].z >> 8) > 1u && (bq[z].x < (uint32_t)kq[z] || (bq[z].x == (uint32_t)kq[z] && (bq[z].z & 16u)));
+						// Two chunks at a time: the rest of a small bucket -- up to VG_SCAN_W more entries -- arrives together (one wait;
+						// anything deeper is rare and goes one by one); then each chunk's exact contexts are appended (qv.cc:850-937),
+						// reference hit first, then SNP hit.  An ambiguous k-mer with exactly two positions carries both in its entry
+						// (flag PAIR, set by vg_inline_pairs), so only k-mers with 3-10 copies still read their auxiliary row.
+						#pragma unroll
+						for (uint32_t z0 = 0; z0 < 4; z0 += 2) {
+							constexpr uint32_t SW = VG_SCAN_W;
+							uint4 sv[2][SW];
+							#pragma unroll
+							for (uint32_t y = 0; y < 2; y++) {
+								const uint32_t cnt = bq[z0 + y].z >> 8, lo = bq[z0 + y].w;
+								#pragma unroll
+								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = gather<uint4>(d.mx + (lo + 1u + x)); }
+							}
+							#pragma unroll
+							for (uint32_t y = 0; y < 2; y++) {
+								const uint32_t z = z0 + y;
 								if (z >= m) continue;
-								// slots [a, b) of the line belong to the chunk's HI32 bucket
-								const uint32_t jb = (uint32_t)(kq[z] >> 32) & 7u;
-								const bool ovfl = (hq[z].z >> 31) != 0u;
-								uint32_t a = (jb && !ovfl) ? (hq[z].x >> (4u * (jb - 1u))) & 15u : 0u;
-								uint32_t bend = !ovfl ? (hq[z].x >> (4u * jb)) & 15u : 0u;
-								if (bend < a) bend = a;
 								cur.add(S_CHUNKS, 1);
+								const uint4 b = bq[z];
 								const uint32_t key = (uint32_t)kq[z];
 								// hit state: position (or row index), second position of a PAIR, flags 1 hit, 2 ambiguous, 4 PAIR
 								uint32_t rp = 0, rp2 = 0, rf = 0, sp = 0, sp2 = 0, sf = 0;
-								if (ovfl) {
-									// a group of more than 14 slots (low-complexity HI29): its entries {low half, position, flags | bucket << 8, second
-									// position} lie in gx_ovf, sorted; bisect to the first entry of the bucket with the key, take what matches
-									const uint32_t cnt = hq[z].x, j = jb;
-									const uint4 *e0 = d.gx_ovf + hq[z].w;
-									uint32_t ea = 0, eb = cnt;
-									while (ea < eb) { const uint32_t mm = ea + ((eb - ea) >> 1); const uint4 v = e0[mm]; if ((v.z >> 8) < j || ((v.z >> 8) == j && v.x < key)) ea = mm + 1; else eb = mm; }
-									for (; ea < cnt; ea++) {
-										const uint4 v = e0[ea];
-										if ((v.z >> 8) != j || v.x != key) break;
+								if ((b.z & 1u) && b.x == key) {                        // the inline first entry (dx flags: 2 SNP, 4 ambiguous, 8 PAIR)
+									const uint32_t f = 1u | (((b.z >> 2) & 1u) << 1) | (((b.z >> 3) & 1u) << 2);
+									if (b.z & 2u) { sp = b.y; sp2 = b.w; sf = f; } else { rp = b.y; rp2 = b.w; rf = f; }
+								}
+								if (more[z]) {
+									const uint32_t cnt = b.z >> 8, lo = b.w, hi = lo + cnt;
+									auto take = [&](const uint4 v) {                     // mx flags: 1 SNP, 2 ambiguous, 4 PAIR
 										const uint32_t f = 1u | (v.z & 2u) | (v.z & 4u);
 										if (v.z & 1u) { sp = v.y; sp2 = v.w; sf = f; } else { rp = v.y; rp2 = v.w; rf = f; }
-									}
-								} else {
-									// 3 bits per slot: SNP entry, ambiguous, continuation (a PAIR's second position sits in the slot behind it)
-									auto mt3 = [&](uint32_t s) -> uint32_t { return (s < 10u ? hq[z].y >> (3u * s) : hq[z].z >> (3u * (s - 10u))) & 7u; };
-									auto take = [&](uint32_t s, uint32_t lo, uint32_t pos, uint32_t nxt_pos) {
-										if (s >= bend || lo != key) return;
-										const uint32_t mt = mt3(s);
-										if (mt & 4u) return;
-										const bool pair = s + 1u < bend && (mt3(s + 1u) & 4u);
-										const uint32_t f = 1u | (mt & 2u) | (pair ? 4u : 0u);
-										if (mt & 1u) { sp = pos; sp2 = nxt_pos; sf = f; } else { rp = pos; rp2 = nxt_pos; rf = f; }
 									};
-									// four slots arrive together (cache hits); three are consumed per round -- the fourth is the "slot behind" of the
-									// third -- and a bucket rarely has more (the slot beyond the line's last reads as zeros: the table is padded)
-									const uint2 *line = (const uint2 *)d.gx + ((kq[z] >> 35) << 4) + 2u;
-									for (; a < bend; a += 3u) {
-										const uint4 s01 = gather<uint4, 8>(line + a);
-										uint4 s23 = make_uint4(0, 0, 0, 0);
-										if (bend > a + 2u) s23 = gather<uint4, 8>(line + a + 2u);
-										take(a, s01.x, s01.y, s01.w);
-										take(a + 1u, s01.z, s01.w, s23.y);
-										take(a + 2u, s23.x, s23.y, s23.w);
+									#pragma unroll
+									for (uint32_t x = 0; x < SW; x++) if (x + 1u < cnt && sv[y][x].x == key) take(sv[y][x]);
+									if (cnt > SW + 1u && sv[y][SW - 1].x <= key) {      // the bucket goes on and may still hold the key
+										uint32_t e = lo + SW + 1u;
+										if (cnt > 8u) { uint32_t eb = hi; while (e < eb) { const uint32_t mm = e + ((eb - e) >> 1); if (d.mx[mm].x < key) e = mm + 1; else eb = mm; } }
+										for (; e < hi; e++) {
+											const uint4 v = d.mx[e];
+											if (v.x < key) continue;
+											if (v.x > key) break;
+											take(v);
+										}
 									}
 								}
 								const bool r_ok = (rf & 1u) && ((rf & 4u) || rp != POS_AMBIGUOUS), s_ok = (sf & 1u) && ((sf & 4u) || sp != POS_AMBIGUOUS);
