@@ -98,6 +98,8 @@ uint64_t vg_index_device_bytes(const vg_index *ix);
 #define VG_VIEW_SNP_PROBE  8u   /* strided-probe view of the SNP dictionary (iterate_snp_dict, qv.cc:413-464)              */
 #define VG_VIEW_SNP_JG32  16u   /* HI32 jump table of the SNP dictionary (indexes too large for the merged view)           */
 #define VG_VIEW_SNP_SIG   64u   /* ... its 16-bit signature form (the default; the probe view is built under VG_NO_SIG_VIEW)    */
+#define VG_VIEW_SEC_IS_BF 128u  /* the reference bit vector was verified to be the LO32 set of the dictionary: the LO32-ordered
+                                   view answers its probes too (false e.g. for an index built from a soft-masked FASTA)   */
 #define VG_VIEW_HX        32u   /* paired HI32 table of both dictionaries (indexes too large for the merged view)          */
 uint32_t vg_index_views(const vg_index *ix);
 

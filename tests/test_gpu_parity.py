@@ -76,7 +76,7 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
 
 
 @pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_MX+VG_NO_HX", "VG_NO_MX+VG_NO_SNP_JG32", "VG_NO_MX+VG_NO_SEC+VG_NO_PROBE_VIEW", "VG_NO_SEC", "VG_PACK_OVERLAP",
-                                  "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW"])
+                                  "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW", "VG_NO_SIG_VIEW", "VG_NO_BF_FROM_SEC"])
 def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
     """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view, strided-probe
     view); the pack kernel can run on the ingest stream.  Each has a fallback / alternative; all must give the reference's bits.
@@ -87,6 +87,8 @@ def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, 
     r = ftiny_reads
     _, _, so = _oracle_counts(prefix, r)
     with GenoIndex.open(prefix) as gx:
+        # (F-tiny's FASTA is upper case: its reference bit vector is the LO32 set of its dictionary, which the loader verifies)
+        assert ("sec_is_bf" in gx.views) == ("VG_NO_BF_FROM_SEC" not in knob and "VG_NO_SEC" not in knob), gx.views
         gx.set_stats(False)
         step = r.n // 5 + 1
         for lo in range(0, r.n, step):

@@ -149,6 +149,40 @@ __global__ void vg_make_sec_keys(const uint64_t *__restrict__ kmer, uint64_t n, 
 	}
 }
 
+// 12-byte records of the LO32-ordered view (DevIndex::sec3) from the sorted keys (LO32 << 32 | HI32) and the entries they name
+__global__ void vg_make_sec3(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ sidx, const RefEnt *__restrict__ ref, uint64_t n, uint32_t *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t k = skey[i];
+		const RefEnt e = ref[sidx[i]];
+		out[3 * i] = (uint32_t)k;
+		out[3 * i + 1] = e.pos;
+		out[3 * i + 2] = ((uint32_t)(k >> 32) & 0x7FFFFFFFu) | (e.amb ? 0x80000000u : 0u);
+	}
+}
+// Is the reference bit vector exactly the set of LO32 values of the dictionary (qv.cc:955 tests bit hash32(LO32), and hash32 is a
+// bijection)?  out[0]: dictionary LO32 values whose bit is NOT set; out[1]: distinct LO32 values; out[2]: bits set in the vector.
+__global__ void vg_sec_bf_check(const uint64_t *__restrict__ skey, uint64_t n, const uint64_t *__restrict__ bf, unsigned long long *__restrict__ out)
+{
+	unsigned long long miss = 0, distinct = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t lo = (uint32_t)(skey[i] >> 32);
+		if (i == 0 || lo != (uint32_t)(skey[i - 1] >> 32)) {
+			distinct++;
+			const uint32_t h = hash32(lo);
+			if (!((bf[h >> 6] >> (h & 63u)) & 1ull)) miss++;
+		}
+	}
+	if (miss) atomicAdd(&out[0], miss);
+	if (distinct) atomicAdd(&out[1], distinct);
+}
+__global__ void vg_popcount_words(const uint64_t *__restrict__ w, uint64_t n, unsigned long long *__restrict__ out)
+{
+	unsigned long long c = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) c += (unsigned long long)__popcll(w[i]);
+	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+	if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
 // merged exact-match view: after the stable sort, val = index into the concatenation [ref | snp]
 __global__ void vg_make_mx_entries(const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, uint64_t n_ref,
                                    const uint32_t *__restrict__ rpos, const uint8_t *__restrict__ ramb, const uint32_t *__restrict__ spos, const uint8_t *__restrict__ samb,
@@ -657,7 +691,7 @@ struct ScratchBuf {
 // main stream while the (rare, latency-bound) lane tiers of batch k finish on the tail stream.
 constexpr int NSLOT = 3;            // (5 and 8 were measured: no gain at 8 M-read batches, 10-30 % slower at 1 M -- more pack kernels run ahead and get in the wave kernel's way)
 struct Slot {
-	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr;  uint64_t list_cap = 0;
+	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr, *listD = nullptr;  uint64_t list_cap = 0;   // spill lists: main -> second tier (A), second -> third (D), third -> lane tier (B), lost (C)
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
@@ -701,7 +735,7 @@ struct vg_index {
 	int cus = 256;
 	int lane_grid_blocks = 0, wave_grid = 0;
 	uint32_t work_chunk = 128;            // reads a main-tier wave pulls from the launch's work counter at a time (VG_WORK_CHUNK)
-	uint32_t w2_chunk = 8, w2_wpc = 2;    // deep-list tier: reads a wave pulls at a time (VG_W2_CHUNK), workgroups per CU of its grid (VG_W2_WPC)
+	uint32_t w2_chunk = 8, w2_wpc = 6;    // second tier: reads a wave pulls at a time (VG_W2_CHUNK), workgroups per CU of its grid (VG_W2_WPC)
 	FqStream *d_fq = nullptr;             // FASTQ stream state (vg_fastq_stream_*)
 	bool fq_open = false; int fq_prev_slot = -1;
 };
@@ -772,7 +806,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (ix->ingest) (void)hipStreamSynchronize(ix->ingest);
 	for (void *p : ix->owned) (void)hipFree(p);
 	for (Slot &sl : ix->slot) {
-		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_gate, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
+		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.listD, sl.st_bases, sl.st_quals, sl.st_gate, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
 		for (void *p : extra) if (p) (void)hipFree(p);
 		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5, sl.e_fq, sl.e_in};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -1028,6 +1062,15 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			return fail(VG_EIO, "not an index `vargeno index` wrote: %s", msg);
 		}
 	}
+	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first
+	//      2^32 bits of the 9.6 Gbit reference vector can ever be read (src/generate_bf.h:112-128)
+	{
+		const uint64_t rbits = std::min<uint64_t>(ref_bf_bits, 1ull << 32);
+		uint64_t *r = nullptr, *s2 = nullptr;
+		if ((rc = dev_upload(ix, &r, ref_bf_words, (rbits + 63) / 64))) return rc;
+		if ((rc = dev_upload(ix, &s2, snp_bf_words, (snp_bf_bits + 63) / 64))) return rc;
+		d.ref_bf = r; d.ref_bf_bits = ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = snp_bf_bits;
+	}
 	// The merged view's indices are 32 bits wide: an index of 2^32 or more k-mers (hg38 + full dbSNP), or VG_NO_MX, runs on the
 	// layout without it -- and, its own peak being the tighter one (the paired HI32 table), with another order of construction:
 	// pile-up sites first, columns released as soon as their last reader is done.
@@ -1098,18 +1141,34 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			TempDev<uint64_t> kin; TempDev<uint32_t> vin;
 			if ((rc = kin.alloc(c.n_ref))) return rc;
 			if ((rc = vin.alloc(c.n_ref))) return rc;
-			uint64_t *skey = nullptr; uint32_t *sidx = nullptr, *sjg = nullptr;
-			if ((rc = dev_alloc(ix, &skey, c.n_ref))) return rc;
-			if ((rc = dev_alloc(ix, &sidx, c.n_ref))) return rc;
+			TempDev<uint64_t> skey; TempDev<uint32_t> sidx;
+			uint32_t *sjg = nullptr, *sec3 = nullptr;
+			if ((rc = skey.alloc(c.n_ref)) || (rc = sidx.alloc(c.n_ref))) return rc;
 			if ((rc = dev_alloc(ix, &sjg, (1ull << bits) + 1))) return rc;
 			vg_make_sec_keys<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.n_ref, kin.p, vin.p);
 			HIP_TRY(hipGetLastError());
-			const int se = vg_dev_sort_pairs_u64_u32(kin.p, skey, vin.p, sidx, c.n_ref, st);
+			const int se = vg_dev_sort_pairs_u64_u32(kin.p, skey.p, vin.p, sidx.p, c.n_ref, st);
 			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
-			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, st>>>(skey, c.n_ref, sjg, 1ull << bits, (int)(64 - bits));
+			kin.release(); vin.release();
+			if ((rc = dev_alloc(ix, &sec3, 3 * c.n_ref + 4))) return rc;
+			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, st>>>(skey.p, c.n_ref, sjg, 1ull << bits, (int)(64 - bits));
+			vg_make_sec3<<<2048, 256, 0, st>>>(skey.p, sidx.p, ent, c.n_ref, sec3);
+			// the reference bit vector against the dictionary: when they name the same LO32 values, the view answers qv.cc:955 too
+			unsigned long long chk[3] = {1, 0, 0};
+			if (ref_bf_bits >= (1ull << 32) && !getenv("VG_NO_BF_FROM_SEC")) {
+				TempDev<unsigned long long> dchk;
+				if ((rc = dchk.alloc(3))) return rc;
+				HIP_TRY(hipMemsetAsync(dchk.p, 0, 24, st));
+				vg_sec_bf_check<<<2048, 256, 0, st>>>(skey.p, c.n_ref, d.ref_bf, dchk.p);
+				vg_popcount_words<<<2048, 256, 0, st>>>(d.ref_bf, (1ull << 32) / 64, dchk.p + 2);
+				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipStreamSynchronize(st));
+				HIP_TRY(hipMemcpy(chk, dchk.p, 24, hipMemcpyDeviceToHost));
+			}
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(st));
-			d.sec_key = skey; d.sec_idx = sidx; d.sec_jg = sjg; d.sec_bits = bits;
+			d.sec3 = sec3; d.sec_jg = sjg; d.sec_bits = bits;
+			d.sec_is_bf = (chk[0] == 0 && chk[1] == chk[2]) ? 1u : 0u;
 		}
 	}
 	// the merged view is the last user of the reference dictionary's columns: without it (2^32 or more k-mers in the two
@@ -1242,15 +1301,6 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		}
 	}
 	pc.lap("SNP dictionary, scan view, merged view, direct table");
-	// ---- bit vectors: the reference addresses bit (hash % bits); hash32 is 32 bits wide, so only the first
-	//      2^32 bits of the 9.6 Gbit reference vector can ever be read (src/generate_bf.h:112-128)
-	{
-		const uint64_t rbits = std::min<uint64_t>(ref_bf_bits, 1ull << 32);
-		uint64_t *r = nullptr, *s2 = nullptr;
-		if ((rc = dev_upload(ix, &r, ref_bf_words, (rbits + 63) / 64))) return rc;
-		if ((rc = dev_upload(ix, &s2, snp_bf_words, (snp_bf_bits + 63) / 64))) return rc;
-		d.ref_bf = r; d.ref_bf_bits = ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = snp_bf_bits;
-	}
 	if (want_mx && (rc = build_sites())) return rc;
 	pc.lap("bit vectors, pile-up sites");
 	// ---- scratch of the lane tier, overflow counters, stats
@@ -1466,7 +1516,7 @@ extern "C" uint32_t vg_index_views(const vg_index *ix)
 {
 	if (!ix) return 0;
 	const DevIndex &d = ix->d;
-	return (d.sec_key ? VG_VIEW_SEC : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.dx ? VG_VIEW_DX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u) | (d.hx ? VG_VIEW_HX : 0u) | (d.snp_sig ? VG_VIEW_SNP_SIG : 0u);
+	return (d.sec3 ? VG_VIEW_SEC : 0u) | (d.sec_is_bf ? VG_VIEW_SEC_IS_BF : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.dx ? VG_VIEW_DX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u) | (d.hx ? VG_VIEW_HX : 0u) | (d.snp_sig ? VG_VIEW_SNP_SIG : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1541,13 +1591,17 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		if (big) vg_wave_kernel_big<W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		else vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
-		// tail stream, second tier: the same kernel with deep lists over the spill list (2 waves per CU)
+		// tail stream, second tier: the same kernel with deeper lists over the spill list (up to w2_wpc single-wave workgroups per CU)
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
-		// (its workgroups hold 42 KB of LDS each while they live, in the way of the next batch's main tier: a wave takes at least
+		// (its workgroups hold 26 KB of LDS each while they live, in the way of the next batch's main tier: a wave takes at least
 		// w2_chunk reads at a time, so a few hundred spilled reads wake few of them)
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
-		if (big) vg_wave_kernel_big<W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats);
-		else vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats);
+		if (big) vg_wave_kernel_big<W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listD, &ctr[6], &ctr[5], ix->w2_chunk, ix->d_stats);
+		else vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listD, &ctr[6], &ctr[5], ix->w2_chunk, ix->d_stats);
+		// third tier: the deepest LDS lists, for what the second could not hold
+		const unsigned w3grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
+		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w3grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listD, &ctr[6], sl.listB, &ctr[1], &ctr[7], 2u, ix->d_stats);
+		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w3grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listD, &ctr[6], sl.listB, &ctr[1], &ctr[7], 2u, ix->d_stats);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream
@@ -1598,7 +1652,7 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 	if (need_k > sl.pk_kmer_cap) { if (sl.pk_kmer) (void)hipFree(sl.pk_kmer); sl.pk_kmer = nullptr; sl.pk_kmer_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_kmer, need_k * 8)); sl.pk_kmer_cap = need_k; }
 	if (need_m > sl.pk_meta_cap) { if (sl.pk_meta) (void)hipFree(sl.pk_meta); sl.pk_meta = nullptr; sl.pk_meta_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_meta, need_m * 8)); sl.pk_meta_cap = need_m; }
 	if (n_reads > sl.list_cap) {
-		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC};
+		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC, &sl.listD};
 		sl.list_cap = 0;                                        // a failed allocation below must not leave the old size behind
 		for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; }
 		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));

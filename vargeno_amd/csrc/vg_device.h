@@ -32,13 +32,18 @@ struct DevIndex {
 	const RefEnt   *ref;           // [n_ref]
 	const uint32_t *ref_aux;       // [n_ref_aux][10]
 	uint64_t n_ref;
-	// secondary view of the reference dictionary ordered by (LO32, HI32): every k-mer that shares a chunk's first 16
-	// bases is adjacent, so the 48 "last 16 bases differ in one base" neighbour queries of qv.cc:1213-1296 become
-	// one bucket read.  sec_key = LO32 << 32 | HI32, sec_idx = index into `ref`, sec_jg over the top sec_bits of LO32.
-	const uint64_t *sec_key;       // [n_ref]
-	const uint32_t *sec_idx;       // [n_ref]
+	// secondary view of the reference dictionary ordered by (LO32, HI32): every k-mer that shares a chunk's first 16 bases is
+	// adjacent, so the 48 "last 16 bases differ in one base" neighbour queries of qv.cc:1213-1296 become one bucket read.
+	// One 12-byte record per k-mer {HI32, pos, LO32 & 0x7FFFFFFF | ambig_flag << 31} (r03: what a hit needs -- position or row
+	// index, ambiguity -- comes with the record, so a hit costs no gather of the dictionary entry; the top bit of LO32 is implied
+	// by the bucket), sec_jg over the top sec_bits (>= 14) of LO32.
+	// sec_is_bf: the loader has verified that the reference bit vector is exactly the set of LO32 values of this dictionary
+	// (hash32 is a bijection; it holds for every index `vargeno index` writes from an upper-case FASTA): "is the bit set" is then
+	// "does the bucket hold an entry with this LO32", and the probe of the 512 MiB vector is not made.
+	const uint32_t *sec3;          // [n_ref][3]
 	const uint32_t *sec_jg;        // [2^sec_bits + 1]
 	uint32_t sec_bits;
+	uint32_t sec_is_bf;
 	// merged exact-match view: the reference and SNP dictionaries sorted together by k-mer (reference entry first on
 	// ties) behind ONE jump table over HI32, so the two exact look-ups of a chunk (qv.cc:840-841) cost one
 	// jump-table gather + at most one bucket line instead of two of each.  mx entry: {lo32, pos, flags, pos2} with
@@ -192,6 +197,9 @@ __device__ inline bool hx_may_hold(uint32_t cnt, uint32_t f, uint32_t lo)
 {
 	return cnt > 1u ? (f & hx_bit(lo)) != 0u : (cnt == 1u && f == hx_fp16(lo));
 }
+
+// one 12-byte record (4-byte aligned)
+__device__ __forceinline__ uint3 gather12(const uint32_t *p) { uint3 r; __builtin_memcpy(&r, __builtin_assume_aligned(p, 4), 12); return r; }
 
 // bucket bounds: one 8-byte gather (two adjacent jump-table words)
 __device__ inline void jg_pair(const uint32_t *jg, uint64_t h, uint32_t &lo, uint32_t &hi)

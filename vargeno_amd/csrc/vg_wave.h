@@ -67,7 +67,19 @@ namespace vg {
 #define VG_W1_KMAX 0      // keys a main-tier lane may open before its read goes to the deep tier (0: as many as it has exact contexts).
 #endif                    // The vote of a lane with k keys costs ~k^2 / 2 LDS probes while its 63 neighbours wait.
 constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_WPB = VG_W1_WPB;   // W1_WPB: waves per workgroup of the main tier
-constexpr int W2_ECAP = 48, W2_NCAP = 48;
+// Second tier: 40 exact + 16 neighbour contexts per lane -- 26 KB of LDS per (single-wave) workgroup, i.e. six of them per CU
+// where the 48 + 48 lists of round 2 (42 KB) allowed three and ran two: on a repeat-rich genome (30 % of it in families of
+// near-identical copies: 10 % of the reads outgrow the main tier) that is +22 % reads/s (profiles/ab_hg38_repeats30_r03_tiers.txt;
+// 32 + 12 lists would fit eight per CU but send 5 % of those reads on).  Third tier: the 48 + 48 lists, for the few reads
+// beyond that (65 of 800 000 there); then the generic lane machine with its lists in HBM.
+#ifndef VG_W2_ECAP
+#define VG_W2_ECAP 40
+#endif
+#ifndef VG_W2_NCAP
+#define VG_W2_NCAP 16
+#endif
+constexpr int W2_ECAP = VG_W2_ECAP, W2_NCAP = VG_W2_NCAP;
+constexpr int W3_ECAP = 48, W3_NCAP = 48;
 constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is also what a failed query's -1 truncates to
 #ifndef VG_SEC_W
 #define VG_SEC_W 8
@@ -123,7 +135,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	// stage B pair table: one row per gate-open (owner, chunk) pair of the wave, PCAP rows at a time
 	__shared__ uint32_t P_klo[PCAP][WPB], P_khi[PCAP][WPB], P_lo[PCAP][WPB], P_hi[PCAP][WPB], P_slo[PCAP][WPB], P_shi[PCAP][WPB];
 	__shared__ uint32_t P_meta[PCAP][WPB], P_cnt[PCAP][WPB], P_off[PCAP][WPB], P_hu[PCAP][WPB], P_hidx[HCAP][PCAP][WPB];
-	__shared__ uint8_t P_ecnt[PCAP][WPB];
+	__shared__ uint8_t P_ecnt[PCAP][WPB], P_hamb[PCAP][WPB];
 	__shared__ uint16_t N_cnt[64 * WPB];
 	__shared__ uint8_t N_ovf[64 * WPB];
 	__shared__ unsigned long long Q_state;              // work pool of the workgroup: hi32 = end, lo32 = cursor (may run past the end)
@@ -134,7 +146,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform
 	// The secondary (LO32-ordered) view answers the 48 high-half reference queries with one bucket read.  The counting
 	// build keeps the 48 individual queries because the event counters price each of them.
-	const bool use_sec = !STATS && d.sec_key != nullptr;
+	const bool use_sec = !STATS && d.sec3 != nullptr;
+	const bool bf_from_sec = use_sec && d.sec_is_bf != 0u;          // the reference bit vector is the LO32 set of the dictionary (verified by the loader)
 	const bool use_mx = !STATS && !NOMX && d.mx != nullptr;
 	const bool use_sig = !STATS && d.snp_sig != nullptr;
 	const bool use_probe = !STATS && !use_sig && d.snp_probe != nullptr;
@@ -521,7 +534,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						if (use_sec) jg_pair(d.sec_jg, klo >> (32 - d.sec_bits), b0, b1);
 						const uint64_t rp = (uint64_t)hash32(klo) % d.ref_bf_bits;   // qv.cc:946-956
 						const uint64_t sp = hash40(k & LO40_MASK) % d.snp_bf_bits;
-						if ((gather_bf<uint64_t>(d.ref_bf + (rp >> 6)) >> (rp & 63)) & 1u) fl |= 1u;
+						if (!bf_from_sec) { if ((gather_bf<uint64_t>(d.ref_bf + (rp >> 6)) >> (rp & 63)) & 1u) fl |= 1u; }
 						if ((gather_bf<uint64_t>(d.snp_bf + (sp >> 6)) >> (sp & 63)) & 1u) fl |= 2u;
 						const bool large = hi - lo >= BLOCK_THRESHOLD;
 						// high-half SNP queries are live for a contiguous range of slots u = 3 * (pair - 16) + sel  (qv.cc:1303-1306)
@@ -529,29 +542,33 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						if (fl & 2u) { s_lo = large ? 0u : 12u; s_hi = 48u; } else if (large) { s_lo = 0u; s_hi = 12u; }
 						// high-half ref hits from the LO32-ordered view: every dictionary k-mer with the same first 16 bases
 						// whose last 16 differ in exactly one base, kept sorted by slot
-						uint32_t nh = 0, hu = 0;                                   // hu: slot of hit z in byte z (unsorted)
+						uint32_t nh = 0, hu = 0, hamb = 0;                         // hu: slot of hit z in byte z (unsorted); hamb: bit z = hit z is ambiguous
 						bool sec_ok = use_sec;
-						auto sec_entry = [&](uint64_t key, uint32_t idx) {        // one view entry with this LO32
-							const int dd = onebase((uint64_t)((uint32_t)key ^ khi));
+						auto sec_entry = [&](uint32_t ehi, uint32_t epos, uint32_t eamb) {   // one view entry with this LO32: HI32, position (or row), ambiguity
+							const int dd = onebase((uint64_t)(ehi ^ khi));
 							if (dd < 0) return;
 							if (nh == (uint32_t)HCAP) { sec_ok = false; return; }
-							const uint32_t nbb = ((uint32_t)key >> (2 * dd)) & 3u, base = (khi >> (2 * dd)) & 3u;
-							P_hidx[nh][p][wv] = idx;
+							const uint32_t nbb = (ehi >> (2 * dd)) & 3u, base = (khi >> (2 * dd)) & 3u;
+							P_hidx[nh][p][wv] = epos;
+							hamb |= eamb << nh;
 							hu |= ((uint32_t)dd * 3u + nbb - (nbb > base ? 1u : 0u)) << (8 * nh);
 							nh++;
 						};
-						if (use_sec && (fl & 1u) && b1 > b0) {
+						if (use_sec && (bf_from_sec || (fl & 1u)) && b1 > b0) {
 							if (b1 - b0 <= (uint32_t)SEC_W) {
-								// the usual bucket: its (at most SEC_W) keys and dictionary indices in one go, no search
-								uint64_t key[SEC_W]; uint32_t idx[SEC_W];
+								// the usual bucket: its (at most SEC_W) 12-byte records in one go, no search.  With a verified bit vector the
+								// records also answer "is the bit of this LO32 set" (qv.cc:955): it is iff one of them carries it.
+								uint3 rec[SEC_W];
 								#pragma unroll
-								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; key[z] = gather<uint64_t>(d.sec_key + e); idx[z] = gather<uint32_t>(d.sec_idx + e); }
+								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; rec[z] = gather12(d.sec3 + 3ull * e); }
 								#pragma unroll
-								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) if (b0 + z < b1 && (uint32_t)(key[z] >> 32) == klo) sec_entry(key[z], idx[z]);
+								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) if (b0 + z < b1 && ((rec[z].z ^ klo) & 0x7FFFFFFFu) == 0u) { fl |= 1u; sec_entry(rec[z].x, rec[z].y, rec[z].z >> 31); }
+							} else {
+								// A longer bucket keeps its 48 queries, dealt to 48 lanes in stage B1: walking a popular LO32's run of entries here
+								// (bisection + up to a dozen dependent loads) made one lane hold up its wave -- 4 % of the kernel at hg38 scale.
+								sec_ok = false;
+								if (bf_from_sec) { if ((gather_bf<uint64_t>(d.ref_bf + (rp >> 6)) >> (rp & 63)) & 1u) fl |= 1u; }   // (and its bit is read after all)
 							}
-							// A longer bucket keeps its 48 queries, dealt to 48 lanes in stage B1: walking a popular LO32's run of entries here
-							// (bisection + up to a dozen dependent loads) made one lane hold up its wave -- 4 % of the kernel at hg38 scale.
-							else sec_ok = false;
 						}
 						uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
 						if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
@@ -566,6 +583,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						P_meta[p][wv] = own | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
 						P_cnt[p][wv] = L + nhigh;
 						P_hu[p][wv] = hu;
+						P_hamb[p][wv] = (uint8_t)hamb;
 					}
 				}
 				if constexpr (STATS) {
@@ -627,6 +645,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					const uint4 scan_next = scan_probe(g + 64u);
 					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
 					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
+					uint32_t rdirect = 0;                                     // bit 0: ri holds the entry's POSITION field instead (bit 1: its ambig_flag)
 					LaneStats<STATS> hs;
 					hs.clear();
 					if (valid) {
@@ -707,7 +726,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 									if (rank == h) zsel = z;
 								}
 								u = (hu >> (8 * zsel)) & 0xFFu;
-								ri = P_hidx[zsel][p][wv];
+								ri = P_hidx[zsel][p][wv];                        // (a hit of the LO32-ordered view comes with its position: no entry to fetch)
+								rdirect = 1u | (((uint32_t)P_hamb[p][wv] >> zsel) & 1u) << 1;
 								have_ri = true;
 							} else u = u_lo + h;
 							const uint32_t pair = 16u + u / 3, sel = u % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
@@ -715,7 +735,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							mod = pair;
 							qk = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
 							if (!have_ri && 2 * pair < rsb) {
-								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) if (((hu >> (8 * z)) & 0xFFu) == u) ri = P_hidx[z < (uint32_t)HCAP ? z : 0][p][wv]; }
+								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) if (((hu >> (8 * z)) & 0xFFu) == u) { ri = P_hidx[z < (uint32_t)HCAP ? z : 0][p][wv]; rdirect = 1u | (((uint32_t)P_hamb[p][wv] >> z) & 1u) << 1; } }
 								else q_r = true;
 							}
 							q_s = (large || 2 * pair >= 40u) && 2 * pair < ssb;
@@ -736,7 +756,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					{
 						RefEnt re; SnpEnt se;
 						re.pos = POS_AMBIGUOUS; re.amb = 0; se.pos = POS_AMBIGUOUS; se.key = 0;
-						if (ri != NOHIT) re = gather<RefEnt>(d.ref + ri);
+						if (rdirect) { re.pos = ri; re.amb = rdirect >> 1; }         // ri IS the position (or the row index) here
+						else if (ri != NOHIT) re = gather<RefEnt>(d.ref + ri);
 						if (si != NOHIT) se = gather<SnpEnt>(d.snp + si);
 						const bool r_ok = re.pos != POS_AMBIGUOUS, s_ok = se.pos != POS_AMBIGUOUS;
 						r_aux = r_ok && re.amb != 0; s_aux = s_ok && ((se.key >> 48) & 0xFFu) != 0;
