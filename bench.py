@@ -535,7 +535,10 @@ def main():
                 pass
         gc = None
         if ceiling:
-            gc = {"peak": ceiling["gathers_per_s"], "unit": "random 8-byte gathers/s (tools/gather_probe, 16 GiB table, measured in this run)",
+            # An L2 miss of a random gather moves one 128-byte line (profiles/line_probe_r03_counters.txt), so the chip's measured
+            # random-gather rate IS the HBM roofline for this access shape: lines/s x 128 B
+            gc = {"peak": ceiling["gathers_per_s"], "unit": "random 128-byte lines/s (tools/gather_probe: 8-byte gathers from a 16 GiB table, one line each; measured in this run)",
+                  "peak_GB_per_s": ceiling["gathers_per_s"] * 128 / 1e9,
                   "l2_misses_per_launch": misses, "achieved": (misses / (k_ms * 1e-3)) if misses else None}
             gc["frac"] = (gc["achieved"] / gc["peak"]) if misses else None
         out = {
@@ -559,6 +562,7 @@ def main():
                        "index_bytes_hbm": gx.device_bytes, "index_views": gx.views, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_note,
+                         "traffic_GB_per_s": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None, "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
                          "kernel": "vg_wave_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "algorithmic_bytes_per_read": alg_bytes_per_launch / args.reads, "gather_ceiling": gc},
             "cpu_baseline": cpu,

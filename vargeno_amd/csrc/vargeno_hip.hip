@@ -382,17 +382,24 @@ __global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_
 			// in flight per lane (1 KB per wave) the kernel was bound by latency, not by the memory system (0.50 ms per 8 M reads
 			// for 1.5 GB; the quality strings it used to fetch as well had hidden that)
 			constexpr uint32_t NP = PACK_LDS / (PACK_T * 16);              // pieces per lane: 10
-			uint4 v[NP];
+#ifndef VG_PACK_GROUPS
+#define VG_PACK_GROUPS 1                                               // the pieces go out in this many groups (1: all at once)
+#endif
+			constexpr uint32_t NG = NP / VG_PACK_GROUPS;
 			#pragma unroll
-			for (uint32_t q = 0; q < NP; q++) {
-				const uint64_t i = (uint64_t)threadIdx.x * 16 + (uint64_t)q * PACK_T * 16;
-				if (i + 16 <= span) v[q] = load_policy<VG_PACK_NT != 0, uint4, 1>(bases + base0 + i);     // (a batch may start at any byte)
-			}
-			#pragma unroll
-			for (uint32_t q = 0; q < NP; q++) {
-				const uint64_t i = (uint64_t)threadIdx.x * 16 + (uint64_t)q * PACK_T * 16;
-				if (i + 16 <= span) *reinterpret_cast<uint4 *>(sm + i) = v[q];
-				else if (i < span) for (uint64_t j = i; j < span; j++) sm[j] = bases[base0 + j];
+			for (uint32_t q0 = 0; q0 < NP; q0 += NG) {
+				uint4 v[NG];
+				#pragma unroll
+				for (uint32_t q = 0; q < NG; q++) {
+					const uint64_t i = (uint64_t)threadIdx.x * 16 + (uint64_t)(q0 + q) * PACK_T * 16;
+					if (i + 16 <= span) v[q] = load_policy<VG_PACK_NT != 0, uint4, 1>(bases + base0 + i);     // (a batch may start at any byte)
+				}
+				#pragma unroll
+				for (uint32_t q = 0; q < NG; q++) {
+					const uint64_t i = (uint64_t)threadIdx.x * 16 + (uint64_t)(q0 + q) * PACK_T * 16;
+					if (i + 16 <= span) *reinterpret_cast<uint4 *>(sm + i) = v[q];
+					else if (i < span) for (uint64_t j = i; j < span; j++) sm[j] = bases[base0 + j];
+				}
 			}
 		}
 		__syncthreads();
