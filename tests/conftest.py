@@ -62,6 +62,18 @@ class _HostBinary(os.PathLike):
 BIN = _HostBinary()
 
 
+# jobs started by one test and finished by a later one of the same session (the reference binary at hg38 scale: test_gpu_cli.py
+# starts it, test_gpu_zz_hg38_reference.py compares); whatever is left at the end of the session is killed
+BACKGROUND = {}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    for job in BACKGROUND.values():
+        p = job.get("ref")
+        if p is not None and p.poll() is None:
+            p.kill()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

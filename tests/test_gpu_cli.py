@@ -62,11 +62,11 @@ def test_cli_matches_the_reference_binary_at_scale(tmp_path):
     assert ours == ref
 
 
-@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/vargeno (the reference built by oracle/Makefile in the build container) is not there")
-def test_cli_matches_the_reference_binary_at_hg38_scale(tmp_path):
+def _hg38_cli_job(tmp_dir):
     """BASELINE.json configs[2] shape end to end: the reference binary and the product's `vargeno geno`, both on the hg38-scale
-    index files (shared with bench.py / test_gpu_fullsize.py through VG_BENCH_DIR) and the same 200 000 reads, must write the
-    same bytes.  The reference spends ~4 minutes of its run loading the 43 GB dictionary field by field."""
+    index files (shared with bench.py / test_gpu_fullsize.py through VG_BENCH_DIR) and the same 200 000 reads.  The reference
+    spends ~4 minutes of its run loading the 43 GB dictionary field by field, on one thread: it is started here and left
+    running beside the tests that follow; tests/test_gpu_zz_hg38_reference.py, the last module of the suite, compares."""
     import torch
 
     d = os.environ.get("VG_BENCH_DIR", "/tmp/vg_bench") + "/g3100000000_s10000000_c24"
@@ -83,16 +83,38 @@ def test_cli_matches_the_reference_binary_at_hg38_scale(tmp_path):
     src.release()
     del src
     torch.cuda.empty_cache()
-    fq = str(tmp_path / "reads.fq")
+    fq = os.path.join(tmp_dir, "reads.fq")
     synth.write_fastq(fq, r)
-    ref = subprocess.Popen([REF_BIN, "geno", "idx", fq, "snps.vcf", str(tmp_path / "ref.vcf")], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ref = subprocess.Popen([REF_BIN, "geno", "idx", fq, "snps.vcf", os.path.join(tmp_dir, "ref.vcf")], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    job = {"ref": ref, "ref_vcf": os.path.join(tmp_dir, "ref.vcf"), "ours_vcf": os.path.join(tmp_dir, "ours.vcf"), "ours_rc": None, "ours_err": ""}
     try:
-        p = subprocess.run([BIN, "geno", "idx", fq, "snps.vcf", str(tmp_path / "ours.vcf")], cwd=d, capture_output=True, text=True)
-        assert p.returncode == 0, p.stderr
-        assert ref.wait(timeout=900) == 0
+        p = subprocess.run([BIN, "geno", "idx", fq, "snps.vcf", job["ours_vcf"]], cwd=d, capture_output=True, text=True)
+        job["ours_rc"], job["ours_err"] = p.returncode, p.stderr
+    except BaseException:
+        ref.kill()
+        raise
+    return job
+
+
+def finish_hg38_cli_job(job):
+    try:
+        assert job["ours_rc"] == 0, job["ours_err"]
+        assert job["ref"].wait(timeout=900) == 0
     finally:
-        if ref.poll() is None:
-            ref.kill()
-    ours = open(tmp_path / "ours.vcf", "rb").read()
+        if job["ref"].poll() is None:
+            job["ref"].kill()
+    ours = open(job["ours_vcf"], "rb").read()
     assert ours.count(b"\n") > 50_000
-    assert ours == open(tmp_path / "ref.vcf", "rb").read()
+    assert ours == open(job["ref_vcf"], "rb").read()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/vargeno (the reference built by oracle/Makefile in the build container) is not there")
+def test_cli_at_hg38_scale_runs_and_the_reference_is_started(tmp_path_factory):
+    """First half of the hg38-scale end-to-end check (the second is test_gpu_zz_hg38_reference.py): the product's `vargeno geno`
+    runs to completion here; the reference binary, which needs minutes, keeps running beside the following tests."""
+    import conftest
+
+    job = _hg38_cli_job(str(tmp_path_factory.mktemp("hg38cli")))
+    conftest.BACKGROUND["hg38_cli"] = job
+    assert job["ours_rc"] == 0, job["ours_err"]
+    assert open(job["ours_vcf"], "rb").read().count(b"\n") > 50_000
