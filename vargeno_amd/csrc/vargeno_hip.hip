@@ -226,58 +226,6 @@ __global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__r
 		dx[h] = r;
 	}
 }
-#ifdef VG_DX8
-// EXPERIMENT: the direct table's 64 GiB as one 128-byte line per HI29 group (see vg_wave.h): header {x: 4 bits per bucket -- has a
-// first entry, SNP, ambiguous, PAIR --, y: bits 0-7 bucket has further entries, 8-10 overflow slots used, 11 DEEP, 12-17 slot is the
-// second position of the entry before it, z: 5 bits per overflow slot -- owner bucket, SNP, ambiguous --, w: -}, eight first entries,
-// six overflow slots.  DEEP (more than six further entries): {0, 1 << 11, entries, first entry in mx} + nine offsets.
-__global__ void vg_make_dx8(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ dx, const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos)
-{
-	for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < (1ull << 29); g += (uint64_t)gridDim.x * blockDim.x) {
-		uint32_t b[9];
-		for (int j = 0; j < 9; j++) b[j] = jg[8 * g + j];
-		uint32_t w[32];
-		for (int i = 0; i < 32; i++) w[i] = 0;
-		uint32_t nov = 0;
-		bool deep = b[8] - b[0] > 14u;
-		uint32_t hx_ = 0, hy = 0, hz = 0;
-		for (int j = 0; j < 8 && !deep; j++) {
-			for (uint32_t e = b[j]; e < b[j + 1] && !deep; e++) {
-				const uint4 v = mx[e];                                // row form: flags 1 SNP, 2 ambiguous; y = position or row index
-				uint32_t p0 = v.y, p1 = 0;
-				const bool pair = (v.z & 2u) && aux_pair((v.z & 1u) ? snp_aux_pos : ref_aux, v.y, p0, p1);
-				if (!pair) p0 = v.y;
-				if (e == b[j]) {
-					w[4 + 2 * j] = v.x; w[5 + 2 * j] = p0;
-					hx_ |= (1u | ((v.z & 1u) << 1) | (((v.z >> 1) & 1u) << 2) | (pair ? 8u : 0u)) << (4 * j);
-					if (b[j + 1] - b[j] > 1u) hy |= 1u << j;
-				} else {
-					if (nov >= 6u) { deep = true; break; }
-					w[20 + 2 * nov] = v.x; w[21 + 2 * nov] = p0;
-					hz |= ((uint32_t)j | ((v.z & 1u) << 3) | (((v.z >> 1) & 1u) << 4)) << (5 * nov);
-					nov++;
-				}
-				if (pair) {
-					if (nov >= 6u) { deep = true; break; }
-					w[20 + 2 * nov] = v.x; w[21 + 2 * nov] = p1;
-					hz |= ((uint32_t)j | ((v.z & 1u) << 3) | (((v.z >> 1) & 1u) << 4)) << (5 * nov);
-					hy |= 1u << (12 + nov);
-					nov++;
-				}
-			}
-		}
-		if (deep) {
-			for (int i = 0; i < 32; i++) w[i] = 0;
-			w[0] = 0; w[1] = 1u << 11; w[2] = b[8] - b[0]; w[3] = b[0];
-			for (int j = 0; j < 9; j++) w[4 + j] = b[j] - b[0];
-		} else {
-			w[0] = hx_; w[1] = hy | (nov << 8); w[2] = hz; w[3] = 0;
-		}
-		uint4 *line = dx + 8 * g;
-		for (int q = 0; q < 8; q++) line[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-	}
-}
-#endif
 // the same for the entries of the merged view themselves (read for buckets of several entries); mx flags: 1 SNP, 2 ambiguous, 4 PAIR
 __global__ void vg_inline_pairs(uint4 *__restrict__ mx, uint64_t n, const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos)
 {
@@ -1337,11 +1285,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 				HIP_TRY(hipMemsetAsync(big.p, 0, 4, st));
 				uint32_t too_big = 0;
 				if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (80ull << 30) && hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) == hipSuccess) {
-#ifdef VG_DX8
-					vg_make_dx8<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos);
-#else
 					vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
-#endif
 					HIP_TRY(hipGetLastError());
 					HIP_TRY(hipStreamSynchronize(st));
 					HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));

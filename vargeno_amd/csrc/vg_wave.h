@@ -363,100 +363,6 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
 					}
 				};
-#ifdef VG_DX8
-				if (d.dx) {
-					// EXPERIMENT (-DVG_DX8): the 64 GiB of the direct table laid out as one 128-byte line per HI29 group -- header, the FIRST
-					// entry of each of the eight HI32 buckets at a fixed place ({low half, position} x 8), six overflow slots shared by the
-					// group -- and everything a look-up can need from the line asked for at once (header, own first entry, the overflow
-					// slots: 18 registers), two chunks per wait.  A group with more than six further entries is DEEP: header + nine offsets
-					// into the merged view.
-					uint64_t kq[4] = {0, 0, 0, 0};
-					for (uint32_t c = 0; c < n; c += 4) {
-						const uint32_t m = n - c < 4u ? n - c : 4u;
-						if (m >= 2) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
-						if (m >= 4) chunk_kmer2(c + 2, kq[2], kq[3]); else if (m == 3) kq[2] = chunk_kmer(c + 2);
-						VG_CLKW(9);
-						#pragma unroll
-						for (uint32_t z0 = 0; z0 < 4; z0 += 2) {
-							uint4 H[2], O0[2], O1[2], O2[2]; uint2 P[2];
-							#pragma unroll
-							for (uint32_t y = 0; y < 2; y++) {
-								H[y] = O0[y] = O1[y] = O2[y] = make_uint4(0, 0, 0, 0); P[y] = make_uint2(0, 0);
-								if (z0 + y < m) {
-									const uint4 *line = d.dx + ((kq[z0 + y] >> 35) << 3);
-									H[y] = gather<uint4>(line);
-									P[y] = gather<uint2>((const uint2 *)line + 2 + ((uint32_t)(kq[z0 + y] >> 32) & 7u));
-									O0[y] = gather<uint4>(line + 5); O1[y] = gather<uint4>(line + 6); O2[y] = gather<uint4>(line + 7);
-								}
-							}
-							VG_CLKW(10);
-							#pragma unroll
-							for (uint32_t y = 0; y < 2; y++) {
-								const uint32_t z = z0 + y;
-								if (z >= m) continue;
-								cur.add(S_CHUNKS, 1);
-								const uint32_t key = (uint32_t)kq[z], j = (uint32_t)(kq[z] >> 32) & 7u;
-								uint32_t rp = 0, rp2 = 0, rf = 0, sp = 0, sp2 = 0, sf = 0;
-								if (H[y].y & (1u << 11)) {
-									// DEEP group: bucket j = entries [off[j], off[j + 1]) of the merged view behind index w
-									const uint2 ob = gather<uint2, 4>((const uint32_t *)(d.dx + ((kq[z] >> 35) << 3)) + 4 + j);
-									const uint4 *e0 = d.mx + H[y].w;
-									uint32_t ea = ob.x, eb = ob.y;
-									const uint32_t hi = ob.y;
-									if (eb - ea > 8u) while (ea < eb) { const uint32_t mm = ea + ((eb - ea) >> 1); if (e0[mm].x < key) ea = mm + 1; else eb = mm; }
-									for (; ea < hi; ea++) {
-										const uint4 v = e0[ea];
-										if (v.x < key) continue;
-										if (v.x > key) break;
-										const uint32_t f = 1u | (v.z & 2u) | (v.z & 4u);
-										if (v.z & 1u) { sp = v.y; sp2 = v.w; sf = f; } else { rp = v.y; rp2 = v.w; rf = f; }
-									}
-								} else {
-									const uint32_t nib = (H[y].x >> (4u * j)) & 15u, nsl = (H[y].y >> 8) & 7u;
-									const uint32_t olo[6] = {O0[y].x, O0[y].z, O1[y].x, O1[y].z, O2[y].x, O2[y].z}, opos[6] = {O0[y].y, O0[y].w, O1[y].y, O1[y].w, O2[y].y, O2[y].w};
-									// overflow slot s: owner bucket (3 bits), SNP entry, ambiguous in H.z; "second position of the entry before" in H.y
-									if ((nib & 1u) && P[y].x == key) {
-										uint32_t p2 = 0;
-										if (nib & 8u) {
-											#pragma unroll
-											for (uint32_t s = 6; s-- > 0;) if (s < nsl && ((H[y].z >> (5u * s)) & 7u) == j && ((H[y].y >> (12u + s)) & 1u)) p2 = opos[s];   // (the first such slot: a primary's pair comes first)
-										}
-										const uint32_t f = 1u | ((nib & 4u) ? 2u : 0u) | ((nib & 8u) ? 4u : 0u);
-										if (nib & 2u) { sp = P[y].y; sp2 = p2; sf = f; } else { rp = P[y].y; rp2 = p2; rf = f; }
-									}
-									if ((H[y].y >> j) & 1u) {
-										#pragma unroll
-										for (uint32_t s = 0; s < 6; s++) {
-											const uint32_t mt = (H[y].z >> (5u * s)) & 31u;
-											if (s < nsl && (mt & 7u) == j && !((H[y].y >> (12u + s)) & 1u) && olo[s] == key) {
-												const bool pair = s + 1u < nsl && ((H[y].y >> (13u + s)) & 1u);
-												const uint32_t f = 1u | ((mt & 16u) ? 2u : 0u) | (pair ? 4u : 0u);
-												const uint32_t p2 = s < 5u ? opos[s < 5u ? s + 1u : 5u] : 0u;
-												if (mt & 8u) { sp = opos[s]; sp2 = p2; sf = f; } else { rp = opos[s]; rp2 = p2; rf = f; }
-											}
-										}
-									}
-								}
-								const bool r_ok = (rf & 1u) && ((rf & 4u) || rp != POS_AMBIGUOUS), s_ok = (sf & 1u) && ((sf & 4u) || sp != POS_AMBIGUOUS);
-								const bool r_ax = r_ok && (rf & 6u) == 2u, s_ax = s_ok && (sf & 6u) == 2u;   // ambiguous and not a PAIR: read the row
-								uint32_t rr[4], sr[4];
-								if (r_ax) load_row4(d.ref_aux + (uint64_t)rp * AUX_COLS, 0, rr);
-								if (s_ax) load_row4(d.snp_aux_pos + (uint64_t)sp * AUX_COLS, 0, sr);
-								if (r_ok) {
-									if (rf & 2u) cur.add(S_AUX_REF, 1);
-									if (r_ax) push_row_from(d.ref_aux + (uint64_t)rp * AUX_COLS, rr, c + z);
-									else { push_exact(rp, c + z); if (rf & 4u) push_exact(rp2, c + z); }
-								}
-								if (s_ok) {
-									if (sf & 2u) cur.add(S_AUX_SNP, 1);
-									if (s_ax) push_row_from(d.snp_aux_pos + (uint64_t)sp * AUX_COLS, sr, c + z);
-									else { push_exact(sp, c + z); if (sf & 4u) push_exact(sp2, c + z); }
-								}
-							}
-						}
-					}
-				} else
-#else
 				if (d.dx) {
 					// direct table: the bucket's first entry arrives with the bucket itself.  Up to four chunks -- a whole 150 bp
 					// read -- are in flight at a time: their k-mers come as 16-byte pairs, their buckets go out back to back.
@@ -540,7 +446,6 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						}
 					}
 				} else
-#endif
 				for (uint32_t c = 0; c < n; c += 2) {
 					const bool two = c + 1 < n;
 					const uint64_t k0 = chunk_kmer(c), k1 = two ? chunk_kmer(c + 1) : 0;
