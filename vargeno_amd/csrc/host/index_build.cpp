@@ -479,33 +479,51 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 		const std::string *seq = nullptr;
 		static const std::string empty;
 		seq = &empty;
+		// (100 M lines at hg38 + full dbSNP scale: parsed in place -- no per-line vector or string -- and, the k-mer never shifting
+		// (B2), one hash per SNP instead of 32 of the same)
+		auto atoi_span = [](const char *a, const char *b) -> int {        // atoi() of the text [a, b)
+			while (a < b && isspace((unsigned char)*a)) a++;
+			bool neg = false;
+			if (a < b && (*a == '+' || *a == '-')) { neg = *a == '-'; a++; }
+			long v = 0;
+			while (a < b && *a >= '0' && *a <= '9') { v = v * 10 + (*a - '0'); a++; }
+			return (int)(neg ? -v : v);
+		};
+		const char *const text = vcf_text.data();
+		const char *last_c0 = nullptr; size_t last_c0_len = 0;             // column 0 of the last line that got as far as the chromosome look-up
 		size_t i = 0;
 		while (i < vcf_text.size()) {
-			size_t e = vcf_text.find('\n', i);
-			if (e == std::string::npos) e = vcf_text.size();
+			const char *nl = (const char *)memchr(text + i, '\n', vcf_text.size() - i);
+			const size_t e = nl ? (size_t)(nl - text) : vcf_text.size();
 			const size_t ls = i, le = e;
 			i = e + 1;
-			if (le == ls || vcf_text[ls] == '#') continue;
-			// split(line, '\t')
-			std::vector<std::pair<size_t, size_t>> col;
-			for (size_t a = ls;;) {
-				size_t b = vcf_text.find('\t', a);
-				if (b == std::string::npos || b > le) { col.push_back({a, le}); break; }
-				col.push_back({a, b}); a = b + 1;
+			if (le == ls || text[ls] == '#') continue;
+			// split(line, '\t'): the first five columns
+			const char *cs[5], *ce[5];
+			int nc = 0;
+			for (const char *a = text + ls, *end = text + le; nc < 5;) {
+				const char *t = (const char *)memchr(a, '\t', (size_t)(end - a));
+				cs[nc] = a; ce[nc] = t ? t : end; nc++;
+				if (!t) break;
+				a = t + 1;
 			}
-			if (col.size() < 5) continue;                                  // the reference would index past the vector
-			std::string chr(vcf_text, col[0].first, col[0].second - col[0].first);
-			if (chr.empty() || chr[0] != 'c') chr = "chr" + chr;
-			const int pos = atoi(std::string(vcf_text, col[1].first, col[1].second - col[1].first).c_str()) - 1;
-			const size_t rl = col[3].second - col[3].first, al = col[4].second - col[4].first;
+			if (nc < 5) continue;                                          // the reference would index past the vector
+			const int pos = atoi_span(cs[1], ce[1]) - 1;
+			const size_t rl = (size_t)(ce[3] - cs[3]), al = (size_t)(ce[4] - cs[4]);
 			if (rl > 1 || al > 1) continue;
-			if (chr != pre_chr) {
-				for (const Seq &s : g) if (s.name == chr) { seq = &s.seq; break; }     // not found: previous sequence stays
-				pre_chr = chr;
+			const size_t c0l = (size_t)(ce[0] - cs[0]);
+			if (!(last_c0 && c0l == last_c0_len && memcmp(cs[0], last_c0, c0l) == 0)) {
+				std::string chr(cs[0], c0l);
+				if (chr.empty() || chr[0] != 'c') chr = "chr" + chr;
+				if (chr != pre_chr) {
+					for (const Seq &s : g) if (s.name == chr) { seq = &s.seq; break; }     // not found: previous sequence stays
+					pre_chr = chr;
+				}
+				last_c0 = cs[0]; last_c0_len = c0l;
 			}
 			if (pos < 32 || (size_t)(pos + 32) > seq->size()) continue;
 			if (rl == 0 || al == 0) continue;
-			const char ref_nt = vcf_text[col[3].first], alt_nt = vcf_text[col[4].first];
+			const char ref_nt = *cs[3], alt_nt = *cs[4];
 			if (ref_nt != (*seq)[(size_t)pos] || ref_nt == alt_nt) continue;
 			uint64_t k = 0; bool has_n = false;
 			for (int j = 31; j >= 0 && !has_n; j--) {                        // encode_kmer scans from base 31 down
@@ -515,13 +533,15 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 				else k = (k << 2) | (uint64_t)c;
 			}
 			if (has_n) continue;
+			bool any = false;
 			for (unsigned t = 0; t < 32; t++) {
 				const char nb = t ? (*seq)[(size_t)pos + t] : alt_nt;
 				const int c = base_code((unsigned char)nb);
 				if (c == 4) break;
 				if (c == 7) die("invalid base while building the SNP bit vector");            // shift_kmer asserts, util.c:121
-				sbf.set_atomic(hash40(k & 0xFFFFFFFFFFull) % SNP_BF_BITS);                       // B2: k never shifts
+				any = true;                                                                      // B2: k never shifts -- the same bit every time
 			}
+			if (any) sbf.set_atomic(hash40(k & 0xFFFFFFFFFFull) % SNP_BF_BITS);
 		}
 		if (!opt.quiet) printf("[BloomFilter constructBfFromVCF] bit vector: %llu/%llu\n", (unsigned long long)sbf.count(), (unsigned long long)SNP_BF_BITS);
 		sbf.save(prefix + ".snp.bf");
