@@ -2,9 +2,11 @@
 // hot path (reference: src/qv.cc:760-1558 of medvedevgroup/vargeno), written for gfx950.
 //
 // Everything here is integer / bit work bounded by random gathers; there is no MFMA-shaped
-// computation anywhere on this path.  Measured on MI355X (tools/gather_probe): the chip sustains
-// ~48.7 G random 8-byte gathers/s whatever the table size, i.e. the bound is L1->L2 line requests,
-// so the layout below is chosen to touch as few distinct 64-byte lines per query as possible.
+// computation anywhere on this path.  Measured on MI355X (tools/gather_probe, tools/line_probe): the chip
+// sustains ~49 G random gathers/s from a table far larger than its caches, and every one of them moves a
+// whole 128-byte line from HBM (49 G x 128 B = 6.3 TB/s: that rate IS the HBM roofline of this access
+// shape), so the layout below is chosen to touch as few distinct lines per query as possible -- with as
+// few load instructions as possible: a second load into a line that is already on its way is not free.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -574,8 +574,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
 						else if (sec_ok && s_hi == s_lo) { mode = 1; nhigh = nh; }
 						else { u_lo = 0; nhigh = 48; }
-						// items of the strided scans: one per reference-bucket entry; SNP-bucket entries two per item when their probed values
-						// lie side by side (strided-probe view): the SNP scan is most of stage B's items at hg38 scale, and every round of 64
+						// items of the strided scans: one per reference-bucket entry; SNP-bucket entries eight per item (their signatures lie
+						// side by side in the signature view): the SNP scan is most of stage B's items at hg38 scale, and every round of 64
 						// items pays the full chain of dependent waits of the few items in it that do have something to look up
 						const uint32_t Lsn = shi - slo;
 						const uint32_t L = large ? 48u : (hi - lo) + ((Lsn + sw_m1) >> sw_log);
