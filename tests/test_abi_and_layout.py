@@ -68,6 +68,7 @@ def test_no_gpu_means_error_codes_not_a_cpu_path(ftiny_dir):
     assert rc == -4 and not h.value                           # VG_ENODEV
     assert b"no CPU fallback" in L.vg_last_error()
     assert L.vg_sync(None) == -1 and L.vg_counts_reset(None) == -1      # VG_EINVAL, no crash
+    assert L.vg_index_views(None) == 0 and L.vg_reads_process_device_gated(None, None, None, None, 0) == -1
     from vargeno_amd.api import GenoIndex
     with pytest.raises(_lib.VgError):
         GenoIndex.open(os.path.join(ftiny_dir, "idx"))
