@@ -566,7 +566,9 @@ def main():
                          "kernel": "vg_wave_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                          "algorithmic_bytes_per_read": alg_bytes_per_launch / args.reads, "gather_ceiling": gc},
             "cpu_baseline": cpu,
-            "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "spill_tiers_overlapped": tm["ms_tail"], "of_which_deep_list_wave_tier": tm["ms_deep_lists"], "batches": tm["batches"]},
+            "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "spill_tiers_overlapped": tm["ms_tail"], "of_which_deep_list_wave_tier": tm["ms_deep_lists"], "batches": tm["batches"],
+                                   "note": "spill tiers: elapsed time from the end of a batch's main-tier kernel to the end of its last tier, on the tail stream, under the NEXT batches' "
+                                           "kernels -- mostly waiting (a tier's workgroups are placed when main-tier workgroups of the following batch retire), not work: see reads_per_step_redone_by_deep_list_tier"},
             "reads_per_step_redone_by_deep_list_tier": st["overflow_reads"], "reads_per_step_sent_on_to_lane_tier": st["overflow_deep"],
             "events_per_read": {k: st[k] / args.reads for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
             "input_form": "ASCII bases + offsets + " + ("quality strings" if args.ascii_quals else "one gate word per read (bit c = quality character c < '8')") + ", resident in HBM",
