@@ -183,17 +183,31 @@ __global__ void vg_popcount_words(const uint64_t *__restrict__ w, uint64_t n, un
 	for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
 	if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
+// The merged view is keyed by the CANONICAL form of a k-mer (the smaller of it and its reverse complement, mixed so that the
+// buckets fill evenly; r03): one look-up of a read's chunk then answers both strands -- the entry of the k-mer itself
+// (a hit of the current pass) and the entry of its reverse complement (a hit of the OTHER pass, for the mirrored chunk).  A read of
+// the reverse strand, whose forward pass finds nothing, then runs its one useful pass on the look-ups it has just made.
+// strand bit of entry i (1: the dictionary's k-mer is the reverse complement of its canonical form)
+__global__ void vg_canon_keys(uint64_t *__restrict__ key, uint64_t n, uint32_t *__restrict__ strand_bits)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t k = key[i], r = revcomp64(k), ck = k < r ? k : r;
+		if (k != ck) atomicOr(&strand_bits[i >> 5], 1u << (i & 31));
+		key[i] = fmix64(ck);
+	}
+}
 // merged exact-match view: after the stable sort, val = index into the concatenation [ref | snp]
 __global__ void vg_make_mx_entries(const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, uint64_t n_ref,
                                    const uint32_t *__restrict__ rpos, const uint8_t *__restrict__ ramb, const uint32_t *__restrict__ spos, const uint8_t *__restrict__ samb,
-                                   uint4 *__restrict__ out)
+                                   uint4 *__restrict__ out, const uint32_t *__restrict__ strand_bits)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t v = val[i];
 		const bool is_snp = v >= n_ref;
 		const uint32_t pos = is_snp ? spos[v - n_ref] : rpos[v];
 		const uint32_t amb = is_snp ? samb[v - n_ref] : ramb[v];
-		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1), 0u);
+		const uint32_t strand = (strand_bits[v >> 5] >> (v & 31)) & 1u;                          // flag 8: the dictionary's k-mer is the reverse complement of its canonical form
+		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1) | (strand << 3), 0u);
 	}
 }
 // An ambiguous k-mer (2-10 copies) points at an auxiliary row; when the row holds exactly two positions -- the usual case --
@@ -218,7 +232,7 @@ __global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__r
 			const uint4 e = mx[lo];
 			const uint32_t cnt = hi - lo > 0xFFFFFFu ? 0xFFFFFFu : hi - lo;
 			if (hi - lo > 0xFFFFFFu) atomicOr(too_big, 1u);          // the count field is 24 bits wide: the host keeps the jump-table form
-			r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (cnt << 8), lo);
+			r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (((e.z >> 3) & 1u) << 5) | (cnt << 8), lo);   // (flag 32: strand)
 			if (cnt > 1u && mx[lo + 1].x == e.x) r.z |= 16u;            // TIE: the second entry carries the same k-mer (reference + SNP dictionary)
 			uint32_t p0, p1;
 			if (cnt == 1u && (e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { r.y = p0; r.w = p1; r.z |= 8u; }
@@ -1260,6 +1274,10 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			if (c.n_ref) HIP_TRY(hipMemcpyAsync(kin.p, c.ref_kmer.p, (size_t)c.n_ref * 8, hipMemcpyDeviceToDevice, st));
 			if (c.n_snp) HIP_TRY(hipMemcpyAsync(kin.p + c.n_ref, c.snp_kmer.p, (size_t)c.n_snp * 8, hipMemcpyDeviceToDevice, st));
 			vg_iota_u32<<<2048, 256, 0, st>>>(vin.p, nm);
+			TempDev<uint32_t> strand_bits;
+			if ((rc = strand_bits.alloc(nm / 32 + 2))) return rc;
+			HIP_TRY(hipMemsetAsync(strand_bits.p, 0, (nm / 32 + 2) * 4, st));
+			vg_canon_keys<<<2048, 256, 0, st>>>(kin.p, nm, strand_bits.p);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(st));
 			c.ref_kmer.release();                                  // 23 GB at hg38 scale: the sort below needs the room
@@ -1270,9 +1288,10 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
 			if ((rc = dev_alloc(ix, &mx, nm))) return rc;
 			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(kout.p, nm, mjg, 1ull << 32, 32);
-			vg_make_mx_entries<<<2048, 256, 0, st>>>(kout.p, vout.p, nm, c.n_ref, c.ref_pos.p, c.ref_amb.p, c.snp_pos.p, c.snp_amb.p, mx);
+			vg_make_mx_entries<<<2048, 256, 0, st>>>(kout.p, vout.p, nm, c.n_ref, c.ref_pos.p, c.ref_amb.p, c.snp_pos.p, c.snp_amb.p, mx, strand_bits.p);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(st));
+			strand_bits.release();
 			d.mx_jg = mjg; d.mx = mx;
 			// direct table (64 GiB) in place of the merged jump table (16 GiB) when the device has the room; no bucket may
 			// exceed the 24-bit count field (it would be a >16 M-fold repeated 16-mer)

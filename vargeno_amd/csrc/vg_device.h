@@ -151,6 +151,9 @@ __device__ inline uint64_t revcomp64(uint64_t k)
 	return ~k;
 }
 
+// bijective 64-bit mix (murmur3's finaliser): spreads canonical k-mers evenly over the HI32 buckets of the merged view
+__device__ __host__ inline uint64_t fmix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+
 // Loads with the `nt` bit of gfx950's memory instructions ("nothing will touch this line again soon").  A probe of bare random
 // gathers from a table far larger than L2 (tools/gather_policy_probe, profiles/gather_policy_probe_r02.jsonl) runs at 55.0 G/s
 // with it and 50.9 G/s without, whatever the width (sc0 / sc1 change nothing; an L2-resident table: 250 G/s) -- but the read

@@ -348,6 +348,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 			} else if (use_mx) {
 				// The timed build reads the merged view: one jump-table gather + one bucket line answers both dictionaries.
 				// Two chunks are in flight at a time (their gathers are issued back to back before either is consumed).
+				uint32_t k_strand = 0; bool k_pal = false;                       // strand bit / palindrome flag of the k-mer being looked up (below)
 				auto scan_bucket = [&](uint64_t k, uint32_t lo, uint32_t hi, uint4 first, bool &rhit, uint32_t &rpos, uint32_t &ramb, bool &shit, uint32_t &spos, uint32_t &samb) {
 					const uint32_t key = (uint32_t)k;
 					uint32_t ea = lo;
@@ -359,18 +360,34 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						const uint4 v = (e == lo) ? first : d.mx[e];
 						if (v.x < key) continue;
 						if (v.x > key) break;
+						if (!(k_pal || ((v.z >> 3) & 1u) == k_strand)) continue;      // the entry of the reverse complement: not a hit of this pass
 						if (v.z & 1u) { shit = true; spos = v.y; samb = (v.z >> 1) & 1u; }
 						else { rhit = true; rpos = v.y; ramb = (v.z >> 1) & 1u; }
 					}
 				};
 				if (d.dx) {
-					// direct table: the bucket's first entry arrives with the bucket itself.  Up to four chunks -- a whole 150 bp
-					// read -- are in flight at a time: their k-mers come as 16-byte pairs, their buckets go out back to back.
+					// The merged view and its direct table are keyed by the CANONICAL form of a k-mer (the smaller of it and its reverse
+					// complement, mixed so that the buckets fill evenly; r03), so the bucket of a chunk holds the entry of the chunk's k-mer -- a hit of THIS pass -- and the entry of its reverse complement
+					// -- a hit of the other pass, for the mirrored chunk.  In pass 0 those are collected too (simple ones: one position or a
+					// PAIR), in a block that grows down from the top of the exact-context list; if the forward pass finds nothing at all
+					// -- every read of the reverse strand -- the block IS the exact-context list of pass 1 and the lane goes on as pass 1.
+					// the block of reverse-strand contexts is [rc_top, W_ECAP); RC_BAD: it cannot be used (not pass 0; a hit with several
+					// positions; no room)
+					constexpr uint32_t RC_BAD = 0xFFFFu;
+					uint32_t rc_top = pass != 0u ? RC_BAD : (uint32_t)W_ECAP;
 					for (uint32_t c = 0; c < n; c += 4) {
 						const uint32_t m = n - c < 4u ? n - c : 4u;
 						uint64_t kq[4] = {0, 0, 0, 0};
 						if (m >= 2) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
 						if (m >= 4) chunk_kmer2(c + 2, kq[2], kq[3]); else if (m == 3) kq[2] = chunk_kmer(c + 2);
+						// k-mer -> mixed canonical key; strand bits: bit z = the k-mer is the reverse complement of its canonical form, bit 4 + z = palindrome
+						uint32_t sbits = 0;
+						#pragma unroll
+						for (uint32_t z = 0; z < 4; z++) {
+							const uint64_t kk = kq[z], rr = revcomp64(kk), ck = kk < rr ? kk : rr;
+							sbits |= (kk != ck ? 1u : 0u) << z | (kk == rr ? 1u : 0u) << (4u + z);
+							kq[z] = fmix64(ck);
+						}
 						VG_CLKW(9);
 						uint4 bq[4];
 						#pragma unroll
@@ -402,17 +419,30 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								cur.add(S_CHUNKS, 1);
 								const uint4 b = bq[z];
 								const uint32_t key = (uint32_t)kq[z];
-								// hit state: position (or row index), second position of a PAIR, flags 1 hit, 2 ambiguous, 4 PAIR
+								// hit state: position (or row index), second position of a PAIR, flags 1 hit, 2 ambiguous, 4 PAIR -- for this pass's
+								// strand, and (x...) for the other strand
 								uint32_t rp = 0, rp2 = 0, rf = 0, sp = 0, sp2 = 0, sf = 0;
-								if ((b.z & 1u) && b.x == key) {                        // the inline first entry (dx flags: 2 SNP, 4 ambiguous, 8 PAIR)
-									const uint32_t f = 1u | (((b.z >> 2) & 1u) << 1) | (((b.z >> 3) & 1u) << 2);
-									if (b.z & 2u) { sp = b.y; sp2 = b.w; sf = f; } else { rp = b.y; rp2 = b.w; rf = f; }
-								}
+								const uint32_t ks = (sbits >> z) & 1u;
+								const bool pal = (sbits >> (4u + z)) & 1u;
+								// an entry with this chunk's key (es: its strand bit).  One of the other strand goes straight to the block that grows
+								// down from the top of the list, as an exact context of pass 1's chunk n - 1 - (c + z) -- unless it has several
+								// positions (flag 2, PAIR or not: left to the plain way, which keeps this path small) or there is no room
+								auto note = [&](bool is_snp, uint32_t es, uint32_t p1, uint32_t p2, uint32_t f) {
+									if (pal || es == ks) { if (is_snp) { sp = p1; sp2 = p2; sf = f; } else { rp = p1; rp2 = p2; rf = f; } }
+									if ((pal || es != ks) && rc_top != RC_BAD) {
+										if (f & 2u) rc_top = RC_BAD;
+										else if (p1 != POS_AMBIGUOUS) {
+											if (rc_top <= ecnt) rc_top = RC_BAD;
+											else { const uint32_t c1 = n - 1u - (c + z); rc_top--; E_idx[rc_top][col] = p1 - 32u * c1; E_meta[rc_top][col] = (uint8_t)c1; E_fm[rc_top][col] = 0; }
+										}
+									}
+								};
+								if ((b.z & 1u) && b.x == key)                          // the inline first entry (dx flags: 2 SNP, 4 ambiguous, 8 PAIR, 32 strand)
+									note((b.z & 2u) != 0u, (b.z >> 5) & 1u, b.y, b.w, 1u | (((b.z >> 2) & 1u) << 1) | (((b.z >> 3) & 1u) << 2));
 								if (more[z]) {
 									const uint32_t cnt = b.z >> 8, lo = b.w, hi = lo + cnt;
-									auto take = [&](const uint4 v) {                     // mx flags: 1 SNP, 2 ambiguous, 4 PAIR
-										const uint32_t f = 1u | (v.z & 2u) | (v.z & 4u);
-										if (v.z & 1u) { sp = v.y; sp2 = v.w; sf = f; } else { rp = v.y; rp2 = v.w; rf = f; }
+									auto take = [&](const uint4 v) {                     // mx flags: 1 SNP, 2 ambiguous, 4 PAIR, 8 strand
+										note((v.z & 1u) != 0u, (v.z >> 3) & 1u, v.y, v.w, 1u | (v.z & 2u) | (v.z & 4u));
 									};
 									#pragma unroll
 									for (uint32_t x = 0; x < SW; x++) if (x + 1u < cnt && sv[y][x].x == key) take(sv[y][x]);
@@ -445,10 +475,31 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							}
 						}
 					}
+					// A forward pass without a single exact hit can neither vote nor be walked (the stage-B skip below): the lane goes on as
+					// pass 1 with the contexts collected above -- none at all means that pass 1 has nothing either, and the read is done
+					// (the block holds them in the order they were met, downwards: read upwards that is pass 1's chunk order, with the two
+					// contexts a chunk can have here -- reference hit, SNP hit -- the wrong way round)
+					if (pass == 0u && ecnt == 0u && rc_top != RC_BAD && !ovf) {
+						const uint32_t nrc = (uint32_t)W_ECAP - rc_top;
+						for (uint32_t i = 0; i < nrc;) {
+							const uint32_t a0 = E_idx[rc_top + i][col], m0 = E_meta[rc_top + i][col];
+							if (i + 1u < nrc && E_meta[rc_top + i + 1u][col] == m0) {
+								const uint32_t a1 = E_idx[rc_top + i + 1u][col];
+								E_idx[i][col] = a1; E_meta[i][col] = (uint8_t)m0; E_fm[i][col] = 0;
+								E_idx[i + 1u][col] = a0; E_meta[i + 1u][col] = (uint8_t)m0; E_fm[i + 1u][col] = 0;
+								i += 2u;
+							} else { E_idx[i][col] = a0; E_meta[i][col] = (uint8_t)m0; E_fm[i][col] = 0; i++; }
+						}
+						ecnt = nrc;
+						pass = 1u;
+					}
 				} else
 				for (uint32_t c = 0; c < n; c += 2) {
 					const bool two = c + 1 < n;
-					const uint64_t k0 = chunk_kmer(c), k1 = two ? chunk_kmer(c + 1) : 0;
+					uint64_t k0 = chunk_kmer(c), k1 = two ? chunk_kmer(c + 1) : 0;
+					uint32_t st0, st1; bool pl0, pl1;                              // the merged view is keyed by mixed canonical k-mers
+					{ const uint64_t r = revcomp64(k0), ck = k0 < r ? k0 : r; st0 = k0 != ck; pl0 = k0 == r; k0 = fmix64(ck); }
+					{ const uint64_t r = revcomp64(k1), ck = k1 < r ? k1 : r; st1 = k1 != ck; pl1 = k1 == r; k1 = fmix64(ck); }
 					uint32_t lo0, hi0, lo1 = 0, hi1 = 0;
 					jg_pair(d.mx_jg, k0 >> 32, lo0, hi0);
 					if (two) jg_pair(d.mx_jg, k1 >> 32, lo1, hi1);
@@ -458,11 +509,13 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					uint32_t rpos = 0, ramb = 0, spos = 0, samb = 0;
 					bool rhit = false, shit = false;
 					cur.add(S_CHUNKS, 1);
+					k_strand = st0; k_pal = pl0;
 					scan_bucket(k0, lo0, hi0, f0, rhit, rpos, ramb, shit, spos, samb);
 					emit_exact(c, rhit, rpos, ramb, shit, spos, samb);
 					if (two) {
 						rhit = shit = false;
 						cur.add(S_CHUNKS, 1);
+						k_strand = st1; k_pal = pl1;
 						scan_bucket(k1, lo1, hi1, f1, rhit, rpos, ramb, shit, spos, samb);
 						emit_exact(c + 1, rhit, rpos, ramb, shit, spos, samb);
 					}
