@@ -127,3 +127,51 @@ def test_python_binding_refuses_a_stale_library(monkeypatch):
     with pytest.raises(RuntimeError, match="stale"):
         _lib.lib()
     monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_gate_words_helper_matches_the_quality_strings():
+    """api.gate_words (what bench.py and the GPU tests hand to vg_reads_process_device_gated): bit c of a read's word is set iff
+    quality character c is below '8', for the read's chunk numbers c < len // 32 -- checked on CPU tensors against a plain loop."""
+    import numpy as np
+    import torch
+
+    from vargeno_amd.api import gate_words
+
+    rng = np.random.default_rng(7)
+    lens = rng.integers(0, 300, size=500)
+    lens[:4] = [0, 31, 32, 1022]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    quals = rng.integers(ord("#"), ord("I") + 1, size=int(offs[-1]) + 1, dtype=np.uint8)
+    got = gate_words(torch.from_numpy(quals), torch.from_numpy(offs)).numpy().view(np.uint32)
+    for r, L in enumerate(lens):
+        want = 0
+        for c in range(min(int(L) // 32, 32)):
+            if quals[offs[r] + c] < ord("8"):
+                want |= 1 << c
+        assert int(got[r]) == want, (r, int(L))
+
+
+def test_repeat_rich_genome_option_plants_exact_copies():
+    """synth.genome_and_snps(repeats=F): about that fraction of the 32-mers of the genome occurs more than once."""
+    import numpy as np
+
+    from vargeno_amd import synth
+
+    def dup_fraction(g):
+        seq = np.concatenate(g.seqs)
+        code = np.full(256, 4, np.uint8)
+        for i, ch in enumerate(b"ACGT"):
+            code[ch] = i
+        c = code[seq].astype(np.uint64)
+        k = np.zeros(len(c) - 31, np.uint64)
+        for j in range(32):
+            k |= c[j:len(c) - 31 + j] << np.uint64(2 * j)
+        bad = np.convolve((c > 3).astype(np.int32), np.ones(32, np.int32), "valid") > 0
+        k = k[~bad]
+        _, counts = np.unique(k, return_counts=True)
+        return float((counts[counts > 1]).sum()) / len(k)
+
+    g0, _, _ = synth.genome_and_snps(genome_len=1_000_000, n_snps=1000, n_chroms=2)
+    g3, _, _ = synth.genome_and_snps(genome_len=1_000_000, n_snps=1000, n_chroms=2, repeats=0.3)
+    f0, f3 = dup_fraction(g0), dup_fraction(g3)
+    assert f0 < 0.10 and 0.20 < f3 < 0.45 and f3 > 3 * f0, (f0, f3)
