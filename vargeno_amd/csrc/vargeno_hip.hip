@@ -517,6 +517,7 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 		int cls = 0;
 		if (bad) cls = classify_bad(p, n);
 		if (cls == 1) L.st.add(S_READS_N, 1);
+		if (cls == 0 && gate && n > 32u) cls = 2;                                   // (a gate word has 32 bits: the pack kernel counts such a read invalid too)
 		if (cls == 2) { L.st.add(S_READS_INVALID, 1); if (invalid_reads) atomicAdd(invalid_reads, 1u); }
 		if (cls == 0) {
 			bool ok = false;

@@ -46,15 +46,16 @@ struct DevIndex {
 	const uint32_t *sec_jg;        // [2^sec_bits + 1]
 	uint32_t sec_bits;
 	uint32_t sec_is_bf;
-	// merged exact-match view: the reference and SNP dictionaries sorted together by k-mer (reference entry first on
-	// ties) behind ONE jump table over HI32, so the two exact look-ups of a chunk (qv.cc:840-841) cost one
+	// merged exact-match view: the reference and SNP dictionaries sorted together (reference entry first on ties) by the
+	// CANONICAL form of their k-mers -- key = fmix64(min(k, revcomp k)), flag 8 of an entry: its k-mer is the reverse complement
+	// of that form -- behind ONE jump table over HI32 of the key, so the two exact look-ups of a chunk (qv.cc:840-841) cost one
 	// jump-table gather + at most one bucket line instead of two of each.  mx entry: {lo32, pos, flags, pos2} with
 	// flags bit 0 = SNP-dictionary entry, bit 1 = ambig_flag, bit 2 = PAIR (set once the direct table exists: the k-mer's
 	// auxiliary row holds exactly two positions and they are pos, pos2 -- no row gather in stage A).
 	const uint32_t *mx_jg;         // [2^32 + 1]   (dropped when the direct table below could be allocated)
 	const uint4 *mx;               // [n_ref + n_snp]
 	// direct table over HI32: one 16-byte record per bucket = the bucket's FIRST merged entry inline {lo32, pos, flags,
-	// index of that entry in mx}, flags bit 0 = bucket non-empty, bit 1 = SNP entry, bit 2 = ambig_flag, bit 4 = TIE (the second
+	// index of that entry in mx}, flags bit 0 = bucket non-empty, bit 1 = SNP entry, bit 2 = ambig_flag, bit 5 = strand, bit 4 = TIE (the second
 	// entry has the same k-mer), bit 3 = PAIR (single-
 	// entry buckets only: then the last word is the second position), bits 8.. = entries in the bucket.  A bucket with one entry -- the common case -- is settled, hit or miss, by ONE gather.  64 GiB.
 	const uint4 *dx;

@@ -367,11 +367,12 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				};
 				if (d.dx) {
 					// The merged view and its direct table are keyed by the CANONICAL form of a k-mer (the smaller of it and its reverse
-					// complement, mixed so that the buckets fill evenly; r03), so the bucket of a chunk holds the entry of the chunk's k-mer -- a hit of THIS pass -- and the entry of its reverse complement
-					// -- a hit of the other pass, for the mirrored chunk.  In pass 0 those are collected too (simple ones: one position or a
-					// PAIR), in a block that grows down from the top of the exact-context list; if the forward pass finds nothing at all
-					// -- every read of the reverse strand -- the block IS the exact-context list of pass 1 and the lane goes on as pass 1.
-					// the block of reverse-strand contexts is [rc_top, W_ECAP); RC_BAD: it cannot be used (not pass 0; a hit with several
+					// complement, mixed so that the buckets fill evenly; r03), so the bucket of a chunk holds the entry of the chunk's
+					// k-mer -- a hit of THIS pass -- and the entry of its reverse complement -- a hit of the other pass, for the mirrored
+					// chunk.  In pass 0 those are collected too (the ones with a single position), in a block that grows down from the
+					// top of the exact-context list; if the forward pass finds nothing at all -- every read of the reverse strand --
+					// the block IS the exact-context list of pass 1 and the lane goes on as pass 1.
+					// The block of reverse-strand contexts is [rc_top, W_ECAP); RC_BAD: it cannot be used (not pass 0; a hit with several
 					// positions; no room)
 					constexpr uint32_t RC_BAD = 0xFFFFu;
 					uint32_t rc_top = pass != 0u ? RC_BAD : (uint32_t)W_ECAP;
