@@ -114,9 +114,13 @@ class ReferenceTimer:
     def __init__(self, ref_bin, d, sample_fq, n_reads):
         import threading
 
+        import atexit
+
         self.n = n_reads
         self.res = {}
         self.threads = []
+        self.procs = []
+        atexit.register(self.kill)                     # a bench that dies early must not leave two 65 GB processes behind
         for name, fq in (("empty", os.path.join(d, "cpu_empty.fq")), ("sample", sample_fq)):
             if name == "empty":
                 open(fq, "w").close()
@@ -131,6 +135,7 @@ class ReferenceTimer:
         try:
             t_start = time.time()
             p = subprocess.Popen(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            self.procs.append(p)
             t_proc = None
             for line in p.stderr:                        # stderr is unbuffered on the reference's side
                 if line.startswith(b"Processing"):
@@ -147,10 +152,16 @@ class ReferenceTimer:
         except Exception as e:
             log("[bench] reference binary (%s FASTQ) not timed: %r" % (name, e))
 
+    def kill(self):
+        for p in self.procs:
+            if p.poll() is None:
+                p.kill()
+
     def result(self, timeout=1500):
         t0 = time.time()
         for t in self.threads:
             t.join(max(1.0, timeout - (time.time() - t0)))
+        self.kill()                                     # (only on a timeout is anything still alive)
         if "sample" not in self.res or "empty" not in self.res:
             return None
         a, b = self.res["sample"], self.res["empty"]
