@@ -462,3 +462,58 @@ def test_corrupt_dictionaries_are_refused_not_read(ftiny_dir, tmp_path):
     with pytest.raises(VgError) as e:
         GenoIndex.open(p)
     assert e.value.code == -2 and "auxiliary rows" in str(e.value)
+
+
+def _revcomp_keys(k):
+    """Reverse complement of 32-mers packed two bits a base (A C G T = 0 1 2 3): complement, then reverse the 2-bit fields."""
+    k = ~k.astype(np.uint64)
+    for sh, mask in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF), (16, 0x0000FFFF0000FFFF)):
+        m = np.uint64(mask)
+        k = ((k >> np.uint64(sh)) & m) | ((k & m) << np.uint64(sh))
+    return (k >> np.uint64(32)) | (k << np.uint64(32))
+
+
+@pytest.mark.parametrize("knob", [None, "VG_NO_DIRECT", "VG_NO_MX"])
+def test_self_complementary_and_both_strand_kmers(tmp_path, monkeypatch, knob):
+    """The merged view and the direct table are keyed by min(K, revcomp K) with a strand flag, so that one look-up answers both
+    passes of a read.  The corner cases of that: 32-mers that are their own reverse complement (an entry of BOTH strands), at
+    one position and at two, 32-mers whose reverse complement is in the dictionary too (one key, entries of either strand),
+    reverse-strand reads that run pass 1 on pass 0's look-ups.  synth.f_strands plants them and aims reads of both strands
+    at them, exact and one substitution away; counters and event counts must equal the oracle's (which knows nothing of
+    canonical keys: it follows qv.cc:760-1558 with the reference's two dictionaries) in the counting and the timed build,
+    with the direct table, with the merged view alone and with neither."""
+    import subprocess
+
+    from vargeno_amd import synth
+
+    g, s, r, plants = synth.f_strands()
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    prefix = os.path.join(d, "idx")
+    rk = index_io.read_ref_dict(prefix + ".ref.dict")["ref_kmer"]
+    sk = index_io.read_snp_dict(prefix + ".snp.dict")["snp_kmer"]
+    n_self = int((_revcomp_keys(rk) == rk).sum())
+    n_both = int(np.isin(_revcomp_keys(rk), rk).sum()) - n_self
+    assert n_self >= len(plants) // 3 and n_both >= len(plants) // 2, (n_self, n_both)
+    ox = O.OracleIndex.load(prefix)
+    ox.process(r.bases, r.quals, r.offsets, nthreads=8)
+    so = ox.sites()
+    want = ox.stats.as_dict()
+    assert so["ref_cnt"].sum() + so["alt_cnt"].sum() > 10_000 and want["snp_probe"] > 0
+    if knob:
+        monkeypatch.setenv(knob, "1")
+    with GenoIndex.open(prefix) as gx:
+        assert ("dx" in gx.views) == (knob is None) and ("mx" in gx.views) == (knob != "VG_NO_MX"), gx.views
+        for stats in (True, False):
+            gx.reset()
+            gx.set_stats(stats)
+            gx.submit(r.bases, r.quals, r.offsets)
+            rc, ac = gx.counts()
+            bad = np.nonzero((rc != so["ref_cnt"]) | (ac != so["alt_cnt"]))[0]
+            assert len(bad) == 0, ("stats=%s" % stats, so["pos"][bad[:10]], rc[bad[:10]], so["ref_cnt"][bad[:10]], ac[bad[:10]], so["alt_cnt"][bad[:10]])
+            if stats:
+                st = gx.stats()
+                for k in CMP_STATS:
+                    assert st[k] == want[k], k

@@ -415,6 +415,84 @@ def f_tiny(seed=7):
     return g, s, r
 
 
+def f_strands(seed=31, n_plants=300, n_random_reads=12_000):
+    """Strand corner cases of a canonical-key index (one look-up of min(K, revcomp K) answers both strands): a 300 kbp genome
+    with planted 32-mers that ARE their own reverse complement (X + revcomp X; once, and at two positions), and 32-mers whose
+    reverse complement also occurs on the forward strand, SNPs through and around them, and reads -- both strands, both
+    haplotypes -- placed so that one of their 32-base chunks is exactly a planted 32-mer, a third of them with a substitution
+    inside that chunk (the Hamming-1 search then has the planted k-mer as a neighbour), 40 % gate-open chunks; and SNP k-mers
+    that are their own reverse complement (the alt allele completes the palindrome).
+    Returns (genome, snps, reads, plant_positions)."""
+    rng = np.random.default_rng(seed)
+    g = make_genome(rng, [300_000], ["chr1"], repeats_per_mbp=20.0, microsat_per_mbp=0.0, n_gaps=False)
+    s0 = g.seqs[0]
+    plants = 2_000 + 900 * np.arange(n_plants, dtype=np.int64)
+    for i, p in enumerate(plants):
+        p = int(p)
+        if i % 3 == 1:                                               # K here, revcomp K 350 bases on: both on the forward strand
+            s0[p + 350:p + 382] = _COMP[s0[p:p + 32][::-1]]
+            continue
+        x = random_bases(rng, 16)
+        s0[p:p + 16] = x
+        s0[p + 16:p + 32] = _COMP[x[::-1]]                           # K == revcomp K
+        if i % 3 == 2:
+            s0[p + 350:p + 382] = s0[p:p + 32]                       # ... at two positions
+    s = make_snps(rng, g, 9_000)
+    # a SNP k-mer that is its own reverse complement: next to every single-position plant, the same 32-mer with one base changed
+    # in the reference and a SNP there whose alt allele restores it (donor genotypes 0/1 and 1/1 alternate)
+    xp, xref, xalt = [], [], []
+    for i, p in enumerate(plants[0::3]):
+        p = int(p)
+        j = int(rng.integers(0, 32))
+        s0[p + 350:p + 382] = s0[p:p + 32]
+        xalt.append(s0[p + j])
+        s0[p + 350 + j] = ACGT[(_CODE[s0[p + j]] + 1 + i % 3) % 4]
+        xref.append(s0[p + 350 + j])
+        xp.append(p + 350 + j + 1)
+    keep = ~np.isin(s.pos, xp)
+    pos = np.concatenate([s.pos[keep], np.array(xp, dtype=np.int64)])
+    order = np.argsort(pos, kind="stable")
+    nx = len(xp)
+    cat = lambda a, b, dt: np.concatenate([a[keep], np.asarray(b, dtype=dt)])[order]
+    with_caf = s._with_caf
+    s = SnpSet(cat(s.chrom, np.zeros(nx), np.int32), pos[order], cat(s.ref, xref, np.uint8), cat(s.alt, xalt, np.uint8),
+               cat(s.caf_ref, np.full(nx, 0.6), np.float64), cat(s.caf_alt, np.full(nx, 0.4), np.float64),
+               cat(s.genotype, 1 + np.arange(nx) % 2, np.uint8))
+    s._with_caf = with_caf
+    s.ref = np.concatenate(g.seqs)[s.pos - 1]                        # (a plant may have overwritten the base under a drawn SNP)
+    clash = s.ref == s.alt
+    s.alt[clash] = ACGT[(_CODE[s.ref[clash]] + 1) % 4]
+    h0, h1, _ = haplotypes(g, s)
+    L = 150
+    starts, rev = [], []
+    for p in plants:
+        for q in (int(p), int(p) + 350):
+            for c in range(4):
+                starts += [q - 32 * c, q + 32 * (c + 1) - L]         # chunk c of the forward read / of the reverse read is [q, q+32)
+                rev += [False, True]
+    starts, rev = np.array(starts, dtype=np.int64), np.array(rev)
+    starts, rev = np.tile(starts, 2), np.tile(rev, 2)
+    hap = np.repeat([False, True], len(starts) // 2)
+    m = len(starts)
+    gi = starts[:, None] + np.arange(L)[None, :]
+    b = np.where(hap[:, None], h1[gi], h0[gi])
+    mut = np.nonzero(rng.random(m) < 1.0 / 3.0)[0]                   # one substitution somewhere in the read's planted chunk
+    tgt = np.tile(np.repeat(np.repeat(plants, 2) + np.tile([0, 350], len(plants)), 8), 2)   # the planted interval each read was made for
+    where = tgt[mut] - starts[mut] + rng.integers(0, 32, size=len(mut))
+    cur = _CODE[b[mut, where]]
+    b[mut, where] = ACGT[(cur + rng.integers(1, 4, size=len(mut), dtype=np.uint8)) % 4]
+    b[rev] = _COMP[b[rev][:, ::-1]]
+    total = m * L
+    q_hi = rng.integers(ord(":"), ord("I") + 1, size=total, dtype=np.uint8)
+    q_lo = rng.integers(ord("#"), ord("7") + 1, size=total, dtype=np.uint8)
+    quals = np.where(rng.random(total) < 0.40, q_lo, q_hi).astype(np.uint8)
+    placed = Reads(b.reshape(-1).copy(), quals, (np.arange(m + 1, dtype=np.uint64) * np.uint64(L)))
+    rnd = make_reads(rng, g, s, n_random_reads, lengths=(150, 101, 250), err=0.01, lowq=0.40)
+    reads = Reads(np.concatenate([placed.bases, rnd.bases]), np.concatenate([placed.quals, rnd.quals]),
+                  np.concatenate([placed.offsets, rnd.offsets[1:] + placed.offsets[-1]]).astype(np.uint64))
+    return g, s, reads, plants
+
+
 def _fasta_norm(stream):
     """What the reference's FASTA reader makes of a sequence's characters (fasta_parser.c:7-25): ACGT in either case -> upper
     case, ANY other character that is not a newline -> 'N' (IUPAC codes, blanks, carriage returns all count as a base)."""
