@@ -16,6 +16,9 @@ Produces
   fquirk.*     irregular FASTA / VCF inputs (synth.f_quirk: IUPAC codes, blanks and carriage returns in sequence lines, long
                names, multi-allelic / indel / out-of-order / repeated records, odd INFO fields ...): sha256 list + the
                reference's output VCF.
+  fstrands.*   strand corner cases (synth.f_strands: reference and SNP k-mers that are their own reverse complement, k-mers
+               whose reverse complement is in the dictionary too, reads of both strands aimed at them): sha256 list + the
+               reference's output VCF.
 Fixtures are data (inputs and reference outputs); no reference source text is stored here.
 """
 import gzip
@@ -68,7 +71,7 @@ def run(name, gen, work, commit_all):
     if name == "fquirk":
         synth.write_quirk(d, gen())
     else:
-        g, s, r = gen()
+        g, s, r = gen()[:3]
         synth.write_fasta(os.path.join(d, "ref.fa"), g)
         synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
         synth.write_fastq(os.path.join(d, "reads.fq"), r)
@@ -103,7 +106,7 @@ if __name__ == "__main__":
     work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/vg_golden"
     if not os.path.exists(REF_BIN):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall", "fdense", "fquirk"]
+    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall", "fdense", "fquirk", "fstrands"]
     if "ftiny" in which:
         run("ftiny", synth.f_tiny, work, True)
     if "fsmall" in which:
@@ -112,6 +115,8 @@ if __name__ == "__main__":
         run("fdense", synth.f_dense, work, False)
     if "fquirk" in which:
         run("fquirk", synth.f_quirk, work, False)
+    if "fstrands" in which:
+        run("fstrands", synth.f_strands, work, False)
     # the reference's own test data (test/snp.vcf, test/expected_output): data files, copied verbatim
     if os.path.isdir("/root/reference/test"):
         shutil.copy("/root/reference/test/snp.vcf", os.path.join(OUT, "reftest.snp.vcf"))

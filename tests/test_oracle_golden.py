@@ -206,3 +206,47 @@ def test_reference_written_dictionaries_satisfy_what_the_loader_checks(ftiny_dir
         assert np.all(kmer[1:] > kmer[:-1])
         multi = (amb != 0) & (pos != 0xFFFFFFFF)
         assert multi.sum() > 0 and np.all(pos[multi] < n_aux)
+
+
+def test_oracle_reproduces_reference_vcf_on_fstrands(tmp_path):
+    """Fourth pin: the strand corner cases (synth.f_strands) the device's canonical-key views have to get right -- reference
+    and SNP k-mers that are their own reverse complement (at one position and at two), k-mers whose reverse complement is in
+    the dictionary as well, reads of both strands aimed at them, exact and one substitution away.  The fixture must hold those
+    cases (counted from the dictionary files), the product's index must be the reference's byte for byte, and the oracle's
+    calls the reference's."""
+    import subprocess
+
+    from conftest import BIN
+
+    g, s, r, plants = synth.f_strands()
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    want = read_sha256_list("fstrands")
+    for fn in ("ref.fa", "snps.vcf", "idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf", "idx.snp.bf"):
+        assert _sha(os.path.join(d, fn)) == want[fn], fn
+    synth.write_fastq(os.path.join(d, "reads.fq"), r)
+    assert _sha(os.path.join(d, "reads.fq")) == want["reads.fq"]
+
+    def revcomp(k):                                                  # 32-mers, two bits a base: complement, reverse the fields
+        k = ~k.astype(np.uint64)
+        for sh, mask in ((2, 0x3333333333333333), (4, 0x0F0F0F0F0F0F0F0F), (8, 0x00FF00FF00FF00FF), (16, 0x0000FFFF0000FFFF)):
+            k = ((k >> np.uint64(sh)) & np.uint64(mask)) | ((k & np.uint64(mask)) << np.uint64(sh))
+        return (k >> np.uint64(32)) | (k << np.uint64(32))
+
+    rk = index_io.read_ref_dict(os.path.join(d, "idx.ref.dict"))["ref_kmer"]
+    sk = index_io.read_snp_dict(os.path.join(d, "idx.snp.dict"))["snp_kmer"]
+    assert int((revcomp(rk) == rk).sum()) >= 2 * (len(plants) // 3)                 # self-complementary reference k-mers
+    assert int(np.isin(revcomp(rk), rk).sum()) >= len(plants)                       # ... + pairs present on both strands
+    assert int((revcomp(sk) == sk).sum()) >= len(plants) // 3 - 5                   # self-complementary SNP k-mers
+    ix = O.OracleIndex.load(os.path.join(d, "idx"))
+    assert ix.process(r.bases, r.quals, r.offsets, nthreads=4) == 0
+    mine = O.calls_by_key(ix.sites(), index_io.read_chrlens(os.path.join(d, "idx.chrlens")))
+    ref = O.parse_vcf_calls(os.path.join(GOLDEN, "fstrands.out.vcf.gz"))
+    assert len(ref) > 8_000
+    assert mine == ref
+    # the sites under the planted self-complementary SNP k-mers are among the called ones
+    called = {int(k.split("$")[1]) for k in ref}
+    xs = [int(p) for p in s.pos if 2_350 <= p and (int(p) - 2_351) % 2_700 < 32]
+    assert len(xs) >= len(plants) // 3 and sum(1 for p in xs if p in called) >= len(plants) // 3 - 5
