@@ -38,6 +38,8 @@ def host_binary():
     for the tool itself and for the HIP library it links."""
     import subprocess
 
+    if os.environ.get("VARGENO_TEST_BIN"):                           # e.g. csrc/vargeno_asan (`make asan`): the CPU tests of the
+        return os.environ["VARGENO_TEST_BIN"]                        # host tools under AddressSanitizer + UBSan
     path = os.path.join(CSRC, "vargeno")
     if not _host_binary_checked:
         assert os.path.exists(path), "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % path
