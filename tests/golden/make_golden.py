@@ -6,6 +6,8 @@ committed outputs.  Usage:  python tests/golden/make_golden.py [workdir]
 Produces
   ftiny.*      60 kbp / 2 951 SNPs / 4 000 reads -- committed whole: inputs, the reference-written
                dict files, the set bits of its bit-vector files, its output VCF.
+  ftiny.info_<kind>.sha256  the reference's index files when the SNP list's INFO column is one of vcf_variants.INFO_KINDS
+               (records without a CAF key after records with one at another place; no CAF on the first record; unknown names)
   ftiny.out.<kind>.vcf.gz   the reference's output when the SNP list it annotates is one of tests/vcf_variants.py
                (GT already declared, FORMAT/sample columns present, "chr"-prefixed names, blank lines)
   fsmall.*     F-small of SURVEY.md §8c (300 kbp / 29 868 SNPs / 40 000 reads): inputs are a pure
@@ -93,6 +95,13 @@ def run(name, gen, work, commit_all):
                 f.write(vcf_variants.make(text, kind))
             subprocess.check_call([REF_BIN, "geno", "idx", "reads.fq", "snps.%s.vcf" % kind, "out.%s.vcf" % kind], cwd=d, stdout=subprocess.DEVNULL)
             gz(os.path.join(d, "out.%s.vcf" % kind), os.path.join(OUT, "%s.out.%s.vcf.gz" % (name, kind)))
+        for kind in vcf_variants.INFO_KINDS:                                 # INFO-column variants, index side: sha256 of the reference's files
+            with open(os.path.join(d, "info_%s.vcf" % kind), "w") as f:
+                f.write(vcf_variants.info_variant(text, kind))
+            subprocess.check_call([REF_BIN, "index", "ref.fa", "info_%s.vcf" % kind, "ix_" + kind], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with open(os.path.join(OUT, "%s.info_%s.sha256" % (name, kind)), "w") as f:
+                for ext in ("chrlens", "ref.dict", "snp.dict", "ref.bf", "snp.bf"):
+                    f.write("%s  idx.%s\n" % (sha(os.path.join(d, "ix_%s.%s" % (kind, ext))), ext))
         for fn in ("ref.fa", "snps.vcf", "reads.fq", "idx.ref.dict", "idx.snp.dict"):
             gz(os.path.join(d, fn), os.path.join(OUT, "%s.%s.gz" % (name, fn)))
         shutil.copy(os.path.join(d, "idx.chrlens"), os.path.join(OUT, name + ".idx.chrlens"))

@@ -37,6 +37,68 @@ def test_index_files_are_byte_identical_to_the_reference(name, gen, tmp_path):
         assert _sha(os.path.join(d, fn)) == want[fn], fn
 
 
+@pytest.mark.parametrize("piece", [None, "1", "300"])
+def test_snp_list_parsed_in_pieces_gives_the_reference_files(ftiny_dir, tmp_path, piece):
+    """`vargeno index` parses the SNP list in pieces, in parallel.  What the reference carries from line to line -- the place
+    of the token after the last CAF key (read by records that have none), frequencies given up for good when the first record
+    has no CAF key, the sequence of the last chromosome name it found (bit-vector pass) -- must come out the same however the
+    text is cut: pieces of one line, of a few lines, of the whole file (VARGENO_PARSE_PIECE), on F-tiny's list, on three
+    variants of its INFO / CHROM columns (tests/vcf_variants.py) and on F-quirk's irregular one; the files' sha256 are the
+    reference binary's (tests/golden/make_golden.py)."""
+    import shutil
+
+    import vcf_variants
+
+    d = str(tmp_path)
+    env = dict(os.environ, VARGENO_NO_LITE="1")
+    if piece:
+        env["VARGENO_PARSE_PIECE"] = piece
+    shutil.copy(os.path.join(ftiny_dir, "ref.fa"), os.path.join(d, "ref.fa"))
+    text = open(os.path.join(ftiny_dir, "snps.vcf")).read()
+    cases = [("plain", text, read_sha256_list("ftiny"))]
+    cases += [(k, vcf_variants.info_variant(text, k), read_sha256_list("ftiny.info_" + k)) for k in vcf_variants.INFO_KINDS]
+    assert len({w["idx.snp.dict"] for _, _, w in cases}) == len(cases)              # the variants do change the dictionary
+    # (the bit-vector pass keeps whole header lines as names, generate_bf.cc:60-75: it never finds F-tiny's "chr2 second", and
+    # reads every record of chromosome 2 against the sequence found last, chr1 -- in the plain list already)
+    for kind, vtext, want in cases:
+        with open(os.path.join(d, kind + ".vcf"), "w") as f:
+            f.write(vtext)
+        p = subprocess.run([BIN, "index", "ref.fa", kind + ".vcf", "ix_" + kind], cwd=d, env=env, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        for ext in ("chrlens", "ref.dict", "snp.dict", "ref.bf", "snp.bf"):
+            assert _sha(os.path.join(d, "ix_%s.%s" % (kind, ext))) == want["idx." + ext], (kind, ext)
+            os.remove(os.path.join(d, "ix_%s.%s" % (kind, ext)))
+        if kind == "unknownchr":                                                     # one message per record, in file order
+            names = [ln.split()[3] for ln in p.stderr.splitlines() if ln.startswith("[Error] chromosome name")]
+            expect = [ln.split("\t")[0] for ln in vtext.splitlines() if ln.startswith("scaffold_")]
+            assert len(expect) > 100 and names == ["chr" + e for e in expect]
+    # two records whose REF disagrees with the FASTA: the first one in file order is the one reported (dictgen.c:666-672),
+    # after the messages of the records before it and none of those after it
+    lines = cases[3][1].splitlines(keepends=True)
+    data = [i for i, ln in enumerate(lines) if not ln.startswith("#") and ln.split("\t")[0] in ("1", "2")]
+    bad = []
+    for i in (data[len(data) // 3], data[2 * len(data) // 3]):
+        c = lines[i].split("\t")
+        c[3] = "A" if c[3] != "A" else "C"
+        c[4] = "G" if c[3] != "G" else "T"
+        lines[i] = "\t".join(c)
+        bad.append((c[0], int(c[1]) - 1, sum(1 for ln in lines[:i] if ln.startswith("scaffold_"))))
+    with open(os.path.join(d, "bad.vcf"), "w") as f:
+        f.write("".join(lines))
+    p = subprocess.run([BIN, "index", "ref.fa", "bad.vcf", "ix_bad"], cwd=d, env=env, capture_output=True, text=True)
+    assert p.returncode == 1
+    assert "Mismatch found between reference sequence and SNP file at 0-based index %d in chr%s." % (bad[0][1], bad[0][0]) in p.stderr
+    assert "index %d in chr%s." % (bad[1][1], bad[1][0]) not in p.stderr
+    assert sum(1 for ln in p.stderr.splitlines() if ln.startswith("[Error] chromosome name")) == bad[0][2]
+    q = os.path.join(d, "quirk")
+    os.mkdir(q)
+    synth.write_quirk(q, synth.f_quirk())
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=q, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    want = read_sha256_list("fquirk")
+    for fn in ("idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf", "idx.snp.bf"):
+        assert _sha(os.path.join(q, fn)) == want[fn], fn
+
+
 def test_index_rejects_what_the_reference_rejects(tmp_path):
     d = str(tmp_path)
     g, s, _ = synth.f_tiny()

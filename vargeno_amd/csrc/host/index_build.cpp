@@ -420,6 +420,8 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 	const int nthreads = opt.threads > 0 ? opt.threads : omp_get_max_threads();
 	omp_set_num_threads(nthreads);
 	PhaseTimer pt;
+	// the SNP list is parsed in pieces of this many bytes (cut at line ends), in parallel; VARGENO_PARSE_PIECE: tests make it tiny
+	const size_t parse_piece_bytes = getenv("VARGENO_PARSE_PIECE") ? (size_t)std::max(1, atoi(getenv("VARGENO_PARSE_PIECE"))) : (size_t)4 << 20;
 	const std::string fa = slurp(fasta);
 	const std::string vcf_text = slurp(vcf);
 	pt.lap("inputs read");
@@ -475,12 +477,13 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 
 		// constructBfFromVcf, generate_bf.cc:179-277
 		BitVec sbf(SNP_BF_BITS);
-		std::string pre_chr = "XO";
-		const std::string *seq = nullptr;
 		static const std::string empty;
-		seq = &empty;
-		// (100 M lines at hg38 + full dbSNP scale: parsed in place -- no per-line vector or string -- and, the k-mer never shifting
-		// (B2), one hash per SNP instead of 32 of the same)
+		// (100 M lines at hg38 + full dbSNP scale: parsed in place -- no per-line vector or string --, the k-mer never shifting
+		// (B2), one hash per SNP instead of 32 of the same; and in parallel over pieces of the text.  The reference's loop carries
+		// one thing from line to line: the sequence of the last chromosome name it FOUND in the FASTA (a name it does not find
+		// leaves the previous sequence in place, generate_bf.cc:204-215; before the first one found there is no sequence and
+		// every record is out of range).  A piece that starts with names it cannot find does not know that sequence yet: those
+		// records wait for a serial sweep over the pieces, which hands each piece the last sequence found before it.)
 		auto atoi_span = [](const char *a, const char *b) -> int {        // atoi() of the text [a, b)
 			while (a < b && isspace((unsigned char)*a)) a++;
 			bool neg = false;
@@ -490,41 +493,37 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 			return (int)(neg ? -v : v);
 		};
 		const char *const text = vcf_text.data();
-		const char *last_c0 = nullptr; size_t last_c0_len = 0;             // column 0 of the last line that got as far as the chromosome look-up
-		size_t i = 0;
-		while (i < vcf_text.size()) {
-			const char *nl = (const char *)memchr(text + i, '\n', vcf_text.size() - i);
-			const size_t e = nl ? (size_t)(nl - text) : vcf_text.size();
-			const size_t ls = i, le = e;
-			i = e + 1;
-			if (le == ls || text[ls] == '#') continue;
+		struct NameCache { const char *c0 = nullptr; size_t len = 0; const std::string *found = nullptr; };     // column 0 of the last record looked up, and what it named
+		// one record, text [ls, le).  seq: the sequence in force (nullptr = not known yet); returns false if the record has to wait
+		auto record = [&](size_t ls, size_t le, const std::string *&seq, NameCache &nc_) -> bool {
+			if (le == ls || text[ls] == '#') return true;
 			// split(line, '\t'): the first five columns
 			const char *cs[5], *ce[5];
 			int nc = 0;
 			for (const char *a = text + ls, *end = text + le; nc < 5;) {
-				const char *t = (const char *)memchr(a, '\t', (size_t)(end - a));
-				cs[nc] = a; ce[nc] = t ? t : end; nc++;
-				if (!t) break;
-				a = t + 1;
+				const char *tb = (const char *)memchr(a, '\t', (size_t)(end - a));
+				cs[nc] = a; ce[nc] = tb ? tb : end; nc++;
+				if (!tb) break;
+				a = tb + 1;
 			}
-			if (nc < 5) continue;                                          // the reference would index past the vector
+			if (nc < 5) return true;                                       // the reference would index past the vector
 			const int pos = atoi_span(cs[1], ce[1]) - 1;
 			const size_t rl = (size_t)(ce[3] - cs[3]), al = (size_t)(ce[4] - cs[4]);
-			if (rl > 1 || al > 1) continue;
+			if (rl > 1 || al > 1) return true;
 			const size_t c0l = (size_t)(ce[0] - cs[0]);
-			if (!(last_c0 && c0l == last_c0_len && memcmp(cs[0], last_c0, c0l) == 0)) {
+			if (!(nc_.c0 && c0l == nc_.len && memcmp(cs[0], nc_.c0, c0l) == 0)) {
 				std::string chr(cs[0], c0l);
 				if (chr.empty() || chr[0] != 'c') chr = "chr" + chr;
-				if (chr != pre_chr) {
-					for (const Seq &s : g) if (s.name == chr) { seq = &s.seq; break; }     // not found: previous sequence stays
-					pre_chr = chr;
-				}
-				last_c0 = cs[0]; last_c0_len = c0l;
+				nc_.found = nullptr;
+				for (const Seq &s : g) if (s.name == chr) { nc_.found = &s.seq; break; }
+				nc_.c0 = cs[0]; nc_.len = c0l;
 			}
-			if (pos < 32 || (size_t)(pos + 32) > seq->size()) continue;
-			if (rl == 0 || al == 0) continue;
+			if (nc_.found) seq = nc_.found;                                // not found: the previous sequence stays
+			else if (!seq) return false;
+			if (pos < 32 || (size_t)(pos + 32) > seq->size()) return true;
+			if (rl == 0 || al == 0) return true;
 			const char ref_nt = *cs[3], alt_nt = *cs[4];
-			if (ref_nt != (*seq)[(size_t)pos] || ref_nt == alt_nt) continue;
+			if (ref_nt != (*seq)[(size_t)pos] || ref_nt == alt_nt) return true;
 			uint64_t k = 0; bool has_n = false;
 			for (int j = 31; j >= 0 && !has_n; j--) {                        // encode_kmer scans from base 31 down
 				const int c = base_code((unsigned char)(*seq)[(size_t)pos - 32 + (size_t)j]);
@@ -532,16 +531,51 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 				else if (c == 7) die("invalid base in reference sequence near a SNP");
 				else k = (k << 2) | (uint64_t)c;
 			}
-			if (has_n) continue;
+			if (has_n) return true;
 			bool any = false;
-			for (unsigned t = 0; t < 32; t++) {
-				const char nb = t ? (*seq)[(size_t)pos + t] : alt_nt;
+			for (unsigned tt = 0; tt < 32; tt++) {
+				const char nb = tt ? (*seq)[(size_t)pos + tt] : alt_nt;
 				const int c = base_code((unsigned char)nb);
 				if (c == 4) break;
 				if (c == 7) die("invalid base while building the SNP bit vector");            // shift_kmer asserts, util.c:121
 				any = true;                                                                      // B2: k never shifts -- the same bit every time
 			}
 			if (any) sbf.set_atomic(hash40(k & 0xFFFFFFFFFFull) % SNP_BF_BITS);
+			return true;
+		};
+		struct Piece { size_t lo, hi; const std::string *last_found = nullptr; std::vector<std::pair<size_t, size_t>> waiting; std::string err; };
+		std::vector<Piece> pieces;
+		for (size_t lo = 0; lo < vcf_text.size();) {
+			size_t hi = std::min(vcf_text.size(), lo + parse_piece_bytes);
+			if (hi < vcf_text.size()) {
+				const char *nl = (const char *)memchr(text + hi, '\n', vcf_text.size() - hi);
+				hi = nl ? (size_t)(nl - text) + 1 : vcf_text.size();
+			}
+			Piece pc; pc.lo = lo; pc.hi = hi;
+			pieces.push_back(std::move(pc));
+			lo = hi;
+		}
+		#pragma omp parallel for schedule(dynamic, 1)
+		for (long pi = 0; pi < (long)pieces.size(); pi++) {
+			Piece &pc = pieces[(size_t)pi];
+			const std::string *seq = nullptr;
+			NameCache cache;
+			try {
+				for (size_t i = pc.lo; i < pc.hi;) {
+					const char *nl = (const char *)memchr(text + i, '\n', pc.hi - i);
+					const size_t e = nl ? (size_t)(nl - text) : pc.hi;
+					if (!record(i, e, seq, cache)) pc.waiting.emplace_back(i, e);
+					i = e + 1;
+				}
+			} catch (const Error &e) { pc.err = e.msg; }
+			pc.last_found = seq;
+		}
+		const std::string *carry = &empty;
+		for (Piece &pc : pieces) {
+			NameCache cache;
+			for (const auto &w : pc.waiting) { const std::string *seq = carry; record(w.first, w.second, seq, cache); }
+			if (!pc.err.empty()) die(pc.err);
+			if (pc.last_found) carry = pc.last_found;
 		}
 		if (!opt.quiet) printf("[BloomFilter constructBfFromVCF] bit vector: %llu/%llu\n", (unsigned long long)sbf.count(), (unsigned long long)SNP_BF_BITS);
 		sbf.save(prefix + ".snp.bf");
@@ -562,91 +596,173 @@ void build_index(const std::string &fasta, const std::string &vcf, const std::st
 	// ---- SNP dictionary: make_snp_dict_from_vcf, dictgen.c:561-794
 	{
 		struct SnpRec { const Seq *chrom; uint32_t index, start_index; uint8_t ref_u, alt, f1, f2; };     // one accepted VCF line
-		std::vector<SnpRec> snps;
 		const bool ref_has_chr = !ref[0].name.empty() && ref[0].name[0] == 'c';
-		int freq_index = -1; bool has_freq = true;
-		const Seq *chrom = nullptr; uint32_t start_index = 1;
-		std::string line; Fields fl; std::vector<size_t> tok;
-		size_t i = 0;
-		while (i < vcf_text.size()) {
-			// fgets(line, 6000): at most 5999 characters per piece
-			size_t e = vcf_text.find('\n', i);
-			size_t le = (e == std::string::npos) ? vcf_text.size() : e + 1;
-			if (le - i > 5999) le = i + 5999;
-			line.assign(vcf_text, i, le - i);
-			i = le;
-			if (line[0] == '#' || line[0] == '\n') continue;
-			split_line_ref(line, fl);
-			if (fl.start.size() < 8) continue;                                  // the reference dereferences NULL here
-			char chrom_name[50]; size_t ci;
-			if (fl.at(0, 0) != 'c' && ref_has_chr) {
-				chrom_name[0] = 'c'; chrom_name[1] = 'h'; chrom_name[2] = 'r';
-				for (ci = 0; !isspace((unsigned char)fl.at(0, ci)) && fl.at(0, ci) && ci + 3 < 49; ci++) chrom_name[ci + 3] = fl.at(0, ci);
-				chrom_name[ci + 3] = '\0';
-			} else {
-				for (ci = 0; !isspace((unsigned char)fl.at(0, ci)) && fl.at(0, ci) && ci < 49; ci++) chrom_name[ci] = fl.at(0, ci);
-				chrom_name[ci] = '\0';
+		// The reference's loop over the lines carries two things from line to line, both about the INFO column: `has_freq`
+		// (cleared for good if the first record that gets that far has no CAF key) and `freq_index` (the token after the last
+		// "CAF..." key seen so far: a record without one reads the token at the place the last record with one had it).  The
+		// chromosome look-up repeats for every record whose name is not found, so it carries nothing.  So: the text is
+		// parsed in pieces, in parallel; the first piece runs alone up to the first record that reaches the INFO column, which
+		// settles `has_freq`; a record without a CAF key that comes before any record with one IN ITS PIECE waits for a serial
+		// sweep over the pieces, which knows `freq_index` at the start of each piece; messages to stderr are kept per piece
+		// and printed in file order; the first failure in file order is the one reported.
+		struct Piece {
+			size_t lo, hi;
+			std::vector<SnpRec> recs;
+			std::vector<std::pair<size_t, std::pair<size_t, size_t>>> waiting;      // (record index, its line's text [a, b))
+			int freq_index_out = -1;                                               // freq_index after the piece (-1: no CAF key in it)
+			std::string msgs, err;
+		};
+		// tokens of the INFO column (vcf_split_line, dictgen.c:538-553: split on ';' and '=', running on into what follows)
+		auto info_tokens = [](const std::string &line, size_t p, std::vector<size_t> &tok) {
+			tok.clear();
+			auto ch = [&](size_t q) { return q < line.size() ? line[q] : '\0'; };
+			while (ch(p) && !is_ws(ch(p))) {
+				tok.push_back(p);
+				while (ch(p) != ';' && ch(p) != '=') { if (ch(p) && !is_ws(ch(p))) ++p; else break; }
+				++p;
 			}
-			const char ref_base = (char)toupper((unsigned char)fl.at(3, 0));
-			const int ref_u = base_code((unsigned char)ref_base);
-			if (ref_u == 7) continue;
-			if (!isspace((unsigned char)fl.at(3, 1))) continue;
-			if (!isspace((unsigned char)fl.at(4, 1))) continue;
-			if (chrom == nullptr || chrom->name != chrom_name) {
-				chrom = nullptr; start_index = 0;
-				uint32_t si = 1;
-				for (const Seq &s : ref) { if (s.name == chrom_name) { chrom = &s; start_index = si; break; } si += (uint32_t)s.seq.size(); }
-				if (chrom == nullptr) {
-					fprintf(stderr, "[Error] chromosome name %s in VCF file not found in reference genome FASTA file\n. Usually this is because the FASTA file has chromesome name as \"chr1\" while the VCF file has chromosome name as \"1\" without the \"chr\"\n", chrom_name);
-					continue;
-				}
-			}
-			const unsigned index = (unsigned)atoi(line.c_str() + fl.start[1]) - 1u;
-			if (index >= chrom->seq.size() || toupper((unsigned char)chrom->seq[index]) != ref_base) {
-				char msg[256];
-				snprintf(msg, sizeof msg, "Mismatch found between reference sequence and SNP file at 0-based index %u in %s.", index, chrom->name.c_str());
-				fprintf(stderr, "%s\n", msg);
-				die(msg);
-			}
-			if (index < 32 || (size_t)index + 32 > chrom->seq.size()) continue;
-			const char a2 = (char)toupper((unsigned char)fl.at(4, 0));
-			if (!(ref_base == 'A' || ref_base == 'C' || ref_base == 'G' || ref_base == 'T')) continue;
-			if (!(a2 == 'A' || a2 == 'C' || a2 == 'G' || a2 == 'T')) continue;
-			// allele frequencies: vcf_split_line (dictgen.c:538-553) tokenises INFO on ';' and '=' and keeps going
-			// into whatever follows the field; the token after the LAST one starting with "CAF" is "ref,alt".
+		};
+		auto freqs_at = [](const std::string &line, const std::vector<size_t> &tok, int freq_index, uint8_t &f1, uint8_t &f2) {
+			// the reference reads info_split[freq_index], which may be a stale pointer when this line has fewer
+			// tokens than the line that set freq_index; defined here as 0.5/0.5 for that case.
 			float freq1 = 0.5f, freq2 = 0.5f;
-			if (has_freq) {
-				tok.clear();
-				size_t p = fl.start[7];
-				auto ch = [&](size_t q) { return q < line.size() ? line[q] : '\0'; };
-				while (ch(p) && !is_ws(ch(p))) {
-					tok.push_back(p);
-					while (ch(p) != ';' && ch(p) != '=') { if (ch(p) && !is_ws(ch(p))) ++p; else break; }
-					++p;
-				}
-				for (size_t t = 0; t < tok.size(); t++) if (line.compare(tok[t], 3, "CAF") == 0) freq_index = (int)t + 1;
-				if (freq_index == -1) has_freq = false;
+			if (freq_index >= 0 && (size_t)freq_index < tok.size()) {
+				const char *p = line.c_str() + tok[(size_t)freq_index];
+				freq1 = (float)atof(p);
+				while (*p && *p != ',') p++;
+				if (*p == ',') p++;
+				freq2 = (float)atof(p);
 			}
-			if (has_freq) {
-				// the reference reads info_split[freq_index], which may be a stale pointer when this line has fewer
-				// tokens than the line that set freq_index; defined here as 0.5/0.5 for that case.
-				if ((size_t)freq_index < tok.size()) {
-					const char *p = line.c_str() + tok[(size_t)freq_index];
-					freq1 = (float)atof(p);
-					while (*p && *p != ',') p++;
-					if (*p == ',') p++;
-					freq2 = (float)atof(p);
+			f1 = (uint8_t)(freq1 * 0xff); f2 = (uint8_t)(freq2 * 0xff);
+		};
+		// mode 0: the whole piece, `has_freq` known.  mode 1: from pc.lo up to and including the first record that reaches the
+		// INFO column (the very first piece, `has_freq` still open); pc.lo is moved past what was read.
+		bool has_freq = true;
+		auto parse_piece = [&](Piece &pc, int mode) {
+			const Seq *chrom = nullptr; uint32_t start_index = 1;
+			int freq_index = -1;                                               // of this piece so far
+			std::string line; Fields fl; std::vector<size_t> tok;
+			size_t i = pc.lo;
+			try {
+				while (i < pc.hi) {
+					// fgets(line, 6000): at most 5999 characters per piece
+					const char *nl = (const char *)memchr(vcf_text.data() + i, '\n', pc.hi - i);
+					size_t le = nl ? (size_t)(nl - vcf_text.data()) + 1 : pc.hi;
+					if (le - i > 5999) le = i + 5999;
+					const size_t ls = i;
+					line.assign(vcf_text, i, le - i);
+					i = le;
+					if (mode == 1) pc.lo = i;
+					if (line[0] == '#' || line[0] == '\n') continue;
+					split_line_ref(line, fl);
+					if (fl.start.size() < 8) continue;                                  // the reference dereferences NULL here
+					char chrom_name[50]; size_t ci;
+					if (fl.at(0, 0) != 'c' && ref_has_chr) {
+						chrom_name[0] = 'c'; chrom_name[1] = 'h'; chrom_name[2] = 'r';
+						for (ci = 0; !isspace((unsigned char)fl.at(0, ci)) && fl.at(0, ci) && ci + 3 < 49; ci++) chrom_name[ci + 3] = fl.at(0, ci);
+						chrom_name[ci + 3] = '\0';
+					} else {
+						for (ci = 0; !isspace((unsigned char)fl.at(0, ci)) && fl.at(0, ci) && ci < 49; ci++) chrom_name[ci] = fl.at(0, ci);
+						chrom_name[ci] = '\0';
+					}
+					const char ref_base = (char)toupper((unsigned char)fl.at(3, 0));
+					const int ref_u = base_code((unsigned char)ref_base);
+					if (ref_u == 7) continue;
+					if (!isspace((unsigned char)fl.at(3, 1))) continue;
+					if (!isspace((unsigned char)fl.at(4, 1))) continue;
+					if (chrom == nullptr || chrom->name != chrom_name) {
+						chrom = nullptr; start_index = 0;
+						uint32_t si = 1;
+						for (const Seq &s : ref) { if (s.name == chrom_name) { chrom = &s; start_index = si; break; } si += (uint32_t)s.seq.size(); }
+						if (chrom == nullptr) {
+							pc.msgs += std::string("[Error] chromosome name ") + chrom_name + " in VCF file not found in reference genome FASTA file\n. Usually this is because the FASTA file has chromesome name as \"chr1\" while the VCF file has chromosome name as \"1\" without the \"chr\"\n";
+							continue;
+						}
+					}
+					const unsigned index = (unsigned)atoi(line.c_str() + fl.start[1]) - 1u;
+					if (index >= chrom->seq.size() || toupper((unsigned char)chrom->seq[index]) != ref_base) {
+						char msg[256];
+						snprintf(msg, sizeof msg, "Mismatch found between reference sequence and SNP file at 0-based index %u in %s.", index, chrom->name.c_str());
+						pc.msgs += msg; pc.msgs += "\n";
+						die(msg);
+					}
+					if (index < 32 || (size_t)index + 32 > chrom->seq.size()) continue;
+					const char a2 = (char)toupper((unsigned char)fl.at(4, 0));
+					if (!(ref_base == 'A' || ref_base == 'C' || ref_base == 'G' || ref_base == 'T')) continue;
+					if (!(a2 == 'A' || a2 == 'C' || a2 == 'G' || a2 == 'T')) continue;
+					// allele frequencies: the token after the LAST one starting with "CAF" is "ref,alt"
+					uint8_t f1 = (uint8_t)(0.5f * 0xff), f2 = f1;
+					bool wait = false;
+					if (has_freq) {
+						info_tokens(line, fl.start[7], tok);
+						for (size_t tt = 0; tt < tok.size(); tt++) if (line.compare(tok[tt], 3, "CAF") == 0) freq_index = (int)tt + 1;
+						if (freq_index == -1) {
+							if (mode == 1) has_freq = false;                             // the first such record of the file: no frequencies at all
+							else wait = true;                                            // the place of the last CAF key before this piece
+						} else freqs_at(line, tok, freq_index, f1, f2);
+					}
+					const bool stop = mode == 1;
+					do {
+						if (a2 == ref_base) break;
+						// the 32 k-mers over the SNP exist only if the 63 bases around it are ACGT (dictgen.c:751-790)
+						const std::string &seq = chrom->seq;
+						bool clean = true;
+						for (unsigned j = 0; j < 63 && clean; j++) if (j != 31 && base_code((unsigned char)seq[index - 31 + j]) >= 4) clean = false;
+						if (base_code((unsigned char)seq[index - 32]) >= 4) clean = false;
+						if (!clean) break;
+						if (wait) pc.waiting.push_back({pc.recs.size(), {ls, le}});
+						pc.recs.push_back(SnpRec{chrom, index, start_index, (uint8_t)ref_u, (uint8_t)base_code((unsigned char)a2), f1, f2});
+					} while (false);
+					if (stop) break;
 				}
+			} catch (const Error &e) { pc.err = e.msg; }
+			pc.freq_index_out = freq_index;
+		};
+		std::vector<Piece> pieces;
+		{
+			Piece head; head.lo = 0; head.hi = vcf_text.size();
+			parse_piece(head, 1);                                                  // settles has_freq; head.lo: where the rest starts
+			const size_t rest = head.lo;
+			head.lo = 0; head.hi = rest;
+			const bool failed = !head.err.empty();
+			pieces.push_back(std::move(head));
+			for (size_t lo = rest; !failed && lo < vcf_text.size();) {
+				size_t hi = std::min(vcf_text.size(), lo + parse_piece_bytes);
+				if (hi < vcf_text.size()) {
+					const char *nl = (const char *)memchr(vcf_text.data() + hi, '\n', vcf_text.size() - hi);
+					hi = nl ? (size_t)(nl - vcf_text.data()) + 1 : vcf_text.size();
+				}
+				Piece pc; pc.lo = lo; pc.hi = hi;
+				pieces.push_back(std::move(pc));
+				lo = hi;
 			}
-			const uint8_t f1 = (uint8_t)(freq1 * 0xff), f2 = (uint8_t)(freq2 * 0xff);
-			if (a2 == ref_base) continue;
-			// the 32 k-mers over the SNP exist only if the 63 bases around it are ACGT (dictgen.c:751-790)
-			const std::string &seq = chrom->seq;
-			bool clean = true;
-			for (unsigned j = 0; j < 63 && clean; j++) if (j != 31 && base_code((unsigned char)seq[index - 31 + j]) >= 4) clean = false;
-			if (base_code((unsigned char)seq[index - 32]) >= 4) clean = false;
-			if (!clean) continue;
-			snps.push_back(SnpRec{chrom, index, start_index, (uint8_t)ref_u, (uint8_t)base_code((unsigned char)a2), f1, f2});
+		}
+		#pragma omp parallel for schedule(dynamic, 1)
+		for (long pi = 1; pi < (long)pieces.size(); pi++) parse_piece(pieces[(size_t)pi], 0);
+		std::vector<size_t> rec_begin(pieces.size() + 1, 0);
+		{
+			int freq_index = -1;                                               // at the start of the piece
+			std::string line; std::vector<size_t> tok; Fields fl;
+			for (size_t pi = 0; pi < pieces.size(); pi++) {
+				Piece &pc = pieces[pi];
+				for (const auto &w : pc.waiting) {
+					line.assign(vcf_text, w.second.first, w.second.second - w.second.first);
+					split_line_ref(line, fl);
+					info_tokens(line, fl.start[7], tok);
+					freqs_at(line, tok, freq_index, pc.recs[w.first].f1, pc.recs[w.first].f2);
+				}
+				if (!pc.msgs.empty()) fputs(pc.msgs.c_str(), stderr);
+				if (!pc.err.empty()) die(pc.err);
+				if (pc.freq_index_out != -1) freq_index = pc.freq_index_out;
+				rec_begin[pi + 1] = rec_begin[pi] + pc.recs.size();
+			}
+		}
+		std::vector<SnpRec> snps(rec_begin.back());
+		#pragma omp parallel for schedule(dynamic, 1)
+		for (long pi = 0; pi < (long)pieces.size(); pi++) {
+			Piece &pc = pieces[(size_t)pi];
+			if (!pc.recs.empty()) memcpy(snps.data() + rec_begin[(size_t)pi], pc.recs.data(), pc.recs.size() * sizeof(SnpRec));
+			std::vector<SnpRec>().swap(pc.recs);
 		}
 		pt.lap("SNP list parsed");
 		// k-mer t of a SNP covers bases [index - 31 + t, index + t], the SNP's alt base at offset 31 - t
