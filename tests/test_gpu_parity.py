@@ -517,3 +517,43 @@ def test_self_complementary_and_both_strand_kmers(tmp_path, monkeypatch, knob):
                 st = gx.stats()
                 for k in CMP_STATS:
                     assert st[k] == want[k], k
+
+
+@pytest.mark.parametrize("seed,knob", [(1, None), (2, None), (3, None), (4, "VG_NO_MX"), (5, "VG_NO_DIRECT"), (6, "VG_NO_MX+VG_NO_HX")])
+def test_low_complexity_genomes(tmp_path, monkeypatch, seed, knob):
+    """synth.f_lowcomplex: genomes made of microsatellites (runs of A, AT, ACGT are their own reverse complement), hairpins,
+    tandem and dispersed copies (auxiliary rows, POS_AMBIGUOUS), one SNP per 25 bases -- k-mers that collide with themselves,
+    with their reverse complements and with each other, a different mix for every seed.  (On seeds 1-15 the oracle's calls
+    were checked against the reference binary's in the build container; tests/test_oracle_golden.py keeps seed 1.)  Counters
+    and event counts of both builds equal the oracle's, on the shipped layout and on the fall-back ones."""
+    import subprocess
+
+    from vargeno_amd import synth
+
+    g, s, r = synth.f_lowcomplex(seed)
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    prefix = os.path.join(d, "idx")
+    ox = O.OracleIndex.load(prefix)
+    ox.process(r.bases, r.quals, r.offsets, nthreads=8)
+    so = ox.sites()
+    want = ox.stats.as_dict()
+    assert want["aux_ref"] > 500 and so["ref_cnt"].sum() + so["alt_cnt"].sum() > 5_000
+    for k in (knob.split("+") if knob else ()):
+        monkeypatch.setenv(k, "1")
+    with GenoIndex.open(prefix) as gx:
+        for stats in (True, False):
+            gx.reset()
+            gx.set_stats(stats)
+            gx.submit(r.bases, r.quals, r.offsets)
+            rc, ac = gx.counts()
+            bad = np.nonzero((rc != so["ref_cnt"]) | (ac != so["alt_cnt"]))[0]
+            assert len(bad) == 0, ("stats=%s" % stats, so["pos"][bad[:10]], rc[bad[:10]], so["ref_cnt"][bad[:10]], ac[bad[:10]], so["alt_cnt"][bad[:10]])
+            if stats:
+                st = gx.stats()
+                for k in CMP_STATS:
+                    assert st[k] == want[k], k
+    for fn in ("idx.ref.bf", "idx.snp.bf"):
+        os.remove(os.path.join(d, fn))

@@ -250,3 +250,32 @@ def test_oracle_reproduces_reference_vcf_on_fstrands(tmp_path):
     called = {int(k.split("$")[1]) for k in ref}
     xs = [int(p) for p in s.pos if 2_350 <= p and (int(p) - 2_351) % 2_700 < 32]
     assert len(xs) >= len(plants) // 3 and sum(1 for p in xs if p in called) >= len(plants) // 3 - 5
+
+
+def test_oracle_reproduces_reference_vcf_on_flowcomplex(tmp_path):
+    """Fifth pin: synth.f_lowcomplex(1) -- microsatellites whose runs are their own reverse complement, hairpins, tandem and
+    dispersed copies (auxiliary rows, POS_AMBIGUOUS), one SNP per 25 bases.  Index files byte-identical to the reference's,
+    then GT and GQ of every record it called.  (Seeds 1-15 were compared the same way when the fixture was made.)"""
+    import subprocess
+
+    from conftest import BIN
+
+    g, s, r = synth.f_lowcomplex(1)
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    want = read_sha256_list("flowcomplex")
+    for fn in ("ref.fa", "snps.vcf", "idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf", "idx.snp.bf"):
+        assert _sha(os.path.join(d, fn)) == want[fn], fn
+    ix = O.OracleIndex.load(os.path.join(d, "idx"))
+    assert ix.process(r.bases, r.quals, r.offsets, nthreads=4) == 0
+    mine = O.calls_by_key(ix.sites(), index_io.read_chrlens(os.path.join(d, "idx.chrlens")))
+    ref = O.parse_vcf_calls(os.path.join(GOLDEN, "flowcomplex.out.vcf.gz"))
+    assert len(ref) == 2082
+    assert mine == ref
+    st = ix.stats.as_dict()
+    rd = index_io.read_ref_dict(os.path.join(d, "idx.ref.dict"))
+    assert st["aux_ref"] > 2000 and st["scan_oob"] > 0 and int((rd["ref_pos"] == 0xFFFFFFFF).sum()) > 500
+    for fn in ("idx.ref.bf", "idx.snp.bf"):
+        os.remove(os.path.join(d, fn))

@@ -736,3 +736,47 @@ def reads_to_host(bases, quals, offsets, lo=0, hi=None):
     hi = len(o) - 1 if hi is None else hi
     b0, b1 = int(o[lo]), int(o[hi])
     return Reads(bases[b0:b1].cpu().numpy(), quals[b0:b1].cpu().numpy(), (o[lo:hi + 1] - o[lo]).astype(np.uint64))
+
+
+def f_lowcomplex(seed, genome_len=60_000, n_reads=6_000):
+    """A small genome made of what makes k-mers collide with themselves and with their reverse complements: microsatellites
+    of unit length 1-6 (among them A, AT, ACGT, whose runs are their own reverse complement), inverted repeats (a segment
+    followed by its reverse complement: hairpins), tandem and dispersed copies (2-14 of them: auxiliary rows and, above ten,
+    POS_AMBIGUOUS), between stretches of random sequence; one SNP per ~25 bases; reads of both strands, 1 % errors, 40 % gate-open
+    chunks, lengths 150 / 101 / 64 / 250.  A function of the seed alone; meant to be drawn for many seeds."""
+    rng = np.random.default_rng(seed)
+    parts, total = [], 0
+    while total < genome_len:
+        kind = int(rng.integers(0, 6))
+        if kind <= 1:
+            seg = random_bases(rng, int(rng.integers(200, 1500)))
+        elif kind == 2:
+            unit = [b"A", b"AT", b"ACGT", b"AC", b"AAT", b"CG", b"AGCT", b"TTAGGG"][int(rng.integers(0, 8))]
+            if rng.random() < 0.3:
+                unit = bytes(random_bases(rng, int(rng.integers(1, 7))))
+            seg = np.tile(np.frombuffer(unit, dtype=np.uint8), int(rng.integers(40, 400)) // len(unit) + 1)
+        elif kind == 3:
+            half = random_bases(rng, int(rng.integers(20, 300)))
+            gap = random_bases(rng, int(rng.integers(0, 12)))
+            seg = np.concatenate([half, gap, _COMP[half[::-1]]])
+        elif kind == 4:
+            unit = random_bases(rng, int(rng.integers(33, 400)))
+            seg = np.tile(unit, int(rng.integers(2, 15)))
+        else:
+            if not parts:
+                continue
+            src = parts[int(rng.integers(0, len(parts)))]
+            a = int(rng.integers(0, max(1, len(src) - 40)))
+            seg = src[a:a + int(rng.integers(40, 600))].copy()
+            if rng.random() < 0.5:
+                seg = _COMP[seg[::-1]]
+            m = rng.random(len(seg)) < (0.0 if rng.random() < 0.5 else 0.02)
+            seg[m] = random_bases(rng, int(m.sum()))
+        parts.append(np.ascontiguousarray(seg))
+        total += len(seg)
+    cat = np.concatenate(parts)
+    cut = int(len(cat) * 0.6)
+    g = Genome(["chr1", "chr2"], [cat[:cut].copy(), cat[cut:].copy()])
+    s = make_snps(rng, g, len(cat) // 25)
+    r = make_reads(rng, g, s, n_reads, lengths=(150, 150, 101, 64, 250), err=0.01, lowq=0.40)
+    return g, s, r
