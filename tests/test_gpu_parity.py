@@ -517,6 +517,8 @@ def test_self_complementary_and_both_strand_kmers(tmp_path, monkeypatch, knob):
                 st = gx.stats()
                 for k in CMP_STATS:
                     assert st[k] == want[k], k
+    for fn in ("idx.ref.bf", "idx.snp.bf"):
+        os.remove(os.path.join(d, fn))
 
 
 @pytest.mark.parametrize("seed,knob", [(1, None), (2, None), (3, None), (4, "VG_NO_MX"), (5, "VG_NO_DIRECT"), (6, "VG_NO_MX+VG_NO_HX")])
