@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off differential run on the MI355X (profiles/fuzz_lowcomplex_r03.txt): synth.f_lowcomplex for as many seeds as fit
 in the time given, index by `vargeno index`, HIP path (counting and timed build) against the oracle; every third seed on a
-fall-back layout.  The -m gpu suite keeps seeds 1-6 (tests/test_gpu_parity.py::test_low_complexity_genomes)."""
+fall-back layout; with a third argument "stress" the reads have 90 % gate-open chunks, 3 % errors, lengths 33-300 and lower-case
+bases (profiles/fuzz_lowcomplex_stress_r03.txt).  The -m gpu suite keeps seeds 1-6 (tests/test_gpu_parity.py::test_low_complexity_genomes)."""
 import os
 import shutil
 import subprocess
@@ -21,12 +22,15 @@ from vargeno_amd.api import GenoIndex  # noqa: E402
 
 BIN = os.path.join(ROOT, "vargeno_amd", "csrc", "vargeno")
 first, budget = int(sys.argv[1]), float(sys.argv[2])
+STRESS = len(sys.argv) > 3 and sys.argv[3] == "stress"      # reads with 90 % gate-open chunks, 3 % errors, lengths 33-300, lower case
 t0 = time.time()
 seed, fails = first, 0
 KNOBS = (None, None, "VG_NO_MX", None, None, "VG_NO_DIRECT", None, None, "VG_NO_MX+VG_NO_HX")
 while time.time() - t0 < budget:
     knob = KNOBS[seed % len(KNOBS)]
-    g, s, r = synth.f_lowcomplex(seed)
+    g, s, r = synth.f_lowcomplex(seed, n_reads=10 if STRESS else 6_000)
+    if STRESS:
+        r = synth.make_reads(np.random.default_rng(1000 + seed), g, s, 6000, lengths=(150, 101, 64, 33, 250, 300), err=0.03, lowq=0.9, lower_frac=0.02)
     d = tempfile.mkdtemp(prefix="lc%d_" % seed)
     synth.write_fasta(os.path.join(d, "ref.fa"), g)
     synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
