@@ -13,7 +13,18 @@ sequences with planted repeats, ~10 M SNPs, 8 M x 150 bp reads per step at 0.5 %
 (SURVEY.md §8d), seed 20261002; the index (~240 GB with its re-laid-out views) is resident in HBM.  `--workload chr22`
 runs configs[1] (40 Mbp, 1 M SNPs, 1 M-read steps; about a minute end to end).
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg38|chr22]
+Input form.  `value` is timed on the form the reference consumes: ASCII bases + the reads' quality STRINGS
+(vg_reads_process_device).  The reduced form -- one gate word per read, what the device-side FASTQ framing hands the read loop
+(vg_reads_process_device_gated) -- is timed in the same run and reported as `other_input_form` (`--gate-words` swaps the two).
+
+Secondary configurations (N = 1, default workload only; `--secondary none` switches them off).  After the main line's legs the
+same run measures, each with its own roofline and a parity check against the oracle: the 50 % low-quality stress profile on the
+index that is already open; then, as child processes of this one (each prints its own JSON line, which becomes an entry of
+`secondary`): chr22-scale (configs[1]), the repeat-rich hg38-size genome (--repeats 0.3), and the index of configs[4] (hg38 +
+100 M SNPs) on one replica.  A leg is skipped, with the reason stated, when the run's time budget ($VG_BENCH_BUDGET_S, default
+1500 s) would not hold it; a failing leg never fails the main line.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hg38|chr22|hg38f]
 `--gpus N` with N > 1 starts the N ranks itself (one per GPU, `python -m torch.distributed.run`, before anything in this
 process touches a GPU); under an external torchrun (WORLD_SIZE set) it runs as one rank of that job.
 """
@@ -63,7 +74,10 @@ def parse_args():
     ap.add_argument("--cpu-reference", choices=["auto", "yes", "no"], default="auto",
                     help="time the reference binary (oracle/_ref/vargeno) on the host, beside the GPU legs, as the cpu_baseline of record: auto = yes unless the "
                          "workload is hg38f (the reference cannot run it: int index into a > 2^31-entry SNP dictionary, qv.cc:447) or the host is short of memory")
-    ap.add_argument("--ascii-quals", action="store_true", help="hand the read loop the quality STRINGS (vg_reads_process_device) instead of one gate word per read")
+    ap.add_argument("--gate-words", action="store_true", help="time `value` on the reduced input form (one gate word per read, vg_reads_process_device_gated) and report the quality-string form beside it, instead of the other way round")
+    ap.add_argument("--secondary", default="auto", help="secondary configurations measured after the main line: auto (= all, for the default workload at N = 1), none, or a comma list of lowq50,chr22,repeats30,hg38f")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the `sustained` leg: blocks of K steps back to back for at least this long (0 = skip)")
+    ap.add_argument("--cleanup", action="store_true", help="remove this run's index files when done (the secondary legs' child runs do)")
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the secondary end-to-end number (FASTQ text in pinned host memory -> counters)")
     args = ap.parse_args()
@@ -71,6 +85,7 @@ def parse_args():
         if getattr(args, k) is None:
             setattr(args, k, v)
     args.cpu_sample = min(args.cpu_sample, args.reads)
+    args.ascii_quals = not args.gate_words
     return args
 
 
@@ -104,12 +119,14 @@ def build_index_files(args, g, s, d, prefix):
 
 class ReferenceTimer:
     """The reference itself (oracle/_ref/vargeno, built from the reference sources by oracle/Makefile in the build container) on the
-    GPU box's host, one thread -- it has no other mode -- next to the GPU legs: two `geno` child processes, one over the
-    sample's FASTQ and one over an empty FASTQ, started as soon as the index files exist and left alone until the GPU legs
-    are done.  The reference prints "Processing..." right before its read loop (qv.cc:753) and creates the output VCF right
-    after the calling scan that follows the loop (qv.cc:1573-1637), so
+    GPU box's host, one thread -- it has no other mode: two `geno` child processes, one over the sample's FASTQ and one over an
+    empty FASTQ, started as soon as the index files exist.  The reference prints "Processing..." right before its read loop
+    (qv.cc:753) and creates the output VCF right after the calling scan that follows the loop (qv.cc:1573-1637), so
         read loop = (sample: VCF created - "Processing...") - (empty: VCF created - "Processing...")
-    whatever its minutes of start-up (16 GiB jump table) took on a host that is busy with the rest of the bench."""
+    whatever its minutes of start-up (16 GiB jump table) took.  The start-up may overlap anything; the LOOP is timed in a quiet
+    window: every leg of this bench that loads the host's cores (the many-thread oracle runs, `vargeno index` of a secondary
+    configuration) first calls wait_quiet(), which blocks while a reference process is between "Processing..." and its exit,
+    and the seconds of such work that overlapped a loop all the same are reported (`contended_s`, 0 by construction)."""
 
     def __init__(self, ref_bin, d, sample_fq, n_reads):
         import threading
@@ -120,6 +137,8 @@ class ReferenceTimer:
         self.res = {}
         self.threads = []
         self.procs = []
+        self.loops = {}                                # name -> [t "Processing...", t exit or None]
+        self.heavy = []                                # [t0, t1] of host-heavy legs of the bench
         atexit.register(self.kill)                     # a bench that dies early must not leave two 65 GB processes behind
         for name, fq in (("empty", os.path.join(d, "cpu_empty.fq")), ("sample", sample_fq)):
             if name == "empty":
@@ -140,6 +159,7 @@ class ReferenceTimer:
             for line in p.stderr:                        # stderr is unbuffered on the reference's side
                 if line.startswith(b"Processing"):
                     t_proc = time.time()
+                    self.loops[name] = [t_proc, None]
                     break
             t_vcf = None
             while p.poll() is None:
@@ -147,15 +167,37 @@ class ReferenceTimer:
                     t_vcf = time.time()
                 time.sleep(0.02)
             t_end = time.time()
+            if name in self.loops:
+                self.loops[name][1] = t_end
             if p.returncode == 0 and t_proc is not None:
                 self.res[name] = {"startup": t_proc - t_start, "loop_and_scan": (t_vcf or t_end) - t_proc, "wall": t_end - t_start}
         except Exception as e:
             log("[bench] reference binary (%s FASTQ) not timed: %r" % (name, e))
 
+    def in_loop(self):
+        return any(v[1] is None for v in list(self.loops.values()))
+
+    def wait_quiet(self, what, timeout=600.0):
+        """Call before a leg that loads the host's cores: blocks while a reference process is inside its timed span."""
+        t0 = time.time()
+        while self.in_loop() and time.time() - t0 < timeout:
+            time.sleep(0.05)
+        if time.time() - t0 > 0.5:
+            log("[bench] %s held back %.1fs: the reference binary was inside its timed read loop" % (what, time.time() - t0))
+
+    def heavy_begin(self):
+        self.heavy.append([time.time(), None])
+
+    def heavy_end(self):
+        self.heavy[-1][1] = time.time()
+
     def kill(self):
         for p in self.procs:
             if p.poll() is None:
                 p.kill()
+
+    def alive(self):
+        return any(t.is_alive() for t in self.threads)
 
     def result(self, timeout=1500):
         t0 = time.time()
@@ -168,10 +210,27 @@ class ReferenceTimer:
         loop = a["loop_and_scan"] - b["loop_and_scan"]
         if loop <= 0:
             return None
-        return {"value": self.n / loop, "unit": "reads/s", "cores": 1, "kind": "reference",
+        contended = 0.0
+        for l0, l1 in self.loops.values():
+            for h0, h1 in self.heavy:
+                contended += max(0.0, min(l1 or time.time(), h1 or time.time()) - max(l0, h0))
+        return {"value": self.n / loop, "unit": "reads/s", "cores": 1, "kind": "reference", "contended_s": round(contended, 2),
                 "sample": "oracle/_ref/vargeno geno (the reference's own binary, its only mode: one thread) on the first %d reads of batch 0: %.1f s from \"Processing...\" to the "
-                          "output VCF's creation, minus %.1f s of the same span on an empty FASTQ (the calling scan); start-up %.0f s, not counted; "
-                          "ran beside the GPU legs of this bench" % (self.n, a["loop_and_scan"], b["loop_and_scan"], a["startup"])}
+                          "output VCF's creation, minus %.1f s of the same span on an empty FASTQ (the calling scan); start-up %.0f s, not counted; the two processes ran "
+                          "side by side, and the bench's host-heavy legs (many-thread oracle runs, index builds) were held back while either was inside that span: "
+                          "%.1f s of such work overlapped it" % (self.n, a["loop_and_scan"], b["loop_and_scan"], a["startup"], contended)}
+
+
+class NoRef:
+    """Stand-in when the reference is not being timed."""
+    def wait_quiet(self, what, timeout=0):
+        pass
+
+    def heavy_begin(self):
+        pass
+
+    def heavy_end(self):
+        pass
 
 
 def gather_ceiling():
@@ -190,12 +249,15 @@ def gather_ceiling():
         return None
 
 
-def measure_ingest(gx, batch, log, chunk_mb=64, reps=3):
-    """Batch 0 as FASTQ text in page-locked host memory, streamed to the device in 64 MiB chunks `reps` times; the counters of
-    the first pass must equal those of the resident batch.  Returns the secondary bench number."""
+def measure_ingest(gx, batch, log, reps=3):
+    """Batch 0 as FASTQ text in page-locked host memory, streamed through the library `reps` times, along both of its ingest paths:
+    (a) the text itself crosses the link in 64 MiB chunks and is framed on the device (vg_fastq_stream_begin);
+    (b) host threads inside the library frame and 2-bit pack 256 MiB chunks, the packed form (48 bytes per read) crosses the link
+        (vg_fastq_stream_begin_packed; the thread count is the library's choice for this host).
+    The counters of each path's first pass must equal those of the resident batch.  Returns the secondary bench number: the
+    faster path's, with both listed."""
     import torch
 
-    from vargeno_amd import synth
     from vargeno_amd.api import pinned_buffer
 
     tb, tq, to = batch[:3]
@@ -218,23 +280,172 @@ def measure_ingest(gx, batch, log, chunk_mb=64, reps=3):
     m[:, 11 + L] = 10; m[:, 12 + L] = ord("+"); m[:, 13 + L] = 10
     m[:, 14 + L:14 + 2 * L] = tq.cpu().numpy().reshape(n, L)
     m[:, 14 + 2 * L] = 10
-    step = chunk_mb << 20
-    chunks = [text[a:a + step] for a in range(0, len(text), step)]
-    gx.reset()
-    got = gx.fastq_stream(chunks)
-    assert got[0] == n and got[1] == len(text) and not got[3], "FASTQ stream framed %r of %d records" % (got, n)
-    assert torch.equal(gx.counts_tensor(), want), "counters through the FASTQ stream != counters of the resident batch"
-    gx.sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        gx.fastq_stream(chunks)
-    dt = time.perf_counter() - t0
+    paths = {}
+    for name, chunk_mb, threads, what in (("device_framing", 64, None, "vg_fastq_stream_begin: the text crosses PCIe in %d MiB chunks, record framing + packing on the device"),
+                                          ("host_packing", 256, -1, "vg_fastq_stream_begin_packed: host threads inside the library frame and 2-bit pack %d MiB chunks, 48 bytes per read cross PCIe")):
+        step = chunk_mb << 20
+        chunks = [text[a:a + step] for a in range(0, len(text), step)]
+        try:
+            gx.reset()
+            got = gx.fastq_stream(chunks, host_threads=threads)
+            assert got[0] == n and got[1] == len(text) and not got[3], "FASTQ stream framed %r of %d records" % (got, n)
+            assert torch.equal(gx.counts_tensor(), want), "counters through the FASTQ stream (%s) != counters of the resident batch" % name
+            gx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                gx.fastq_stream(chunks, host_threads=threads)
+            dt = time.perf_counter() - t0
+            paths[name] = {"value": reps * n / dt, "unit": "reads/s", "text_GB_per_s": reps * n * rec / dt / 1e9, "reads": reps * n, "bytes_per_read_of_text": rec,
+                           "path": "FASTQ text in pinned host memory -> " + what % chunk_mb + " -> read loop -> counters; counters of the first pass identical to the resident batch"}
+            log("[bench] ingest end to end, %s: %.3g reads/s (%.1f GB/s of FASTQ text)" % (name, paths[name]["value"], paths[name]["text_GB_per_s"]))
+        except Exception as e:
+            paths[name] = {"failed": repr(e)}
+            log("[bench] ingest leg %s failed: %r" % (name, e))
     del m, text, owner
-    out = {"value": reps * n / dt, "unit": "reads/s", "text_GB_per_s": reps * n * rec / dt / 1e9, "reads": reps * n, "bytes_per_read": rec,
-           "path": "FASTQ text in pinned host memory -> vg_fastq_stream_push (%d MiB chunks: H2D over PCIe, record framing on the device) -> read loop -> counters; "
-                   "counters of the first pass identical to the resident batch" % chunk_mb}
-    log("[bench] ingest end to end: %.3g reads/s (%.1f GB/s of FASTQ text)" % (out["value"], out["text_GB_per_s"]))
+    ok = {k: v for k, v in paths.items() if "value" in v}
+    if not ok:
+        return {"failed": paths}
+    best = max(ok, key=lambda k: ok[k]["value"])
+    out = dict(ok[best])
+    out["chosen"] = best
+    out["host_threads_available"] = os.cpu_count()
+    out["paths"] = paths
     return out
+
+
+T_START = time.time()
+BUDGET_S = float(os.environ.get("VG_BENCH_BUDGET_S", "1500"))
+# (estimated wall seconds, bench.py arguments) of the secondary legs that run as child processes, in this order
+CHILD_LEGS = [("chr22", 120, ["--workload", "chr22", "--steps", "40", "--warmup", "5"]),
+              ("repeats30", 330, ["--workload", "hg38", "--repeats", "0.3"]),
+              ("hg38f", 560, ["--workload", "hg38f", "--steps", "10", "--warmup", "3"])]
+
+
+def main_kernel_name(views):
+    """The kernel the main tier of this handle launches (vargeno_hip.hip, enqueue_batch): the instantiation for an index
+    without the merged view is a kernel of its own."""
+    return "vg_wave_kernel_big" if "mx" not in views else "vg_wave_kernel"
+
+
+def traffic_for(args, build_id):
+    """HBM traffic and L2 misses of the dominant kernel cannot be counted inside a timed run: they come from the separate
+    rocprofv3 --pmc passes of this same command, committed under profiles/ -- and only of THIS build of the library: a traffic
+    file is stamped with the vg_build_id() it was measured on and with the workload it was measured for."""
+    import glob
+
+    traffic, misses, note = None, None, "no profiles/traffic_*.json for this workload"
+    want = {"genome": args.genome, "snps": args.snps, "reads": args.reads}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
+        try:
+            tj = json.load(open(path))
+            w = dict(tj["workload"])
+            if {k: w.get(k) for k in want} != want or float(w.get("lowq", 0.08)) != args.lowq or float(w.get("repeats", 0.0)) != args.repeats or bool(w.get("gate_words", True)) != bool(args.gate_words):
+                continue
+            if tj.get("build_id") != build_id:
+                note = "%s was measured on build %s, this is build %s: not quoted" % (os.path.basename(path), tj.get("build_id"), build_id)
+                continue
+            traffic, misses = tj["traffic_bytes_per_launch"], tj.get("TCC_MISS_sum")
+            note = "%s (separate rocprofv3 --pmc passes of this command on this build; %s)" % (os.path.basename(path), tj.get("traffic_formula", "FETCH_SIZE + WRITE_SIZE"))
+            break
+        except Exception:
+            pass
+    return traffic, misses, note
+
+
+def timed_block(gx, run, batches, steps, first=0):
+    """K steps back to back over the rotating batches, then fold + clamp + fetch of the counters ("first submit
+    -> counters reduced and fetched"); returns seconds."""
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run(batches[(first + i) % len(batches)])
+    fetched = gx.counts()
+    dt = time.perf_counter() - t0
+    del fetched
+    return dt
+
+
+def check_against_oracle(gx, ox, run, batch, n_check, st_full, ref):
+    """Parity of one batch (its first n_check reads) against the oracle: site counters of the counting build and of the timed
+    build, and the event counters.  Returns (parity dict, seconds the many-thread oracle run took, host reads)."""
+    from vargeno_amd import synth
+
+    n_all = len(batch[2]) - 1
+    n_check = min(n_check, n_all)
+    r0 = synth.reads_to_host(*batch[:3], 0, n_check)
+    nt = min(os.cpu_count() or 1, 64)
+    ref.wait_quiet("the oracle's %d-thread run" % nt)
+    ref.heavy_begin()
+    ox.reset()
+    t0 = time.time()
+    ox.process(r0.bases, r0.quals, r0.offsets, nthreads=nt)
+    t_all = time.time() - t0
+    ref.heavy_end()
+    so = ox.sites()
+    want = ox.stats.as_dict()
+    if n_check == n_all:
+        sub, st = batch, st_full
+    else:                                                   # a slice of the batch: its own counted pass
+        b1 = int(batch[2][n_check].item())
+        sub = (batch[0][:b1], batch[1][:b1], batch[2][:n_check + 1].contiguous(), batch[3][:n_check].contiguous())
+        gx.set_stats(True)
+        gx.reset()
+        run(sub)
+        st = gx.stats()
+    rc, ac = gx.counts()                                    # (of the counted pass just made -- the caller's, for a whole batch)
+    bad = int((rc != so["ref_cnt"]).sum() + (ac != so["alt_cnt"]).sum())
+    assert bad == 0, "HIP counters != oracle at %d of %d site counters" % (bad, 2 * len(rc))
+    for k, v in want.items():
+        assert st[k] == v, "event counter %s: hip %d oracle %d" % (k, st[k], v)
+    # the timed build (event counting off; it reads the re-laid-out views) must give the same counters, in both input forms
+    gx.set_stats(False)
+    for strings in (True, False):
+        gx.reset()
+        run(sub, strings=strings)
+        rc2, ac2 = gx.counts()
+        assert np.array_equal(rc2, so["ref_cnt"]) and np.array_equal(ac2, so["alt_cnt"]), "timed build (%s) != oracle" % ("quality strings" if strings else "gate words")
+    par = {"equal": True, "reads": int(n_check), "site_counters": int(2 * len(rc)), "event_counters": len(want), "increments": int(rc.astype(np.int64).sum() + ac.astype(np.int64).sum()),
+           "builds": "counting build, timed build with quality strings, timed build with gate words", "against": "oracle/vg_oracle.c (pinned on the reference binary, tests/test_oracle_golden.py)"}
+    log("[bench] parity: %d site counters (counting build + timed build in both input forms) and %d event counters identical to the oracle on %d reads" % (2 * len(rc), len(want), n_check))
+    return par, t_all, r0
+
+
+def roofline_of(alg_bytes, k_ms, reads, kernel):
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "kernel": kernel, "kernel_ms": k_ms,
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_read": alg_bytes / reads}
+
+
+def run_child_leg(name, est, extra, args, ref):
+    """One secondary configuration as a child process of this one (which holds no index any more): its own bench.py line."""
+    left = BUDGET_S - (time.time() - T_START)
+    if left < est:
+        return {"skipped": "time budget: %.0f s of $VG_BENCH_BUDGET_S = %.0f s left, this leg is estimated at %d s" % (left, BUDGET_S, est)}
+    ref.wait_quiet("secondary leg %s" % name)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--secondary", "none", "--no-gather-probe", "--no-ingest", "--cpu-reference", "no", "--sustain-seconds", "0",
+           "--cleanup", "--cpu-sample", "200000"] + extra
+    if args.workdir_given:
+        cmd += ["--workdir", args.workdir]
+    t0 = time.time()
+    log("[bench] secondary leg %s: %s" % (name, " ".join(cmd[2:])))
+    try:
+        ref.heavy_begin()
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=max(60.0, min(left - 20.0, 2.5 * est)))
+        ref.heavy_end()
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"skipped": "child run failed (rc %d): %s" % (p.returncode, (p.stderr or "").strip().splitlines()[-1:] or ["no output"]), "wall_s": time.time() - t0}
+        j = json.loads(lines[-1])
+        rf = j["roofline"]
+        return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "input_form": j["input_form"],
+                "other_input_form": j.get("other_input_form") and {k: j["other_input_form"][k] for k in ("input", "value", "ms_per_step")},
+                "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "algorithmic_bytes_per_read", "traffic", "traffic_source")},
+                "parity": j.get("parity"), "device_ms_per_step": j.get("device_ms_per_step"), "reads_per_step_redone_by_deep_list_tier": j.get("reads_per_step_redone_by_deep_list_tier"),
+                "index_bytes_hbm": j["config"].get("index_bytes_hbm"), "index_views": j["config"].get("index_views"), "cpu_port_reads_per_s": (j.get("cpu_baseline") or {}).get("value"), "wall_s": time.time() - t0}
+    except subprocess.TimeoutExpired:
+        ref.heavy_end()
+        return {"skipped": "child run exceeded its share of the time budget", "wall_s": time.time() - t0}
+    except Exception as e:
+        return {"skipped": "child run failed: %r" % (e,), "wall_s": time.time() - t0}
 
 
 def main():
@@ -248,8 +459,15 @@ def main():
 
     from vargeno_amd import synth
 
+    default_workload = args.workload == "hg38" and args.repeats == 0.0 and args.lowq == 0.08 and args.genome == PRESETS["hg38"]["genome"] and args.snps == PRESETS["hg38"]["snps"] and args.reads == PRESETS["hg38"]["reads"]
+    if args.secondary == "auto":
+        legs = ["lowq50", "chr22", "repeats30", "hg38f"] if (default_workload and world == 1 and args.cpu_sample > 0) else []
+    else:
+        legs = [x for x in args.secondary.split(",") if x and x != "none"]
+
     # ---- data set + index files: host only (rank 0 builds, the others wait for its marker file) ----------------------------
     tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms) + ("_r%g" % args.repeats if args.repeats else "")
+    args.workdir_given = args.workdir is not None
     if args.workdir is None:
         # index files: ~16 bytes per base of the genome + ~550 bytes per SNP (hg38 + 10 M SNPs: 48 GB; + 100 M SNPs: 104 GB).
         # /tmp unless it lacks the room for an index that is not there yet and /dev/shm (memory-backed) has it
@@ -286,6 +504,7 @@ def main():
     dev_index = local_rank % max(ndev, 1)               # one rank per GPU (VG_BENCH_BACKEND=gloo lets ranks share a GPU for plumbing tests)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev                                      # where the small bookkeeping collectives live
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(dev_index)
@@ -301,7 +520,7 @@ def main():
     else:
         n_seen = 1
 
-    from vargeno_amd.api import GenoIndex, all_reduce_counts, shard_range
+    from vargeno_amd.api import GenoIndex, all_reduce_counts, gate_words, shard_range
 
     # reads resident in HBM: NB batches of this rank's part of the read stream + (N > 1) one stream every rank knows
     t0 = time.time()
@@ -309,6 +528,10 @@ def main():
     del g, s
     batches = [src.batch(rank * 1000 + b, args.reads, lowq=args.lowq) for b in range(args.batches)]
     common = src.batch(999_999, min(args.reads, 1_000_000), lowq=args.lowq) if world > 1 else None
+    # the stress profile's batches (50 % low-quality characters) wait on the host until their leg
+    lowq_host = None
+    if "lowq50" in legs:
+        lowq_host = [tuple(t.cpu() for t in src.batch(700_000 + b, args.reads, lowq=0.5)) for b in range(2)]
     src.release()
     del src
     torch.cuda.synchronize(dev)
@@ -337,17 +560,17 @@ def main():
             log("[bench] reference binary started on the host (sample FASTQ of %d reads written in %.1fs; %.0f GB of host memory available)" % (args.cpu_sample, time.time() - t0, avail_gb))
         else:
             log("[bench] reference binary NOT timed: %.0f GB of host memory available, %.0f wanted" % (avail_gb, need_gb))
+    ref = ref_timer or NoRef()
 
     t0 = time.time()
     gx = GenoIndex.open(prefix, device=dev_index)
+    t_open = time.time() - t0
     if rank == 0:
-        log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (time.time() - t0, gx.device_bytes / 1e9, gx.num_sites))
+        log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (t_open, gx.device_bytes / 1e9, gx.num_sites))
 
-    # The resident batches: ASCII bases + offsets + one gate word per read (bit c = quality character c < '8': all the path reads of
-    # a quality string, qv.cc:836, 943; vg_reads_process_device_gated -- the form the device-side FASTQ framing hands the read loop too).
-    # --ascii-quals hands over the quality strings themselves instead (vg_reads_process_device); both forms are timed, see below.
-    from vargeno_amd.api import gate_words
-
+    # The resident batches: ASCII bases + quality strings + offsets (the form the reference consumes, vg_reads_process_device) and, for
+    # the reduced form, one gate word per read (bit c = quality character c < '8': all the path reads of a quality string,
+    # qv.cc:836, 943; vg_reads_process_device_gated -- what the device-side FASTQ framing hands the read loop).  Both forms are timed.
     batches = [tuple(b) + (gate_words(b[1], b[2]),) for b in batches]
     torch.cuda.synchronize(dev)
 
@@ -363,36 +586,27 @@ def main():
     run(batches[0])
     st = gx.stats()
     alg_bytes_per_launch = st["alg_bytes"]
-    cpu = None
+    cpu, parity, ox = None, None, None
     if rank == 0 and world == 1 and args.cpu_sample > 0:        # the CPU legs (and the parity check they feed) run at N = 1 only
         from oracle import oracle as O
 
         t0 = time.time()
         ox = O.OracleIndex.load(prefix)
         log("[bench] oracle index load: %.1fs" % (time.time() - t0))
-        r0 = synth.reads_to_host(*batches[0][:3])
         ncores = os.cpu_count() or 1
         nt = min(ncores, 64)
         # every host core first: the whole batch, which is also what the parity check compares
-        t0 = time.time()
-        ox.process(r0.bases, r0.quals, r0.offsets, nthreads=nt)
-        t_all = time.time() - t0
         if not args.no_check:
-            so = ox.sites()
-            rc, ac = gx.counts()
-            bad = int((rc != so["ref_cnt"]).sum() + (ac != so["alt_cnt"]).sum())
-            assert bad == 0, "HIP counters != oracle at %d of %d site counters" % (bad, 2 * len(rc))
-            want = ox.stats.as_dict()
-            for k, v in want.items():
-                assert st[k] == v, "event counter %s: hip %d oracle %d" % (k, st[k], v)
-            # the timed build (event counting off; it reads the re-laid-out views) must give the same counters
-            gx.set_stats(False)
-            gx.reset()
-            run(batches[0])
-            rc2, ac2 = gx.counts()
-            assert np.array_equal(rc2, so["ref_cnt"]) and np.array_equal(ac2, so["alt_cnt"]), "timed build != oracle"
-            log("[bench] parity: %d site counters (both builds) and %d event counters identical to the oracle on the %d reads of batch 0" % (2 * len(rc), len(want), r0.n))
-        # one thread on a bounded sample (the reference is single-threaded: this is the baseline of record)
+            parity, t_all, r0 = check_against_oracle(gx, ox, run, batches[0], args.reads, st, ref)
+        else:
+            r0 = synth.reads_to_host(*batches[0][:3])
+            ref.wait_quiet("the oracle's %d-thread run" % nt)
+            ref.heavy_begin()
+            t0 = time.time()
+            ox.process(r0.bases, r0.quals, r0.offsets, nthreads=nt)
+            t_all = time.time() - t0
+            ref.heavy_end()
+        # one thread on a bounded sample (the reference is single-threaded: this is the baseline of record when the reference binary is not timed)
         ns = args.cpu_sample
         sub = r0.slice(0, ns)
         t_cpu, passes = 0.0, 0
@@ -407,10 +621,13 @@ def main():
         tried = {str(nt): r0.n / t_all}
         best_nt, best_t = nt, t_all
         if ncores > nt:
+            ref.wait_quiet("the oracle's %d-thread run" % ncores)
+            ref.heavy_begin()
             ox.reset()
             t0 = time.time()
             ox.process(r0.bases, r0.quals, r0.offsets, nthreads=ncores)
             t_more = time.time() - t0
+            ref.heavy_end()
             tried[str(ncores)] = r0.n / t_more
             if t_more < best_t:
                 best_nt, best_t = ncores, t_more
@@ -418,8 +635,10 @@ def main():
                "sample": "%d pass(es) over the first %d reads of batch 0, oracle/vg_oracle.c, 1 thread, %.1f s" % (passes, ns, t_cpu),
                "all_cores": {"value": r0.n / best_t, "threads": best_nt, "host_cores": ncores, "reads_per_s_by_threads": tried,
                              "sample": "batch 0 (%d reads), %.1f s" % (r0.n, best_t)}}
-        ox.close()
         del r0, sub
+        if "lowq50" not in legs:
+            ox.close()
+            ox = None
 
     # ---- secondary number (N = 1): end to end from FASTQ text in pinned HOST memory -- H2D over PCIe, framing on the device, the
     #      read loop -- through vg_fastq_stream_push.  Never `value`: the metric is quoted on batches resident in HBM. -------------
@@ -468,11 +687,14 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         run(batches[i % args.batches])
-    local_sum = None
+    local_sum, t_reduce = None, None
     if world > 1:
         gx.sync()
+        t_steps_done = time.perf_counter()
         local_sum = gx.counts_tensor().sum(dtype=torch.int64).reshape(1).to(coll_dev)      # this rank's increments, before the exchange (checked below)
+        t1 = time.perf_counter()
         all_reduce_counts(gx)                           # one RCCL all-reduce of the per-site counters over xGMI
+        t_reduce = time.perf_counter() - t1
     fetched = gx.counts()                               # "first submit -> counters reduced and fetched": fold, clamp at 63, device -> host
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -480,6 +702,7 @@ def main():
     elapsed = time.perf_counter() - t0
     del fetched
     tm = gx.timing()                                    # HIP events on the library's own streams, averaged over the K batches
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -488,11 +711,18 @@ def main():
         dist.all_reduce(local_sum)
         total_after = int(gx.counts_tensor().sum(dtype=torch.int64).item())
         assert total_after == int(local_sum.item()), "reduced counters hold %d increments, the ranks made %d" % (total_after, int(local_sum.item()))
+        # what every rank saw, so that a scaling run explains itself: main-tier kernel ms, steps' wall ms, the exchange's ms
+        mine = torch.tensor([tm["ms_main"], 1e3 * (t_steps_done - t0) / args.steps, 1e3 * t_reduce], dtype=torch.float64, device=coll_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
         if rank == 0:
             verification["timed_region_increments"] = total_after
+            per_rank = {"kernel_ms": [float(x[0]) for x in allr], "ms_per_step_before_exchange": [float(x[1]) for x in allr], "all_reduce_ms": [float(x[2]) for x in allr],
+                        "all_reduce_bytes": int(gx.counts_tensor().numel()) * 4, "backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
+                        "devices_visible": ndev, "ranks_seen_by_the_collective": n_seen}
 
-    # ---- the other input form, for the record (N = 1): the same K steps with the quality strings handed over (or, under --ascii-quals, the gate words)
-    other_form = None
+    # ---- the other input form, for the record (N = 1): the same K steps with the gate words handed over (or, under --gate-words, the strings)
+    other_form, sustained = None, None
     if rank == 0 and world == 1:
         gx.reset()
         for i in range(min(args.warmup, 2)):
@@ -505,8 +735,70 @@ def main():
         gx.counts()
         dt = time.perf_counter() - t0
         tm2 = gx.timing()
-        other_form = {"input": "quality strings (vg_reads_process_device)" if not args.ascii_quals else "gate words (vg_reads_process_device_gated)",
+        other_form = {"input": "quality strings (vg_reads_process_device)" if not args.ascii_quals else "one gate word per read (vg_reads_process_device_gated)",
                       "value": args.reads * args.steps / dt, "unit": "reads/s", "ms_per_step": 1e3 * dt / args.steps, "pack_ms": tm2["ms_pack"], "wave_ms": tm2["ms_main"]}
+        # ---- sustained: blocks of K steps (each with its fetch, like the timed region) back to back for args.sustain_seconds, so that clocks
+        #      and the atomics' contention at steady state are on record (the timed region above lasts tens of milliseconds)
+        if args.sustain_seconds > 0:
+            gx.reset()
+            blocks, t_s0 = [], time.perf_counter()
+            while time.perf_counter() - t_s0 < args.sustain_seconds or len(blocks) < 3:
+                blocks.append(1e3 * timed_block(gx, run, batches, args.steps, first=len(blocks) * args.steps) / args.steps)
+            t_s = time.perf_counter() - t_s0
+            gx.timing()
+            sustained = {"seconds": t_s, "blocks": len(blocks), "steps": len(blocks) * args.steps, "reads": len(blocks) * args.steps * args.reads, "value": len(blocks) * args.steps * args.reads / t_s, "unit": "reads/s",
+                         "ms_per_step": {"min": float(np.min(blocks)), "median": float(np.median(blocks)), "max": float(np.max(blocks)), "first": blocks[0], "last": blocks[-1]},
+                         "note": "blocks of %d steps + fold/clamp/fetch of the counters, back to back without a reset (the counters keep summing; the clamp is applied at fetch)" % args.steps}
+            log("[bench] sustained: %.2f s, %d steps, %.4g reads/s, ms/step min %.3f median %.3f max %.3f" % (t_s, sustained["steps"], sustained["value"], sustained["ms_per_step"]["min"], sustained["ms_per_step"]["median"], sustained["ms_per_step"]["max"]))
+
+    from vargeno_amd._lib import lib as _vg_lib
+
+    build_id = _vg_lib().vg_build_id().decode()
+    views, dev_bytes = gx.views, gx.device_bytes
+    kernel = main_kernel_name(views)
+
+    # ---- secondary leg on the open index: the stress profile (50 % low-quality characters: 3 gate-open chunks per read) ------------
+    secondary = {}
+    if rank == 0 and "lowq50" in legs and lowq_host is not None and ox is not None:
+        try:
+            t_leg = time.time()
+            del batches[1:]                                    # make room: the main line's batches are done with
+            torch.cuda.empty_cache()
+            lb = [tuple(t.to(dev) for t in hb) for hb in lowq_host]
+            lb = [tuple(b) + (gate_words(b[1], b[2]),) for b in lb]
+            lowq_host = None
+            torch.cuda.synchronize(dev)
+            gx.set_stats(True)
+            gx.reset()
+            run(lb[0])
+            st_l = gx.stats()
+            par_l, _, _ = check_against_oracle(gx, ox, run, lb[0], 1_000_000, st_l, ref)
+            gx.set_stats(False)
+            gx.reset()
+            for i in range(3):
+                run(lb[i % 2])
+            gx.sync()
+            gx.timing()
+            gx.reset()
+            dt = timed_block(gx, run, lb, args.steps)
+            tm_l = gx.timing()
+            secondary["lowq50"] = {"workload": "the main line's index, 50 %% low-quality characters (SURVEY.md §8d stress profile: %.2f gate-open chunks per read), %d x 150 bp reads per step rotating over 2 resident batches" % (st_l["gate_open"] / args.reads, args.reads),
+                                   "value": args.reads * args.steps / dt, "unit": "reads/s", "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps,
+                                   "input_form": "quality strings" if args.ascii_quals else "gate words",
+                                   "roofline": roofline_of(st_l["alg_bytes"], tm_l["ms_main"], args.reads, kernel), "parity": par_l,
+                                   "device_ms_per_step": {"pack": tm_l["ms_pack"], "wave": tm_l["ms_main"], "spill_tiers_overlapped": tm_l["ms_tail"]},
+                                   "reads_per_step_redone_by_deep_list_tier": st_l["overflow_reads"], "wall_s": time.time() - t_leg}
+            log("[bench] secondary lowq50: %.4g reads/s, %.3f ms/step, kernel %.3f ms, frac %.3f" % (secondary["lowq50"]["value"], secondary["lowq50"]["ms_per_step"], tm_l["ms_main"], secondary["lowq50"]["roofline"]["frac"]))
+            del lb
+        except Exception as e:                                 # a secondary leg never fails the main line
+            secondary["lowq50"] = {"skipped": "failed: %r" % (e,)}
+            log("[bench] secondary lowq50 failed: %r" % (e,))
+    elif rank == 0 and "lowq50" in legs:
+        secondary["lowq50"] = {"skipped": "needs the oracle (--cpu-sample > 0) at N = 1"}
+    if ox is not None:
+        ox.close()
+        ox = None
+
     if rank == 0 and ref_timer is not None:
         # the reference's own binary is the baseline of record; the port (oracle) stays beside it
         t0 = time.time()
@@ -518,32 +810,22 @@ def main():
             if port:
                 cpu["port"] = {k: port[k] for k in ("value", "unit", "cores", "kind", "sample")}
                 cpu["all_cores"] = port.get("all_cores")
+    gx.close()
+    del batches
+    torch.cuda.empty_cache()
+
+    # ---- secondary legs with an index of their own: child processes, one after the other, now that this one holds no index ------
+    if rank == 0:
+        for name, est, extra in CHILD_LEGS:
+            if name in legs:
+                secondary[name] = run_child_leg(name, est, extra, args, NoRef())
+                sk = secondary[name].get("skipped")
+                log("[bench] secondary %s: %s" % (name, sk if sk else "%.4g reads/s, %.3f ms/step, frac %.3f, parity %s" % (secondary[name]["value"], secondary[name]["ms_per_step"], secondary[name]["roofline"]["frac"], (secondary[name].get("parity") or {}).get("equal"))))
+
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         k_ms = tm["ms_main"]
-        achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
-        # HBM traffic and L2 misses of the dominant kernel cannot be counted inside a timed run: they come from the separate
-        # rocprofv3 --pmc passes of this same command, committed under profiles/ (null for any other workload)
-        # -- and only of THIS build of the library: a traffic file is stamped with the vg_build_id() it was measured on
-        from vargeno_amd._lib import lib as _vg_lib
-
-        build_id = _vg_lib().vg_build_id().decode()
-        traffic, misses, traffic_note = None, None, "no profiles/traffic_*.json for this workload"
-        import glob
-
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r*.json")), reverse=True):
-            try:
-                tj = json.load(open(path))
-                if tj["workload"] != {"genome": args.genome, "snps": args.snps, "reads": args.reads} or args.lowq != 0.08 or args.repeats != 0.0:
-                    continue
-                if tj.get("build_id") != build_id:
-                    traffic_note = "%s was measured on build %s, this is build %s: not quoted" % (os.path.basename(path), tj.get("build_id"), build_id)
-                    continue
-                traffic, misses = tj["traffic_bytes_per_launch"], tj.get("TCC_MISS_sum")
-                traffic_note = "%s (separate rocprofv3 --pmc passes of this command on this build; %s)" % (os.path.basename(path), tj.get("traffic_formula", "FETCH_SIZE + WRITE_SIZE"))
-                break
-            except Exception:
-                pass
+        traffic, misses, traffic_note = traffic_for(args, build_id)
         gc = None
         if ceiling:
             # An L2 miss of a random gather moves one 128-byte line (profiles/line_probe_r03_counters.txt), so the chip's measured
@@ -552,6 +834,9 @@ def main():
                   "peak_GB_per_s": ceiling["gathers_per_s"] * 128 / 1e9,
                   "l2_misses_per_launch": misses, "achieved": (misses / (k_ms * 1e-3)) if misses else None}
             gc["frac"] = (gc["achieved"] / gc["peak"]) if misses else None
+        roof = roofline_of(alg_bytes_per_launch, k_ms, args.reads, kernel)
+        roof.update({"traffic": traffic, "traffic_source": traffic_note, "traffic_GB_per_s": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                     "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None, "gather_ceiling": gc})
         out = {
             "metric": "reads/sec genotyped (whole node), hg38+dbSNP 30×; achieved HBM GB/s vs peak",
             "value": world * args.reads * args.steps / elapsed,
@@ -570,25 +855,30 @@ def main():
                                        args.genome, args.chroms, args.snps, args.reads, args.batches, 100 * args.lowq,
                                        "" if not args.repeats else "; REPEAT-RICH genome: %g%% of it in planted families of near-identical copies (2-10 and 11-200 copies), 50 microsatellites per Mbp" % (100 * args.repeats)),
                        "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps,
-                       "index_bytes_hbm": gx.device_bytes, "index_views": gx.views, "lib_build_id": build_id,
+                       "index_bytes_hbm": dev_bytes, "index_views": views, "index_open_s": t_open, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_note,
-                         "traffic_GB_per_s": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None, "traffic_frac_of_peak": (traffic / (k_ms * 1e-3) / 1e9 / 8000.0) if traffic else None,
-                         "kernel": "vg_wave_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "algorithmic_bytes_per_read": alg_bytes_per_launch / args.reads, "gather_ceiling": gc},
+            "roofline": roof,
             "cpu_baseline": cpu,
+            "parity": parity,
             "device_ms_per_step": {"pack": tm["ms_pack"], "wave": k_ms, "spill_tiers_overlapped": tm["ms_tail"], "of_which_deep_list_wave_tier": tm["ms_deep_lists"], "batches": tm["batches"],
                                    "note": "spill tiers: elapsed time from the end of a batch's main-tier kernel to the end of its last tier, on the tail stream, under the NEXT batches' "
                                            "kernels -- mostly waiting (a tier's workgroups are placed when main-tier workgroups of the following batch retire), not work: see reads_per_step_redone_by_deep_list_tier"},
             "reads_per_step_redone_by_deep_list_tier": st["overflow_reads"], "reads_per_step_sent_on_to_lane_tier": st["overflow_deep"],
             "events_per_read": {k: st[k] / args.reads for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr")},
-            "input_form": "ASCII bases + offsets + " + ("quality strings" if args.ascii_quals else "one gate word per read (bit c = quality character c < '8')") + ", resident in HBM",
+            "input_form": "ASCII bases + offsets + " + ("quality strings (what the reference reads; vg_reads_process_device)" if args.ascii_quals else "one gate word per read (bit c = quality character c < '8'; vg_reads_process_device_gated)") + ", resident in HBM",
             "other_input_form": other_form,
+            "sustained": sustained,
             "ingest_end_to_end": ingest,
             "multi_gpu_verification": verification,
+            "multi_gpu_per_rank": per_rank,
+            "secondary": secondary if legs else None,
+            "bench_wall_s": time.time() - T_START,
         }
         print(json.dumps(out), flush=True)
-    gx.close()
+    if args.cleanup and rank == 0:
+        import shutil
+
+        shutil.rmtree(d, ignore_errors=True)
     if world > 1:
         dist.destroy_process_group()
 

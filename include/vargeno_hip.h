@@ -53,6 +53,7 @@ typedef struct {
 	uint64_t overflow_deep;      /* of those, reads that outgrew the deep lists too and went to the
 	                                generic lane tier (one read per lane, lists in HBM scratch)   */
 	uint64_t alg_bytes;          /* sum of unit cost x event count                            */
+	uint64_t overflow_third;     /* of overflow_reads, reads the second wave tier passed on to the third (r04) */
 } vg_stats;
 
 /* Kernel timing, averaged over the batches processed since the previous vg_timing_get, from HIP
@@ -124,6 +125,15 @@ int  vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t
 int  vg_reads_process_device_gated(vg_index *ix, const uint8_t *d_bases, const uint32_t *d_gate_words,
                                    const uint64_t *d_offsets, uint64_t n_reads);
 
+/* A batch that is already framed and 2-bit packed, in HOST memory -- SURVEY.md §8b's "pre-packed 2-bit + the <= 31 quality chars the
+ * gate can see", the latter reduced to the comparison's result: kmers = the reads' chunk k-mers one read after the other
+ * (encode_kmer, util.c:89-111: A0 C1 G2 T3, character k[0] in bits 0-1), chunk_offsets[r] = chunks before read r
+ * (chunk_offsets[0] = 0, [n_reads] = total), meta[r] = gate bits of read r (bit c = quality character c < '8', qv.cc:836, 943) with
+ * bit 62 set for a read the reference skips (an N in its trimmed part, qv.cc:815-828) and bit 63 for one it aborts on (another
+ * character outside ACGTacgt, util.c:103) -- 48 bytes per 150 bp read where its FASTQ record has ~315.  Blocking copies: the
+ * arrays are free when the call returns; the read loop is only enqueued.  VG_EBADREAD: a read of more than 31 chunks. */
+int  vg_reads_submit_packed(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads);
+
 /* Same again, starting from raw FASTQ text (host memory): replaces the four fgets() + strlen of qv.cc:760-784.
  *
  * Stream form -- the caller only moves bytes.  vg_fastq_stream_push takes the next chunk of the file, cut anywhere; the device
@@ -137,6 +147,14 @@ int  vg_reads_process_device_gated(vg_index *ix, const uint8_t *d_bases, const u
  * line shorter than the read's chunk count, or lines shorter than 8 bytes on average: frame the rest on the host
  * (vg_reads_submit).  One stream at a time per handle; chunks of less than 2 GiB. */
 int  vg_fastq_stream_begin(vg_index *ix);
+/* The same stream with the framing AND the 2-bit packing done by host threads inside the library (r04): the rules
+ * are the device framing's (records = four lines counted from the start of the stream, lines of at most 1023 characters, a
+ * quality character for every chunk; anything else refuses the chunk and the rest of the stream), but what crosses the link is
+ * the packed form (8 bytes per chunk + 16 per read instead of the text: 6.5 x fewer bytes for 150 bp reads), so a host with cores
+ * to spare ingests several times faster than the link can move text.  host_threads > 0: that many; 0: device framing after all
+ * (same as vg_fastq_stream_begin); < 0: the library decides (half the hardware threads, at most 96; device framing on hosts with
+ * fewer than 16; $VG_PACK_THREADS overrides).  push / end are the calls above and report the same things. */
+int  vg_fastq_stream_begin_packed(vg_index *ix, int host_threads);
 int  vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t nbytes);
 int  vg_fastq_stream_end(vg_index *ix, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start, int *refused);
 
@@ -145,6 +163,21 @@ int  vg_fastq_stream_end(vg_index *ix, uint64_t *n_records, uint64_t *consumed, 
  * nothing was processed. */
 int  vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbytes,
                      uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start);
+
+/* The host-side framing + packing on its own (no device is touched): for a caller that packs on its own threads and hands the
+ * batches to vg_reads_submit_packed.  A packer is a stream like the one above: push chunks cut anywhere; each push returns the
+ * complete records it framed (arrays sized with vg_packer_reads_cap / _kmers_cap of the chunk's length); vg_packer_end reports
+ * records, bytes consumed, the start of the last framed record and whether a chunk was refused (nothing of a refused chunk or of
+ * what follows it is returned). */
+typedef struct vg_packer vg_packer;
+int  vg_packer_create(int host_threads, vg_packer **out);
+void vg_packer_destroy(vg_packer *pk);
+int  vg_packer_begin(vg_packer *pk);
+uint64_t vg_packer_reads_cap(uint64_t nbytes);
+uint64_t vg_packer_kmers_cap(uint64_t nbytes);
+int  vg_packer_push(vg_packer *pk, const uint8_t *text, uint64_t nbytes, uint64_t *kmers, uint64_t kmers_cap, uint64_t *meta,
+                    uint64_t *chunk_offsets, uint64_t reads_cap, uint64_t *n_reads, uint64_t *n_chunks, uint64_t *n_invalid);
+int  vg_packer_end(vg_packer *pk, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start, int *refused);
 
 int  vg_sync(vg_index *ix);                       /* drain the stream                          */
 int  vg_stats_get(vg_index *ix, vg_stats *out);   /* implies vg_sync                           */

@@ -8,7 +8,8 @@ name=$1; shift
 mkdir -p variants
 C=vargeno_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -DVG_LIB_BUILD_ID=\"variant-$name\" "$@" -c -o variants/$name.o $C/vargeno_hip.hip
-[ -f $C/vg_sort.o ] || make -s -C $C vg_sort.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o variants/$name.so variants/$name.o $C/vg_sort.o -ldl
+[ -f $C/vg_sort.o ] || make -s -C $C $PWD/$C/vg_sort.o
+make -s -C $C $PWD/$C/vg_hostpack.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o variants/$name.so variants/$name.o $C/vg_sort.o $C/vg_hostpack.o -ldl -lpthread
 rm -f variants/$name.o
 echo built variants/$name.so

@@ -1,5 +1,6 @@
-"""FASTQ framing on the device (vg_fastq_submit) against the flat-batch path and, for a truncated final record,
-against the reference's own output (tests/golden/ftiny.trunc.*, captured from oracle/_ref)."""
+"""FASTQ framing on the device (vg_fastq_submit, vg_fastq_stream_begin) and on host threads inside the library
+(vg_fastq_stream_begin_packed: framed + 2-bit packed on the host, r04) against the flat-batch path and, for a truncated
+final record, against the reference's own output (tests/golden/ftiny.trunc.*, captured from oracle/_ref)."""
 import gzip
 import os
 import subprocess
@@ -66,8 +67,8 @@ def test_incomplete_tail_is_left_to_the_caller_and_long_lines_are_refused(ftiny_
         assert n == 1 and used == len(ok_rec)
 
 
-@pytest.mark.parametrize("host_framing,replicas", [("0", "1"), ("1", "1"), ("0", "2")])
-def test_cli_truncated_final_record_matches_the_reference(ftiny_dir, tmp_path, host_framing, replicas):
+@pytest.mark.parametrize("host_framing,replicas,pack_threads", [("0", "1", "0"), ("1", "1", "0"), ("0", "2", "0"), ("0", "1", "3"), ("0", "2", "2")])
+def test_cli_truncated_final_record_matches_the_reference(ftiny_dir, tmp_path, host_framing, replicas, pack_threads):
     """The reference's fgets() returns NULL on the missing quality line and keeps the previous record's
     buffer (qv.cc:761-763): the gate of the truncated read is the PREVIOUS read's quality string."""
     want_path = os.path.join(GOLDEN, "ftiny.trunc.out.vcf.gz")
@@ -76,17 +77,19 @@ def test_cli_truncated_final_record_matches_the_reference(ftiny_dir, tmp_path, h
     fq = tmp_path / "reads_trunc.fq"
     fq.write_bytes(b"\n".join(lines[:4 * k + 3]))
     # (two replicas: each streams its own record-aligned half of the file; on a one-GPU box they share the device)
-    env = dict(os.environ, VARGENO_HOST_FASTQ=host_framing, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1")
+    # (pack_threads: 0 = the text is framed on the device; n = n host threads per replica frame + pack it inside the library)
+    env = dict(os.environ, VARGENO_HOST_FASTQ=host_framing, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1", VARGENO_PACK_THREADS=pack_threads)
     p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(tmp_path / "out.vcf")],
                        env=env, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert (tmp_path / "out.vcf").read_bytes() == gzip.open(want_path, "rb").read()
 
 
-def test_stream_frames_records_across_arbitrary_cuts(ftiny_dir, ftiny_reads):
+@pytest.mark.parametrize("host_threads", [None, 1, 5])
+def test_stream_frames_records_across_arbitrary_cuts(ftiny_dir, ftiny_reads, host_threads):
     """vg_fastq_stream_*: the file cut into chunks anywhere -- mid-line, mid-record, one byte, a whole megabyte -- gives the
-    counters and event counts of the flat batch; the device carries the unfinished record over by itself and the host
-    gets its only answer at the end."""
+    counters and event counts of the flat batch; the unfinished record is carried over inside the library and the host
+    gets its only answer at the end.  host_threads None: framed on the device; n: framed + packed by n host threads."""
     prefix = os.path.join(ftiny_dir, "idx")
     text = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read()
     (rc0, ac0), st0 = _counts_flat(prefix, ftiny_reads)
@@ -99,7 +102,7 @@ def test_stream_frames_records_across_arbitrary_cuts(ftiny_dir, ftiny_reads):
             if len(cuts) > 400:                                       # keep the tiny steps to the head of the file
                 cuts.append(len(text))
         with GenoIndex.open(prefix) as gx:
-            n, used, last, refused = gx.fastq_stream(text[a:b] for a, b in zip(cuts[:-1], cuts[1:]))
+            n, used, last, refused = gx.fastq_stream((text[a:b] for a, b in zip(cuts[:-1], cuts[1:])), host_threads=host_threads)
             assert (n, used, refused) == (ftiny_reads.n, len(text), False)
             assert text[last:last + 1] == b"@" and text[last:].count(b"\n") == 4
             rc, ac = gx.counts()
@@ -109,11 +112,14 @@ def test_stream_frames_records_across_arbitrary_cuts(ftiny_dir, ftiny_reads):
             assert st[k] == st0[k], (trial, k)
 
 
-def test_stream_stops_at_the_first_chunk_it_cannot_frame(ftiny_dir):
+@pytest.mark.parametrize("host_threads", [None, 4])
+def test_stream_stops_at_the_first_chunk_it_cannot_frame(ftiny_dir, host_threads):
     prefix = os.path.join(ftiny_dir, "idx")
     rec = b"@r\n" + b"ACGT" * 10 + b"\n+\n" + b"I" * 40 + b"\n"
     long_rec = b"@r\n" + b"A" * 1023 + b"\n+\n" + b"I" * 1023 + b"\n"
     with GenoIndex.open(prefix) as gx:
+        _stream = gx.fastq_stream
+        gx.fastq_stream = lambda chunks: _stream(chunks, host_threads=host_threads)
         # an incomplete tail is simply not consumed
         n, used, last, refused = gx.fastq_stream([rec * 2 + rec[:17], rec[17:] + b"@r\nAC"])
         assert (n, used, last, refused) == (3, 3 * len(rec), 2 * len(rec), False)
@@ -148,10 +154,10 @@ def test_cli_long_line_in_the_middle_of_the_file_falls_back_to_host_framing(ftin
         fq = tmp_path / ("reads_long_%d.fq" % at)
         fq.write_bytes(b"\n".join(lines[:k] + odd + lines[k:]) + b"\n")
         outs = []
-        for host, replicas in (("1", "1"), ("0", "1"), ("0", "2")):
-            out = tmp_path / ("out%d_%s_%s.vcf" % (at, host, replicas))
+        for host, replicas, pack in (("1", "1", "0"), ("0", "1", "0"), ("0", "2", "0"), ("0", "1", "4"), ("0", "2", "2")):
+            out = tmp_path / ("out%d_%s_%s_%s.vcf" % (at, host, replicas, pack))
             env = dict(os.environ, VARGENO_HOST_FASTQ=host, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_READERS="3", VARGENO_VERBOSE="1",
-                       VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1")
+                       VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1", VARGENO_PACK_THREADS=pack)
             p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(out)], env=env, capture_output=True, text=True)
             assert p.returncode == 0, p.stderr
             assert "reads: %d " % (len(lines) // 4 + 2) in p.stderr, p.stderr       # the odd record counts as two
@@ -169,3 +175,68 @@ def test_an_empty_stream_on_a_used_handle_reports_nothing(ftiny_dir):
         assert first[0] > 0 and first[1] == len(text) and not first[3]
         for _ in range(3):
             assert gx.fastq_stream([]) == (0, 0, 0, False)
+
+
+@pytest.mark.parametrize("variant", ["crlf", "plus_id"])
+def test_crlf_line_ends_and_named_separator_lines_against_the_reference_binary(ftiny_dir, tmp_path, variant):
+    """FASTQ files as other tools write them: CRLF line ends (fgets keeps the '\\r': it becomes the last character of the read
+    line, where strlen(read) - 1 cuts the '\\n' only, and of the quality line) and '+<id>' separator lines.  The REFERENCE BINARY
+    genotypes the file on the GPU box's host; the product's CLI must write the same VCF through every framing: on the host,
+    on the device, packed by host threads.  (Read lengths are chosen so that no '\\r' lands inside a chunk: 150 + 1 characters.)"""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "vargeno")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/vargeno not built (make -C oracle ref, build container only)")
+    lines = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read().split(b"\n")[:-1][:4 * 3000]
+    if variant == "crlf":
+        keep = [i for i in range(0, len(lines), 4) if len(lines[i + 1]) % 32 != 31]     # a '\\r' inside the last chunk would make the reference abort
+        text = b"".join(b"\r\n".join(lines[i:i + 4]) + b"\r\n" for i in keep)
+    else:
+        text = b"".join(b"\n".join([lines[i], lines[i + 1], b"+" + lines[i][1:], lines[i + 3]]) + b"\n" for i in range(0, len(lines), 4))
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(text)
+    want = tmp_path / "ref.vcf"
+    p = subprocess.run([ref_bin, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(want)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    for host, pack in (("1", "0"), ("0", "0"), ("0", "3")):
+        out = tmp_path / ("out_%s_%s.vcf" % (host, pack))
+        env = dict(os.environ, VARGENO_HOST_FASTQ=host, VARGENO_CHUNK_MB="1", VARGENO_PACK_THREADS=pack)
+        p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(out)], env=env, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert out.read_bytes() == want.read_bytes(), (variant, host, pack)
+    assert want.read_bytes().count(b"\n") > 100
+
+
+@pytest.mark.parametrize("force_generic", ["0", "1"])
+def test_packed_batches_equal_flat_batches_through_every_tier(ftiny_dir, ftiny_reads, monkeypatch, force_generic):
+    """vg_reads_submit_packed with batches framed + packed by the library's host packer (vg_packer_*), in odd batch sizes: site
+    counters and event counters of the flat ASCII batch.  With VG_FORCE_GENERIC=1 the lane machine alone reads the packed form."""
+    from vargeno_amd.api import HostPacker
+
+    prefix = os.path.join(ftiny_dir, "idx")
+    text = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read()
+    (rc0, ac0), st0 = _counts_flat(prefix, ftiny_reads)
+    monkeypatch.setenv("VG_FORCE_GENERIC", force_generic)
+    pk = HostPacker(3)
+    with GenoIndex.open(prefix) as gx:
+        for stats in (True, False):
+            gx.reset()
+            gx.set_stats(stats)
+            pk.begin()
+            total = 0
+            for a in range(0, len(text), 777_777):
+                k, m, o, bad = pk.push(text[a:a + 777_777])
+                total += len(m)
+                if len(m):
+                    gx.submit_packed(k, m, o)
+            assert total == ftiny_reads.n and pk.end()[1] == len(text)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, rc0) and np.array_equal(ac, ac0), stats
+            if stats:
+                st = gx.stats()
+                for key in ("reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr"):
+                    assert st[key] == st0[key], key
+        # a packed read of more than 31 chunks cannot come from a FASTQ line the reference reads: refused
+        with pytest.raises(VgError) as e:
+            gx.submit_packed(np.zeros(32, np.uint64), np.zeros(1, np.uint64), np.array([0, 32], np.uint64))
+        assert e.value.code == -6
+    pk.close()

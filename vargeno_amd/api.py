@@ -107,11 +107,23 @@ class GenoIndex:
         check(lib().vg_fastq_submit(self._h, _ptr(text), len(text), C.byref(n), C.byref(used), C.byref(last)))
         return int(n.value), int(used.value), int(last.value)
 
-    def fastq_stream(self, chunks):
+    def submit_packed(self, kmers, meta, chunk_offsets):
+        """Host batch that is already framed and 2-bit packed (see HostPacker): uint64 chunk k-mers, uint64 meta words, uint64
+        chunk_offsets[n+1]."""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64)
+        chunk_offsets = np.ascontiguousarray(chunk_offsets, dtype=np.uint64)
+        check(lib().vg_reads_submit_packed(self._h, _ptr(kmers), _ptr(meta), _ptr(chunk_offsets), len(chunk_offsets) - 1))
+
+    def fastq_stream(self, chunks, host_threads=None):
         """FASTQ text as a stream of byte chunks cut anywhere (numpy uint8 arrays / bytes; pinned host memory copies at link
-        speed): the device frames records across the cuts.  Returns (records, bytes consumed, start of the last framed
-        record, refused) once everything pushed has been processed."""
-        check(lib().vg_fastq_stream_begin(self._h))
+        speed): records are framed across the cuts -- on the device (host_threads None or 0), or framed and 2-bit packed by
+        that many host threads inside the library (-1: the library picks).  Returns (records, bytes consumed, start of the
+        last framed record, refused) once everything pushed has been processed."""
+        if host_threads is None:
+            check(lib().vg_fastq_stream_begin(self._h))
+        else:
+            check(lib().vg_fastq_stream_begin_packed(self._h, int(host_threads)))
         for ch in chunks:
             a = np.frombuffer(ch, dtype=np.uint8) if isinstance(ch, (bytes, bytearray, memoryview)) else np.ascontiguousarray(ch, dtype=np.uint8)
             check(lib().vg_fastq_stream_push(self._h, _ptr(a), len(a)))
@@ -197,6 +209,43 @@ class GenoIndex:
         return torch.as_tensor(_Alias(), device="cuda:%d" % self.device)
 
 
+class HostPacker:
+    """The host-side FASTQ framing + 2-bit packing of the library on its own (vg_packer_*: no device involved)."""
+
+    def __init__(self, threads=1):
+        self._h = C.c_void_p()
+        check(lib().vg_packer_create(int(threads), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().vg_packer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def begin(self):
+        check(lib().vg_packer_begin(self._h))
+
+    def push(self, text):
+        """-> (kmers uint64[chunks], meta uint64[n], chunk_offsets uint64[n+1], n_invalid) of the complete records framed."""
+        a = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else np.ascontiguousarray(text, dtype=np.uint8)
+        rc_, kc_ = int(lib().vg_packer_reads_cap(len(a))), int(lib().vg_packer_kmers_cap(len(a)))
+        kmers, meta, offs = np.zeros(kc_, np.uint64), np.zeros(rc_, np.uint64), np.zeros(rc_ + 1, np.uint64)
+        n, nc, bad = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib().vg_packer_push(self._h, _ptr(a), len(a), _ptr(kmers), kc_, _ptr(meta), _ptr(offs), rc_, C.byref(n), C.byref(nc), C.byref(bad)))
+        return kmers[:nc.value].copy(), meta[:n.value].copy(), offs[:n.value + 1].copy(), int(bad.value)
+
+    def end(self):
+        """-> (records, bytes consumed, start of the last framed record, refused)"""
+        n, used, last, refused = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
+        check(lib().vg_packer_end(self._h, C.byref(n), C.byref(used), C.byref(last), C.byref(refused)))
+        return int(n.value), int(used.value), int(last.value), bool(refused.value)
+
+
 def pinned_buffer(nbytes):
     """Page-locked host memory: (numpy uint8 view, owner).  Keep `owner` alive as long as the view is used."""
     p = lib().vg_host_alloc_pinned(int(nbytes))
@@ -275,9 +324,12 @@ def gate_words(d_quals, d_offsets):
     off = d_offsets.to(torch.int64)
     n_chunks = ((off[1:] - off[:-1]) >> 5).clamp(max=32)
     out = torch.zeros(len(off) - 1, dtype=torch.int64, device=d_quals.device)
+    if d_quals.numel() == 0:
+        return out.to(torch.int32)
+    sq = d_quals.view(torch.int8)                       # the path compares a signed char with '8' (qv.cc:836): bytes >= 0x80 are below it
     for c in range(int(n_chunks.max().item()) if len(n_chunks) else 0):
         live = n_chunks > c
         idx = torch.where(live, off[:-1] + c, torch.zeros_like(off[:-1]))
-        low = (d_quals[idx].to(torch.int16) < 56) & live
+        low = (sq[idx].to(torch.int16) < 56) & live
         out |= low.to(torch.int64) << c
     return out.to(torch.int32) if out.numel() == 0 else (out & 0xFFFFFFFF).to(torch.int64).view(torch.int32)[::2].contiguous()

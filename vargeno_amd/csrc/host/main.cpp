@@ -8,7 +8,10 @@
 //                         the FASTQ file, counters summed with RCCL
 //   VARGENO_SHARE_DEVICES=1  allow more replicas than GPUs (replica g on device g % GPUs): small indexes, one-GPU test boxes
 //   VARGENO_BATCH=n       reads per batch of the host-framed path (default 4194304)
-//   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk sent to the device (default 64)
+//   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk handed to the library (default 64; 256 when the host packs)
+//   VARGENO_PACK_THREADS=n  host threads (per replica) that frame and 2-bit pack the FASTQ text inside the library, so that 48 bytes
+//                         per read cross the link instead of ~315 of text (default: half the hardware threads shared among the
+//                         replicas, at most 96; 0, or a host with fewer than 16 hardware threads: the text is framed on the device)
 //   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default: an eighth of the hardware threads, 8 to 32)
 //   VARGENO_HOST_FASTQ=1  frame the FASTQ on the host (the reference's four fgets per record) instead of on the device
 //   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
@@ -59,7 +62,7 @@ struct StreamResult {
 	int refused = 0;
 	std::string error;                                               // empty: fine
 };
-static StreamResult stream_range(vg_index *ix, int fd, uint64_t lo, uint64_t hi, uint64_t chunk, int n_readers)
+static StreamResult stream_range(vg_index *ix, int fd, uint64_t lo, uint64_t hi, uint64_t chunk, int n_readers, int pack_threads)
 {
 	StreamResult res;
 	const uint64_t fsize = hi - lo;                                  // the stream's length
@@ -100,7 +103,7 @@ static StreamResult stream_range(vg_index *ix, int fd, uint64_t lo, uint64_t hi,
 			cv.notify_all();
 		}
 	});
-	int rc = vg_fastq_stream_begin(ix);
+	int rc = pack_threads > 0 ? vg_fastq_stream_begin_packed(ix, pack_threads) : vg_fastq_stream_begin(ix);
 	for (uint64_t i = 0; i < n_chunks && rc == VG_OK; i++) {
 		{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return left[(size_t)i] == 0 || io_error; }); if (io_error) break; }
 		rc = vg_fastq_stream_push(ix, ring[(size_t)(i % NBUF)], std::min(chunk, fsize - i * chunk));
@@ -200,9 +203,12 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		struct stat sb;
 		if (fstat(fd, &sb) != 0) { close(fd); fprintf(stderr, "vargeno: cannot stat %s\n", fastq.c_str()); return EXIT_FAILURE; }
 		const uint64_t fsize = (uint64_t)sb.st_size;
-		const uint64_t chunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", 64)) << 20;
 		// one thread copies ~2 GB/s out of the page cache: enough of them to keep a 50 GB/s link busy, if the host has the cores
 		const int hw = (int)std::thread::hardware_concurrency();
+		// a host with cores to spare frames + packs the text itself (6.5 x fewer bytes over the link); otherwise the device frames it
+		int pack_threads = env_int("VARGENO_PACK_THREADS", -1);
+		if (pack_threads < 0) pack_threads = hw >= 16 ? std::max(2, std::min(hw / 2, 96) / ngpu) : 0;
+		const uint64_t chunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", pack_threads > 0 ? 256 : 64)) << 20;
 		const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
 		std::vector<uint64_t> cut;
 		const bool cuts_ok = range_cuts(fd, fsize, ngpu, cut);
@@ -214,7 +220,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 			std::vector<std::thread> th;
 			for (int g = 0; g < ngpu; g++)
 				if (cut[(size_t)g] < cut[(size_t)g + 1] || g == 0)
-					th.emplace_back([&, g] { res[(size_t)g] = stream_range(ix[(size_t)g], fd, cut[(size_t)g], cut[(size_t)g + 1], chunk, std::max(2, n_readers / ngpu)); });
+					th.emplace_back([&, g] { res[(size_t)g] = stream_range(ix[(size_t)g], fd, cut[(size_t)g], cut[(size_t)g + 1], chunk, std::max(2, n_readers / ngpu), pack_threads); });
 			for (auto &t : th) t.join();
 			for (int g = 0; g < ngpu; g++) if (!res[(size_t)g].error.empty()) { fprintf(stderr, "vargeno: %s\n", res[(size_t)g].error.c_str()); exit(EXIT_FAILURE); }
 			int last_range = 0;                                         // the last range that holds bytes

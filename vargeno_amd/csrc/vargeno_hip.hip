@@ -9,6 +9,7 @@
 #include "../../include/vargeno_hip.h"
 #include "vg_device.h"
 #include "vg_wave.h"
+#include "vg_hostpack.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -477,16 +478,19 @@ __global__ void vg_clamp_counters(const uint32_t *__restrict__ cnt, uint64_t n_s
 __global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 {
 	cum[0] += ctr[0]; cum[1] += ctr[1]; cum[2] += ctr[2]; cum[3] += ctr[3];     // wave-tier overflow, lane-tier overflow, lost, reads with a non-ACGTN character
+	cum[4] += ctr[6];                                                            // reads the second wave tier passed on to the third
 }
 
 // One lane = one read: forward pass, then the reverse-complement retry (src/qv.cc:1504-1510).
 // A read touches the counters only at the end of its last pass, so a lane that runs out of scratch
 // simply drops the read onto the overflow list and the same kernel re-runs it with a deep scratch.
+// bases == nullptr: the batch came 2-bit packed (vg_reads_submit_packed, the host-packed FASTQ stream): chunk k-mers and flag words
+// are read from pk_kmer / pk_meta (the layout the pack kernel writes) instead of being encoded from text.
 template <bool STATS>
 __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
                                                       const uint64_t *__restrict__ offsets, uint64_t n_reads_arg, const uint32_t *__restrict__ read_ids,
                                                       const uint32_t *__restrict__ n_ids, uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats, uint32_t *invalid_reads,
-                                                      const uint32_t *__restrict__ gate)
+                                                      const uint32_t *__restrict__ gate, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta)
 {
 	const uint64_t n_reads = n_ids ? (uint64_t)*n_ids : n_reads_arg;          // a list launch (or a device-framed batch) is sized on the device: no host round trip
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 	Lane<STATS> L(d, s, gtid);
 	LaneStats<STATS> tot;
 	if constexpr (STATS) for (int i = 0; i < S_COUNT; i++) tot.v[i] = 0;
+	const bool packed = bases == nullptr;
 
 	// entry r of the work goes to lane r / n_waves of wave r % n_waves: a list of a dozen deep reads lands on a dozen waves,
 	// not on twelve lanes of one wave that would run their divergent walks one after the other
@@ -503,38 +508,35 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 		const uint64_t off = offsets[rid];
 		const uint32_t n = (uint32_t)((offsets[rid + 1] - off) >> 5);            // src/qv.cc:778-779: len = (read_len/32)*32
 		const uint8_t *p = bases + off;
+		const uint64_t pmeta = packed ? pk_meta[rid] : 0ull;
 		// src/qv.cc:836, 943: the chunk NUMBER indexes the quality string (which is NOT reversed for the second pass, qv.cc:786-806);
 		// a batch may bring the comparison's results as one word per read instead of the strings (a read has at most 31 chunks)
-		const uint32_t gw = gate ? gate[rid] : 0u;
-		auto gate_open = [&](uint32_t c) -> bool { return gate ? ((gw >> (c & 31u)) & 1u) != 0u : (int)(int8_t)quals[off + c] - '8' < 0; };
+		const uint32_t gw = packed ? (uint32_t)pmeta : gate ? gate[rid] : 0u;
+		auto gate_open = [&](uint32_t c) -> bool { return (gate || packed) ? ((gw >> (c & 31u)) & 1u) != 0u : (int)(int8_t)quals[off + c] - '8' < 0; };
+		auto kmer_at = [&](uint32_t c) -> uint64_t { uint64_t b2 = 0; return packed ? pk_kmer[(off >> 5) + c] : encode32(p + 32 * c, b2); };
 		if constexpr (STATS) { for (int i = 0; i < S_COUNT; i++) L.st.v[i] = 0; }
 		L.st.add(S_READS, 1);
 		L.st.add(S_INGEST, 9 * n);
 		L.overflow = false;
 
-		uint64_t bad = 0;
-		for (uint32_t c = 0; c < n; c++) (void)encode32(p + 32 * c, bad);
 		int cls = 0;
-		if (bad) cls = classify_bad(p, n);
+		if (packed) cls = (pmeta & PK_INVALID) ? 2 : (pmeta & PK_SKIP_N) ? 1 : 0;
+		else {
+			uint64_t bad = 0;
+			for (uint32_t c = 0; c < n; c++) (void)encode32(p + 32 * c, bad);
+			if (bad) cls = classify_bad(p, n);
+		}
 		if (cls == 1) L.st.add(S_READS_N, 1);
-		if (cls == 0 && gate && n > 32u) cls = 2;                                   // (a gate word has 32 bits: the pack kernel counts such a read invalid too)
+		if (cls == 0 && (gate || packed) && n > 32u) cls = 2;                       // (a gate word has 32 bits: the pack kernel counts such a read invalid too)
 		if (cls == 2) { L.st.add(S_READS_INVALID, 1); if (invalid_reads) atomicAdd(invalid_reads, 1u); }
 		if (cls == 0) {
 			bool ok = false;
 			L.reset_pass();
-			for (uint32_t c = 0; c < n && !L.overflow; c++) {
-				uint64_t b2 = 0;
-				const uint64_t k = encode32(p + 32 * c, b2);
-				L.do_chunk(k, c, gate_open(c));
-			}
+			for (uint32_t c = 0; c < n && !L.overflow; c++) L.do_chunk(kmer_at(c), c, gate_open(c));
 			if (!L.overflow) ok = L.finish_pass();
 			if (!L.overflow && !ok) {
 				L.reset_pass();
-				for (uint32_t c = 0; c < n && !L.overflow; c++) {
-					uint64_t b2 = 0;
-					const uint64_t k = revcomp64(encode32(p + 32 * (n - 1 - c), b2));
-					L.do_chunk(k, c, gate_open(c));
-				}
+				for (uint32_t c = 0; c < n && !L.overflow; c++) L.do_chunk(revcomp64(kmer_at(n - 1 - c)), c, gate_open(c));
 				if (!L.overflow) (void)L.finish_pass();
 			}
 		}
@@ -718,6 +720,7 @@ struct Slot {
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
 	uint32_t *st_gate = nullptr; uint64_t st_gate_cap = 0;                              // gate words of a batch framed on the device
+	uint64_t *hp_kmers = nullptr, *hp_meta = nullptr, *hp_offsets = nullptr; uint64_t hp_kmers_cap = 0, hp_reads_cap = 0;   // page-locked HOST staging of a batch framed + packed on the host
 	uint8_t *fq_text = nullptr; uint32_t *fq_lines = nullptr, *fq_tiles = nullptr; uint64_t fq_text_cap = 0, fq_lines_cap = 0, fq_tiles_cap = 0;   // FASTQ framing
 	void *fq_tmp = nullptr; uint64_t fq_tmp_cap = 0;                 // scan scratch (grow-only: no allocation per chunk)
 	FqChunk *fq_chunk = nullptr;                                     // this chunk's framing results, device resident
@@ -760,6 +763,9 @@ struct vg_index {
 	uint32_t w2_chunk = 8, w2_wpc = 6;    // second tier: reads a wave pulls at a time (VG_W2_CHUNK), workgroups per CU of its grid (VG_W2_WPC)
 	FqStream *d_fq = nullptr;             // FASTQ stream state (vg_fastq_stream_*)
 	bool fq_open = false; int fq_prev_slot = -1;
+	vgp::Packer *packer = nullptr;        // host-side framing + packing (vg_fastq_stream_begin_packed)
+	bool fq_packed = false;               // the open FASTQ stream is framed + packed on the host
+	uint64_t host_invalid = 0;            // reads with a character other than ACGTN found by the host packer since the last reset
 };
 
 template <class T>
@@ -832,7 +838,10 @@ extern "C" void vg_index_close(vg_index *ix)
 		for (void *p : extra) if (p) (void)hipFree(p);
 		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5, sl.e_fq, sl.e_in};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+		void *host[] = {sl.hp_kmers, sl.hp_meta, sl.hp_offsets};
+		for (void *p : host) if (p) (void)hipHostFree(p);
 	}
+	delete ix->packer;
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
 	if (ix->tail) (void)hipStreamDestroy(ix->tail);
 	if (ix->ingest) (void)hipStreamDestroy(ix->ingest);
@@ -1338,7 +1347,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
 	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 8, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
-	if ((rc = dev_alloc(ix, &ix->d_cum, 4, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_cum, 8, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_clamped, 2 * ix->n_sites + 2))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
@@ -1587,9 +1596,11 @@ static int finish_pending(vg_index *ix)
 // One batch = pack -> wave tier on the main stream, then lane tier (mid scratch) -> lane tier (deep scratch)
 // on the tail stream; the list launches size themselves from device counters, so nothing waits for the host.
 // n_reads: the batch's size, or (d_n_reads given) an upper bound of the size the device holds at d_n_reads
+// d_bases == nullptr: the batch is already packed (sl.pk_kmer / sl.pk_meta hold it, d_offsets = 32 x chunks before each read): no pack kernel
 template <bool STATS>
 static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint32_t *d_gate, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on, const uint32_t *d_n_reads)
 {
+	const bool packed = d_bases == nullptr;
 	uint32_t *ctr = sl.ctr;
 	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
 	if (!ix->force_generic) {
@@ -1605,7 +1616,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T - 1) / PACK_T, (uint64_t)ix->cus * pack_bpc * (256 / PACK_T));
-		vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate);
+		if (!packed) vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate);
 		HIP_TRY(hipEventRecord(sl.e1, ps));
 		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
@@ -1639,13 +1650,13 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
-		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, &ctr[3], d_gate);
+		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, packed ? nullptr : &ctr[3], d_gate, sl.pk_kmer, sl.pk_meta);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	}
 	// ... then the generic lane machine with the deep HBM scratch for whatever is left
-	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate);
+	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta);
 	vg_accumulate_counters<<<1, 1, 0, ix->tail>>>(ctr, ix->d_cum);
 	HIP_TRY(hipEventRecord(sl.e3, ix->tail));
 	HIP_TRY(hipGetLastError());
@@ -1674,6 +1685,7 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 	uint64_t total = total_bases;
 	if (!d_n_reads) HIP_TRY(hipMemcpy(&total, d_offsets + n_reads, 8, hipMemcpyDeviceToHost));
 	if (total >= (1ull << 37)) return fail(VG_ETOOBIG, "a batch of 2^37 bases or more (the kernels address a batch's 32-base slots with 32 bits)");
+	if (total && (!d_bases || (!d_quals && !d_gate))) return fail(VG_EINVAL, "null argument: a batch with bases needs the base text and its quality strings or gate words");
 	const uint64_t need_k = (total >> 5) + 2, need_m = n_reads + 1;
 	// the slot is idle (acquire_slot harvested it), so its buffers may be replaced
 	if (need_k > sl.pk_kmer_cap) { if (sl.pk_kmer) (void)hipFree(sl.pk_kmer); sl.pk_kmer = nullptr; sl.pk_kmer_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_kmer, need_k * 8)); sl.pk_kmer_cap = need_k; }
@@ -1709,6 +1721,68 @@ extern "C" int vg_reads_process_device_gated(vg_index *ix, const uint8_t *d_base
 	int rc = acquire_slot(ix, &sl);
 	if (rc) return rc;
 	return launch_batch(ix, *sl, d_bases, nullptr, d_offsets, n_reads, nullptr, nullptr, 0, d_gate_words);
+}
+
+// A batch that is already 2-bit packed, in HOST memory ("pre-packed 2-bit + the <= 31 quality chars the gate can
+// see", the latter reduced to the comparison's result): the slot's packed-read buffers are filled by copies instead of by the
+// pack kernel.  copy_on: the stream the (asynchronous, page-locked source) copies go to, or nullptr for blocking copies.
+static int launch_packed(vg_index *ix, Slot &sl, const uint64_t *kmers, const uint64_t *meta, const uint64_t *offsets, uint64_t n_reads, uint64_t n_chunks, hipStream_t copy_on)
+{
+	if (n_reads >= (1ull << 32) - (1ull << 24)) return fail(VG_EINVAL, "more than 2^32 - 2^24 reads in one batch");
+	if (n_chunks >= (1ull << 32)) return fail(VG_ETOOBIG, "a batch of 2^32 chunks or more");
+	const uint64_t need_k = n_chunks + 2, need_m = n_reads + 1;
+	if (need_k > sl.pk_kmer_cap) { if (sl.pk_kmer) (void)hipFree(sl.pk_kmer); sl.pk_kmer = nullptr; sl.pk_kmer_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_kmer, need_k * 8)); sl.pk_kmer_cap = need_k; }
+	if (need_m > sl.pk_meta_cap) { if (sl.pk_meta) (void)hipFree(sl.pk_meta); sl.pk_meta = nullptr; sl.pk_meta_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_meta, need_m * 8)); sl.pk_meta_cap = need_m; }
+	if (n_reads + 1 > sl.stage_reads) {
+		if (sl.st_offsets) (void)hipFree(sl.st_offsets);
+		sl.st_offsets = nullptr; sl.stage_reads = 0;
+		HIP_TRY(hipMalloc((void **)&sl.st_offsets, (n_reads + 1) * 8));
+		sl.stage_reads = n_reads + 1;
+	}
+	if (n_reads > sl.list_cap) {
+		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC, &sl.listD};
+		sl.list_cap = 0;
+		for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; }
+		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));
+		sl.list_cap = n_reads;
+	}
+	if (copy_on) {
+		if (n_chunks) HIP_TRY(hipMemcpyAsync(sl.pk_kmer, kmers, n_chunks * 8, hipMemcpyHostToDevice, copy_on));
+		HIP_TRY(hipMemcpyAsync(sl.pk_meta, meta, n_reads * 8, hipMemcpyHostToDevice, copy_on));
+		HIP_TRY(hipMemcpyAsync(sl.st_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, copy_on));
+	} else {
+		if (n_chunks) HIP_TRY(hipMemcpy(sl.pk_kmer, kmers, n_chunks * 8, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(sl.pk_meta, meta, n_reads * 8, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(sl.st_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice));
+	}
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr)
+	                         : enqueue_batch<false>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr);
+}
+
+extern "C" int vg_reads_submit_packed(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads)
+{
+	if (!ix || !chunk_offsets || (n_reads && !meta)) return fail(VG_EINVAL, "null argument");
+	if (n_reads == 0) return VG_OK;
+	return guarded([&]() -> int {
+		HIP_TRY(hipSetDevice(ix->device));
+		if (chunk_offsets[0] != 0) return fail(VG_EINVAL, "chunk_offsets[0] must be 0");
+		uint64_t invalid = 0;
+		for (uint64_t i = 0; i < n_reads; i++) {
+			if (chunk_offsets[i + 1] < chunk_offsets[i]) return fail(VG_EINVAL, "chunk offsets not monotone");
+			if (chunk_offsets[i + 1] - chunk_offsets[i] > 31) return fail(VG_EBADREAD, "a packed read of more than 31 chunks (a FASTQ line the reference can read holds at most 1022 bases, qv.cc:700)");
+			invalid += (meta[i] >> 63) & 1u;
+		}
+		const uint64_t n_chunks = chunk_offsets[n_reads];
+		if (n_chunks && !kmers) return fail(VG_EINVAL, "null argument");
+		std::vector<uint64_t> off(n_reads + 1);
+		for (uint64_t i = 0; i <= n_reads; i++) off[i] = 32 * chunk_offsets[i];       // the flat-batch offsets of the trimmed reads
+		Slot *sl = nullptr;
+		int rc = acquire_slot(ix, &sl);
+		if (rc) return rc;
+		rc = launch_packed(ix, *sl, kmers, meta, off.data(), n_reads, n_chunks, nullptr);
+		if (rc == VG_OK) ix->host_invalid += invalid;
+		return rc;
+	});
 }
 
 static int submit_impl(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads);
@@ -1772,9 +1846,66 @@ static int grow_dev(T **p, uint64_t &cap, uint64_t need)
 	return VG_OK;
 }
 
+static int host_pack_threads_default()
+{
+	unsigned h = std::thread::hardware_concurrency();
+	if (const char *e = getenv("VG_PACK_THREADS")) return std::max(0, atoi(e));
+	return h >= 16 ? (int)std::min(h / 2, 96u) : 0;           // few cores: the device-side framing is the faster path
+}
+
+extern "C" int vg_fastq_stream_begin_packed(vg_index *ix, int host_threads)
+{
+	if (!ix) return fail(VG_EINVAL, "null argument");
+	if (host_threads < 0) host_threads = host_pack_threads_default();
+	if (host_threads == 0) return vg_fastq_stream_begin(ix);
+	return guarded([&]() -> int {
+		HIP_TRY(hipSetDevice(ix->device));
+		if (!ix->packer || ix->packer->threads() != host_threads) { delete ix->packer; ix->packer = nullptr; ix->packer = new vgp::Packer(host_threads); }
+		ix->packer->begin();
+		ix->fq_open = true; ix->fq_packed = true; ix->fq_prev_slot = -1;
+		return VG_OK;
+	});
+}
+
+// one chunk of a host-packed stream: frame + pack into the slot's page-locked staging (host threads; the caller's buffer is free
+// when this returns), then asynchronous copies of the packed form on the ingest stream and the read loop behind them
+static int push_packed(vg_index *ix, const uint8_t *text, uint64_t nbytes)
+{
+	HIP_TRY(hipSetDevice(ix->device));
+	if (ix->packer->poisoned()) return VG_OK;                 // refused earlier: the rest of the stream is the host reader's
+	Slot *slp = nullptr;
+	int rc = acquire_slot(ix, &slp);                            // (its previous batch has finished: the staging is free)
+	if (rc) return rc;
+	Slot &sl = *slp;
+	const uint64_t need_r = vgp::Packer::reads_cap(nbytes) + 1, need_k = vgp::Packer::kmers_cap(nbytes);
+	if (need_k > sl.hp_kmers_cap) {
+		if (sl.hp_kmers) (void)hipHostFree(sl.hp_kmers);
+		sl.hp_kmers = nullptr; sl.hp_kmers_cap = 0;
+		if (hipHostMalloc((void **)&sl.hp_kmers, need_k * 8, hipHostMallocDefault) != hipSuccess) return fail(VG_ENOMEM, "hipHostMalloc(packed staging) failed");
+		sl.hp_kmers_cap = need_k;
+	}
+	if (need_r > sl.hp_reads_cap) {
+		if (sl.hp_meta) (void)hipHostFree(sl.hp_meta);
+		if (sl.hp_offsets) (void)hipHostFree(sl.hp_offsets);
+		sl.hp_meta = sl.hp_offsets = nullptr; sl.hp_reads_cap = 0;
+		if (hipHostMalloc((void **)&sl.hp_meta, need_r * 8, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&sl.hp_offsets, need_r * 8, hipHostMallocDefault) != hipSuccess)
+			return fail(VG_ENOMEM, "hipHostMalloc(packed staging) failed");
+		sl.hp_reads_cap = need_r;
+	}
+	vgp::Staging st;
+	st.kmers = sl.hp_kmers; st.kmers_cap = sl.hp_kmers_cap; st.meta = sl.hp_meta; st.offsets = sl.hp_offsets; st.reads_cap = sl.hp_reads_cap;
+	const vgp::ChunkResult r = ix->packer->push(text, nbytes, st);
+	if (r.refused || r.n_reads == 0) return VG_OK;
+	hipStream_t is = ix->ingest_stream ? ix->ingest : ix->stream;
+	rc = launch_packed(ix, sl, sl.hp_kmers, sl.hp_meta, sl.hp_offsets, r.n_reads, r.n_chunks, is);
+	if (rc == VG_OK) ix->host_invalid += r.n_invalid;
+	return rc;
+}
+
 extern "C" int vg_fastq_stream_begin(vg_index *ix)
 {
 	if (!ix) return fail(VG_EINVAL, "null argument");
+	ix->fq_packed = false;
 	HIP_TRY(hipSetDevice(ix->device));
 	hipStream_t is = ix->ingest_stream ? ix->ingest : ix->stream;
 	HIP_TRY(hipMemsetAsync(ix->d_fq, 0, sizeof(FqStream), is));
@@ -1790,6 +1921,7 @@ extern "C" int vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t 
 	if (!ix->fq_open) return fail(VG_EINVAL, "vg_fastq_stream_push without vg_fastq_stream_begin");
 	if (nbytes == 0) return VG_OK;
 	if (nbytes >= (1ull << 31)) return fail(VG_EINVAL, "FASTQ chunk of 2 GiB or more");
+	if (ix->fq_packed) return guarded([&] { return push_packed(ix, text, nbytes); });
 	HIP_TRY(hipSetDevice(ix->device));
 	const int slot_no = ix->next_slot;
 	Slot *slp = nullptr;
@@ -1870,6 +2002,16 @@ extern "C" int vg_fastq_stream_end(vg_index *ix, uint64_t *n_records, uint64_t *
 	if (!ix) return fail(VG_EINVAL, "null argument");
 	if (!ix->fq_open) return fail(VG_EINVAL, "vg_fastq_stream_end without vg_fastq_stream_begin");
 	ix->fq_open = false;
+	if (ix->fq_packed) {
+		ix->fq_packed = false;
+		int rc = finish_pending(ix);
+		if (rc) return rc;
+		if (n_records) *n_records = ix->packer->records();
+		if (consumed) *consumed = ix->packer->consumed();
+		if (last_record_start) *last_record_start = ix->packer->last_record_start();
+		if (refused) *refused = ix->packer->poisoned() ? 1 : 0;
+		return VG_OK;
+	}
 	return fq_collect(ix, true, n_records, consumed, last_record_start, refused);
 }
 
@@ -1894,6 +2036,54 @@ extern "C" int vg_fastq_submit(vg_index *ix, const uint8_t *text, uint64_t nbyte
 		*n_records = 0; *consumed = 0;
 		return fail(VG_EBADREAD, "a FASTQ line longer than 1023 characters (reference BUF_SIZE 1024, qv.cc:700), a quality line shorter than the read's chunk count, or lines of fewer than 8 bytes on average: frame this chunk on the host");
 	}
+	return VG_OK;
+}
+
+// ---- host-side framing + packing alone: no device is touched (a caller that packs on its own threads and hands the batches to
+// vg_reads_submit_packed; the CPU test-suite checks the framing rules through these)
+struct vg_packer { vgp::Packer p; explicit vg_packer(int t) : p(t) {} };
+extern "C" int vg_packer_create(int host_threads, vg_packer **out)
+{
+	if (!out) return fail(VG_EINVAL, "null argument");
+	*out = nullptr;
+	return guarded([&]() -> int {
+		int t = host_threads;
+		if (t <= 0) { t = host_pack_threads_default(); if (t <= 0) t = 1; }
+		*out = new vg_packer(t);
+		(*out)->p.begin();
+		return VG_OK;
+	});
+}
+extern "C" void vg_packer_destroy(vg_packer *pk) { delete pk; }
+extern "C" int vg_packer_begin(vg_packer *pk)
+{
+	if (!pk) return fail(VG_EINVAL, "null argument");
+	pk->p.begin();
+	return VG_OK;
+}
+extern "C" uint64_t vg_packer_reads_cap(uint64_t nbytes) { return vgp::Packer::reads_cap(nbytes) + 1; }
+extern "C" uint64_t vg_packer_kmers_cap(uint64_t nbytes) { return vgp::Packer::kmers_cap(nbytes); }
+extern "C" int vg_packer_push(vg_packer *pk, const uint8_t *text, uint64_t nbytes, uint64_t *kmers, uint64_t kmers_cap, uint64_t *meta, uint64_t *chunk_offsets, uint64_t reads_cap,
+                              uint64_t *n_reads, uint64_t *n_chunks, uint64_t *n_invalid)
+{
+	if (!pk || (!text && nbytes) || !kmers || !meta || !chunk_offsets || !n_reads || !n_chunks) return fail(VG_EINVAL, "null argument");
+	return guarded([&]() -> int {
+		vgp::Staging st;
+		st.kmers = kmers; st.kmers_cap = kmers_cap; st.meta = meta; st.offsets = chunk_offsets; st.reads_cap = reads_cap;
+		const vgp::ChunkResult r = pk->p.push(text, nbytes, st);
+		*n_reads = r.n_reads; *n_chunks = r.n_chunks;
+		if (n_invalid) *n_invalid = r.n_invalid;
+		for (uint64_t i = 0; i <= r.n_reads && r.n_reads; i++) chunk_offsets[i] >>= 5;       // the packer writes flat-batch offsets (32 x chunks)
+		return VG_OK;
+	});
+}
+extern "C" int vg_packer_end(vg_packer *pk, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start, int *refused)
+{
+	if (!pk) return fail(VG_EINVAL, "null argument");
+	if (n_records) *n_records = pk->p.records();
+	if (consumed) *consumed = pk->p.consumed();
+	if (last_record_start) *last_record_start = pk->p.last_record_start();
+	if (refused) *refused = pk->p.poisoned() ? 1 : 0;
 	return VG_OK;
 }
 
@@ -1925,7 +2115,7 @@ extern "C" int vg_stats_get(vg_index *ix, vg_stats *out)
 	out->scan_ref = h[S_SCAN_REF]; out->scan_snp = h[S_SCAN_SNP]; out->scan_oob = h[S_SCAN_OOB];
 	out->aux_ref = h[S_AUX_REF]; out->aux_snp = h[S_AUX_SNP]; out->site_test = h[S_SITE_TEST]; out->ctx = h[S_CTX];
 	out->walks = h[S_WALKS]; out->incr = h[S_INCR]; out->ingest_bytes = h[S_INGEST];
-	{ uint32_t c[4]; HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[0]; out->overflow_deep = c[1]; out->reads_invalid = c[3]; }
+	{ uint32_t c[8]; HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[0]; out->overflow_deep = c[1]; out->reads_invalid = c[3] + ix->host_invalid; out->overflow_third = c[4]; }
 	const uint64_t scans = out->gate_open - out->large_block;
 	out->alg_bytes = out->ingest_bytes + 8 * (out->ref_query + out->snp_query) + 9 * out->ref_probe + 11 * out->snp_probe
 	               + 16 * out->gate_open + 16 * scans + 9 * out->scan_ref + 11 * out->scan_snp
@@ -1987,7 +2177,8 @@ extern "C" int vg_counts_reset(vg_index *ix)
 	{ int rc = finish_pending(ix); if (rc) return rc; }
 	HIP_TRY(hipMemsetAsync(ix->d.cnt, 0, (2 * ix->n_sites + 2) * 4, ix->stream));
 	HIP_TRY(hipMemsetAsync(ix->d_stats, 0, S_COUNT * sizeof(unsigned long long), ix->stream));
-	HIP_TRY(hipMemsetAsync(ix->d_cum, 0, 16, ix->stream));
+	HIP_TRY(hipMemsetAsync(ix->d_cum, 0, 32, ix->stream));
+	ix->host_invalid = 0;
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	return VG_OK;
 }

@@ -236,6 +236,14 @@ __device__ inline void load_row4(const uint32_t *row, int j0, uint32_t (&v)[4])
 	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
+// a whole row (AUX_COLS = 10 positions, 8-byte aligned) as three independent gathers: one wait
+__device__ inline void load_row10(const uint32_t *row, uint32_t (&v)[AUX_COLS])
+{
+	const uint4 a = gather<uint4, 8>(row), b = gather<uint4, 8>(row + 4);
+	const uint2 c = gather<uint2, 8>(row + 8);
+	v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = c.x; v[9] = c.y;
+}
+
 // query_ref_dict, src/qv.cc:206-240.  Returns the entry index or -1; lo/hi = bucket of HI32(k); `ent` = the entry
 // found (every probe fetches the whole 16-byte entry, so a hit needs no second gather).  Keys are unique within
 // a bucket, so an equality search returns what bsearch() returns.

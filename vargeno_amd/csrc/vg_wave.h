@@ -31,9 +31,6 @@
 #ifndef VG_SCAN_W
 #define VG_SCAN_W 2        // further entries of a multi-entry bucket fetched together in stage A
 #endif
-#ifndef VG_WALK_BATCH
-#define VG_WALK_BATCH 1
-#endif
 
 // -DVG_STAGE_CLOCKS: development aid, never in the shipped build -- a sample of waves prints the core-clock cycles they spent per stage
 #ifdef VG_STAGE_CLOCKS
@@ -45,7 +42,7 @@
 #endif
 
 #ifdef VG_STAGE_CLOCKS
-__device__ unsigned long long vg_dbg_ovf[8];     // [tier*4 + reason]: 0 exact list, 1 neighbour list, 2 vote keys
+__device__ unsigned long long vg_dbg_ovf[8];     // [tier*4 + reason]: 0 key table full, 1 neighbour list / two scan candidates in one item, 2 a chunk voted twice for a key
 #define VG_OVF(r) atomicAdd(&vg_dbg_ovf[(WPB > 1 ? 0 : 4) + (r)], 1ull)
 #else
 #define VG_OVF(r) do { } while (0)
@@ -53,27 +50,26 @@ __device__ unsigned long long vg_dbg_ovf[8];     // [tier*4 + reason]: 0 exact l
 
 namespace vg {
 
-// List capacities per job-pass (LDS, [slot][lane]).  Two instantiations: the main tier keeps 16 waves per CU
-// resident; the second tier takes the reads that spill from it (repeat regions: aux rows, many keys)
-// with lists 6-8x deeper at 2 waves per CU -- still wave-parallel, so a heavy read costs a few dozen
-// dependent gathers instead of the thousands the sequential lane machine needs.
+// Capacities per job-pass (LDS, [slot][lane]): vote keys and neighbour contexts.  The main tier keeps 16 waves per CU
+// resident; the deeper tiers take the reads that spill from it (more distinct positions than it has key slots, many
+// neighbour contexts) -- still wave-parallel, so a heavy read costs a few dozen dependent gathers instead of the
+// thousands the sequential lane machine needs.
 #ifndef VG_W1_ECAP
-#define VG_W1_ECAP 14     // exact contexts per lane in the main tier (the most that still leaves 4 workgroups per CU; vote keys live with them)
+#define VG_W1_ECAP 14     // vote keys (distinct implied read positions of a pass's exact contexts) per lane in the main tier
+#endif
+#ifndef VG_W1_NCAP
+#define VG_W1_NCAP 6      // neighbour contexts per lane in the main tier (with VG_W1_ECAP: the most that still leaves 4 workgroups per CU)
 #endif
 #ifndef VG_W1_WPB
 #define VG_W1_WPB 4
 #endif
-#ifndef VG_W1_KMAX
-#define VG_W1_KMAX 0      // keys a main-tier lane may open before its read goes to the deep tier (0: as many as it has exact contexts).
-#endif                    // The vote of a lane with k keys costs ~k^2 / 2 LDS probes while its 63 neighbours wait.
-constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = 4, W1_WPB = VG_W1_WPB;   // W1_WPB: waves per workgroup of the main tier
-// Second tier: 40 exact + 16 neighbour contexts per lane -- 26 KB of LDS per (single-wave) workgroup, i.e. six of them per CU
-// where the 48 + 48 lists of round 2 (42 KB) allowed three and ran two: on a repeat-rich genome (30 % of it in families of
-// near-identical copies: 10 % of the reads outgrow the main tier) that is +22 % reads/s (profiles/ab_hg38_repeats30_r03_tiers.txt;
-// 32 + 12 lists would fit eight per CU but send 5 % of those reads on).  Third tier: the 48 + 48 lists, for the few reads
-// beyond that (65 of 800 000 there); then the generic lane machine with its lists in HBM.
+constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = VG_W1_NCAP, W1_WPB = VG_W1_WPB;   // W1_WPB: waves per workgroup of the main tier
+// Second tier: 32 keys + 16 neighbour contexts per lane -- 24 KB of LDS per (single-wave) workgroup, i.e. six of them per CU
+// (measured in r03 with context lists: six workgroups of 40 + 16 against two of 48 + 48 was +22 % reads/s on a repeat-rich
+// genome, profiles/ab_hg38_repeats30_r03_tiers.txt).  Third tier: 48 + 48, for the few reads beyond that; then the generic
+// lane machine with its lists in HBM.
 #ifndef VG_W2_ECAP
-#define VG_W2_ECAP 40
+#define VG_W2_ECAP 32
 #endif
 #ifndef VG_W2_NCAP
 #define VG_W2_NCAP 16
@@ -95,6 +91,9 @@ constexpr uint64_t PK_LONG = 1ull << 61;       // more than 32 chunks: generic t
 
 // context meta word: chunk (5) | mod (5) << 5 | neighbour flag << 10 | new base (2) << 11
 __device__ inline uint32_t mk_meta(uint32_t chunk, uint32_t mod, bool neigh, uint32_t nbase) { return chunk | (mod << 5) | ((neigh ? 1u : 0u) << 10) | (nbase << 11); }
+
+template <bool NARROW> struct KMask { typedef uint32_t type; };
+template <> struct KMask<true> { typedef uint16_t type; };
 
 template <bool STATS>
 __device__ inline uint32_t wave_sum(uint32_t v)
@@ -122,16 +121,26 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
                                              const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
                                              uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
 {
-	// narrow element types: an exact context only needs its chunk number next to the position, a neighbour context 13 bits.
-	// A vote key (qv.cc:132-178) is always created by an exact context -- neighbour contexts never open one, :134-139 -- so its
-	// state lives in that context's slot.  E_idx holds the IMPLIED READ POSITION of a context (k-mer position - 32 chunk; the
-	// k-mer position is recomputed where the walk needs it): that is what the key filter of stage B and the vote compare, one
-	// LDS read per candidate.  First position seen by a key = that of its home context, and E_fm holds
-	// frequency (8 bits) | "several positions" (bit 8); E_fm == 0: the context opened no key.  Keys can therefore never
-	// outnumber the list they live in (at hg38 scale 83 % of the reads that left the main tier had run out of 4 key slots).
-	__shared__ uint32_t E_idx[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB];
-	__shared__ uint16_t N_meta[W_NCAP][64 * WPB], E_fm[W_ECAP][64 * WPB];
-	__shared__ uint8_t E_meta[W_ECAP][64 * WPB];
+	// Exact contexts are kept BY VOTE KEY, not one by one (r04).  A vote key (qv.cc:132-178) is the IMPLIED READ POSITION of a
+	// context (k-mer position - 32 chunk) and is always opened by an exact context -- neighbour contexts never open one,
+	// :134-139.  All the rest of the pass asks of the exact contexts is, per key, WHICH CHUNKS had an exact context with it:
+	//   * the vote's outcome is a function of per-key totals -- by induction over improved_index_table_add, `best` is always a key
+	//     of maximal frequency among the keys that have seen two different k-mer positions (= votes from two different chunks),
+	//     and `ambiguous` says whether another such key has the same frequency -- so the order of the votes does not matter, only
+	//     each key's count (exact contexts + the neighbour contexts of chunks not before the key's first exact chunk) and whether
+	//     two chunks contributed (tests/test_vote_aggregate.py replays the reference's own state machine against this rule);
+	//   * the walk needs every supporting context's k-mer position: key + 32 chunk, for the chunks of the winning key's mask;
+	//   * stage B's filter asks whether a neighbour's implied position is one of the keys.
+	// So a lane holds K_idx[slot] = key, K_mask[slot] = chunks: a read inside a c-copy repeat (4 chunks x c positions: 4c contexts,
+	// which outgrew the 14-context lists of r03 from c = 4 on, twice per read) is c slots.  Dictionary positions of one chunk are
+	// distinct (`vargeno index` skips ALT = REF records, dictgen.c:745), so a chunk cannot vote twice for a key with exact contexts;
+	// should a hand-made index do it anyway the read is passed on, down to the lane machine, which keeps contexts one by one.
+	// The main tier's masks are 16 bits wide (reads of more than 16 chunks -- 543 bases -- start in the next tier).
+	using kmask_t = typename KMask<(WPB > 1)>::type;
+	constexpr uint32_t KMASK_CHUNKS = WPB > 1 ? 16u : 32u;
+	__shared__ uint32_t K_idx[W_ECAP][64 * WPB], N_kpos[W_NCAP][64 * WPB];
+	__shared__ kmask_t K_mask[W_ECAP][64 * WPB];
+	__shared__ uint16_t N_meta[W_NCAP][64 * WPB];
 	// stage B pair table: one row per gate-open (owner, chunk) pair of the wave, PCAP rows at a time
 	__shared__ uint32_t P_klo[PCAP][WPB], P_khi[PCAP][WPB], P_lo[PCAP][WPB], P_hi[PCAP][WPB], P_slo[PCAP][WPB], P_shi[PCAP][WPB];
 	__shared__ uint32_t P_meta[PCAP][WPB], P_cnt[PCAP][WPB], P_off[PCAP][WPB], P_hu[PCAP][WPB], P_hidx[HCAP][PCAP][WPB];
@@ -276,7 +285,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					if (meta & (PK_SKIP_N | PK_INVALID)) {
 						cur.add((meta & PK_INVALID) ? S_READS_INVALID : S_READS_N, 1);
 						if constexpr (STATS) for (int i = 0; i < S_COUNT; i++) tot.v[i] += cur.v[i];
-					} else if (meta & PK_LONG) {
+					} else if ((meta & PK_LONG) || n > KMASK_CHUNKS) {        // more chunks than this tier's key masks have bits
 						overflow_list[atomicAdd(overflow_count, 1u)] = rid;
 					} else {
 						active = true;
@@ -292,13 +301,43 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 #endif
 
 		// ------------------------------------------------------------------ stage A: exact look-ups
-		uint32_t ecnt = 0, ncnt = 0;
+		uint32_t kcnt = 0, ncnt = 0;                             // vote keys of this pass (slots [0, kcnt)), neighbour contexts
 		bool ovf = false;
 		if (active) {
-			// append the exact contexts of chunk c (qv.cc:850-937): reference hit first, then SNP hit; aux rows expanded
+			// an exact context of chunk c at k-mer position p (qv.cc:850-937): find its vote key among slots [lo, hi) of the lane's
+			// table, four candidates per LDS round trip starting at `hint` -- the auxiliary rows of consecutive chunks of a read inside
+			// a repeat list the same copies in the same order, so the slot after the last match is usually the one.  Returns the slot,
+			// or W_ECAP when the key is new (the caller inserts it: the forward list grows up from 0, the reverse-strand block down
+			// from the top).  A chunk that has voted for the key already: dup = true (see above).
+			uint32_t hint = 0;
+			auto key_find = [&](uint32_t q, uint32_t c, uint32_t lo, uint32_t hi, bool &dup) -> uint32_t {
+				uint32_t e = (uint32_t)W_ECAP;
+				const uint32_t cnt = hi - lo;
+				if (cnt) {
+					if (hint < lo || hint >= hi) hint = lo;
+					for (uint32_t done = 0; done < cnt && e == (uint32_t)W_ECAP; done += 4) {
+						uint32_t v[4], at[4];
+						#pragma unroll
+						for (uint32_t z = 0; z < 4; z++) { uint32_t i = hint + done + z; if (i >= hi) i -= cnt; if (i >= hi) i = lo; at[z] = i; v[z] = K_idx[i][col]; }
+						#pragma unroll
+						for (uint32_t z = 0; z < 4; z++) if (e == (uint32_t)W_ECAP && done + z < cnt && v[z] == q) e = at[z];
+					}
+				}
+				if (e != (uint32_t)W_ECAP) {
+					const uint32_t m = K_mask[e][col];
+					if ((m >> c) & 1u) dup = true; else K_mask[e][col] = (kmask_t)(m | (1u << c));
+					hint = e + 1u;
+				}
+				return e;
+			};
 			auto push_exact = [&](uint32_t p, uint32_t c) {
 				cur.add(S_CTX, 1);
-				if (ecnt < W_ECAP) { E_idx[ecnt][col] = p - 32u * c; E_meta[ecnt][col] = (uint8_t)c; E_fm[ecnt][col] = 0; ecnt++; } else { if (!ovf) VG_OVF(0); ovf = true; }
+				if (ovf) return;
+				bool dup = false;
+				const uint32_t q = p - 32u * c;
+				if (key_find(q, c, 0u, kcnt, dup) == (uint32_t)W_ECAP) {
+					if (kcnt < (uint32_t)W_ECAP) { K_idx[kcnt][col] = q; K_mask[kcnt][col] = (kmask_t)(1u << c); kcnt++; hint = kcnt; } else { VG_OVF(0); ovf = true; }
+				} else if (dup) { VG_OVF(2); ovf = true; }
 			};
 			auto push_row = [&](const uint32_t *row, uint32_t c) {               // a row ends at its first 0
 				for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
@@ -308,17 +347,6 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					#pragma unroll
 					for (int j = 0; j < 4; j++) { live = live && v[j] != 0; if (live) push_exact(v[j], c); }
 					if (!live) break;
-				}
-			};
-			auto push_row_from = [&](const uint32_t *row, const uint32_t (&first)[4], uint32_t c) {   // columns 0-3 already in hand
-				bool live = true;
-				#pragma unroll
-				for (int j = 0; j < 4; j++) { live = live && first[j] != 0; if (live) push_exact(first[j], c); }
-				for (int j0 = 4; live && j0 < AUX_COLS; j0 += 4) {
-					uint32_t v[4];
-					load_row4(row, j0, v);
-					#pragma unroll
-					for (int j = 0; j < 4; j++) { live = live && v[j] != 0; if (live) push_exact(v[j], c); }
 				}
 			};
 			auto emit_exact = [&](uint32_t c, bool rhit, uint32_t rpos, uint32_t ramb, bool shit, uint32_t spos, uint32_t samb) {
@@ -413,6 +441,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								#pragma unroll
 								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = gather<uint4>(d.mx + (lo + 1u + x)); }
 							}
+							uint32_t ax_r[2] = {NOHIT, NOHIT}, ax_s[2] = {NOHIT, NOHIT};       // auxiliary rows of the pair's chunks still to expand
 							#pragma unroll
 							for (uint32_t y = 0; y < 2; y++) {
 								const uint32_t z = z0 + y;
@@ -433,8 +462,12 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 									if ((pal || es != ks) && rc_top != RC_BAD) {
 										if (f & 2u) rc_top = RC_BAD;
 										else if (p1 != POS_AMBIGUOUS) {
-											if (rc_top <= ecnt) rc_top = RC_BAD;
-											else { const uint32_t c1 = n - 1u - (c + z); rc_top--; E_idx[rc_top][col] = p1 - 32u * c1; E_meta[rc_top][col] = (uint8_t)c1; E_fm[rc_top][col] = 0; }
+											const uint32_t c1 = n - 1u - (c + z), q1 = p1 - 32u * c1;
+											bool dup = false;
+											if (key_find(q1, c1, rc_top, (uint32_t)W_ECAP, dup) == (uint32_t)W_ECAP) {
+												if (rc_top <= kcnt) rc_top = RC_BAD;
+												else { rc_top--; K_idx[rc_top][col] = q1; K_mask[rc_top][col] = (kmask_t)(1u << c1); }
+											} else if (dup) rc_top = RC_BAD;
 										}
 									}
 								};
@@ -460,38 +493,46 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								}
 								const bool r_ok = (rf & 1u) && ((rf & 4u) || rp != POS_AMBIGUOUS), s_ok = (sf & 1u) && ((sf & 4u) || sp != POS_AMBIGUOUS);
 								const bool r_ax = r_ok && (rf & 6u) == 2u, s_ax = s_ok && (sf & 6u) == 2u;   // ambiguous and not a PAIR: read the row
-								uint32_t rr[4], sr[4];
-								if (r_ax) load_row4(d.ref_aux + (uint64_t)rp * AUX_COLS, 0, rr);
-								if (s_ax) load_row4(d.snp_aux_pos + (uint64_t)sp * AUX_COLS, 0, sr);
 								if (r_ok) {
 									if (rf & 2u) cur.add(S_AUX_REF, 1);
-									if (r_ax) push_row_from(d.ref_aux + (uint64_t)rp * AUX_COLS, rr, c + z);
+									if (r_ax) ax_r[y] = rp;
 									else { push_exact(rp, c + z); if (rf & 4u) push_exact(rp2, c + z); }
 								}
 								if (s_ok) {
 									if (sf & 2u) cur.add(S_AUX_SNP, 1);
-									if (s_ax) push_row_from(d.snp_aux_pos + (uint64_t)sp * AUX_COLS, sr, c + z);
+									if (s_ax) ax_s[y] = sp;
 									else { push_exact(sp, c + z); if (sf & 4u) push_exact(sp2, c + z); }
 								}
 							}
+							// the auxiliary rows (k-mers with 3-10 copies) after the pair's other contexts, a reference row WHOLE in one wait: a read
+							// inside a repeat waited up to three times per chunk for its row's columns four at a time (the order in which a
+							// pass's contexts reach the key table does not matter)
+							#pragma nounroll
+							for (uint32_t y = 0; y < 2; y++) {
+								if (ax_r[y] == NOHIT) continue;
+								uint32_t rw[AUX_COLS];
+								load_row10(d.ref_aux + (uint64_t)ax_r[y] * AUX_COLS, rw);
+								// one push site, the column picked by selects: unrolled copies of the key search cost more registers than the row
+								// (with both rows of the pair in flight at once the kernel spills: 48 bytes of scratch per lane)
+								#pragma nounroll
+								for (uint32_t j = 0; j < (uint32_t)AUX_COLS; j++) {
+									const uint32_t v = j == 0 ? rw[0] : j == 1 ? rw[1] : j == 2 ? rw[2] : j == 3 ? rw[3] : j == 4 ? rw[4] : j == 5 ? rw[5] : j == 6 ? rw[6] : j == 7 ? rw[7] : j == 8 ? rw[8] : rw[9];
+									if (v == 0) break;                           // a row ends at its first 0
+									push_exact(v, c + z0 + y);
+								}
+							}
+							// (an SNP k-mer with several positions is rare -- it takes an SNP inside identical copies: row by row)
+							#pragma unroll
+							for (uint32_t y = 0; y < 2; y++) if (ax_s[y] != NOHIT) push_row(d.snp_aux_pos + (uint64_t)ax_s[y] * AUX_COLS, c + z0 + y);
 						}
 					}
 					// A forward pass without a single exact hit can neither vote nor be walked (the stage-B skip below): the lane goes on as
-					// pass 1 with the contexts collected above -- none at all means that pass 1 has nothing either, and the read is done
-					// (the block holds them in the order they were met, downwards: read upwards that is pass 1's chunk order, with the two
-					// contexts a chunk can have here -- reference hit, SNP hit -- the wrong way round)
-					if (pass == 0u && ecnt == 0u && rc_top != RC_BAD && !ovf) {
+					// pass 1 with the keys collected above -- none at all means that pass 1 has nothing either, and the read is done
+					// (the order of the keys does not matter, see the key table's description)
+					if (pass == 0u && kcnt == 0u && rc_top != RC_BAD && !ovf) {
 						const uint32_t nrc = (uint32_t)W_ECAP - rc_top;
-						for (uint32_t i = 0; i < nrc;) {
-							const uint32_t a0 = E_idx[rc_top + i][col], m0 = E_meta[rc_top + i][col];
-							if (i + 1u < nrc && E_meta[rc_top + i + 1u][col] == m0) {
-								const uint32_t a1 = E_idx[rc_top + i + 1u][col];
-								E_idx[i][col] = a1; E_meta[i][col] = (uint8_t)m0; E_fm[i][col] = 0;
-								E_idx[i + 1u][col] = a0; E_meta[i + 1u][col] = (uint8_t)m0; E_fm[i + 1u][col] = 0;
-								i += 2u;
-							} else { E_idx[i][col] = a0; E_meta[i][col] = (uint8_t)m0; E_fm[i][col] = 0; i++; }
-						}
-						ecnt = nrc;
+						for (uint32_t i = 0; i < nrc; i++) { K_idx[i][col] = K_idx[rc_top + i][col]; K_mask[i][col] = K_mask[rc_top + i][col]; }
+						kcnt = nrc;
 						pass = 1u;
 					}
 				} else
@@ -547,7 +588,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 #ifdef VG_NO_HOPELESS_SKIP
 			const bool hopeless = false;
 #else
-			const bool hopeless = !STATS && ecnt == 0;
+			const bool hopeless = !STATS && kcnt == 0;
 #endif
 			const uint32_t pend = (active && !ovf && !hopeless) ? (n >= 32 ? gates : (gates & ((1u << n) - 1u))) : 0u;
 			const uint32_t my_np = (uint32_t)__popc(pend);
@@ -564,7 +605,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					while (bits) {
 						const uint32_t c = (uint32_t)__ffs((int)bits) - 1;
 						bits &= bits - 1;
-						if (q >= w0 && q < w0 + PCAP) { P_meta[q - w0][wv] = lane | (c << 6); P_ecnt[q - w0][wv] = (uint8_t)ecnt; }
+						if (q >= w0 && q < w0 + PCAP) { P_meta[q - w0][wv] = lane | (c << 6); P_ecnt[q - w0][wv] = (uint8_t)kcnt; }
 						q++;
 					}
 				}
@@ -796,10 +837,10 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						}
 						if (q_r || q_s) dual_query(d, hs, qk, q_r, q_s, ri, si);
 					}
-					// is `position` the implied read position of one of the owner's exact hits?
+					// is `position` one of the owner's vote keys (the implied read position of one of its exact hits)?
 					auto in_keys = [&](uint32_t position) -> bool {
 						bool f = false;
-						for (uint32_t e = 0; e < o_ecnt; e++) f |= E_idx[e][col0 + own] == position;
+						for (uint32_t e = 0; e < o_ecnt; e++) f |= K_idx[e][col0 + own] == position;
 						return f;
 					};
 					// acceptance (site / SNP-base tests) + key filter -> bit j: ref candidate j kept, bit 10+j: snp candidate j kept.
@@ -820,31 +861,29 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							if (!site_loose(d, hs, rpos + mod)) { hs.add(S_CTX, 1); if (in_keys(rpos - 32u * c)) keepm |= 1u; }
 						}
 						if (r_aux) {
-							const uint32_t *row = d.ref_aux + (uint64_t)rpos * AUX_COLS;
+							// the whole row in one wait, then the site bytes of all its positions in a second one (r03 went through the row four
+							// columns at a time: up to six dependent waits for a neighbour k-mer with nine copies)
 							hs.add(S_AUX_REF, 1);
-							for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
-								uint32_t v[4], sb[4];
-								load_row4(row, j0, v);
-								#pragma unroll
-								for (int j = 0; j < 4; j++) { const uint64_t a = (uint64_t)v[j] + mod; sb[j] = d.pile[v[j] && a < d.pile_len ? a : 0]; if (!(v[j] && a < d.pile_len)) sb[j] = 0; }
-								bool live = true;
-								uint32_t cand = 0;
-								#pragma unroll
-								for (int j = 0; j < 4; j++) {
-									live = live && v[j] != 0;
-									if (!live) continue;
-									hs.add(S_SITE_TEST, 1);
-									if (sb[j] & 15u) continue;
-									hs.add(S_CTX, 1);
-									cand |= 1u << j;
-								}
-								while (cand) {                                       // accepted columns are few: one key-filter loop, not four
-									const uint32_t j = (uint32_t)__ffs((int)cand) - 1;
-									cand &= cand - 1;
-									const uint32_t pp = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : v[3];
-									if (in_keys(pp - 32u * c)) keepm |= 1u << (j0 + j);
-								}
-								if (!live) break;
+							uint32_t v[AUX_COLS], sb[AUX_COLS];
+							load_row10(d.ref_aux + (uint64_t)rpos * AUX_COLS, v);
+							#pragma unroll
+							for (int j = 0; j < AUX_COLS; j++) { const uint64_t a = (uint64_t)v[j] + mod; const bool in = v[j] && a < d.pile_len; sb[j] = d.pile[in ? a : 0]; if (!in) sb[j] = 0; }
+							bool live = true;
+							uint32_t cand = 0;
+							#pragma unroll
+							for (int j = 0; j < AUX_COLS; j++) {
+								live = live && v[j] != 0;
+								if (!live) continue;
+								hs.add(S_SITE_TEST, 1);
+								if (sb[j] & 15u) continue;
+								hs.add(S_CTX, 1);
+								cand |= 1u << j;
+							}
+							while (cand) {                                           // accepted columns are few: one key-filter loop
+								const uint32_t j = (uint32_t)__ffs((int)cand) - 1;
+								cand &= cand - 1;
+								const uint32_t pp = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : j == 3 ? v[3] : j == 4 ? v[4] : j == 5 ? v[5] : j == 6 ? v[6] : j == 7 ? v[7] : j == 8 ? v[8] : v[9];
+								if (in_keys(pp - 32u * c)) keepm |= 1u << j;
 							}
 						}
 						if (s_ok && !s_aux) {
@@ -937,70 +976,31 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 		if (active) {
 			bool processed = false;
 			if (!ovf) {
+				// improved_index_table_add, qv.cc:132-178, from per-key totals (see the key table's description): a key's frequency is the
+				// number of its exact contexts (one per chunk of its mask) plus its neighbour contexts from chunks not before its first
+				// exact chunk (an earlier one found no key to vote for, :134-139); it takes part once two different chunks have voted
+				// for it (:163-165); the pass is processed iff ONE key has the highest frequency (:1375).  Frequencies stay far below
+				// the reference's uint8_t wrap (at most one exact context per chunk and W_NCAP neighbour contexts).
 				int best = -1; bool amb = false;
-				// improved_index_table_add, qv.cc:132-178.  A key is named by the exact context that opened it ("home").  The first
-				// exact context always opens key 0 -- for most reads the only key -- which lives in registers; the others keep
-				// their state in E_fm[home].  `upto`: exact contexts consumed so far (homes lie below it; an exact context that opens
-				// a key is number `upto` itself).
-				uint32_t k0_idx = 0, k0_fm = 0;
-				[[maybe_unused]] uint32_t nkeys = 0;
-				auto vote = [&](uint32_t index, uint32_t kpos, bool neigh, uint32_t upto) {
-					int e = -1;
-					if (k0_fm && k0_idx == index) e = 0;
-					else {
-						// the first exact context below `upto` with this implied position IS the key's home (whichever context came first
-						// opened the key): four candidates per LDS round trip, no look at E_fm
-						for (uint32_t i0 = 1; i0 < upto && e < 0; i0 += 4) {
-							uint32_t v[4];
-							#pragma unroll
-							for (uint32_t z = 0; z < 4; z++) v[z] = E_idx[i0 + z < (uint32_t)W_ECAP ? i0 + z : (uint32_t)W_ECAP - 1][col];
-							#pragma unroll
-							for (uint32_t z = 0; z < 4; z++) if (e < 0 && i0 + z < upto && v[z] == index) e = (int)(i0 + z);
+				uint32_t bestf = 0, target = 0, bmask = 0;
+				for (uint32_t e = 0; e < kcnt; e++) {
+					const uint32_t idx = K_idx[e][col], m = K_mask[e][col];
+					uint32_t f = (uint32_t)__popc(m), chunks = m;
+					if (ncnt) {
+						const uint32_t first = (uint32_t)__ffs((int)m) - 1u;
+						for (uint32_t i = 0; i < ncnt; i++) {
+							const uint32_t c = N_meta[i][col] & 31u;
+							if (c >= first && N_kpos[i][col] - 32u * c == idx) { f++; chunks |= 1u << c; }
 						}
 					}
-					uint32_t first, fm;
-					if (e < 0) {
-						if (neigh) return;                                                // :134-139
-						e = (int)upto;                                                    // this exact context (number `upto`) opens the key
-						first = kpos; fm = 0;
-						if (e == 0) k0_idx = index;
-						if constexpr (WPB > 1 && VG_W1_KMAX > 0) { if (++nkeys > (uint32_t)VG_W1_KMAX) { if (!ovf) VG_OVF(2); ovf = true; } }
-					} else if (e == 0) { first = k0_idx + 32u * (E_meta[0][col] & 31u); fm = k0_fm; }
-					else { first = index + 32u * (E_meta[e][col] & 31u); fm = E_fm[e][col]; }
-					const uint32_t freq = (fm + 1) & 0xFFu;                                 // uint8_t freq, :146
-					const uint32_t multi = (fm >> 8) | (kpos != first ? 1u : 0u);           // |set| >= 2, :163-165
-					// (a frequency that wraps to 0 with a single position would read as "no key": 256 contexts on one key cannot happen
-					// with at most W_ECAP + W_NCAP contexts in the lists)
-					if (e == 0) k0_fm = freq | (multi << 8); else E_fm[e][col] = (uint16_t)(freq | (multi << 8));
-					if (!multi) return;
-					if (best < 0) { best = e; amb = false; }
-					else if (e == best) amb = false;
-					else {
-						const uint32_t bf = (best == 0 ? k0_fm : (uint32_t)E_fm[best][col]) & 0xFFu;
-						if (freq == bf) amb = true;
-						else if (freq > bf) { best = e; amb = false; }
-					}
-				};
-				// chunk by chunk, a chunk's exact contexts before its neighbour contexts: a merge of the two lists (each is in
-				// chunk order), one step per context
-				{
-					uint32_t ei = 0, ni = 0;
-					uint32_t ce = ecnt ? (uint32_t)(E_meta[0][col] & 31u) : 99u, cn = ncnt ? (uint32_t)(N_meta[0][col] & 31u) : 99u;
-					while ((ce != 99u || cn != 99u) && !ovf) {             // 99 = list exhausted (chunk numbers are < 32)
-						const bool ex = ce <= cn;
-						const uint32_t c = ex ? ce : cn;
-						const uint32_t q = ex ? E_idx[ei][col] : N_kpos[ni][col] - 32u * c;     // implied read position
-						vote(q, q + 32u * c, !ex, ei);                     // exact contexts consumed so far = where a new key would live
-						if (ex) { ei++; ce = ei < ecnt ? (uint32_t)(E_meta[ei][col] & 31u) : 99u; }
-						else { ni++; cn = ni < ncnt ? (uint32_t)(N_meta[ni][col] & 31u) : 99u; }
-					}
+					if (!(chunks & (chunks - 1u))) continue;
+					if (f > bestf) { best = (int)e; bestf = f; amb = false; target = idx; bmask = m; }
+					else if (f == bestf) amb = true;
 				}
 				VG_CLK(4);
 				if (!ovf) {
 					cur.add(S_PASSES, 1);
-					const uint32_t bfm = best < 0 ? 0u : best == 0 ? k0_fm : (uint32_t)E_fm[best][col];
-					const uint32_t target = best < 0 ? 0u : best == 0 ? k0_idx : E_idx[best][col];
-					processed = best >= 0 && !amb && (bfm & 0xFFu) > 1;          // qv.cc:1375
+					processed = best >= 0 && !amb;                               // qv.cc:1375 (a key that takes part has at least two votes)
 					if (processed) {
 						cur.add(S_PASSES_OK, 1);
 						// Timed build, reads of up to four chunks (150 bp): all supporting contexts lie in [target, target + 32 n), which
@@ -1027,12 +1027,19 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							VG_CLKW(6);
 							// one loop over both lists and no lambda: a select over variables captured by reference becomes a select of
 							// addresses, which parks the whole closure in scratch memory
-							const uint32_t nctx = ecnt + ncnt;
-							for (uint32_t i = 0; i < nctx; i++) {
-								uint32_t p, c, mod = NOMOD;
-								if (i < ecnt) { c = E_meta[i][col] & 31u; p = E_idx[i][col] + 32u * c; }
-								else { const uint32_t mt = N_meta[i - ecnt][col]; p = N_kpos[i - ecnt][col]; c = mt & 31u; mod = (mt >> 5) & 31u; }
-								if (p - 32u * c != target) continue;
+							// the supporting contexts: the winning key's exact contexts (one per chunk of its mask, at target + 32 chunk), then
+							// the neighbour contexts with its implied position (whether or not they voted, qv.cc:1386-1502)
+							uint32_t em = bmask, ni = 0;
+							for (;;) {
+								uint32_t c, mod = NOMOD;
+								if (em) { c = (uint32_t)__ffs((int)em) - 1u; em &= em - 1u; }
+								else {
+									if (ni >= ncnt) break;
+									const uint32_t mt = N_meta[ni][col], p = N_kpos[ni][col];
+									ni++;
+									c = mt & 31u; mod = (mt >> 5) & 31u;
+									if (p - 32u * c != target) continue;
+								}
 								const uint32_t fi = pass ? n - 1u - c : c;
 								uint64_t kk = fi == 0 ? f0 : fi == 1 ? f1 : fi == 2 ? f2 : f3;
 								if (pass) kk = revcomp64(kk);
@@ -1056,36 +1063,29 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							VG_CLKW(8);
 						} else {
 						// Reads of more than four chunks, and the counting build: the byte-per-position walk of qv.cc:1386-1436 -- per
-						// supporting context its k-mer and its 32-byte pile window (up to WB contexts' gathers go out together), then
-						// one rank-block gather + atomic per counted base.
-						constexpr int WB = VG_WALK_BATCH;
-						uint32_t it = 0;
-						const uint32_t nctx = ecnt + ncnt;
-						auto count = [&](uint32_t p, uint32_t which) { cur.add(S_INCR, 1); bump_site(d, p, which); };
-						while (it < nctx) {
-							bool h[WB]; uint32_t wp[WB], wc[WB], wm[WB], wn[WB];
-							#pragma unroll
-							for (int b = 0; b < WB; b++) {
-								h[b] = false; wp[b] = 0; wc[b] = 0; wm[b] = NOMOD; wn[b] = 0;
-								while (it < nctx && !h[b]) {
-									const uint32_t i = it++;
-									if (i < ecnt) { wc[b] = E_meta[i][col] & 31u; wp[b] = E_idx[i][col] + 32u * wc[b]; wm[b] = NOMOD; }
-									else { const uint32_t mt = N_meta[i - ecnt][col]; wp[b] = N_kpos[i - ecnt][col]; wc[b] = mt & 31u; wm[b] = (mt >> 5) & 31u; wn[b] = (mt >> 11) & 3u; }
-									h[b] = wp[b] - 32u * wc[b] == target;
-								}
-								if (h[b]) { cur.add(S_WALKS, 1); if ((uint64_t)wp[b] + 32 > d.pile_len) h[b] = false; }
-							}
-							uint64_t kf[WB]; uint4 pw[WB][2];
-							#pragma unroll
-							for (int b = 0; b < WB; b++) if (h[b]) { kf[b] = chunk_kmer(wc[b]); load_pile_window(d, wp[b], pw[b]); }
-							#pragma unroll
-							for (int b = 0; b < WB; b++) if (h[b]) {
-								uint64_t kk = kf[b];
-								if (wm[b] < 32u) kk = (kk & ~(3ull << (2 * wm[b]))) | ((uint64_t)wn[b] << (2 * wm[b]));
-								walk_matches(pw[b], kk, wp[b], wm[b], count);
-							}
+					// supporting context its k-mer and its 32-byte pile window, then one rank-block gather + atomic per counted base
+					// (the base a neighbour context was found with lies at the one position the walk leaves out, :1397)
+					auto count = [&](uint32_t p, uint32_t which) { cur.add(S_INCR, 1); bump_site(d, p, which); };
+					uint32_t em = bmask, ni = 0;
+					for (;;) {
+						uint32_t c, wp, mod = NOMOD;
+						if (em) { c = (uint32_t)__ffs((int)em) - 1u; em &= em - 1u; wp = target + 32u * c; }
+						else {
+							if (ni >= ncnt) break;
+							const uint32_t mt = N_meta[ni][col];
+							wp = N_kpos[ni][col];
+							ni++;
+							c = mt & 31u; mod = (mt >> 5) & 31u;
+							if (wp - 32u * c != target) continue;
 						}
-						}
+						cur.add(S_WALKS, 1);
+						if ((uint64_t)wp + 32 > d.pile_len) continue;
+						const uint64_t kk = chunk_kmer(c);
+						uint4 pw[2];
+						load_pile_window(d, wp, pw);
+						walk_matches(pw, kk, wp, mod, count);
+					}
+					}
 					}
 				}
 			}
