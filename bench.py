@@ -358,7 +358,7 @@ def timed_block(gx, run, batches, steps, first=0):
     t0 = time.perf_counter()
     for i in range(steps):
         run(batches[(first + i) % len(batches)])
-    fetched = gx.counts()
+    fetched = gx.counts(copy=False)
     dt = time.perf_counter() - t0
     del fetched
     return dt
@@ -695,7 +695,7 @@ def main():
         t1 = time.perf_counter()
         all_reduce_counts(gx)                           # one RCCL all-reduce of the per-site counters over xGMI
         t_reduce = time.perf_counter() - t1
-    fetched = gx.counts()                               # "first submit -> counters reduced and fetched": fold, clamp at 63, device -> host
+    fetched = gx.counts(copy=False)                     # "first submit -> counters reduced and fetched": fold, clamp at 63, device -> (page-locked) host
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -732,7 +732,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             run(batches[i % args.batches], strings=not args.ascii_quals)
-        gx.counts()
+        gx.counts(copy=False)
         dt = time.perf_counter() - t0
         tm2 = gx.timing()
         other_form = {"input": "quality strings (vg_reads_process_device)" if not args.ascii_quals else "one gate word per read (vg_reads_process_device_gated)",
@@ -754,7 +754,7 @@ def main():
     from vargeno_amd._lib import lib as _vg_lib
 
     build_id = _vg_lib().vg_build_id().decode()
-    views, dev_bytes = gx.views, gx.device_bytes
+    views, dev_bytes, plan_text = gx.views, gx.device_bytes, gx.plan
     kernel = main_kernel_name(views)
 
     # ---- secondary leg on the open index: the stress profile (50 % low-quality characters: 3 gate-open chunks per read) ------------
@@ -855,7 +855,7 @@ def main():
                                        args.genome, args.chroms, args.snps, args.reads, args.batches, 100 * args.lowq,
                                        "" if not args.repeats else "; REPEAT-RICH genome: %g%% of it in planted families of near-identical copies (2-10 and 11-200 copies), 50 microsatellites per Mbp" % (100 * args.repeats)),
                        "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps,
-                       "index_bytes_hbm": dev_bytes, "index_views": views, "index_open_s": t_open, "lib_build_id": build_id,
+                       "index_bytes_hbm": dev_bytes, "index_views": views, "index_plan": plan_text, "index_open_s": t_open, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -84,6 +84,17 @@ void  vg_host_free_pinned(void *p);
  * vg_index_open reads <prefix>.ref.dict/.snp.dict/.ref.bf/.snp.bf; vg_index_create takes the same
  * content from memory. */
 int  vg_index_open(const char *prefix, int device, vg_index **out);
+/* The same with a device-memory budget for this replica (bytes; 0 = the device's whole memory less 12 GiB, which is what
+ * vg_index_open assumes -- $VG_MAX_DEVICE_BYTES, when set, is its budget).  Which optional views are built is decided from the
+ * dictionaries' sizes and the budget alone, in a fixed order, before anything is allocated -- never from what happens to be free at
+ * that moment: the same files and the same budget always give the same vg_index_views().  A caller that shares the device must say
+ * how much of it is its own; when an allocation the plan had room for fails all the same, the call fails with VG_ENOMEM instead of
+ * silently building a slower layout.  VG_ENOMEM also when the budget is below the smallest layout.  While the handle is being
+ * built the device holds up to ~20 % more than the final size (sort buffers of the merged view). */
+int  vg_index_open_ex(const char *prefix, int device, uint64_t max_device_bytes, vg_index **out);
+/* What the budget bought, in words: planned bytes, views kept, views left out with what each costs ("" for a null handle).
+ * The string lives as long as the handle. */
+const char *vg_index_plan(const vg_index *ix);
 int  vg_index_create(const vg_index_arrays *a, int device, vg_index **out);
 void vg_index_close(vg_index *ix);               /* qv.cc:1775-1786 */
 

@@ -96,3 +96,18 @@ def test_cli_range_cuts_at_eight_replicas(tmp_path):
         assert all(x in starts for x in c), (nrec, c)
         if nrec >= 16:
             assert len(set(c)) == 9                                # every replica got a range
+
+
+def test_the_all_reduce_of_eight_replicas_against_a_mock_of_eight_devices(tmp_path):
+    """vg_counts_allreduce_devices's order of operations (vargeno_amd/csrc/vg_allreduce_plan.h: the product instantiates it with HIP
+    + RCCL) run against a mock of the devices (tests/allreduce_mock.cpp, compiled here): 8 replicas on 8 devices -- the target's
+    shape, which no test box has --, replicas sharing devices in every mix, one device only.  The mock insists on what RCCL
+    does: one rank per device, every rank joining exactly once inside a group; afterwards every replica must hold the sum."""
+    import subprocess
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "allreduce_mock")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-o", exe, os.path.join(here, "allreduce_mock.cpp")])
+    for devs, ranks in (([0, 1, 2, 3, 4, 5, 6, 7], 8), ([0, 0, 0, 0, 0, 0, 0, 0], 1), ([0, 1, 0, 1, 2, 2, 3, 0], 4), ([3], 1), ([7, 6, 5, 4, 3, 2, 1, 0], 8), ([0, 0, 1], 2), ([1, 0, 0, 0], 2)):
+        p = subprocess.run([exe] + [str(d) for d in devs], capture_output=True, text=True)
+        assert p.returncode == 0 and p.stdout.strip() == "ok %d" % ranks, (devs, p.stdout, p.stderr)

@@ -559,3 +559,41 @@ def test_low_complexity_genomes(tmp_path, monkeypatch, seed, knob):
                     assert st[k] == want[k], k
     for fn in ("idx.ref.bf", "idx.snp.bf"):
         os.remove(os.path.join(d, fn))
+
+
+def test_a_device_memory_budget_decides_the_views_and_nothing_else_does(ftiny_dir, ftiny_reads):
+    """vg_index_open_ex: the views a replica holds follow from the index and the byte budget alone -- the same budget gives the
+    same views every time, whatever else lives on the device (here: a 6 GiB tensor of somebody else's); a smaller budget drops
+    views in the documented order (direct table first), says so in vg_index_plan, and the results never change; a budget below
+    the smallest layout is refused."""
+    import torch
+
+    from vargeno_amd._lib import VgError
+
+    prefix = os.path.join(ftiny_dir, "idx")
+    r = ftiny_reads
+    _, _, so = _oracle_counts(prefix, r)
+    GiB = 1 << 30
+    seen = {}
+    # F-tiny: the smallest layout is planned at ~20.5 GiB (the 16 GiB jump table is always there, 1.8 GiB of lane-tier scratch, 2 GiB
+    # reserved for batch slots); the LO32 and signature views are tiny here, the merged view adds 16 GiB, the direct table 48 more
+    for budget in (200 * GiB, 60 * GiB, 40 * GiB, 21 * GiB, 200 * GiB, 60 * GiB):
+        hog = torch.empty(6 * GiB, dtype=torch.uint8, device="cuda:0") if len(seen) % 2 else None
+        with GenoIndex.open(prefix, max_device_bytes=budget) as gx:
+            views, plan = tuple(gx.views), gx.plan
+            gx.set_stats(False)
+            gx.submit(r.bases, r.quals, r.offsets)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), (budget, views)
+            assert gx.device_bytes <= budget
+        del hog
+        if budget in seen:
+            assert seen[budget] == (views, plan), "the same budget gave different views"
+        seen[budget] = (views, plan)
+        print("budget %3d GiB: %s | %s" % (budget // GiB, ",".join(views), plan))
+    assert "dx" in seen[200 * GiB][0] and "mx" in seen[200 * GiB][0] and "nothing left out" in seen[200 * GiB][1]
+    assert "dx" not in seen[60 * GiB][0] and "mx" in seen[60 * GiB][0] and "LEFT OUT" in seen[60 * GiB][1] and "direct table" in seen[60 * GiB][1]
+    assert "mx" not in seen[21 * GiB][0] and "sec" in seen[21 * GiB][0]
+    with pytest.raises(VgError) as e:
+        GenoIndex.open(prefix, max_device_bytes=10 * GiB)
+    assert e.value.code == -3 and "budget" in str(e.value)

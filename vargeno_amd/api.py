@@ -31,10 +31,22 @@ class GenoIndex:
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
-    def open(cls, prefix, device=0):
+    def open(cls, prefix, device=0, max_device_bytes=None):
+        """max_device_bytes: this replica's device-memory budget (vg_index_open_ex); None: vg_index_open (the whole device)."""
         h = C.c_void_p()
-        check(lib().vg_index_open(os.fsencode(prefix), device, C.byref(h)))
+        if max_device_bytes is None:
+            check(lib().vg_index_open(os.fsencode(prefix), device, C.byref(h)))
+        else:
+            check(lib().vg_index_open_ex(os.fsencode(prefix), device, int(max_device_bytes), C.byref(h)))
         return cls(h, device)
+
+    @property
+    def plan(self):
+        """What the device-memory budget bought (vg_index_plan): views kept, views left out and what each costs."""
+        try:
+            return lib().vg_index_plan(self._h).decode()
+        except AttributeError:                                   # an older build loaded for an A/B run (VARGENO_HIP_LIB)
+            return ""
 
     @classmethod
     def create(cls, arrays, device=0):
@@ -78,6 +90,7 @@ class GenoIndex:
         if self._h:
             lib().vg_index_close(self._h)
             self._h = None
+        self._pin = None
 
     def __enter__(self):
         return self
@@ -182,11 +195,19 @@ class GenoIndex:
         check(lib().vg_sites_fetch(self._h, _ptr(pos), *[_ptr(x) for x in u8]))
         return dict(pos=pos, ref_base=u8[0], alt_base=u8[1], ref_freq=u8[2], alt_freq=u8[3])
 
-    def counts(self):
+    def counts(self, copy=True):
+        """Clamped counters (ref, alt).  copy=False: views of a page-locked buffer that the next call overwrites (the device-to-host
+        copy then runs at link speed instead of through the runtime's pageable staging: bench.py's timed fetch)."""
         n = self.num_sites
-        r, a = np.empty(n, np.uint8), np.empty(n, np.uint8)
-        check(lib().vg_counts_fetch(self._h, _ptr(r), _ptr(a)))
-        return r, a
+        if copy:
+            r, a = np.empty(n, np.uint8), np.empty(n, np.uint8)
+            check(lib().vg_counts_fetch(self._h, _ptr(r), _ptr(a)))
+            return r, a
+        if getattr(self, "_pin", None) is None or len(self._pin[0]) != 2 * n:
+            self._pin = pinned_buffer(max(2 * n, 1))
+        buf = self._pin[0]
+        check(lib().vg_counts_fetch(self._h, _ptr(buf[:n]), _ptr(buf[n:])))
+        return buf[:n], buf[n:2 * n]
 
     def reset(self):
         check(lib().vg_counts_reset(self._h))

@@ -13,6 +13,8 @@
 //                         per read cross the link instead of ~315 of text (default: half the hardware threads shared among the
 //                         replicas, at most 96; 0, or a host with fewer than 16 hardware threads: the text is framed on the device)
 //   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default: an eighth of the hardware threads, 8 to 32)
+//   VARGENO_MAX_DEVICE_GB=x  device-memory budget per replica (vg_index_open_ex): which re-laid-out views the replica holds follows
+//                         from the index and this number alone (default: the whole device); VARGENO_VERBOSE=1 prints the plan
 //   VARGENO_HOST_FASTQ=1  frame the FASTQ on the host (the reference's four fgets per record) instead of on the device
 //   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
 #include <fcntl.h>
@@ -178,11 +180,14 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		std::vector<std::thread> th;
 		std::vector<int> rcs((size_t)ngpu, 0);
 		std::vector<std::string> errs((size_t)ngpu);
-		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_index_open(prefix.c_str(), g % have, &ix[(size_t)g]); if (rcs[(size_t)g]) errs[(size_t)g] = vg_last_error(); });
+		const char *bgt = getenv("VARGENO_MAX_DEVICE_GB");
+		const uint64_t budget = bgt && *bgt ? (uint64_t)(atof(bgt) * 1e9) : 0ull;
+		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_index_open_ex(prefix.c_str(), g % have, budget, &ix[(size_t)g]); if (rcs[(size_t)g]) errs[(size_t)g] = vg_last_error(); });
 		for (auto &t : th) t.join();
 		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) { fprintf(stderr, "vargeno: cannot load index %s on GPU %d (%d): %s\n", prefix.c_str(), g, rcs[(size_t)g], errs[(size_t)g].c_str()); return EXIT_FAILURE; }
 	}
 	for (auto *h : ix) VG_CHECK(vg_set_stats(h, env_int("VARGENO_STATS", 0)));
+	if (env_int("VARGENO_VERBOSE", 0)) fprintf(stderr, "index replica: %s\n", vg_index_plan(ix[0]));
 
 	fprintf(stderr, "Processing...\n");
 	struct timespec t_loaded; clock_gettime(CLOCK_MONOTONIC, &t_loaded);

@@ -10,6 +10,7 @@
 #include "vg_device.h"
 #include "vg_wave.h"
 #include "vg_hostpack.h"
+#include "vg_allreduce_plan.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -314,45 +315,6 @@ __global__ void vg_make_snp_entries(const uint64_t *__restrict__ kmer, const uin
 // ------------------------------------------------------------------------------------------------
 // kernels: the read loop
 // ------------------------------------------------------------------------------------------------
-
-// 8 ASCII bases (little-endian in v) -> 16 bits, base 0 in bits 0-1 (encode_kmer, src/util.c:89-111:
-// A0 C1 G2 T3, case-insensitive).  `bad` gets a non-zero value if any byte is not one of ACGTacgt.
-__device__ inline uint32_t pack8(uint64_t v, uint64_t &bad)
-{
-	const uint64_t K01 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full;
-	const uint64_t u = v & 0xDFDFDFDFDFDFDFDFull;
-	auto eq = [&](uint64_t c) { const uint64_t z = u ^ (c * K01); return ~(((z & K7F) + K7F) | z | K7F); };   // 0x80 in each byte equal to c
-	const uint64_t ok = eq(0x41) | eq(0x43) | eq(0x47) | eq(0x54);
-	bad |= ok ^ 0x8080808080808080ull;
-	uint64_t x = (v >> 1) & 0x0303030303030303ull;     // A0 C1 G3 T2
-	x ^= (x >> 1) & K01;                               // A0 C1 G2 T3
-	x = (x | (x >> 6)) & 0x000F000F000F000Full;
-	x = (x | (x >> 12)) & 0x000000FF000000FFull;
-	x = (x | (x >> 24)) & 0xFFFFull;
-	return (uint32_t)x;
-}
-
-__device__ inline uint64_t load8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-
-__device__ inline uint64_t encode32(const uint8_t *p, uint64_t &bad)
-{
-	return (uint64_t)pack8(load8(p), bad) | ((uint64_t)pack8(load8(p + 8), bad) << 16) |
-	       ((uint64_t)pack8(load8(p + 16), bad) << 32) | ((uint64_t)pack8(load8(p + 24), bad) << 48);
-}
-
-// Exact classification when some byte is not ACGT: the reference encodes chunk 0..n-1, each from base
-// 31 down to 0, and the FIRST offending character decides: N/n -> skip the read (src/qv.cc:815-828),
-// anything else -> assert(0) (src/util.c:103).  1 = N, 2 = invalid.
-__device__ inline int classify_bad(const uint8_t *p, uint32_t n)
-{
-	for (uint32_t c = 0; c < n; c++)
-		for (int j = 31; j >= 0; j--) {
-			const uint8_t ch = p[32 * c + j] & 0xDF;
-			if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') continue;
-			return ch == 'N' ? 1 : 2;
-		}
-	return 0;
-}
 
 // Streaming pre-pass: ASCII -> chunk k-mers + one flag word per read (gate bits: chunk c is gate-open iff
 // qual[c] < '8', src/qv.cc:836, 943 -- the chunk NUMBER indexes the quality string).  Chunk c of read r
@@ -763,6 +725,8 @@ struct vg_index {
 	uint32_t w2_chunk = 8, w2_wpc = 6;    // second tier: reads a wave pulls at a time (VG_W2_CHUNK), workgroups per CU of its grid (VG_W2_WPC)
 	FqStream *d_fq = nullptr;             // FASTQ stream state (vg_fastq_stream_*)
 	bool fq_open = false; int fq_prev_slot = -1;
+	uint64_t max_device_bytes = 0;        // the caller's budget for this replica (vg_index_open_ex; 0: the whole device)
+	std::string plan_text;                // what the budget bought: views kept / left out (vg_index_plan)
 	vgp::Packer *packer = nullptr;        // host-side framing + packing (vg_fastq_stream_begin_packed)
 	bool fq_packed = false;               // the open FASTQ stream is framed + packed on the host
 	uint64_t host_invalid = 0;            // reads with a character other than ACGTN found by the host packer since the last reset
@@ -1054,6 +1018,59 @@ static int init_handle(vg_index *ix, int device)
 	return VG_OK;
 }
 
+// Which optional views a replica gets is decided BEFORE anything is built, from the dictionaries' sizes and a byte budget alone
+// (vg_index_open_ex; without one: the device's total memory less 12 GiB) -- never from what happens to be free at that moment, so
+// the same files and the same budget always give the same views (r03 asked hipMemGetInfo while building: a caller that shared
+// the device got the slower layout without being told).  Views are taken in a fixed order while the planned total stays within
+// the budget; vg_index_plan() says what was kept, what was left out and what that costs.
+struct ViewPlan {
+	bool mx = false, dx = false, sec = false, sig = false, probe = false, hx = false, jg32 = false;
+	uint64_t base = 0, total = 0, budget = 0;
+	std::string text;
+};
+static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits, uint64_t snp_bf_bits, uint64_t budget_arg, uint64_t device_total, int cus)
+{
+	ViewPlan p;
+	const uint64_t GiB = 1ull << 30, n = c.n_ref, m = c.n_snp, J32 = ((1ull << 32) + 1) * 4;
+	p.budget = budget_arg ? budget_arg : (device_total > 12 * GiB ? device_total - 12 * GiB : device_total);
+	const uint64_t plen = maxp + 64, sites = m / 32 + 1;                       // (an SNP seeds at most one site; ~32 k-mers per SNP)
+	const uint64_t scratch = (uint64_t)cus * 8 * 256 * (64 * 16 + 32 * 12) + 4096ull * (16384 * 16 + 2048 * 12);
+	// what every layout holds: both dictionaries in file order with their jump tables, auxiliary rows, bit vectors, pile-up
+	// sites and counters, lane-tier scratch, and room for three batch slots of a few million reads
+	p.base = J32 + 16 * n + 40 * c.n_ref_aux + ((1ull << 24) + 1) * 4 + 16 * m + 50 * c.n_snp_aux + std::min<uint64_t>(ref_bf_bits, 1ull << 32) / 8 + snp_bf_bits / 8
+	       + plen + plen / 4 + sites * 32 + scratch + 2 * GiB;
+	p.total = p.base;
+	const bool can_mx = !getenv("VG_NO_MX") && n + m < (1ull << 32);
+	uint32_t bits = 14;
+	while (bits < 30 && (1ull << bits) < n) bits++;
+	char line[512];
+	std::string kept, dropped;
+	auto take = [&](bool allowed, uint64_t bytes, const char *name, const char *cost, bool &flag) {
+		if (!allowed) return;
+		if (p.total + bytes <= p.budget) { flag = true; p.total += bytes; snprintf(line, sizeof line, "%s%s %.1f GB", kept.empty() ? "" : ", ", name, bytes / 1e9); kept += line; }
+		else { snprintf(line, sizeof line, "%s%s (%.1f GB; %s)", dropped.empty() ? "" : "; ", name, bytes / 1e9, cost); dropped += line; }
+	};
+	const bool want_probe = !getenv("VG_NO_PROBE_VIEW");
+	take(want_probe && !getenv("VG_NO_SIG_VIEW"), (m + 16) * 2, "signature view of the strided SNP scan", "the scan reads the dictionary entries themselves: 11 lines per 8 entries instead of 1", p.sig);
+	take(want_probe && getenv("VG_NO_SIG_VIEW") != nullptr, (m + 1) * 8, "probe view of the strided SNP scan", "the scan reads the dictionary entries themselves", p.probe);
+	take(!getenv("VG_NO_SEC"), 12 * n + 16 + ((1ull << bits) + 1) * 4, "LO32-ordered view", "the 48 high-half neighbour queries of a gate-open chunk are made one by one: ~2 x the stage-B time", p.sec);
+	if (can_mx) {
+		take(true, 16 * (n + m) + J32, "merged exact-match view", "two look-ups per chunk instead of one, no both-strands shortcut: ~+45 % kernel time (r03 A/B)", p.mx);
+		take(p.mx && !getenv("VG_NO_DIRECT"), (1ull << 32) * 16 - J32, "direct table", "a jump-table gather in front of every exact look-up: ~+15 % kernel time (r02 A/B)", p.dx);
+	} else {
+		const bool want32 = !getenv("VG_NO_SNP_JG32");
+		take(want32 && !getenv("VG_NO_HX"), ((1ull << 32) + 1) * 16 - J32, "paired HI32 table", "separate jump tables, no absence filters: +25 % kernel time (r03: 6.34 vs 5.03 ms)", p.hx);
+		take(want32 && !p.hx, J32, "HI32 jump table of the SNP dictionary", "SNP look-ups bisect HI24 buckets of ~190 entries: 8 dependent probes", p.jg32);
+	}
+	snprintf(line, sizeof line, "budget %.1f GB (%s): %.1f GB planned = %.1f GB of dictionaries, tables, sites and scratch", p.budget / 1e9,
+	         budget_arg ? "the caller's, vg_index_open_ex" : "the device's memory less 12 GiB", p.total / 1e9, p.base / 1e9);
+	p.text = line;
+	if (!kept.empty()) p.text += " + " + kept;
+	p.text += dropped.empty() ? "; nothing left out" : "; LEFT OUT for the budget: " + dropped;
+	if (p.base > p.budget) p.text += "; THE BUDGET IS BELOW THE SMALLEST LAYOUT";
+	return p;
+}
+
 // From the columns (device) + the two bit vectors (host words) to the resident index.
 static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const uint64_t *ref_bf_words, uint64_t snp_bf_bits, const uint64_t *snp_bf_words, PhaseClock &pc)
 {
@@ -1105,7 +1122,13 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	// The merged view's indices are 32 bits wide: an index of 2^32 or more k-mers (hg38 + full dbSNP), or VG_NO_MX, runs on the
 	// layout without it -- and, its own peak being the tighter one (the paired HI32 table), with another order of construction:
 	// pile-up sites first, columns released as soon as their last reader is done.
-	const bool want_mx = !getenv("VG_NO_MX") && c.n_ref + c.n_snp < (1ull << 32);
+	size_t dev_free = 0, dev_total = 0;
+	(void)hipMemGetInfo(&dev_free, &dev_total);
+	const ViewPlan plan = plan_views(c, maxp, ref_bf_bits, snp_bf_bits, ix->max_device_bytes, (uint64_t)dev_total, ix->cus);
+	ix->plan_text = plan.text;
+	if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] %s\n", plan.text.c_str());
+	if (plan.base > plan.budget) return fail(VG_ENOMEM, "the device-memory budget is below the smallest layout of this index: %s", plan.text.c_str());
+	const bool want_mx = plan.mx;
 	auto build_sites = [&]() -> int {
 		// ---- pile-up sites (src/qv.cc:602-603, 637-659)
 		{
@@ -1166,7 +1189,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		HIP_TRY(hipStreamSynchronize(st));
 		d.ref_jg = jg; d.ref = ent;
 		// secondary view ordered by (LO32, HI32): device radix sort of the swapped k-mers + a jump table over LO32's top bits
-		if (!getenv("VG_NO_SEC")) {
+		if (plan.sec) {
 			uint32_t bits = 14;
 			while (bits < 30 && (1ull << bits) < c.n_ref) bits++;          // ~1-3 entries per bucket
 			TempDev<uint64_t> kin; TempDev<uint32_t> vin;
@@ -1209,11 +1232,10 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	// ---- paired HI32 table in place of the two HI32 jump tables (an index without merged view): built in two passes so that only
 	// one 16 GiB jump table is alive next to it; without the room (or with VG_NO_HX) the jump tables stay
 	uint4 *hx = nullptr;
-	if (!want_mx && !getenv("VG_NO_HX") && !getenv("VG_NO_SNP_JG32")) {
-		size_t free_b = 0, total_b = 0;
-		const uint64_t later = (c.n_snp + 1) * 16ull + (getenv("VG_NO_PROBE_VIEW") ? 0ull : (c.n_snp + 16) * (getenv("VG_NO_SIG_VIEW") ? 8ull : 2ull)) + (6ull << 30);     // SNP entries + probe view + scratch, still to come
+	if (plan.hx) {
 		const uint64_t hx_bytes = ((1ull << 32) + 1) * 16ull;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b + ((1ull << 32) + 1) * 4ull > hx_bytes + later && hipMalloc((void **)&hx, hx_bytes) == hipSuccess) {
+		if (hipMalloc((void **)&hx, hx_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(VG_ENOMEM, "hipMalloc(paired HI32 table) failed although the plan had the room -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str()); }
+		{
 			uint32_t *rjg = const_cast<uint32_t *>(d.ref_jg);
 			vg_hx_fill_ref<<<ix->cus * 32, 256, 0, st>>>(rjg, d.ref, hx);
 			HIP_TRY(hipGetLastError());
@@ -1228,9 +1250,6 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(hx); return fail(VG_ENODEV, "building the paired HI32 table failed"); }
 			ix->owned.push_back(hx); ix->dev_bytes += hx_bytes;
 			d.hx = hx;
-		} else {
-			(void)hipGetLastError();
-			hx = nullptr;
 		}
 		pc.lap("paired HI32 table");
 	}
@@ -1247,14 +1266,14 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		if (!want_mx) { c.snp_pos.release(); c.snp_info.release(); c.snp_amb.release(); }     // (the sites are built: the entries were their last reader)
 		// the strided scan's view of the SNP dictionary: signatures (2 bytes per entry) by default, the probed values themselves
 		// (8 bytes per entry) under VG_NO_SIG_VIEW, neither under VG_NO_PROBE_VIEW
-		if (!getenv("VG_NO_PROBE_VIEW") && !getenv("VG_NO_SIG_VIEW")) {
+		if (plan.sig) {
 			uint16_t *sv = nullptr;
 			if ((rc = dev_alloc(ix, &sv, c.n_snp + 16))) return rc;
 			vg_make_snp_sig<<<2048, 256, 0, st>>>(c.snp_kmer.p, jg, c.n_snp, sv);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(st));
 			d.snp_sig = sv;
-		} else if (!getenv("VG_NO_PROBE_VIEW")) {
+		} else if (plan.probe) {
 			uint64_t *pv = nullptr;
 			if ((rc = dev_alloc(ix, &pv, c.n_snp + 1))) return rc;
 			vg_make_snp_probe<<<2048, 256, 0, st>>>(c.snp_kmer.p, jg, c.n_snp, pv);
@@ -1264,16 +1283,13 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		}
 		// an index too large for the merged view gets a HI32 jump table of the SNP dictionary instead (17 GB): its HI24 buckets hold
 		// ~190 entries there, 8 dependent bisection probes per look-up
-		if (!want_mx && !d.hx && !getenv("VG_NO_SNP_JG32")) {
-			size_t free_b = 0, total_b = 0;
-			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (40ull << 30)) {
-				uint32_t *j32 = nullptr;
-				if ((rc = dev_alloc(ix, &j32, (1ull << 32) + 1))) return rc;
-				vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, j32, 1ull << 32, 32);
-				HIP_TRY(hipGetLastError());
-				HIP_TRY(hipStreamSynchronize(st));
-				d.snp_jg32 = j32;
-			}
+		if (plan.jg32) {
+			uint32_t *j32 = nullptr;
+			if ((rc = dev_alloc(ix, &j32, (1ull << 32) + 1))) return rc;
+			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, j32, 1ull << 32, 32);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(st));
+			d.snp_jg32 = j32;
 		}
 		if (!want_mx) c.snp_kmer.release();                        // its last readers (probe view, HI32 tables) are done
 		// merged exact-match view (both dictionaries behind one HI32 jump table); its indices are 32 bits wide
@@ -1305,21 +1321,19 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			d.mx_jg = mjg; d.mx = mx;
 			// direct table (64 GiB) in place of the merged jump table (16 GiB) when the device has the room; no bucket may
 			// exceed the 24-bit count field (it would be a >16 M-fold repeated 16-mer)
-			if (!getenv("VG_NO_DIRECT")) {
+			if (plan.dx) {
 				kout.release(); vout.release(); c.ref_pos.release(); c.ref_amb.release();
-				size_t free_b = 0, total_b = 0;
 				uint4 *dx = nullptr;
 				TempDev<uint32_t> big;
 				if ((rc = big.alloc(1))) return rc;
 				HIP_TRY(hipMemsetAsync(big.p, 0, 4, st));
 				uint32_t too_big = 0;
-				if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > (80ull << 30) && hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) == hipSuccess) {
-					vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
-					HIP_TRY(hipGetLastError());
-					HIP_TRY(hipStreamSynchronize(st));
-					HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
-				}
-				if (dx && too_big) { (void)hipFree(dx); dx = nullptr; }          // a bucket of more than 2^24 - 1 entries: jump-table form
+				if (hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) != hipSuccess) { (void)hipGetLastError(); return fail(VG_ENOMEM, "hipMalloc(direct table) failed although the plan had the room -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str()); }
+				vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
+				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipStreamSynchronize(st));
+				HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
+				if (too_big) { (void)hipFree(dx); dx = nullptr; ix->plan_text += "; direct table not kept: a bucket of more than 2^24 - 1 entries"; }          // jump-table form
 				if (dx) {
 					vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
 					HIP_TRY(hipGetLastError());
@@ -1330,8 +1344,6 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 					for (size_t z = 0; z < ix->owned.size(); z++) if (ix->owned[z] == (void *)mjg) { ix->owned.erase(ix->owned.begin() + (long)z); break; }
 					(void)hipFree(mjg); ix->dev_bytes -= ((1ull << 32) + 1) * 4;
 					d.mx_jg = nullptr;
-				} else {
-					(void)hipGetLastError();                     // not enough memory: keep the jump-table form
 				}
 			}
 		}
@@ -1353,6 +1365,13 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
 	HIP_TRY(hipStreamSynchronize(st));
 	return VG_OK;
+}
+
+// $VG_MAX_DEVICE_BYTES: the budget of vg_index_open / vg_index_create (vg_index_open_ex takes it as an argument)
+static uint64_t env_budget()
+{
+	const char *e = getenv("VG_MAX_DEVICE_BYTES");
+	return e && *e ? strtoull(e, nullptr, 10) : 0ull;
 }
 
 static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
@@ -1378,6 +1397,7 @@ extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **
 	*out = nullptr;
 	vg_index *ix = new (std::nothrow) vg_index();
 	if (!ix) return fail(VG_ENOMEM, "host allocation failed");
+	ix->max_device_bytes = env_budget();
 	int rc = guarded([&] { return create_impl(a, device, ix); });
 	if (rc) { vg_index_close(ix); return rc; }
 	*out = ix;
@@ -1534,18 +1554,25 @@ static int open_impl(const char *prefix, int device, vg_index *ix)
 	return build_on_device(ix, c, rbits, rw.data(), sbits, sw.data(), pc);
 }
 
-extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
+extern "C" int vg_index_open_ex(const char *prefix, int device, uint64_t max_device_bytes, vg_index **out)
 {
 	if (!prefix || !out) return fail(VG_EINVAL, "null argument");
 	*out = nullptr;
 	vg_index *ix = new (std::nothrow) vg_index();
 	if (!ix) return fail(VG_ENOMEM, "host allocation failed");
+	ix->max_device_bytes = max_device_bytes;
 	int rc = guarded([&] { return open_impl(prefix, device, ix); });
 	if (rc) { vg_index_close(ix); return rc; }
 	*out = ix;
 	return VG_OK;
 }
 
+extern "C" const char *vg_index_plan(const vg_index *ix) { return ix ? ix->plan_text.c_str() : ""; }
+
+extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
+{
+	return vg_index_open_ex(prefix, device, env_budget(), out);
+}
 extern "C" uint64_t vg_index_device_bytes(const vg_index *ix) { return ix ? ix->dev_bytes : 0; }
 extern "C" uint64_t vg_num_sites(const vg_index *ix) { return ix ? ix->n_sites : 0; }
 extern "C" uint32_t vg_index_views(const vg_index *ix)
@@ -1616,7 +1643,9 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T - 1) / PACK_T, (uint64_t)ix->cus * pack_bpc * (256 / PACK_T));
-		if (!packed) vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate);
+		const bool fused = VG_FUSE_PACK && !packed && !getenv("VG_NO_FUSE");          // the main tier encodes the reads itself (experiment)
+		const FuseIn fin{fused ? d_bases : nullptr, d_quals, d_gate, &ctr[3]}, nofuse{nullptr, nullptr, nullptr, nullptr};
+		if (!packed && !fused) vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate);
 		HIP_TRY(hipEventRecord(sl.e1, ps));
 		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
@@ -1626,20 +1655,20 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		ix->cnt4_dirty = true;
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 64 * W1_WPB - 1) / (64 * W1_WPB), (uint64_t)ix->wave_grid / W1_WPB);
 		const bool big = !STATS && ix->d.mx == nullptr;                // an index without the merged view: the kernel built for it
-		if (big) vg_wave_kernel_big<W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
-		else vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats);
+		if (big) vg_wave_kernel_big<W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats, fin);
+		else vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats, fin);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		// tail stream, second tier: the same kernel with deeper lists over the spill list (up to w2_wpc single-wave workgroups per CU)
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		// (its workgroups hold 26 KB of LDS each while they live, in the way of the next batch's main tier: a wave takes at least
 		// w2_chunk reads at a time, so a few hundred spilled reads wake few of them)
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
-		if (big) vg_wave_kernel_big<W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listD, &ctr[6], &ctr[5], ix->w2_chunk, ix->d_stats);
-		else vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listD, &ctr[6], &ctr[5], ix->w2_chunk, ix->d_stats);
+		if (big) vg_wave_kernel_big<W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listD, &ctr[6], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
+		else vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listD, &ctr[6], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		// third tier: the deepest LDS lists, for what the second could not hold
 		const unsigned w3grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
-		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w3grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listD, &ctr[6], sl.listB, &ctr[1], &ctr[7], 2u, ix->d_stats);
-		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w3grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listD, &ctr[6], sl.listB, &ctr[1], &ctr[7], 2u, ix->d_stats);
+		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w3grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listD, &ctr[6], sl.listB, &ctr[1], &ctr[7], 2u, ix->d_stats, nofuse);
+		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w3grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listD, &ctr[6], sl.listB, &ctr[1], &ctr[7], 2u, ix->d_stats, nofuse);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream
@@ -2259,46 +2288,35 @@ extern "C" int vg_counts_allreduce_devices(vg_index **handles, int n)
 	for (int i = 0; i < n; i++) { int rc = finish_pending(handles[i]); if (rc) return rc; }
 	if (handles[0]->n_sites == 0) return VG_OK;
 	return guarded([&]() -> int {
-		const uint64_t words = 2 * handles[0]->n_sites;
-		std::vector<vg_index *> reps;                               // the first replica on each device
-		std::vector<int> rep_of((size_t)n, -1);
-		for (int i = 0; i < n; i++) {
-			for (size_t k = 0; k < reps.size(); k++) if (reps[k]->device == handles[i]->device) rep_of[(size_t)i] = (int)k;
-			if (rep_of[(size_t)i] < 0) { rep_of[(size_t)i] = (int)reps.size(); reps.push_back(handles[i]); }
-		}
-		for (int i = 0; i < n; i++) {                               // every replica is idle (finish_pending): fold the guests into their device's first
-			vg_index *rep = reps[(size_t)rep_of[(size_t)i]];
-			if (rep == handles[i]) continue;
-			HIP_TRY(hipSetDevice(rep->device));
-			vg_add_counters<<<(unsigned)std::min<uint64_t>((words + 255) / 256, 4096), 256, 0, rep->stream>>>(rep->d.cnt, handles[i]->d.cnt, words);
-			HIP_TRY(hipGetLastError());
-		}
-		const int nr = (int)reps.size();
-		std::vector<int> devs((size_t)nr);
-		for (int i = 0; i < nr; i++) devs[(size_t)i] = reps[(size_t)i]->device;
-		std::vector<ncclComm_t> comms((size_t)nr, nullptr);
-		ncclResult_t rc = R.comm_init_all(comms.data(), nr, devs.data());
-		if (rc != ncclSuccess) return fail(VG_ENODEV, "ncclCommInitAll: %s", R.error_string(rc));
-		rc = R.group_start();
-		for (int i = 0; i < nr && rc == ncclSuccess; i++) {
-			vg_index *ix = reps[(size_t)i];
-			if (hipSetDevice(ix->device) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
-			rc = R.all_reduce(ix->d.cnt, ix->d.cnt, (size_t)words, ncclUint32, ncclSum, comms[(size_t)i], ix->stream);
-		}
-		const ncclResult_t rc2 = R.group_end();
-		int out = VG_OK;
-		if (rc != ncclSuccess || rc2 != ncclSuccess) out = fail(VG_ENODEV, "RCCL all-reduce of the site counters: %s", R.error_string(rc != ncclSuccess ? rc : rc2));
-		for (int i = 0; i < n && out == VG_OK; i++) {               // the guests take their device's result (same stream: after the all-reduce)
-			vg_index *rep = reps[(size_t)rep_of[(size_t)i]];
-			if (rep == handles[i]) continue;
-			if (hipSetDevice(rep->device) != hipSuccess || hipMemcpyAsync(handles[i]->d.cnt, rep->d.cnt, words * 4, hipMemcpyDeviceToDevice, rep->stream) != hipSuccess)
-				out = fail(VG_ENODEV, "copy of the reduced counters to a replica on the same device failed");
-		}
-		for (int i = 0; i < nr; i++) {
-			if (hipSetDevice(reps[(size_t)i]->device) == hipSuccess && hipStreamSynchronize(reps[(size_t)i]->stream) != hipSuccess && out == VG_OK)
-				out = fail(VG_ENODEV, "stream synchronisation after the all-reduce failed");
-		}
-		for (ncclComm_t c : comms) if (c) (void)R.comm_destroy(c);
-		return out;
+		// the order of operations lives in vg_allreduce_plan.h (so that it can be run against a mock); this is its HIP + RCCL backend
+		struct Backend {
+			vg_index **h; const Rccl &R; uint64_t words; std::vector<ncclComm_t> comms; ncclResult_t last = ncclSuccess;
+			int device_of(int i) { return h[i]->device; }
+			int add_into(int dst, int src)
+			{
+				if (hipSetDevice(h[dst]->device) != hipSuccess) return VG_ENODEV;
+				vg_add_counters<<<(unsigned)std::min<uint64_t>((words + 255) / 256, 4096), 256, 0, h[dst]->stream>>>(h[dst]->d.cnt, h[src]->d.cnt, words);
+				return hipGetLastError() == hipSuccess ? 0 : VG_ENODEV;
+			}
+			int comm_init(const int *devs, int nr) { comms.assign((size_t)nr, nullptr); last = R.comm_init_all(comms.data(), nr, devs); return last == ncclSuccess ? 0 : VG_ENODEV; }
+			int group_start() { last = R.group_start(); return last == ncclSuccess ? 0 : VG_ENODEV; }
+			int group_end() { const ncclResult_t r = R.group_end(); if (r != ncclSuccess) last = r; return r == ncclSuccess ? 0 : VG_ENODEV; }
+			int all_reduce(int i, int rank)
+			{
+				if (hipSetDevice(h[i]->device) != hipSuccess) { last = ncclUnhandledCudaError; return VG_ENODEV; }
+				last = R.all_reduce(h[i]->d.cnt, h[i]->d.cnt, (size_t)words, ncclUint32, ncclSum, comms[(size_t)rank], h[i]->stream);
+				return last == ncclSuccess ? 0 : VG_ENODEV;
+			}
+			int copy_from(int dst, int src)
+			{
+				return hipSetDevice(h[src]->device) == hipSuccess && hipMemcpyAsync(h[dst]->d.cnt, h[src]->d.cnt, words * 4, hipMemcpyDeviceToDevice, h[src]->stream) == hipSuccess ? 0 : VG_ENODEV;
+			}
+			int sync(int i) { return hipSetDevice(h[i]->device) == hipSuccess && hipStreamSynchronize(h[i]->stream) == hipSuccess ? 0 : VG_ENODEV; }
+			void comm_destroy() { for (ncclComm_t c : comms) if (c) (void)R.comm_destroy(c); comms.clear(); }
+		} B{handles, R, 2 * handles[0]->n_sites, {}};
+		const char *where = "";
+		const int rc = run_allreduce(B, n, &where);
+		if (rc) return fail(rc, "RCCL exchange of the site counters failed at: %s (%s)", where, B.last != ncclSuccess ? R.error_string(B.last) : "HIP error");
+		return VG_OK;
 	});
 }

@@ -155,6 +155,45 @@ __device__ inline uint64_t revcomp64(uint64_t k)
 // bijective 64-bit mix (murmur3's finaliser): spreads canonical k-mers evenly over the HI32 buckets of the merged view
 __device__ __host__ inline uint64_t fmix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
 
+// 8 ASCII bases (little-endian in v) -> 16 bits, base 0 in bits 0-1 (encode_kmer, src/util.c:89-111:
+// A0 C1 G2 T3, case-insensitive).  `bad` gets a non-zero value if any byte is not one of ACGTacgt.
+__device__ inline uint32_t pack8(uint64_t v, uint64_t &bad)
+{
+	const uint64_t K01 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full;
+	const uint64_t u = v & 0xDFDFDFDFDFDFDFDFull;
+	auto eq = [&](uint64_t c) { const uint64_t z = u ^ (c * K01); return ~(((z & K7F) + K7F) | z | K7F); };   // 0x80 in each byte equal to c
+	const uint64_t ok = eq(0x41) | eq(0x43) | eq(0x47) | eq(0x54);
+	bad |= ok ^ 0x8080808080808080ull;
+	uint64_t x = (v >> 1) & 0x0303030303030303ull;     // A0 C1 G3 T2
+	x ^= (x >> 1) & K01;                               // A0 C1 G2 T3
+	x = (x | (x >> 6)) & 0x000F000F000F000Full;
+	x = (x | (x >> 12)) & 0x000000FF000000FFull;
+	x = (x | (x >> 24)) & 0xFFFFull;
+	return (uint32_t)x;
+}
+
+__device__ inline uint64_t load8(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+__device__ inline uint64_t encode32(const uint8_t *p, uint64_t &bad)
+{
+	return (uint64_t)pack8(load8(p), bad) | ((uint64_t)pack8(load8(p + 8), bad) << 16) |
+	       ((uint64_t)pack8(load8(p + 16), bad) << 32) | ((uint64_t)pack8(load8(p + 24), bad) << 48);
+}
+
+// Exact classification when some byte is not ACGT: the reference encodes chunk 0..n-1, each from base
+// 31 down to 0, and the FIRST offending character decides: N/n -> skip the read (src/qv.cc:815-828),
+// anything else -> assert(0) (src/util.c:103).  1 = N, 2 = invalid.
+__device__ inline int classify_bad(const uint8_t *p, uint32_t n)
+{
+	for (uint32_t c = 0; c < n; c++)
+		for (int j = 31; j >= 0; j--) {
+			const uint8_t ch = p[32 * c + j] & 0xDF;
+			if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') continue;
+			return ch == 'N' ? 1 : 2;
+		}
+	return 0;
+}
+
 // Loads with the `nt` bit of gfx950's memory instructions ("nothing will touch this line again soon").  A probe of bare random
 // gathers from a table far larger than L2 (tools/gather_policy_probe, profiles/gather_policy_probe_r02.jsonl) runs at 55.0 G/s
 // with it and 50.9 G/s without, whatever the width (sc0 / sc1 change nothing; an L2-resident table: 250 G/s) -- but the read
@@ -329,6 +368,10 @@ __device__ inline void dual_query(const DevIndex &d, ST &st, uint64_t k, bool wa
 	if (sa < sb) st.add(S_SNP_PROBE, ceil_log2_p1(sb - sa));
 	const uint32_t rkey = (uint32_t)k;
 	const uint64_t skey = k & LO40_MASK;
+#ifdef VG_DBG_SHALLOW
+	if (rb - ra > 4u) rb = ra;                                      // timing experiment only (wrong results): what do the deep bisections cost?
+	if (sb - sa > 4u) sb = sa;
+#endif
 	while (ra < rb || sa < sb) {
 		const bool pr = ra < rb, ps = sa < sb;
 		const uint32_t rm = ra + ((rb - ra) >> 1), sm = sa + ((sb - sa) >> 1);
@@ -341,27 +384,32 @@ __device__ inline void dual_query(const DevIndex &d, ST &st, uint64_t k, bool wa
 	}
 }
 
-// The exact look-ups of TWO chunks in both dictionaries in lock step, for an index without the merged view: four bucket-bound
-// gathers go out together, then every bisection step probes all four buckets at once -- 1 + max depth waits for what four
-// separate queries would spend ~12 on.  SNP buckets come from the HI32 jump table when the index has one.  The entries found
+// The exact look-ups of Z chunks (the four of a 150 bp read, r04; r03: two) in both dictionaries in lock step, for an index without
+// the merged view: their bucket-bound gathers go out together, then every bisection step probes all 2 Z buckets at once -- 1 + max
+// depth waits for what 2 Z separate queries would spend ~3 each on.  SNP buckets come from the HI32 jump table when the index has one.  The entries found
 // are returned whole (every probe fetches 16 bytes).  Not for the counting build: no events are booked.
-__device__ inline void exact_pair_nomx(const DevIndex &d, const uint64_t (&k)[2], const bool (&want)[2], bool (&rhit)[2], RefEnt (&re)[2], bool (&shit)[2], SnpEnt (&se)[2])
+template <int Z>
+__device__ inline void exact_multi_nomx(const DevIndex &d, const uint64_t (&k)[Z], const bool (&want)[Z], uint32_t (&rhit)[Z], uint32_t (&rpos)[Z], uint32_t (&shit)[Z], uint32_t (&spos)[Z])
 {
-	uint32_t ra[2] = {0, 0}, rb[2] = {0, 0}, sa[2] = {0, 0}, sb[2] = {0, 0};
+	// rhit / shit: 0 = miss, 1 = hit, 3 = hit on an entry with several positions (pos is then the auxiliary row); only the
+	// position and that flag leave the loop -- whole entries kept for four look-ups were what the kernel spilled (40 bytes of
+	// scratch per lane in r03)
+	uint32_t ra[Z], rb[Z], sa[Z], sb[Z];
 	#pragma unroll
-	for (int z = 0; z < 2; z++) {
-		rhit[z] = shit[z] = false;
+	for (int z = 0; z < Z; z++) {
+		ra[z] = rb[z] = sa[z] = sb[z] = 0;
+		rhit[z] = shit[z] = 0; rpos[z] = spos[z] = 0;
 		if (!want[z]) continue;
 		if (d.hx) { hx_bounds(d, k[z], true, true, ra[z], rb[z], sa[z], sb[z]); continue; }
 		jg_pair(d.ref_jg, k[z] >> 32, ra[z], rb[z]);
 		if (d.snp_jg32) jg_pair(d.snp_jg32, k[z] >> 32, sa[z], sb[z]); else jg_pair(d.snp_jg, k[z] >> 40, sa[z], sb[z]);
 	}
 	for (;;) {
-		bool pr[2], ps[2], any = false;
-		uint32_t rm[2], sm[2];
-		RefEnt er[2]; SnpEnt es[2];
+		bool pr[Z], ps[Z], any = false;
+		uint32_t rm[Z], sm[Z];
+		RefEnt er[Z]; SnpEnt es[Z];
 		#pragma unroll
-		for (int z = 0; z < 2; z++) {
+		for (int z = 0; z < Z; z++) {
 			pr[z] = ra[z] < rb[z]; ps[z] = sa[z] < sb[z];
 			any = any || pr[z] || ps[z];
 			rm[z] = ra[z] + ((rb[z] - ra[z]) >> 1); sm[z] = sa[z] + ((sb[z] - sa[z]) >> 1);
@@ -370,14 +418,14 @@ __device__ inline void exact_pair_nomx(const DevIndex &d, const uint64_t (&k)[2]
 		}
 		if (!any) break;
 		#pragma unroll
-		for (int z = 0; z < 2; z++) {
+		for (int z = 0; z < Z; z++) {
 			if (pr[z]) {
 				const uint32_t key = (uint32_t)k[z];
-				if (er[z].lo == key) { rhit[z] = true; re[z] = er[z]; ra[z] = rb[z]; } else if (er[z].lo < key) ra[z] = rm[z] + 1; else rb[z] = rm[z];
+				if (er[z].lo == key) { rhit[z] = 1u | (er[z].amb ? 2u : 0u); rpos[z] = er[z].pos; ra[z] = rb[z]; } else if (er[z].lo < key) ra[z] = rm[z] + 1; else rb[z] = rm[z];
 			}
 			if (ps[z]) {
 				const uint64_t key = k[z] & LO40_MASK, ek = es[z].key & LO40_MASK;
-				if (ek == key) { shit[z] = true; se[z] = es[z]; sa[z] = sb[z]; } else if (ek < key) sa[z] = sm[z] + 1; else sb[z] = sm[z];
+				if (ek == key) { shit[z] = 1u | (((es[z].key >> 48) & 0xFFu) ? 2u : 0u); spos[z] = es[z].pos; sa[z] = sb[z]; } else if (ek < key) sa[z] = sm[z] + 1; else sb[z] = sm[z];
 			}
 		}
 	}

@@ -127,7 +127,7 @@ inline uint64_t classify_bad(const uint8_t *p, uint32_t n)
 	return 0;
 }
 
-struct Out {                               // what one thread framed
+struct alignas(128) Out {                   // what one thread framed (its own cache lines: the vectors' end pointers move with every record)
 	std::vector<uint64_t> kmers, meta;
 	std::vector<uint8_t> nch;
 	uint64_t n_invalid = 0;

@@ -92,6 +92,18 @@ constexpr uint64_t PK_LONG = 1ull << 61;       // more than 32 chunks: generic t
 // context meta word: chunk (5) | mod (5) << 5 | neighbour flag << 10 | new base (2) << 11
 __device__ inline uint32_t mk_meta(uint32_t chunk, uint32_t mod, bool neigh, uint32_t nbase) { return chunk | (mod << 5) | ((neigh ? 1u : 0u) << 10) | (nbase << 11); }
 
+// -DVG_FUSE_PACK (experiment, r04): the main tier encodes the reads itself as it takes them (no pack kernel in front of it):
+// a lane loads its own read's bases, packs them (SWAR, like the pack kernel), writes k-mers and flag word where the later
+// stages, the deeper tiers and the lane machine read them.  bases == nullptr: the batch is packed already.
+struct FuseIn {
+	const uint8_t *bases, *quals;
+	const uint32_t *gate;
+	uint32_t *invalid_reads;
+};
+#ifndef VG_FUSE_PACK
+#define VG_FUSE_PACK 0
+#endif
+
 template <bool NARROW> struct KMask { typedef uint32_t type; };
 template <> struct KMask<true> { typedef uint16_t type; };
 
@@ -119,7 +131,8 @@ template <bool STATS, int W_ECAP, int W_NCAP, int WPB, bool NOMX>
 __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                              const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                              const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
-                                             uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
+                                             uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats,
+                                             const FuseIn fuse)
 {
 	// Exact contexts are kept BY VOTE KEY, not one by one (r04).  A vote key (qv.cc:132-178) is the IMPLIED READ POSITION of a
 	// context (k-mer position - 32 chunk) and is always opened by an exact context -- neighbour contexts never open one,
@@ -274,9 +287,40 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				if (rank < take) {
 					rid = read_ids ? read_ids[cursor + rank] : (uint32_t)(cursor + rank);
 					const uint64_t off = offsets[rid];
-					const uint64_t meta = pk_meta[rid];
 					n = (uint32_t)((offsets[rid + 1] - off) >> 5);
 					slot0 = (uint32_t)(off >> 5);
+					uint64_t meta;
+					if (VG_FUSE_PACK && WPB > 1 && fuse.bases) {
+						// encode the read here: chunk k-mers out of the lane's own 32 n bases (16-byte loads at the read's own alignment, two
+						// chunks' worth in flight: four spill registers), the flag word as the pack kernel makes it
+						uint64_t bad = 0;
+						meta = 0;
+						uint64_t *dst = const_cast<uint64_t *>(pk_kmer) + slot0;
+						const uint8_t *src = fuse.bases + off;
+						for (uint32_t c0 = 0; c0 < n; c0 += 2) {
+							const bool two = c0 + 1 < n;
+							uint4 t[4];
+							#pragma unroll
+							for (uint32_t q = 0; q < 4; q++) if (q < 2 || two) t[q] = load_policy<false, uint4, 1>(src + 32 * c0 + 16 * q);
+							#pragma unroll
+							for (uint32_t z = 0; z < 2; z++) if (z == 0 || two) {
+								const uint4 a = t[2 * z], b = t[2 * z + 1];
+								const uint64_t k = (uint64_t)pack8(((uint64_t)a.y << 32) | a.x, bad) | ((uint64_t)pack8(((uint64_t)a.w << 32) | a.z, bad) << 16) |
+								                   ((uint64_t)pack8(((uint64_t)b.y << 32) | b.x, bad) << 32) | ((uint64_t)pack8(((uint64_t)b.w << 32) | b.z, bad) << 48);
+								dst[c0 + z] = k;
+							}
+						}
+						if (fuse.gate) meta = n >= 32 ? fuse.gate[rid] : (fuse.gate[rid] & ((1u << n) - 1u));
+						else for (uint32_t c0 = 0; c0 < n && c0 < 32; c0 += 4) {
+							uint32_t q4;
+							__builtin_memcpy(&q4, fuse.quals + off + c0, 4);       // c0 + 4 <= n + 3 <= the read's own length
+							for (uint32_t j = 0; j < 4 && c0 + j < n && c0 + j < 32; j++) if ((int)(int8_t)(q4 >> (8 * j)) - '8' < 0) meta |= 1ull << (c0 + j);
+						}
+						if (bad) meta |= classify_bad(src, n) == 1 ? PK_SKIP_N : PK_INVALID;
+						if (n > 32) meta |= fuse.gate ? PK_INVALID : PK_LONG;
+						if (meta & PK_INVALID) atomicAdd(fuse.invalid_reads, 1u);
+						const_cast<uint64_t *>(pk_meta)[rid] = meta;
+					} else meta = pk_meta[rid];
 					gates = (uint32_t)meta;
 					pass = 0;
 					cur.clear();
@@ -340,13 +384,18 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				} else if (dup) { VG_OVF(2); ovf = true; }
 			};
 			auto push_row = [&](const uint32_t *row, uint32_t c) {               // a row ends at its first 0
-				for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
-					uint32_t v[4];
-					load_row4(row, j0, v);
-					bool live = true;
-					#pragma unroll
-					for (int j = 0; j < 4; j++) { live = live && v[j] != 0; if (live) push_exact(v[j], c); }
-					if (!live) break;
+				// the whole row in one wait; one push site, the column picked by selects (unrolled copies of the key search cost more
+				// registers than the row)
+#ifdef VG_DBG_NO_ROWS
+				return;                                                 // timing experiment only (wrong results): what do the rows cost?
+#endif
+				uint32_t rw[AUX_COLS];
+				load_row10(row, rw);
+				#pragma nounroll
+				for (uint32_t j = 0; j < (uint32_t)AUX_COLS; j++) {
+					const uint32_t v = j == 0 ? rw[0] : j == 1 ? rw[1] : j == 2 ? rw[2] : j == 3 ? rw[3] : j == 4 ? rw[4] : j == 5 ? rw[5] : j == 6 ? rw[6] : j == 7 ? rw[7] : j == 8 ? rw[8] : rw[9];
+					if (v == 0) break;
+					push_exact(v, c);
 				}
 			};
 			auto emit_exact = [&](uint32_t c, bool rhit, uint32_t rpos, uint32_t ramb, bool shit, uint32_t spos, uint32_t samb) {
@@ -360,17 +409,19 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				}
 			};
 			if constexpr (NOMX) {
-				// An index without the merged view: both dictionaries of two chunks at a time, bisected in lock step
-				for (uint32_t c = 0; c < n; c += 2) {
-					uint64_t kq[2] = {0, 0};
-					const bool want[2] = {true, c + 1 < n};
-					if (want[1]) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
-					bool rhit[2], shit[2]; RefEnt re[2]; SnpEnt se[2];
-					exact_pair_nomx(d, kq, want, rhit, re, shit, se);
+				// An index without the merged view: both dictionaries of four chunks at a time, bisected in lock step
+				for (uint32_t c = 0; c < n; c += 4) {
+					const uint32_t m = n - c < 4u ? n - c : 4u;
+					uint64_t kq[4] = {0, 0, 0, 0};
+					const bool want[4] = {true, m >= 2, m >= 3, m >= 4};
+					if (m >= 2) chunk_kmer2(c, kq[0], kq[1]); else kq[0] = chunk_kmer(c);
+					if (m >= 4) chunk_kmer2(c + 2, kq[2], kq[3]); else if (m == 3) kq[2] = chunk_kmer(c + 2);
+					uint32_t rhit[4], shit[4], rpos[4], spos[4];
+					exact_multi_nomx<4>(d, kq, want, rhit, rpos, shit, spos);
 					#pragma unroll
-					for (uint32_t z = 0; z < 2; z++) if (want[z]) {
+					for (uint32_t z = 0; z < 4; z++) if (want[z]) {
 						cur.add(S_CHUNKS, 1);
-						emit_exact(c + z, rhit[z], rhit[z] ? re[z].pos : 0u, rhit[z] ? re[z].amb : 0u, shit[z], shit[z] ? se[z].pos : 0u, shit[z] ? (uint32_t)((se[z].key >> 48) & 0xFFu) : 0u);
+						emit_exact(c + z, rhit[z] != 0u, rpos[z], rhit[z] >> 1, shit[z] != 0u, spos[z], shit[z] >> 1);
 					}
 				}
 			} else if (use_mx) {
@@ -507,20 +558,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							// the auxiliary rows (k-mers with 3-10 copies) after the pair's other contexts, a reference row WHOLE in one wait: a read
 							// inside a repeat waited up to three times per chunk for its row's columns four at a time (the order in which a
 							// pass's contexts reach the key table does not matter)
+							// (with both rows of the pair in flight at once the kernel spills: 48 bytes of scratch per lane)
 							#pragma nounroll
-							for (uint32_t y = 0; y < 2; y++) {
-								if (ax_r[y] == NOHIT) continue;
-								uint32_t rw[AUX_COLS];
-								load_row10(d.ref_aux + (uint64_t)ax_r[y] * AUX_COLS, rw);
-								// one push site, the column picked by selects: unrolled copies of the key search cost more registers than the row
-								// (with both rows of the pair in flight at once the kernel spills: 48 bytes of scratch per lane)
-								#pragma nounroll
-								for (uint32_t j = 0; j < (uint32_t)AUX_COLS; j++) {
-									const uint32_t v = j == 0 ? rw[0] : j == 1 ? rw[1] : j == 2 ? rw[2] : j == 3 ? rw[3] : j == 4 ? rw[4] : j == 5 ? rw[5] : j == 6 ? rw[6] : j == 7 ? rw[7] : j == 8 ? rw[8] : rw[9];
-									if (v == 0) break;                           // a row ends at its first 0
-									push_exact(v, c + z0 + y);
-								}
-							}
+							for (uint32_t y = 0; y < 2; y++) if (ax_r[y] != NOHIT) push_row(d.ref_aux + (uint64_t)ax_r[y] * AUX_COLS, c + z0 + y);
 							// (an SNP k-mer with several positions is rare -- it takes an SNP inside identical copies: row by row)
 							#pragma unroll
 							for (uint32_t y = 0; y < 2; y++) if (ax_s[y] != NOHIT) push_row(d.snp_aux_pos + (uint64_t)ax_s[y] * AUX_COLS, c + z0 + y);
@@ -1118,9 +1158,9 @@ template <bool STATS, int W_ECAP, int W_NCAP, int WPB>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
-                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
+                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats, const FuseIn fuse)
 {
-	vg_wave_body<STATS, W_ECAP, W_NCAP, WPB, false>(d, pk_kmer, pk_meta, offsets, n_reads_arg, read_ids, n_ids, overflow_list, overflow_count, work_next, WORK_CHUNK_ARG, stats);
+	vg_wave_body<STATS, W_ECAP, W_NCAP, WPB, false>(d, pk_kmer, pk_meta, offsets, n_reads_arg, read_ids, n_ids, overflow_list, overflow_count, work_next, WORK_CHUNK_ARG, stats, fuse);
 }
 
 // the timed build for an index without the merged view (see vg_wave_body)
@@ -1128,9 +1168,9 @@ template <int W_ECAP, int W_NCAP, int WPB>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel_big(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
-                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats)
+                                                     uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats, const FuseIn fuse)
 {
-	vg_wave_body<false, W_ECAP, W_NCAP, WPB, true>(d, pk_kmer, pk_meta, offsets, n_reads_arg, read_ids, n_ids, overflow_list, overflow_count, work_next, WORK_CHUNK_ARG, stats);
+	vg_wave_body<false, W_ECAP, W_NCAP, WPB, true>(d, pk_kmer, pk_meta, offsets, n_reads_arg, read_ids, n_ids, overflow_list, overflow_count, work_next, WORK_CHUNK_ARG, stats, fuse);
 }
 
 }  // namespace vg
