@@ -854,7 +854,7 @@ def main():
                                        "hg38-scale (BASELINE.json configs[2])" if args.genome >= 10 ** 9 else "chr22-scale (BASELINE.json configs[1])",
                                        args.genome, args.chroms, args.snps, args.reads, args.batches, 100 * args.lowq,
                                        "" if not args.repeats else "; REPEAT-RICH genome: %g%% of it in planted families of near-identical copies (2-10 and 11-200 copies), 50 microsatellites per Mbp" % (100 * args.repeats)),
-                       "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps,
+                       "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps, "lowq": args.lowq, "repeats": args.repeats, "gate_words": bool(args.gate_words),
                        "index_bytes_hbm": dev_bytes, "index_views": views, "index_plan": plan_text, "index_open_s": t_open, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
             "roofline": roof,

@@ -9,7 +9,7 @@ mkdir -p variants
 C=vargeno_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -DVG_LIB_BUILD_ID=\"variant-$name\" "$@" -c -o variants/$name.o $C/vargeno_hip.hip
 [ -f $C/vg_sort.o ] || make -s -C $C $PWD/$C/vg_sort.o
-make -s -C $C $PWD/$C/vg_hostpack.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o variants/$name.so variants/$name.o $C/vg_sort.o $C/vg_hostpack.o -ldl -lpthread
+make -s -C $C $PWD/$C/vg_hostpack.o $PWD/$C/vg_hostpack_avx2.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o variants/$name.so variants/$name.o $C/vg_sort.o $C/vg_hostpack.o $C/vg_hostpack_avx2.o -ldl -lpthread
 rm -f variants/$name.o
 echo built variants/$name.so

@@ -132,7 +132,7 @@ def lib():
 
 
 # the files (in this order) whose sha256 csrc/Makefile compiles into the library as vg_build_id()
-LIB_SOURCES = [os.path.join(HERE, "..", "include", "vargeno_hip.h")] + [os.path.join(HERE, "csrc", f) for f in ("vg_device.h", "vg_wave.h", "vargeno_hip.hip", "vg_sort.hip", "vg_hostpack.h", "vg_hostpack.cpp", "vg_allreduce_plan.h")]
+LIB_SOURCES = [os.path.join(HERE, "..", "include", "vargeno_hip.h")] + [os.path.join(HERE, "csrc", f) for f in ("vg_device.h", "vg_wave.h", "vargeno_hip.hip", "vg_sort.hip", "vg_hostpack.h", "vg_hostpack.cpp", "vg_allreduce_plan.h", "vg_hostpack_impl.h", "vg_hostpack_impl.inc", "vg_hostpack_avx2.cpp")]
 
 
 def source_build_id():

@@ -1875,11 +1875,30 @@ static int grow_dev(T **p, uint64_t &cap, uint64_t need)
 	return VG_OK;
 }
 
-static int host_pack_threads_default()
+// CPUs this process may actually use: the hardware threads, capped by a cgroup CPU quota (cpu.max: "<quota> <period>" -- the GPU
+// boxes of this pool give a container 16 CPUs' worth of time on a 256-thread host; threads beyond the quota only take time from
+// each other, and a spinning one takes it from the working ones)
+static unsigned usable_cpus()
 {
 	unsigned h = std::thread::hardware_concurrency();
+	if (h == 0) h = 1;
+	for (const char *path : {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"}) {
+		FILE *f = fopen(path, "r");
+		if (!f) continue;
+		long long q = -1, per = 100000;
+		char a[64] = "";
+		if (fscanf(f, "%63s %lld", a, &per) >= 1 && strcmp(a, "max") != 0) q = atoll(a);
+		fclose(f);
+		if (q > 0 && per > 0) { const unsigned c = (unsigned)((q + per - 1) / per); if (c && c < h) h = c; }
+		break;
+	}
+	return h;
+}
+static int host_pack_threads_default()
+{
 	if (const char *e = getenv("VG_PACK_THREADS")) return std::max(0, atoi(e));
-	return h >= 16 ? (int)std::min(h / 2, 96u) : 0;           // few cores: the device-side framing is the faster path
+	const unsigned c = usable_cpus();
+	return c >= 8 ? (int)std::min(c - 1, 96u) : 0;             // (one CPU stays with the thread that feeds the device) few CPUs: the device-side framing is the faster path
 }
 
 extern "C" int vg_fastq_stream_begin_packed(vg_index *ix, int host_threads)
@@ -1924,7 +1943,7 @@ static int push_packed(vg_index *ix, const uint8_t *text, uint64_t nbytes)
 	vgp::Staging st;
 	st.kmers = sl.hp_kmers; st.kmers_cap = sl.hp_kmers_cap; st.meta = sl.hp_meta; st.offsets = sl.hp_offsets; st.reads_cap = sl.hp_reads_cap;
 	const vgp::ChunkResult r = ix->packer->push(text, nbytes, st);
-	if (r.refused || r.n_reads == 0) return VG_OK;
+	if (r.n_reads == 0) return VG_OK;                            // (a refused block poisons the stream; the records framed before it are still this batch)
 	hipStream_t is = ix->ingest_stream ? ix->ingest : ix->stream;
 	rc = launch_packed(ix, sl, sl.hp_kmers, sl.hp_meta, sl.hp_offsets, r.n_reads, r.n_chunks, is);
 	if (rc == VG_OK) ix->host_invalid += r.n_invalid;

@@ -7,10 +7,7 @@
 // thread frame and pack the records that START in its piece -- straight into per-thread buffers that a third, short sweep
 // copies to their place in the caller's (pinned) staging arrays.  The record that straddles two chunks is put together from
 // the carried bytes and handled by the calling thread.
-#include "vg_hostpack.h"
-
-#include <emmintrin.h>
-#include <string.h>
+#include "vg_hostpack_impl.h"
 
 #include <atomic>
 #include <condition_variable>
@@ -23,7 +20,6 @@ namespace vgp {
 
 namespace {
 
-constexpr uint64_t MAX_LINE = 1023;          // fgets(buf, 1024, f): at most 1023 characters per call, newline included (qv.cc:700, 760-763)
 constexpr uint64_t MAX_CARRY = 1u << 16;     // an unfinished record of more than 64 KiB: refused (as on the device)
 
 // ---- a small pool: the caller is thread 0; workers spin briefly for the next job before they sleep (a chunk is ~1 ms of work) ----
@@ -47,7 +43,7 @@ public:
 		{ std::lock_guard<std::mutex> g(mu_); gen_.fetch_add(1, std::memory_order_release); }
 		cv_.notify_all();
 		f(0);
-		for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++) { if (spin > 2000) std::this_thread::yield(); }
+		for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; spin++) { if (spin > 2000) std::this_thread::yield(); else __builtin_ia32_pause(); }
 	}
 private:
 	void worker(int id)
@@ -55,7 +51,7 @@ private:
 		uint64_t seen = 0;
 		for (;;) {
 			uint64_t g = gen_.load(std::memory_order_acquire);
-			for (int spin = 0; g == seen && spin < 20000; spin++) g = gen_.load(std::memory_order_acquire);
+			for (int spin = 0; g == seen && spin < 4000; spin++) { g = gen_.load(std::memory_order_acquire); __builtin_ia32_pause(); }
 			if (g == seen) {
 				std::unique_lock<std::mutex> lk(mu_);
 				cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
@@ -77,110 +73,46 @@ private:
 	bool stop_ = false;
 };
 
-// ---- text helpers ------------------------------------------------------------------------------------------------------------
-inline uint64_t count_newlines(const uint8_t *p, uint64_t n)
-{
-	uint64_t c = 0, i = 0;
-	const __m128i nl = _mm_set1_epi8('\n');
-	for (; i + 64 <= n; i += 64) {
-		const unsigned m0 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i)), nl));
-		const unsigned m1 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 16)), nl));
-		const unsigned m2 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 32)), nl));
-		const unsigned m3 = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i *)(p + i + 48)), nl));
-		c += (uint64_t)__builtin_popcountll((uint64_t)m0 | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32) | ((uint64_t)m3 << 48));
-	}
-	for (; i < n; i++) c += p[i] == '\n';
-	return c;
-}
-
-// 8 ASCII bases (little-endian in v) -> 16 bits, base 0 in bits 0-1 (encode_kmer, util.c:89-111: A0 C1 G2 T3, either case);
-// `bad` collects a non-zero value when a byte is not one of ACGTacgt
-inline uint32_t pack8(uint64_t v, uint64_t &bad)
-{
-	const uint64_t K01 = 0x0101010101010101ull, K7F = 0x7F7F7F7F7F7F7F7Full;
-	const uint64_t u = v & 0xDFDFDFDFDFDFDFDFull;
-	auto eq = [&](uint64_t c) { const uint64_t z = u ^ (c * K01); return ~(((z & K7F) + K7F) | z | K7F); };   // 0x80 in each byte equal to c
-	bad |= (eq(0x41) | eq(0x43) | eq(0x47) | eq(0x54)) ^ 0x8080808080808080ull;
-	uint64_t x = (v >> 1) & 0x0303030303030303ull;     // A0 C1 G3 T2
-	x ^= (x >> 1) & K01;                               // A0 C1 G2 T3
-	x = (x | (x >> 6)) & 0x000F000F000F000Full;
-	x = (x | (x >> 12)) & 0x000000FF000000FFull;
-	x = (x | (x >> 24)) & 0xFFFFull;
-	return (uint32_t)x;
-}
-inline uint64_t pack32(const uint8_t *p, uint64_t &bad)
-{
-	uint64_t w[4];
-	memcpy(w, p, 32);
-	return (uint64_t)pack8(w[0], bad) | ((uint64_t)pack8(w[1], bad) << 16) | ((uint64_t)pack8(w[2], bad) << 32) | ((uint64_t)pack8(w[3], bad) << 48);
-}
-// the FIRST offending character in the reference's scan order decides (chunk 0 .. n-1, each from base 31 down to 0):
-// N / n -> the read is skipped (qv.cc:815-828), anything else -> assert(0) (util.c:103)
-inline uint64_t classify_bad(const uint8_t *p, uint32_t n)
-{
-	for (uint32_t c = 0; c < n; c++)
-		for (int j = 31; j >= 0; j--) {
-			const uint8_t ch = p[32 * c + j] & 0xDF;
-			if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') continue;
-			return ch == 'N' ? META_SKIP_N : META_INVALID;
-		}
-	return 0;
-}
-
-struct alignas(128) Out {                   // what one thread framed (its own cache lines: the vectors' end pointers move with every record)
-	std::vector<uint64_t> kmers, meta;
-	std::vector<uint8_t> nch;
-	uint64_t n_invalid = 0;
-	uint64_t last_rec = 0;                 // start (in the aligned text) of the last record framed here
-	uint64_t stop_at = ~0ull;              // start of a record this thread found incomplete (the tail begins there)
-	bool bad = false;
-	void clear() { kmers.clear(); meta.clear(); nch.clear(); n_invalid = 0; last_rec = 0; stop_at = ~0ull; bad = false; }
-};
-
-enum Framed { REC_OK, REC_INCOMPLETE, REC_BAD };
-
-// the record starting at a[r]: its four newlines (each line at most MAX_LINE characters, newline included), then its packed form
-inline Framed frame_record(const uint8_t *a, uint64_t N, uint64_t r, uint64_t &next, Out &o)
-{
-	uint64_t e[4], pos = r;
-	for (int l = 0; l < 4; l++) {
-		const uint64_t room = N - pos, lim = room < MAX_LINE ? room : MAX_LINE;
-		const uint8_t *q = lim ? (const uint8_t *)memchr(a + pos, '\n', (size_t)lim) : nullptr;
-		if (!q) return room >= MAX_LINE ? REC_BAD : REC_INCOMPLETE;      // 1023 characters without a newline: beyond one fgets(); fewer: the text ends inside the record
-		e[l] = (uint64_t)(q - a);
-		pos = e[l] + 1;
-	}
-	next = pos;
-	const uint64_t s1 = e[0] + 1, s3 = e[2] + 1;
-	const uint64_t len = e[1] - s1, qlen = e[3] - s3;          // without their newlines
-	const uint32_t n = (uint32_t)(len >> 5);                   // qv.cc:778-779: ((strlen(read) - 1) / 32) chunks
-	if (qlen < n) return REC_BAD;                              // qual[c] would show the reference's stale buffer (qv.cc:836): host reader
-	uint64_t bad = 0, meta = 0;
-	for (uint32_t c = 0; c < n; c++) o.kmers.push_back(pack32(a + s1 + 32 * c, bad));
-	for (uint32_t c = 0; c < n; c++) if ((int)(int8_t)a[s3 + c] - '8' < 0) meta |= 1ull << c;     // n <= 31: a line holds at most 1022 bases
-	if (bad) { meta |= classify_bad(a + s1, n); if (meta & META_INVALID) o.n_invalid++; }
-	o.meta.push_back(meta);
-	o.nch.push_back((uint8_t)n);
-	o.last_rec = r;
-	return REC_OK;
-}
-
 }  // namespace
+
+// the baseline build of the hot loops lives in this file
+#define VGP_NS base
+#include "vg_hostpack_impl.inc"
+#undef VGP_NS
+static Framed frame_record_base(const uint8_t *a, uint64_t N, uint64_t r, uint64_t *next, Out &o) { return base::frame_record(a, N, r, *next, o); }
+const Kernels &kernels_base()
+{
+	static const Kernels k{base::count_newlines, base::frame_piece, base::frame_piece_guess, frame_record_base, "sse"};
+	return k;
+}
+static const Kernels &pick_kernels()
+{
+	__builtin_cpu_init();
+	const char *e = getenv("VG_PACK_ISA");                      // "sse": the baseline build whatever the CPU (tests compare the two)
+	if (e && !strcmp(e, "sse")) return kernels_base();
+	return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") ? kernels_avx2() : kernels_base();
+}
 
 struct Packer::Impl {
 	Pool pool;
+	const Kernels &K;
 	std::vector<Out> outs;                 // one per thread
 	Out head;                              // the record put together from the carried bytes
 	std::vector<uint8_t> carry, tmp;
 	std::vector<uint64_t> starts, r0, c0;  // per piece: owned line starts; prefix sums of reads / chunks
+	std::vector<uint64_t> gs, ge;          // per piece: where its guessed framing began / ended
+	uint64_t two_sweep_blocks = 0;         // blocks whose guesses did not line up (framed the exact way)
 	uint64_t stream_pos = 0, n_records = 0, n_consumed = 0, last_record = 0;
 	bool poison = false;
-	explicit Impl(int t) : pool(t), outs((size_t)(t < 1 ? 1 : t)) {}
+	explicit Impl(int t) : pool(t), K(pick_kernels()), outs((size_t)(t < 1 ? 1 : t)) {}
+	// one block: the complete records of carry + text[0, nbytes), placed at reads R0.. / chunks C0.. of the staging arrays
+	bool block(const uint8_t *text, uint64_t nbytes, const Staging &out, uint64_t R0, uint64_t C0, ChunkResult &res);
 };
 
 Packer::Packer(int threads) : p(new Impl(threads)) {}
 Packer::~Packer() { delete p; }
 int Packer::threads() const { return p->pool.size(); }
+const char *Packer::isa() const { return p->K.name; }
 uint64_t Packer::records() const { return p->n_records; }
 uint64_t Packer::consumed() const { return p->n_consumed; }
 uint64_t Packer::last_record_start() const { return p->last_record; }
@@ -193,14 +125,31 @@ void Packer::begin()
 	p->poison = false;
 }
 
+// A chunk goes through in BLOCKS of threads x 512 KiB, one piece per thread (should a block need the exact two sweeps, a piece
+// stays in its thread's L2 in between).  A block the framing rules refuse poisons
+// the stream from its first byte on; the records of the blocks before it stay framed (the host reader takes over at `consumed`).
 ChunkResult Packer::push(const uint8_t *text, uint64_t nbytes, const Staging &out)
 {
 	Impl &s = *p;
 	ChunkResult res;
 	if (s.poison) { res.refused = true; return res; }
-	auto refuse = [&]() { s.poison = true; res = ChunkResult(); res.refused = true; return res; };
+	const uint64_t BLOCK = (uint64_t)s.pool.size() << 19;
+	for (uint64_t o = 0; o < nbytes && !s.poison; o += BLOCK) {
+		const uint64_t len = nbytes - o < BLOCK ? nbytes - o : BLOCK;
+		ChunkResult r;
+		if (!s.block(text + o, len, out, res.n_reads, res.n_chunks, r)) { s.poison = true; break; }
+		res.n_reads += r.n_reads; res.n_chunks += r.n_chunks; res.n_invalid += r.n_invalid;
+	}
+	out.offsets[res.n_reads] = 32 * res.n_chunks;
+	res.refused = s.poison;
+	return res;
+}
+
+bool Packer::Impl::block(const uint8_t *text, uint64_t nbytes, const Staging &out, uint64_t R0, uint64_t C0, ChunkResult &res)
+{
+	Impl &s = *this;
 	const uint64_t carry_len = s.carry.size();
-	// ---- the record that began in an earlier chunk
+	// ---- the record that began in an earlier block
 	uint64_t head_len = 0;                                      // bytes of `text` that complete it
 	s.head.clear();
 	bool have_head = false;
@@ -208,15 +157,15 @@ ChunkResult Packer::push(const uint8_t *text, uint64_t nbytes, const Staging &ou
 		const uint64_t take = nbytes < 4 * (MAX_LINE + 1) ? nbytes : 4 * (MAX_LINE + 1);
 		s.tmp.assign(s.carry.begin(), s.carry.end());
 		s.tmp.insert(s.tmp.end(), text, text + take);
+		s.tmp.resize(s.tmp.size() + 64, 0);                     // (the vector compares read whole words: slack behind the text)
 		uint64_t next = 0;
-		const Framed f = frame_record(s.tmp.data(), s.tmp.size(), 0, next, s.head);
-		if (f == REC_BAD) return refuse();
+		const Framed f = s.K.frame_record(s.tmp.data(), carry_len + take, 0, &next, s.head);
+		if (f == REC_BAD) return false;
 		if (f == REC_INCOMPLETE) {
-			if (take < nbytes) return refuse();                 // four lines do not fit 4 x 1024 bytes: a line beyond fgets' reach
+			if (take < nbytes) return false;                    // four lines do not fit 4 x 1024 bytes: a line beyond fgets' reach
 			s.carry.insert(s.carry.end(), text, text + nbytes); // still unfinished: keep collecting
 			s.stream_pos += nbytes;
-			if (s.carry.size() > MAX_CARRY) return refuse();
-			return res;
+			return s.carry.size() <= MAX_CARRY;
 		}
 		head_len = next - carry_len;
 		have_head = true;
@@ -229,84 +178,81 @@ ChunkResult Packer::push(const uint8_t *text, uint64_t nbytes, const Staging &ou
 	if (np > T) np = T;
 	if (np < 1) np = 1;
 	s.starts.assign((size_t)np + 1, 0);
+	s.gs.assign((size_t)np, 0); s.ge.assign((size_t)np, 0);
 	auto bound = [&](int i) { return (uint64_t)i * N / (uint64_t)np; };
-	// sweep 1: line starts owned by every piece (a line start at q is owned by the piece holding q; q = 0 belongs to piece 0)
-	s.pool.run([&](int t) {
-		for (int i = t; i < np; i += T) {
-			const uint64_t b0 = bound(i), b1 = bound(i + 1);
-			const uint64_t lo = b0 ? b0 - 1 : 0, hi = b1 ? b1 - 1 : 0;       // newlines at [lo, hi) open the line starts in [b0, b1) (b0 = 0: but for the start itself)
-			s.starts[(size_t)i + 1] = (i == 0 ? 1u : 0u) + (hi > lo ? count_newlines(a + lo, hi - lo) : 0);
+	// ONE sweep: every piece guesses where its first record starts and frames on from there; the guesses are then checked against
+	// each other -- piece t must have begun exactly where the pieces before it ended (or framed nothing when they reach past it),
+	// which by induction from piece 0 (it starts at a record start by construction) makes the framing the sequential one
+	bool exact = getenv("VG_PACK_TWO_SWEEPS") != nullptr;
+	if (!exact) {
+		s.pool.run([&](int t) {
+			Out &o = s.outs[(size_t)t];
+			o.clear();
+			if (t >= np || N == 0) return;
+			s.K.frame_piece_guess(a, N, bound(t), bound(t + 1), t == 0, o, s.gs[(size_t)t], s.ge[(size_t)t]);
+		});
+		uint64_t cur = N ? s.ge[0] : 0;                             // where the next record starts, as far as the pieces checked so far go
+		bool stopped = N == 0 || s.outs[0].stop_at != ~0ull || s.outs[0].bad;
+		for (int t = 1; t < np && !exact; t++) {
+			const Out &o = s.outs[(size_t)t];
+			const bool owns = !stopped && cur < bound(t + 1);         // the sequential framing has a record start inside this piece
+			if (owns) {
+				if (s.gs[(size_t)t] != cur) exact = true;              // a wrong guess: count lines instead
+				else { cur = s.ge[(size_t)t]; stopped = o.stop_at != ~0ull || o.bad; }
+			} else if (o.rn != 0 || o.bad) exact = true;               // it framed something the sequential framing does not start here
 		}
-	});
-	for (int i = 0; i < np; i++) s.starts[(size_t)i + 1] += s.starts[(size_t)i];
-	// sweep 2: every piece frames the records that start in it
-	s.pool.run([&](int t) {
-		Out &o = s.outs[(size_t)t];
-		o.clear();
-		if (t >= np || N == 0) return;
-		// (np <= T: piece t is thread t's)
-		const uint64_t b0 = bound(t), b1 = bound(t + 1);
-		const uint64_t g0 = s.starts[(size_t)t];                // stream-wide number (within this aligned text) of the first line start owned here
-		uint64_t skip = (4 - (g0 & 3)) & 3;                     // owned line starts to pass before one that opens a record
-		uint64_t r;
-		if (t == 0) r = 0;
-		else {
-			// owned line starts = positions after the newlines at [b0 - 1, b1 - 1)
-			uint64_t pos = b0 - 1;
-			r = ~0ull;
-			while (pos < b1 - 1) {
-				const uint8_t *q = (const uint8_t *)memchr(a + pos, '\n', (size_t)(b1 - 1 - pos));
-				if (!q) break;
-				const uint64_t at = (uint64_t)(q - a) + 1;        // a line start in [b0, b1)
-				if (skip == 0) { r = at; break; }
-				skip--;
-				pos = at;
-			}
-			if (r == ~0ull) return;                             // no record starts in this piece
-		}
-		while (r < b1 && r < N) {
-			uint64_t next = 0;
-			const Framed f = frame_record(a, N, r, next, o);
-			if (f == REC_BAD) { o.bad = true; return; }
-			if (f == REC_INCOMPLETE) { o.stop_at = r; return; }
-			r = next;
-		}
-	});
+	}
+	if (exact) {
+		// the exact way: sweep 1 counts the line starts of every piece, a prefix sum numbers them, sweep 2 frames from the first line
+		// start whose number is a multiple of four
+		s.pool.run([&](int t) {
+			if (t >= np) return;
+			const uint64_t b0 = bound(t), b1 = bound(t + 1);
+			const uint64_t lo = b0 ? b0 - 1 : 0, hi = b1 ? b1 - 1 : 0;          // newlines at [lo, hi) open the line starts in [b0, b1) (b0 = 0: but for the start itself)
+			s.starts[(size_t)t + 1] = (t == 0 ? 1u : 0u) + (hi > lo ? s.K.count_newlines(a + lo, hi - lo) : 0);
+		});
+		for (int i = 0; i < np; i++) s.starts[(size_t)i + 1] += s.starts[(size_t)i];
+		s.pool.run([&](int t) {
+			Out &o = s.outs[(size_t)t];
+			o.clear();
+			if (t >= np || N == 0) return;
+			s.K.frame_piece(a, N, bound(t), bound(t + 1), s.starts[(size_t)t], t == 0, o);
+		});
+		s.two_sweep_blocks++;
+	}
 	uint64_t tail = N;                                          // where the unfinished last record begins (N: the text ends with a complete record)
 	for (int t = 0; t < np; t++) {
 		const Out &o = s.outs[(size_t)t];
-		if (o.bad) return refuse();
+		if (o.bad) return false;
 		if (o.stop_at < tail) tail = o.stop_at;
 	}
-	if (N - tail > MAX_CARRY) return refuse();
+	if (N - tail > MAX_CARRY) return false;
 	// ---- totals, then every thread copies its part to its place
 	s.r0.assign((size_t)np + 1, 0); s.c0.assign((size_t)np + 1, 0);
-	const uint64_t hr = have_head ? s.head.meta.size() : 0, hc = have_head ? s.head.kmers.size() : 0;
-	s.r0[0] = hr; s.c0[0] = hc;
-	for (int t = 0; t < np; t++) { s.r0[(size_t)t + 1] = s.r0[(size_t)t] + s.outs[(size_t)t].meta.size(); s.c0[(size_t)t + 1] = s.c0[(size_t)t] + s.outs[(size_t)t].kmers.size(); }
-	const uint64_t R = s.r0[(size_t)np], C = s.c0[(size_t)np];
-	if (R + 1 > out.reads_cap || C > out.kmers_cap) return refuse();     // lines of fewer than 8 bytes on average: not this path's business
+	s.r0[0] = R0 + (have_head ? s.head.rn : 0); s.c0[0] = C0 + (have_head ? s.head.kn : 0);
+	for (int t = 0; t < np; t++) { s.r0[(size_t)t + 1] = s.r0[(size_t)t] + s.outs[(size_t)t].rn; s.c0[(size_t)t + 1] = s.c0[(size_t)t] + s.outs[(size_t)t].kn; }
+	const uint64_t R1 = s.r0[(size_t)np], C1 = s.c0[(size_t)np];
+	if (R1 + 1 > out.reads_cap || C1 > out.kmers_cap) return false;      // lines of fewer than 8 bytes on average: not this path's business
 	auto place = [&](const Out &o, uint64_t rr, uint64_t cc) {
-		if (!o.kmers.empty()) memcpy(out.kmers + cc, o.kmers.data(), o.kmers.size() * 8);
-		if (!o.meta.empty()) memcpy(out.meta + rr, o.meta.data(), o.meta.size() * 8);
+		if (o.kn) memcpy(out.kmers + cc, o.kmers, o.kn * 8);
+		if (o.rn) memcpy(out.meta + rr, o.meta, o.rn * 8);
 		uint64_t c = cc;
-		for (size_t k = 0; k < o.nch.size(); k++) { out.offsets[rr + k] = 32 * c; c += o.nch[k]; }
+		for (uint64_t k = 0; k < o.rn; k++) { out.offsets[rr + k] = 32 * c; c += o.nch[k]; }
 	};
-	if (have_head) place(s.head, 0, 0);
+	if (have_head) place(s.head, R0, C0);
 	s.pool.run([&](int t) { if (t < np) place(s.outs[(size_t)t], s.r0[(size_t)t], s.c0[(size_t)t]); });
-	out.offsets[R] = 32 * C;
-	res.n_reads = R; res.n_chunks = C;
+	res.n_reads = R1 - R0; res.n_chunks = C1 - C0;
 	res.n_invalid = have_head ? s.head.n_invalid : 0;
 	uint64_t last_in_a = ~0ull;
-	for (int t = 0; t < np; t++) { res.n_invalid += s.outs[(size_t)t].n_invalid; if (!s.outs[(size_t)t].meta.empty()) last_in_a = s.outs[(size_t)t].last_rec; }
+	for (int t = 0; t < np; t++) { res.n_invalid += s.outs[(size_t)t].n_invalid; if (s.outs[(size_t)t].rn) last_in_a = s.outs[(size_t)t].last_rec; }
 	// ---- stream state
 	if (last_in_a != ~0ull) s.last_record = s.stream_pos + head_len + last_in_a;
 	else if (have_head) s.last_record = s.stream_pos - carry_len;
 	s.carry.assign(a + tail, a + N);
 	s.stream_pos += nbytes;
 	s.n_consumed = s.stream_pos - s.carry.size();
-	s.n_records += R;
-	return res;
+	s.n_records += res.n_reads;
+	return true;
 }
 
 }  // namespace vgp

@@ -35,6 +35,7 @@ public:
 	Packer(const Packer &) = delete;
 	Packer &operator=(const Packer &) = delete;
 	int threads() const;
+	const char *isa() const;                                   // which build of the hot loops this CPU gets ("avx2+bmi2" / "sse")
 	void begin();                                              // a new stream
 	// worst-case sizes of the staging buffers for a chunk of nbytes (lines of at least 8 bytes on average, like the device framing)
 	static uint64_t reads_cap(uint64_t nbytes) { return nbytes / 32 + 64; }

@@ -81,6 +81,10 @@ constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is 
 #define VG_SEC_W 8
 #endif
 constexpr int SEC_W = VG_SEC_W;   // entries of an LO32-view bucket fetched in one go (buckets average 1-3 entries; hg38: 2.7)
+#ifndef VG_SEC_LONG
+#define VG_SEC_LONG 256
+#endif
+constexpr uint32_t SEC_LONG = VG_SEC_LONG;   // a longer bucket, up to this many entries, is dealt to the lanes record by record in stage B1
 constexpr int PCAP = 32;         // rows of the stage-B pair table (a wave with more gate-open chunks takes several windows)
 constexpr int HCAP = 4;          // high-half reference hits per pair kept from the LO32-ordered view (more: the 48 queries are issued)
 
@@ -210,7 +214,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	bool active = false;
 #ifdef VG_STAGE_CLOCKS
 	long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-	uint32_t iters = 0;
+	uint32_t iters = 0, dbg_pairs = 0, dbg_items = 0, dbg_rounds = 0, dbg_dq = 0, dbg_rows = 0, dbg_large = 0, dbg_secbad = 0;
 #endif
 	uint32_t rid = 0, n = 0, gates = 0, pass = 0;
 	uint32_t slot0 = 0;                                  // first k-mer slot of the read (a batch holds < 2^37 bases: checked on the host)
@@ -384,17 +388,53 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				} else if (dup) { VG_OVF(2); ovf = true; }
 			};
 			auto push_row = [&](const uint32_t *row, uint32_t c) {               // a row ends at its first 0
-				// the whole row in one wait; one push site, the column picked by selects (unrolled copies of the key search cost more
-				// registers than the row)
+				// The whole row in one wait.  Then the row against the key table AS A BLOCK: the rows of a read's consecutive chunks list the
+				// same copies of a repeat in the same order (positions 32 apart), so once column 0 has found its key at slot s, column j
+				// is expected at slot s + j -- ten LDS reads in one round trip, one mask update each -- and the first row of a pass
+				// (empty table: a row's positions are distinct, hence its keys) is appended without a search.  What does not line up
+				// (diverged copies) takes the one-by-one path.  r03 / the first key-table build pushed 4 x 10 contexts one by one,
+				// each a search of the table: a third of the kernel's time on the repeat-rich genome (profiles/ab_chr22_repeats30_r04.txt).
 #ifdef VG_DBG_NO_ROWS
 				return;                                                 // timing experiment only (wrong results): what do the rows cost?
 #endif
 				uint32_t rw[AUX_COLS];
 				load_row10(row, rw);
+				uint32_t todo = 0;                                      // columns left to the one-by-one path
+				if (!ovf) {
+					uint32_t r = 0;
+					#pragma unroll
+					for (int j = 0; j < AUX_COLS; j++) if (r == (uint32_t)j && rw[j] != 0) r = (uint32_t)j + 1u;      // live columns
+					cur.add(S_CTX, r);
+					const uint32_t bit = 1u << c, back = 32u * c;
+					if (kcnt == 0 && r <= (uint32_t)W_ECAP) {
+						#pragma unroll
+						for (int j = 0; j < AUX_COLS; j++) if ((uint32_t)j < r) { K_idx[j][col] = rw[j] - back; K_mask[j][col] = (kmask_t)bit; }
+						kcnt = r; hint = 0;
+					} else if (r) {
+						bool dup = false;
+						const uint32_t s0 = key_find(rw[0] - back, c, 0u, kcnt, dup);
+						if (dup) { VG_OVF(2); ovf = true; }
+						else if (s0 == (uint32_t)W_ECAP) todo = (1u << r) - 1u;      // column 0 is new: no anchor
+						else {
+							uint32_t kv[AUX_COLS], km[AUX_COLS];
+							#pragma unroll
+							for (int j = 1; j < AUX_COLS; j++) { const uint32_t e = s0 + (uint32_t)j < (uint32_t)W_ECAP ? s0 + (uint32_t)j : (uint32_t)W_ECAP - 1u; kv[j] = K_idx[e][col]; km[j] = K_mask[e][col]; }
+							#pragma unroll
+							for (int j = 1; j < AUX_COLS; j++) if ((uint32_t)j < r) {
+								const uint32_t e = s0 + (uint32_t)j;
+								if (e < kcnt && kv[j] == rw[j] - back && !(km[j] & bit)) K_mask[e][col] = (kmask_t)(km[j] | bit);
+								else todo |= 1u << j;
+							}
+							hint = s0 + r < kcnt ? s0 + r : 0u;
+						}
+					}
+				}
 				#pragma nounroll
-				for (uint32_t j = 0; j < (uint32_t)AUX_COLS; j++) {
+				while (todo && !ovf) {
+					const uint32_t j = (uint32_t)__ffs((int)todo) - 1u;
+					todo &= todo - 1u;
 					const uint32_t v = j == 0 ? rw[0] : j == 1 ? rw[1] : j == 2 ? rw[2] : j == 3 ? rw[3] : j == 4 ? rw[4] : j == 5 ? rw[5] : j == 6 ? rw[6] : j == 7 ? rw[7] : j == 8 ? rw[8] : rw[9];
-					if (v == 0) break;
+					cur.add(S_CTX, (uint32_t)-1);                            // (push_exact counts it again)
 					push_exact(v, c);
 				}
 			};
@@ -678,7 +718,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						// high-half ref hits from the LO32-ordered view: every dictionary k-mer with the same first 16 bases
 						// whose last 16 differ in exactly one base, kept sorted by slot
 						uint32_t nh = 0, hu = 0, hamb = 0;                         // hu: slot of hit z in byte z (unsorted); hamb: bit z = hit z is ambiguous
-						bool sec_ok = use_sec;
+						bool sec_ok = use_sec, longsec = false;
+						uint32_t sec_b0 = 0;
 						auto sec_entry = [&](uint32_t ehi, uint32_t epos, uint32_t eamb) {   // one view entry with this LO32: HI32, position (or row), ambiguity
 							const int dd = onebase((uint64_t)(ehi ^ khi));
 							if (dd < 0) return;
@@ -698,15 +739,23 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; rec[z] = gather12(d.sec3 + 3ull * e); }
 								#pragma unroll
 								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) if (b0 + z < b1 && ((rec[z].z ^ klo) & 0x7FFFFFFFu) == 0u) { fl |= 1u; sec_entry(rec[z].x, rec[z].y, rec[z].z >> 31); }
+							} else if (b1 - b0 <= SEC_LONG) {
+								// A longer bucket -- a popular first half: the diverged copies of a repeat family -- is dealt to the lanes of stage B1
+								// RECORD BY RECORD (r04): adjacent lanes read adjacent 12-byte records, one wait, no search, and a record that is a
+								// neighbour carries its position.  r03 turned such a chunk into 48 dictionary queries of three dependent gathers
+								// each: 7 % of the gate-open chunks of the repeat-rich genome made half of its stage-B items that way.
+								longsec = true;
+								sec_b0 = b0;
 							} else {
-								// A longer bucket keeps its 48 queries, dealt to 48 lanes in stage B1: walking a popular LO32's run of entries here
-								// (bisection + up to a dozen dependent loads) made one lane hold up its wave -- 4 % of the kernel at hg38 scale.
+								// beyond that the 48 queries stay (walking the run here -- bisection + dependent loads -- made one lane hold up its
+								// wave: 4 % of the kernel at hg38 scale, r02)
 								sec_ok = false;
 								if (bf_from_sec) { if ((gather_bf<uint64_t>(d.ref_bf + (rp >> 6)) >> (rp & 63)) & 1u) fl |= 1u; }   // (and its bit is read after all)
 							}
 						}
 						uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
-						if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
+						if (longsec) { u_lo = s_lo; nhigh = (b1 - b0) + (s_hi - s_lo); hu = b1 - b0; }      // the bucket's records, then the live SNP slots
+						else if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
 						else if (sec_ok && s_hi == s_lo) { mode = 1; nhigh = nh; }
 						else { u_lo = 0; nhigh = 48; }
 						// items of the strided scans: one per reference-bucket entry; SNP-bucket entries eight per item (their signatures lie
@@ -715,8 +764,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						const uint32_t Lsn = shi - slo;
 						const uint32_t L = large ? 48u : (hi - lo) + ((Lsn + sw_m1) >> sw_log);
 						P_klo[p][wv] = klo; P_khi[p][wv] = khi; P_lo[p][wv] = lo; P_hi[p][wv] = hi; P_slo[p][wv] = slo; P_shi[p][wv] = shi;
-						P_meta[p][wv] = own | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | (nhigh << 25);
+						P_meta[p][wv] = own | (c << 6) | (fl << 11) | ((large ? 1u : 0u) << 13) | (mode << 14) | ((sec_ok ? 1u : 0u) << 15) | (nh << 16) | (u_lo << 19) | ((nhigh < 63u ? nhigh : 63u) << 25) | ((longsec ? 1u : 0u) << 31);
 						P_cnt[p][wv] = L + nhigh;
+						if (longsec) P_hidx[0][p][wv] = sec_b0;
 						P_hu[p][wv] = hu;
 						P_hamb[p][wv] = (uint8_t)hamb;
 					}
@@ -774,9 +824,16 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					return v;
 				};
 				uint4 scan_cur = scan_probe(lane);
+#ifdef VG_STAGE_CLOCKS
+				dbg_pairs += np; dbg_items += T;
+				{ uint32_t lg = 0, sb = 0; if (lane < np) { const uint32_t mt = P_meta[lane][wv]; lg = (mt >> 13) & 1u; sb = ((mt >> 11) & 1u) && !((mt >> 15) & 1u) ? 1u : 0u; } dbg_large += wave_sum<false>(lg); dbg_secbad += wave_sum<false>(sb); }
+#endif
 				for (uint32_t t0 = 0; t0 < T; t0 += 64) {
 					const uint32_t g = t0 + lane;
 					const bool valid = g < T;
+#ifdef VG_STAGE_CLOCKS
+					dbg_rounds++;
+#endif
 					const uint4 scan_next = scan_probe(g + 64u);
 					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
 					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
@@ -848,9 +905,24 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								}
 							}
 						} else {                                                 // qv.cc:1213-1365
-							const uint32_t h = t - L;
+							uint32_t h = t - L;
 							uint32_t u;
-							bool have_ri = false;
+							bool have_ri = false, slot_item = true;
+							const bool longsec = (meta >> 31) != 0u;
+							if (longsec) {
+								const uint32_t S = P_hu[p][wv];
+								if (h < S) {
+									// one record of the chunk's LO32 bucket: a dictionary k-mer with the chunk's first half whose last half differs in
+									// exactly one base is a high-half neighbour (qv.cc:1213-1296), and the record carries its position
+									slot_item = false;
+									const uint3 rec = gather12(d.sec3 + 3ull * ((uint64_t)P_hidx[0][p][wv] + h));
+									if (((rec.z ^ klo) & 0x7FFFFFFFu) == 0u && (bf_from_sec || (fl & 1u))) {
+										const int dd = onebase((uint64_t)(rec.x ^ khi));
+										if (dd >= 0) { ri = rec.y; rdirect = 1u | ((rec.z >> 31) << 1); mod = 16u + (uint32_t)dd; nbase = (rec.x >> (2 * dd)) & 3u; }
+									}
+								} else h -= S;
+							}
+							if (slot_item) {
 							if (mode == 1) {                                     // the h-th hit in slot order
 								const uint32_t hu = P_hu[p][wv];
 								uint32_t zsel = 0;
@@ -869,12 +941,16 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							nbase = sel + (sel >= base ? 1u : 0u);
 							mod = pair;
 							qk = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
-							if (!have_ri && 2 * pair < rsb) {
+							if (!have_ri && !longsec && 2 * pair < rsb) {
 								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) if (((hu >> (8 * z)) & 0xFFu) == u) { ri = P_hidx[z < (uint32_t)HCAP ? z : 0][p][wv]; rdirect = 1u | (((uint32_t)P_hamb[p][wv] >> z) & 1u) << 1; } }
 								else q_r = true;
 							}
 							q_s = (large || 2 * pair >= 40u) && 2 * pair < ssb;
+							}
 						}
+#ifdef VG_STAGE_CLOCKS
+						dbg_dq += (q_r || q_s) ? 1u : 0u;
+#endif
 						if (q_r || q_s) dual_query(d, hs, qk, q_r, q_s, ri, si);
 					}
 					// is `position` one of the owner's vote keys (the implied read position of one of its exact hits)?
@@ -1143,6 +1219,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 		VG_CLK(5);
 	}
 #ifdef VG_STAGE_CLOCKS
+	{ const uint32_t dq = wave_sum<false>(dbg_dq); if (!STATS && lane == 0 && (blockIdx.x % 97u) == 0 && wv == 0) printf("DBG blk %u iters %u pairs %u items %u rounds %u dualq %u large %u secbad %u\n", blockIdx.x, iters, dbg_pairs, dbg_items, dbg_rounds, dq, dbg_large, dbg_secbad); }
 	if (!STATS && lane == 0 && (blockIdx.x % 97u) == 0 && wv == 0)
 		printf("CLK blk %u iters %u refill %lld A %lld B0 %lld B1 %lld vote %lld walk %lld wload %lld wloop %lld watom %lld Akmer %lld Adx %lld Ascan %lld ecap %d\n", blockIdx.x, iters, clk[0], clk[1], clk[2], clk[3], clk[4], clk[5], clk[6], clk[7], clk[8], clk[9], clk[10], clk[11], W_ECAP);
 #endif
