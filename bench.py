@@ -309,6 +309,11 @@ def measure_ingest(gx, batch, log, reps=3):
     out = dict(ok[best])
     out["chosen"] = best
     out["host_threads_available"] = os.cpu_count()
+    try:                                                          # a container's CPU quota bounds the host-packing path (cgroup v2 cpu.max: "<quota> <period>")
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        out["host_cpu_quota"] = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:
+        out["host_cpu_quota"] = None
     out["paths"] = paths
     return out
 

@@ -101,7 +101,12 @@ with GenoIndex.open(prefix, device=dev) as gx:
     gx.set_stats(False)
     for _ in range(times):
         gx.submit(sub.bases, sub.quals, sub.offsets)
+    gx.sync()
+    import time
+    t0 = time.perf_counter()
     all_reduce_counts(gx)
+    # (so that the first run on a box with two GPUs explains itself: what the exchange moved, how long it took, over what)
+    print("rank %d of %d on cuda:%d, backend %s: all-reduce of %d bytes in %.3f ms" % (rank, dist.get_world_size(), dev, backend, gx.counts_tensor().numel() * 4, 1e3 * (time.perf_counter() - t0)), flush=True)
     rc, ac = gx.counts()
     raw = gx.counts_tensor().clone().cpu().numpy()
 np.savez(os.path.join(out, "rank%d.npz" % rank), rc=rc, ac=ac, raw=raw)
@@ -121,6 +126,8 @@ def _run_ranks(tmp_path, prefix, backend, times):
         env.pop(k, None)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-4000:]
+    print(p.stdout[-1500:])
+    assert p.stdout.count("all-reduce of") == 2
     return [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(2)]
 
 
@@ -156,6 +163,8 @@ def test_bench_starts_its_own_ranks(tmp_path):
     v = line["multi_gpu_verification"]
     assert v["sharded_equals_single_rank"] and v["increments"] > 0 and v["timed_region_increments"] > 0
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    pr = line["multi_gpu_per_rank"]                                      # what every rank saw: a scaling run explains itself
+    assert len(pr["kernel_ms"]) == 2 and len(pr["all_reduce_ms"]) == 2 and pr["all_reduce_bytes"] > 0 and pr["ranks_seen_by_the_collective"] == 2
 
 
 def test_allreduce_with_the_callers_own_communicator(ftiny_dir, ftiny_reads):

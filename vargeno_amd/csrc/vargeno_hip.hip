@@ -1358,7 +1358,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
-	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 8, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
+	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 16, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
 	if ((rc = dev_alloc(ix, &ix->d_cum, 8, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_clamped, 2 * ix->n_sites + 2))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true))) return rc;
@@ -1639,7 +1639,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 			HIP_TRY(hipEventRecord(sl.e_in, produced_on));
 			HIP_TRY(hipStreamWaitEvent(ps, sl.e_in, 0));
 		}
-		HIP_TRY(hipMemsetAsync(ctr, 0, 32, ps));
+		HIP_TRY(hipMemsetAsync(ctr, 0, 64, ps));
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
 		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T - 1) / PACK_T, (uint64_t)ix->cus * pack_bpc * (256 / PACK_T));
@@ -1898,7 +1898,10 @@ static int host_pack_threads_default()
 {
 	if (const char *e = getenv("VG_PACK_THREADS")) return std::max(0, atoi(e));
 	const unsigned c = usable_cpus();
-	return c >= 8 ? (int)std::min(c - 1, 96u) : 0;             // (one CPU stays with the thread that feeds the device) few CPUs: the device-side framing is the faster path
+	// (three CPUs stay with the thread that feeds the device and the runtime's own threads: a process that asks for more CPU time than
+	// its quota is stopped for the rest of the 100 ms period, which costs more than the threads bring)  Few CPUs: the device-side
+	// framing is the faster path.
+	return c >= 8 ? (int)std::min(c - 3, 96u) : 0;
 }
 
 extern "C" int vg_fastq_stream_begin_packed(vg_index *ix, int host_threads)
