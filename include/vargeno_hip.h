@@ -48,12 +48,11 @@ typedef struct {
 	         refbf_pos, snpbf_pos, large_block, ref_query, snp_query, ref_probe, snp_probe,
 	         scan_ref, scan_snp, scan_oob, aux_ref, aux_snp, site_test, ctx, walks, incr,
 	         ingest_bytes;
-	uint64_t overflow_reads;     /* reads that outgrew the main wave tier's LDS lists and were redone by
-	                                the deep-list wave tier (same kernel, lists 3-12x deeper)  */
+	uint64_t overflow_reads;     /* reads that outgrew the main wave tier's LDS tables and were redone by
+	                                the deep wave tier (same kernel, tables 3-7x deeper)       */
 	uint64_t overflow_deep;      /* of those, reads that outgrew the deep lists too and went to the
 	                                generic lane tier (one read per lane, lists in HBM scratch)   */
 	uint64_t alg_bytes;          /* sum of unit cost x event count                            */
-	uint64_t overflow_third;     /* of overflow_reads, reads the second wave tier passed on to the third (r04) */
 } vg_stats;
 
 /* Kernel timing, averaged over the batches processed since the previous vg_timing_get, from HIP

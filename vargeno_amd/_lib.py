@@ -14,7 +14,7 @@ VG_ERRORS = {-1: "VG_EINVAL", -2: "VG_EIO", -3: "VG_ENOMEM", -4: "VG_ENODEV", -5
 STAT_FIELDS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chunks", "gate_open",
                "refbf_pos", "snpbf_pos", "large_block", "ref_query", "snp_query", "ref_probe", "snp_probe",
                "scan_ref", "scan_snp", "scan_oob", "aux_ref", "aux_snp", "site_test", "ctx", "walks", "incr",
-               "ingest_bytes", "overflow_reads", "overflow_deep", "alg_bytes", "overflow_third"]
+               "ingest_bytes", "overflow_reads", "overflow_deep", "alg_bytes"]
 
 # every symbol include/vargeno_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = ["vg_last_error", "vg_build_id", "vg_device_count", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_open_ex", "vg_index_plan", "vg_index_create", "vg_index_close",

@@ -440,7 +440,6 @@ __global__ void vg_clamp_counters(const uint32_t *__restrict__ cnt, uint64_t n_s
 __global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 {
 	cum[0] += ctr[0]; cum[1] += ctr[1]; cum[2] += ctr[2]; cum[3] += ctr[3];     // wave-tier overflow, lane-tier overflow, lost, reads with a non-ACGTN character
-	cum[4] += ctr[6];                                                            // reads the second wave tier passed on to the third
 }
 
 // One lane = one read: forward pass, then the reverse-complement retry (src/qv.cc:1504-1510).
@@ -677,7 +676,7 @@ struct ScratchBuf {
 // main stream while the (rare, latency-bound) lane tiers of batch k finish on the tail stream.
 constexpr int NSLOT = 3;            // (5 and 8 were measured: no gain at 8 M-read batches, 10-30 % slower at 1 M -- more pack kernels run ahead and get in the wave kernel's way)
 struct Slot {
-	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr, *listD = nullptr;  uint64_t list_cap = 0;   // spill lists: main -> second tier (A), second -> third (D), third -> lane tier (B), lost (C)
+	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr;  uint64_t list_cap = 0;   // spill lists: main -> deep tier (A), deep tier -> lane tier (B), lost (C)
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
@@ -722,7 +721,7 @@ struct vg_index {
 	int cus = 256;
 	int lane_grid_blocks = 0, wave_grid = 0;
 	uint32_t work_chunk = 128;            // reads a main-tier wave pulls from the launch's work counter at a time (VG_WORK_CHUNK)
-	uint32_t w2_chunk = 8, w2_wpc = 6;    // second tier: reads a wave pulls at a time (VG_W2_CHUNK), workgroups per CU of its grid (VG_W2_WPC)
+	uint32_t w2_chunk = 8, w2_wpc = 3;    // deep tier: reads a wave pulls at a time (VG_W2_CHUNK), workgroups per CU of its grid (VG_W2_WPC)
 	FqStream *d_fq = nullptr;             // FASTQ stream state (vg_fastq_stream_*)
 	bool fq_open = false; int fq_prev_slot = -1;
 	uint64_t max_device_bytes = 0;        // the caller's budget for this replica (vg_index_open_ex; 0: the whole device)
@@ -798,7 +797,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (ix->ingest) (void)hipStreamSynchronize(ix->ingest);
 	for (void *p : ix->owned) (void)hipFree(p);
 	for (Slot &sl : ix->slot) {
-		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.listD, sl.st_bases, sl.st_quals, sl.st_gate, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
+		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_gate, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
 		for (void *p : extra) if (p) (void)hipFree(p);
 		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5, sl.e_fq, sl.e_in};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -1658,17 +1657,16 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		if (big) vg_wave_kernel_big<W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats, fin);
 		else vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats, fin);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
-		// tail stream, second tier: the same kernel with deeper lists over the spill list (up to w2_wpc single-wave workgroups per CU)
+		// tail stream, the deep tier: the same kernel with deeper tables over the spill list (single-wave workgroups of 42 KB of LDS).
+		// ONE deep tier (r04; r03 had a 40 + 16 tier in front of it): it starts the moment the main tier's workgroups retire, while
+		// the CUs are free.  A tier enqueued behind another one found the NEXT batch's main-tier kernel on every CU and was only placed
+		// when that kernel's workgroups retired, 2.2 ms later -- the tail stream was busy for a whole step, the handle's batch slots
+		// waited for it and the main stream idled 0.2 ms per step (profiles/timeline_hg38_r04_three_tiers.txt).  With vote keys instead
+		// of context lists the deep tier has 0.005-0.3 % of the reads to do, not 10 %.
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
-		// (its workgroups hold 26 KB of LDS each while they live, in the way of the next batch's main tier: a wave takes at least
-		// w2_chunk reads at a time, so a few hundred spilled reads wake few of them)
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
-		if (big) vg_wave_kernel_big<W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listD, &ctr[6], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
-		else vg_wave_kernel<STATS, W2_ECAP, W2_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listD, &ctr[6], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
-		// third tier: the deepest LDS lists, for what the second could not hold
-		const unsigned w3grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * 2);
-		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w3grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listD, &ctr[6], sl.listB, &ctr[1], &ctr[7], 2u, ix->d_stats, nofuse);
-		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w3grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listD, &ctr[6], sl.listB, &ctr[1], &ctr[7], 2u, ix->d_stats, nofuse);
+		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
+		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream
@@ -1720,7 +1718,7 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 	if (need_k > sl.pk_kmer_cap) { if (sl.pk_kmer) (void)hipFree(sl.pk_kmer); sl.pk_kmer = nullptr; sl.pk_kmer_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_kmer, need_k * 8)); sl.pk_kmer_cap = need_k; }
 	if (need_m > sl.pk_meta_cap) { if (sl.pk_meta) (void)hipFree(sl.pk_meta); sl.pk_meta = nullptr; sl.pk_meta_cap = 0; HIP_TRY(hipMalloc((void **)&sl.pk_meta, need_m * 8)); sl.pk_meta_cap = need_m; }
 	if (n_reads > sl.list_cap) {
-		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC, &sl.listD};
+		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC};
 		sl.list_cap = 0;                                        // a failed allocation below must not leave the old size behind
 		for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; }
 		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));
@@ -1769,7 +1767,7 @@ static int launch_packed(vg_index *ix, Slot &sl, const uint64_t *kmers, const ui
 		sl.stage_reads = n_reads + 1;
 	}
 	if (n_reads > sl.list_cap) {
-		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC, &sl.listD};
+		uint32_t **lists[] = {&sl.listA, &sl.listB, &sl.listC};
 		sl.list_cap = 0;
 		for (uint32_t **l : lists) { if (*l) (void)hipFree(*l); *l = nullptr; }
 		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));
@@ -2166,7 +2164,7 @@ extern "C" int vg_stats_get(vg_index *ix, vg_stats *out)
 	out->scan_ref = h[S_SCAN_REF]; out->scan_snp = h[S_SCAN_SNP]; out->scan_oob = h[S_SCAN_OOB];
 	out->aux_ref = h[S_AUX_REF]; out->aux_snp = h[S_AUX_SNP]; out->site_test = h[S_SITE_TEST]; out->ctx = h[S_CTX];
 	out->walks = h[S_WALKS]; out->incr = h[S_INCR]; out->ingest_bytes = h[S_INGEST];
-	{ uint32_t c[8]; HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[0]; out->overflow_deep = c[1]; out->reads_invalid = c[3] + ix->host_invalid; out->overflow_third = c[4]; }
+	{ uint32_t c[8]; HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[0]; out->overflow_deep = c[1]; out->reads_invalid = c[3] + ix->host_invalid; }
 	const uint64_t scans = out->gate_open - out->large_block;
 	out->alg_bytes = out->ingest_bytes + 8 * (out->ref_query + out->snp_query) + 9 * out->ref_probe + 11 * out->snp_probe
 	               + 16 * out->gate_open + 16 * scans + 9 * out->scan_ref + 11 * out->scan_snp

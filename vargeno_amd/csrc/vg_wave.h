@@ -64,18 +64,12 @@ namespace vg {
 #define VG_W1_WPB 4
 #endif
 constexpr int W1_ECAP = VG_W1_ECAP, W1_NCAP = VG_W1_NCAP, W1_WPB = VG_W1_WPB;   // W1_WPB: waves per workgroup of the main tier
-// Second tier: 32 keys + 16 neighbour contexts per lane -- 24 KB of LDS per (single-wave) workgroup, i.e. six of them per CU
-// (measured in r03 with context lists: six workgroups of 40 + 16 against two of 48 + 48 was +22 % reads/s on a repeat-rich
-// genome, profiles/ab_hg38_repeats30_r03_tiers.txt).  Third tier: 48 + 48, for the few reads beyond that; then the generic
-// lane machine with its lists in HBM.
-#ifndef VG_W2_ECAP
-#define VG_W2_ECAP 32
-#endif
-#ifndef VG_W2_NCAP
-#define VG_W2_NCAP 16
-#endif
-constexpr int W2_ECAP = VG_W2_ECAP, W2_NCAP = VG_W2_NCAP;
-constexpr int W3_ECAP = 48, W3_NCAP = 48;
+// Deep tier: 48 keys + 40 neighbour contexts per lane, single-wave workgroups of 42 000 bytes of LDS (a workgroup of it fits where
+// ONE main-tier workgroup has retired: 38 928 + the 4 300 the four of them leave free per CU); then the generic lane machine with
+// its lists in HBM.  (r03 had a 40 + 16 tier in between, six workgroups per CU, for the 10 % of a repeat-rich genome's reads that
+// outgrew 14-context lists; with vote keys 0.3 % do, and a tier enqueued behind another one costs more than it brings -- see
+// enqueue_batch.)
+constexpr int W3_ECAP = 48, W3_NCAP = 40;
 constexpr uint32_t NOHIT = 0xFFFFFFFFu;   // "no entry": (uint32_t)-1, which is also what a failed query's -1 truncates to
 #ifndef VG_SEC_W
 #define VG_SEC_W 8
@@ -598,7 +592,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							// the auxiliary rows (k-mers with 3-10 copies) after the pair's other contexts, a reference row WHOLE in one wait: a read
 							// inside a repeat waited up to three times per chunk for its row's columns four at a time (the order in which a
 							// pass's contexts reach the key table does not matter)
-							// (with both rows of the pair in flight at once the kernel spills: 48 bytes of scratch per lane)
+							// (two or four rows in flight at once, or the rows of all four chunks collected first and pushed at the end: 48 to 1 100
+							// bytes of scratch per lane -- the register allocation of this kernel does not survive a second copy of the block match)
 							#pragma nounroll
 							for (uint32_t y = 0; y < 2; y++) if (ax_r[y] != NOHIT) push_row(d.ref_aux + (uint64_t)ax_r[y] * AUX_COLS, c + z0 + y);
 							// (an SNP k-mer with several positions is rare -- it takes an SNP inside identical copies: row by row)
