@@ -253,7 +253,7 @@ def measure_ingest(gx, batch, log, reps=3):
     """Batch 0 as FASTQ text in page-locked host memory, streamed through the library `reps` times, along both of its ingest paths:
     (a) the text itself crosses the link in 64 MiB chunks and is framed on the device (vg_fastq_stream_begin);
     (b) host threads inside the library frame and 2-bit pack 256 MiB chunks, the packed form (48 bytes per read) crosses the link
-        (vg_fastq_stream_begin_packed; the thread count is the library's choice for this host).
+        (vg_fastq_stream_begin_packed with the CPUs this process may use -- a cgroup quota counts -- less three).
     The counters of each path's first pass must equal those of the resident batch.  Returns the secondary bench number: the
     faster path's, with both listed."""
     import torch
@@ -281,8 +281,16 @@ def measure_ingest(gx, batch, log, reps=3):
     m[:, 14 + L:14 + 2 * L] = tq.cpu().numpy().reshape(n, L)
     m[:, 14 + 2 * L] = 10
     paths = {}
+    quota = None
+    try:                                                          # a container's CPU quota bounds the host-packing path (cgroup v2 cpu.max: "<quota> <period>")
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:
+        pass
+    usable = int(min(os.cpu_count() or 1, quota or 1e9))
+    pack_threads = max(2, min(usable - 3, 96))                    # (the library itself packs on the host only from 32 usable CPUs on; the leg is measured regardless)
     for name, chunk_mb, threads, what in (("device_framing", 64, None, "vg_fastq_stream_begin: the text crosses PCIe in %d MiB chunks, record framing + packing on the device"),
-                                          ("host_packing", 256, -1, "vg_fastq_stream_begin_packed: host threads inside the library frame and 2-bit pack %d MiB chunks, 48 bytes per read cross PCIe")):
+                                          ("host_packing", 256, pack_threads, "vg_fastq_stream_begin_packed: " + str(pack_threads) + " host threads inside the library frame and 2-bit pack %d MiB chunks, 48 bytes per read cross PCIe")):
         step = chunk_mb << 20
         chunks = [text[a:a + step] for a in range(0, len(text), step)]
         try:
@@ -309,11 +317,8 @@ def measure_ingest(gx, batch, log, reps=3):
     out = dict(ok[best])
     out["chosen"] = best
     out["host_threads_available"] = os.cpu_count()
-    try:                                                          # a container's CPU quota bounds the host-packing path (cgroup v2 cpu.max: "<quota> <period>")
-        q = open("/sys/fs/cgroup/cpu.max").read().split()
-        out["host_cpu_quota"] = None if q[0] == "max" else float(q[0]) / float(q[1])
-    except Exception:
-        out["host_cpu_quota"] = None
+    out["host_cpu_quota"] = quota
+    out["host_packing_threads"] = pack_threads
     out["paths"] = paths
     return out
 
@@ -646,12 +651,6 @@ def main():
             ox.close()
             ox = None
 
-    # ---- secondary number (N = 1): end to end from FASTQ text in pinned HOST memory -- H2D over PCIe, framing on the device, the
-    #      read loop -- through vg_fastq_stream_push.  Never `value`: the metric is quoted on batches resident in HBM. -------------
-    ingest = None
-    if rank == 0 and world == 1 and not args.no_ingest:
-        ingest = measure_ingest(gx, batches[0], log)
-
     # ---- N > 1: the sharded path must reproduce one rank.  Every rank takes its shard of one common stream; the all-reduced
     #      counters must equal what rank 0 gets from the whole stream alone. ---------------------------------------------------
     verification = None
@@ -816,6 +815,12 @@ def main():
             if port:
                 cpu["port"] = {k: port[k] for k in ("value", "unit", "cores", "kind", "sample")}
                 cpu["all_cores"] = port.get("all_cores")
+    # ---- secondary number (N = 1): end to end from FASTQ text in pinned HOST memory -- over PCIe as text (framed on the device) or
+    #      framed + packed by host threads -- through vg_fastq_stream_push.  Never `value`: the metric is quoted on batches resident
+    #      in HBM.  After the reference binary has been collected: the host-packing route needs the container's CPUs for itself.
+    ingest = None
+    if rank == 0 and world == 1 and not args.no_ingest:
+        ingest = measure_ingest(gx, batches[0], log)
     gx.close()
     del batches
     torch.cuda.empty_cache()

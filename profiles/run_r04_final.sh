@@ -5,6 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r04_final
 mkdir -p $OUT
 cd $R
+( time timeout 900 python3 -m pytest tests/test_gpu_fastq.py tests/test_gpu_cli.py -k "not hg38" -x -q -m gpu ) > $OUT/pytest_fastq_cli.log 2>&1; tail -3 $OUT/pytest_fastq_cli.log
 ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -22 $OUT/bench_default.err | cut -c1-300
 bash profiles/run_prof_r04.sh r04 > $OUT/prof_default.log 2>&1

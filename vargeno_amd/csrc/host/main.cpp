@@ -10,8 +10,9 @@
 //   VARGENO_BATCH=n       reads per batch of the host-framed path (default 4194304)
 //   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk handed to the library (default 64; 256 when the host packs)
 //   VARGENO_PACK_THREADS=n  host threads (per replica) that frame and 2-bit pack the FASTQ text inside the library, so that 48 bytes
-//                         per read cross the link instead of ~315 of text (default: half the hardware threads shared among the
-//                         replicas, at most 96; 0, or a host with fewer than 16 hardware threads: the text is framed on the device)
+//                         per read cross the link instead of ~315 of text (default: half the CPUs the process may use -- a cgroup
+//                         quota counts --, shared among the replicas, at most 96; 0, or fewer than 32 usable CPUs: the text is
+//                         framed on the device)
 //   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default: an eighth of the hardware threads, 8 to 32)
 //   VARGENO_MAX_DEVICE_GB=x  device-memory budget per replica (vg_index_open_ex): which re-laid-out views the replica holds follows
 //                         from the index and this number alone (default: the whole device); VARGENO_VERBOSE=1 prints the plan
@@ -49,6 +50,19 @@ static void arg_check(int argc, int expected)
 	if (argc - 2 != expected) { print_help(); exit(EXIT_FAILURE); }
 }
 static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e && *e ? atoi(e) : dflt; }
+// CPUs this process may use: the hardware threads, capped by a cgroup CPU quota (cpu.max: "<quota> <period>"; this pool's GPU boxes
+// give a container 16 CPUs' worth of time on a 256-thread host)
+static int usable_cpus()
+{
+	int h = (int)std::thread::hardware_concurrency();
+	if (h <= 0) h = 1;
+	if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		char a[64] = ""; long long per = 100000;
+		if (fscanf(f, "%63s %lld", a, &per) >= 1 && strcmp(a, "max") != 0 && per > 0) { const long long q = atoll(a); const int c = (int)((q + per - 1) / per); if (q > 0 && c > 0 && c < h) h = c; }
+		fclose(f);
+	}
+	return h;
+}
 
 #define VG_CHECK(call)                                                                           \
 	do {                                                                                         \
@@ -209,10 +223,11 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		if (fstat(fd, &sb) != 0) { close(fd); fprintf(stderr, "vargeno: cannot stat %s\n", fastq.c_str()); return EXIT_FAILURE; }
 		const uint64_t fsize = (uint64_t)sb.st_size;
 		// one thread copies ~2 GB/s out of the page cache: enough of them to keep a 50 GB/s link busy, if the host has the cores
-		const int hw = (int)std::thread::hardware_concurrency();
-		// a host with cores to spare frames + packs the text itself (6.5 x fewer bytes over the link); otherwise the device frames it
+		const int hw = usable_cpus();
+		// a host with CPUs to spare frames + packs the text itself (6.5 x fewer bytes over the link); otherwise the device frames it
+		// (from 32 usable CPUs on: below that the reader threads and the packing threads only take time from each other)
 		int pack_threads = env_int("VARGENO_PACK_THREADS", -1);
-		if (pack_threads < 0) pack_threads = hw >= 16 ? std::max(2, std::min(hw / 2, 96) / ngpu) : 0;
+		if (pack_threads < 0) pack_threads = hw >= 32 ? std::max(2, std::min(hw / 2, 96) / ngpu) : 0;
 		const uint64_t chunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", pack_threads > 0 ? 256 : 64)) << 20;
 		const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
 		std::vector<uint64_t> cut;
