@@ -787,10 +787,16 @@ def main():
             gx.reset()
             dt = timed_block(gx, run, lb, args.steps)
             tm_l = gx.timing()
+            roof_l = roofline_of(st_l["alg_bytes"], tm_l["ms_main"], args.reads, kernel)
+            import copy
+
+            a_l = copy.copy(args)
+            a_l.lowq = 0.5
+            roof_l["traffic"], _, roof_l["traffic_source"] = traffic_for(a_l, build_id)
             secondary["lowq50"] = {"workload": "the main line's index, 50 %% low-quality characters (SURVEY.md §8d stress profile: %.2f gate-open chunks per read), %d x 150 bp reads per step rotating over 2 resident batches" % (st_l["gate_open"] / args.reads, args.reads),
                                    "value": args.reads * args.steps / dt, "unit": "reads/s", "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps,
                                    "input_form": "quality strings" if args.ascii_quals else "gate words",
-                                   "roofline": roofline_of(st_l["alg_bytes"], tm_l["ms_main"], args.reads, kernel), "parity": par_l,
+                                   "roofline": roof_l, "parity": par_l,
                                    "device_ms_per_step": {"pack": tm_l["ms_pack"], "wave": tm_l["ms_main"], "spill_tiers_overlapped": tm_l["ms_tail"]},
                                    "reads_per_step_redone_by_deep_list_tier": st_l["overflow_reads"], "wall_s": time.time() - t_leg}
             log("[bench] secondary lowq50: %.4g reads/s, %.3f ms/step, kernel %.3f ms, frac %.3f" % (secondary["lowq50"]["value"], secondary["lowq50"]["ms_per_step"], tm_l["ms_main"], secondary["lowq50"]["roofline"]["frac"]))
