@@ -17,10 +17,11 @@ except Exception as e:
 PY
 }
 c22() { local name=$1; shift; timeout 600 python3 bench.py --workload chr22 --cpu-reference no --no-gather-probe --no-ingest --secondary none --sustain-seconds 0 --steps 40 --warmup 5 "$@" > $OUT/$name.json 2> $OUT/$name.err; summ $name; grep parity $OUT/$name.err | tee -a $OUT/summary.txt; }
-for rep in ${REPS:-0.3 0}; do
-	tag=$( [ $rep = 0 ] && echo def || echo rep30 )
-	VARGENO_HIP_LIB=$R/variants/base0.so c22 ${tag}_base --repeats $rep --cpu-sample 0
-	for v in $VARIANTS; do VARGENO_HIP_LIB=$R/variants/$v.so c22 ${tag}_$v --repeats $rep; done
-	VARGENO_HIP_LIB=$R/variants/base0.so c22 ${tag}_base2 --repeats $rep --cpu-sample 0
-	for v in $VARIANTS; do VARGENO_HIP_LIB=$R/variants/$v.so c22 ${tag}_${v}2 --repeats $rep --cpu-sample 0; done
+for cfg in ${CFGS:-rep30 def}; do
+	case $cfg in rep30) A="--repeats 0.3";; def) A="--repeats 0";; lowq50) A="--repeats 0 --lowq 0.5";; esac
+	tag=$cfg
+	VARGENO_HIP_LIB=$R/variants/base0.so c22 ${tag}_base $A --cpu-sample 0
+	for v in $VARIANTS; do VARGENO_HIP_LIB=$R/variants/$v.so c22 ${tag}_${v}_a $A; done
+	VARGENO_HIP_LIB=$R/variants/base0.so c22 ${tag}_base_b $A --cpu-sample 0
+	for v in $VARIANTS; do VARGENO_HIP_LIB=$R/variants/$v.so c22 ${tag}_${v}_b $A --cpu-sample 0; done
 done

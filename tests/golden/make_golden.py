@@ -21,6 +21,8 @@ Produces
   fstrands.*   strand corner cases (synth.f_strands: reference and SNP k-mers that are their own reverse complement, k-mers
                whose reverse complement is in the dictionary too, reads of both strands aimed at them): sha256 list + the
                reference's output VCF.
+  frepeated.*  synth.f_repeated_records: an SNP list holding the same record one to five times (auxiliary rows that list one position
+               several times; a chunk voting several times for a position): sha256 list + the reference's VCF
   flowcomplex.*  synth.f_lowcomplex(1): microsatellites, hairpins, tandem and dispersed copies, dense SNPs: sha256 list + the
                reference's output VCF.
 Fixtures are data (inputs and reference outputs); no reference source text is stored here.
@@ -72,7 +74,7 @@ def bf_setbits(path):
 def run(name, gen, work, commit_all):
     d = os.path.join(work, name)
     os.makedirs(d, exist_ok=True)
-    if name == "fquirk":
+    if name in ("fquirk", "frepeated"):
         synth.write_quirk(d, gen())
     else:
         g, s, r = gen()[:3]
@@ -117,7 +119,7 @@ if __name__ == "__main__":
     work = sys.argv[1] if len(sys.argv) > 1 else "/tmp/vg_golden"
     if not os.path.exists(REF_BIN):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall", "fdense", "fquirk", "fstrands", "flowcomplex"]
+    which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["ftiny", "fsmall", "fdense", "fquirk", "fstrands", "flowcomplex", "frepeated"]
     if "ftiny" in which:
         run("ftiny", synth.f_tiny, work, True)
     if "fsmall" in which:
@@ -130,6 +132,8 @@ if __name__ == "__main__":
         run("fstrands", synth.f_strands, work, False)
     if "flowcomplex" in which:
         run("flowcomplex", lambda: synth.f_lowcomplex(1), work, False)
+    if "frepeated" in which:
+        run("frepeated", synth.f_repeated_records, work, False)
     # the reference's own test data (test/snp.vcf, test/expected_output): data files, copied verbatim
     if os.path.isdir("/root/reference/test"):
         shutil.copy("/root/reference/test/snp.vcf", os.path.join(OUT, "reftest.snp.vcf"))

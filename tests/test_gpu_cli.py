@@ -12,10 +12,10 @@ from vargeno_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,gen", [("ftiny", synth.f_tiny), ("fsmall", synth.f_small), ("fquirk", synth.f_quirk)])
+@pytest.mark.parametrize("name,gen", [("ftiny", synth.f_tiny), ("fsmall", synth.f_small), ("fquirk", synth.f_quirk), ("frepeated", synth.f_repeated_records)])
 def test_cli_vcf_is_byte_identical_to_the_reference(name, gen, tmp_path):
     d = str(tmp_path)
-    if name == "fquirk":                                                  # irregular FASTA / SNP-list inputs (synth.f_quirk)
+    if name in ("fquirk", "frepeated"):                                   # irregular FASTA / SNP-list inputs (synth.f_quirk); records held up to five times
         synth.write_quirk(d, gen())
     else:
         g, s, r = gen()

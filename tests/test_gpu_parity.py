@@ -521,7 +521,7 @@ def test_self_complementary_and_both_strand_kmers(tmp_path, monkeypatch, knob):
         os.remove(os.path.join(d, fn))
 
 
-@pytest.mark.parametrize("seed,knob", [(1, None), (2, None), (3, None), (4, "VG_NO_MX"), (5, "VG_NO_DIRECT"), (6, "VG_NO_MX+VG_NO_HX")])
+@pytest.mark.parametrize("seed,knob", [(1, None), (2, None), (3, None), (4, "VG_NO_MX"), (5, "VG_NO_DIRECT"), (6, "VG_NO_MX+VG_NO_HX"), (7, "VG_FORCE_AUX_DUPS")])
 def test_low_complexity_genomes(tmp_path, monkeypatch, seed, knob):
     """synth.f_lowcomplex: genomes made of microsatellites (runs of A, AT, ACGT are their own reverse complement), hairpins,
     tandem and dispersed copies (auxiliary rows, POS_AMBIGUOUS), one SNP per 25 bases -- k-mers that collide with themselves,
@@ -546,6 +546,48 @@ def test_low_complexity_genomes(tmp_path, monkeypatch, seed, knob):
     for k in (knob.split("+") if knob else ()):
         monkeypatch.setenv(k, "1")
     with GenoIndex.open(prefix) as gx:
+        for stats in (True, False):
+            gx.reset()
+            gx.set_stats(stats)
+            gx.submit(r.bases, r.quals, r.offsets)
+            rc, ac = gx.counts()
+            bad = np.nonzero((rc != so["ref_cnt"]) | (ac != so["alt_cnt"]))[0]
+            assert len(bad) == 0, ("stats=%s" % stats, so["pos"][bad[:10]], rc[bad[:10]], so["ref_cnt"][bad[:10]], ac[bad[:10]], so["alt_cnt"][bad[:10]])
+            if stats:
+                st = gx.stats()
+                for k in CMP_STATS:
+                    assert st[k] == want[k], k
+    for fn in ("idx.ref.bf", "idx.snp.bf"):
+        os.remove(os.path.join(d, fn))
+
+
+@pytest.mark.parametrize("knob", [None, "VG_NO_DIRECT", "VG_NO_MX"])
+def test_snp_records_held_several_times(tmp_path, monkeypatch, knob):
+    """synth.f_repeated_records: the same SNP record one to five times in the list -> auxiliary rows that list ONE position
+    several times -> a chunk that votes for, and walks, the same context several times (qv.cc:913-933, 1444-1494).  The wave
+    kernel's key table gives a chunk one vote per key: the loader finds such rows (DevIndex::aux_dups, named in vg_index_plan),
+    rows are then expanded column by column and the reads concerned end in the lane machine, which keeps contexts one by one.
+    Counters and event counts of both builds equal the oracle's (which equals the reference's VCF on this fixture:
+    tests/test_oracle_golden.py); the CLI's VCF is compared with the reference's bytes in tests/test_gpu_cli.py."""
+    import subprocess
+
+    from vargeno_amd import synth
+
+    q = synth.f_repeated_records()
+    d = str(tmp_path)
+    synth.write_quirk(d, q)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    prefix = os.path.join(d, "idx")
+    r = q["reads"]
+    ox = O.OracleIndex.load(prefix)
+    ox.process(r.bases, r.quals, r.offsets, nthreads=8)
+    so = ox.sites()
+    want = ox.stats.as_dict()
+    assert want["aux_snp"] > 500 and so["ref_cnt"].sum() + so["alt_cnt"].sum() > 1_000
+    if knob:
+        monkeypatch.setenv(knob, "1")
+    with GenoIndex.open(prefix) as gx:
+        assert "repeat a position" in gx.plan, gx.plan
         for stats in (True, False):
             gx.reset()
             gx.set_stats(stats)

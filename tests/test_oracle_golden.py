@@ -279,3 +279,30 @@ def test_oracle_reproduces_reference_vcf_on_flowcomplex(tmp_path):
     assert st["aux_ref"] > 2000 and st["scan_oob"] > 0 and int((rd["ref_pos"] == 0xFFFFFFFF).sum()) > 500
     for fn in ("idx.ref.bf", "idx.snp.bf"):
         os.remove(os.path.join(d, fn))
+
+
+def test_oracle_reproduces_reference_vcf_on_frepeated(tmp_path):
+    """synth.f_repeated_records: an SNP list that holds the same record up to five times -- auxiliary rows listing ONE position
+    several times, i.e. a chunk that votes, and walks the pile-up, several times for the same context (qv.cc:913-933, 1444-1494).
+    The product's index files must be the reference's (sha256), and the oracle's calls the reference's VCF."""
+    import subprocess
+
+    from conftest import BIN
+
+    q = synth.f_repeated_records()
+    d = str(tmp_path)
+    synth.write_quirk(d, q)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    want = read_sha256_list("frepeated")
+    for fn in ("ref.fa", "snps.vcf", "reads.fq", "idx.chrlens", "idx.ref.dict", "idx.snp.dict", "idx.ref.bf", "idx.snp.bf"):
+        assert _sha(os.path.join(d, fn)) == want[fn], fn
+    r = q["reads"]
+    ix = O.OracleIndex.load(os.path.join(d, "idx"))
+    assert ix.process(r.bases, r.quals, r.offsets) == 0
+    mine = O.calls_by_key(ix.sites(), index_io.read_chrlens(os.path.join(d, "idx.chrlens")))
+    ref = O.parse_vcf_calls(os.path.join(GOLDEN, "frepeated.out.vcf.gz"))
+    assert len(ref) >= 40
+    assert mine == ref
+    assert ix.stats.as_dict()["aux_snp"] > 500
+    for fn in ("idx.ref.bf", "idx.snp.bf"):
+        os.remove(os.path.join(d, fn))

@@ -726,6 +726,7 @@ struct vg_index {
 	bool fq_open = false; int fq_prev_slot = -1;
 	uint64_t max_device_bytes = 0;        // the caller's budget for this replica (vg_index_open_ex; 0: the whole device)
 	std::string plan_text;                // what the budget bought: views kept / left out (vg_index_plan)
+	std::string aux_note;                 // ... and what the loader found in the auxiliary rows, if anything
 	vgp::Packer *packer = nullptr;        // host-side framing + packing (vg_fastq_stream_begin_packed)
 	bool fq_packed = false;               // the open FASTQ stream is framed + packed on the host
 	uint64_t host_invalid = 0;            // reads with a character other than ACGTN found by the host packer since the last reset
@@ -918,6 +919,25 @@ __global__ void vg_check_columns(const uint64_t *__restrict__ kmer, const uint32
 	if (unsorted) atomicAdd(&bad[0], unsorted);
 	if (wild) atomicAdd(&bad[1], wild);
 }
+// An auxiliary row lists the positions of a k-mer with 2-10 occurrences (dictgen.c:63-154); they are distinct unless the SNP list
+// holds the very same record several times (then the k-mer "occurs" that often at one position).  The wave kernel's key table
+// gives a chunk one vote per key, so it has to know (DevIndex::aux_dups): it counts rows with a repeated position.
+__global__ void vg_check_aux_rows(const uint32_t *__restrict__ rows, uint64_t n_rows, unsigned long long *dups)
+{
+	unsigned long long mine = 0;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (uint64_t)gridDim.x * blockDim.x) {
+		uint32_t v[AUX_COLS];
+		for (int j = 0; j < AUX_COLS; j++) v[j] = rows[i * AUX_COLS + j];
+		bool live = true, rep = false;
+		for (int j = 0; j < AUX_COLS; j++) {
+			live = live && v[j] != 0;
+			if (!live) break;
+			for (int k = 0; k < j; k++) rep = rep || v[k] == v[j];
+		}
+		if (rep) mine++;
+	}
+	if (mine) atomicAdd(dups, mine);
+}
 // Pile-up seeding in FILE ORDER, last writer wins (qv.cc:637-659): every position first learns the index of the LAST SNP-dictionary
 // entry that seeds it ...
 __global__ void vg_site_winner(const uint32_t *__restrict__ pos, const uint8_t *__restrict__ info, const uint8_t *__restrict__ amb, uint64_t n, uint32_t *__restrict__ winner)
@@ -1095,14 +1115,22 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		HIP_TRY(hipMemcpy(&maxp, dmax.p, 8, hipMemcpyDeviceToHost));
 		// ---- and what a file that `vargeno index` did not write could get wrong
 		TempDev<unsigned long long> dbad;
-		if ((rc = dbad.alloc(2))) return rc;
-		HIP_TRY(hipMemsetAsync(dbad.p, 0, 16, st));
+		if ((rc = dbad.alloc(3))) return rc;
+		HIP_TRY(hipMemsetAsync(dbad.p, 0, 24, st));
 		if (c.n_ref) vg_check_columns<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, c.n_ref_aux, dbad.p);
 		if (c.n_snp) vg_check_columns<<<2048, 256, 0, st>>>(c.snp_kmer.p, c.snp_pos.p, c.snp_amb.p, c.n_snp, c.n_snp_aux, dbad.p);
+		if (c.n_ref_aux) vg_check_aux_rows<<<1024, 256, 0, st>>>(c.ref_aux, c.n_ref_aux, dbad.p + 2);
+		if (c.n_snp_aux) vg_check_aux_rows<<<1024, 256, 0, st>>>(c.snp_aux_pos, c.n_snp_aux, dbad.p + 2);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(st));
-		unsigned long long bad[2] = {0, 0};
-		HIP_TRY(hipMemcpy(bad, dbad.p, 16, hipMemcpyDeviceToHost));
+		unsigned long long bad[3] = {0, 0, 0};
+		HIP_TRY(hipMemcpy(bad, dbad.p, 24, hipMemcpyDeviceToHost));
+		d.aux_dups = bad[2] || getenv("VG_FORCE_AUX_DUPS") ? 1u : 0u;       // (the knob: tests drive the careful path on ordinary indexes)
+		if (bad[2]) {
+			char msg[200];
+			snprintf(msg, sizeof msg, "%llu auxiliary rows repeat a position (the SNP list holds a record several times): rows are expanded column by column", bad[2]);
+			ix->aux_note = msg;
+		}
 		if (bad[0] || bad[1]) {
 			char msg[200];
 			snprintf(msg, sizeof msg, "k-mers out of order in %llu places, %llu entries naming auxiliary rows the file does not have", bad[0], bad[1]);
@@ -1125,6 +1153,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	(void)hipMemGetInfo(&dev_free, &dev_total);
 	const ViewPlan plan = plan_views(c, maxp, ref_bf_bits, snp_bf_bits, ix->max_device_bytes, (uint64_t)dev_total, ix->cus);
 	ix->plan_text = plan.text;
+	if (!ix->aux_note.empty()) ix->plan_text += "; " + ix->aux_note;
 	if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] %s\n", plan.text.c_str());
 	if (plan.base > plan.budget) return fail(VG_ENOMEM, "the device-memory budget is below the smallest layout of this index: %s", plan.text.c_str());
 	const bool want_mx = plan.mx;

@@ -33,6 +33,7 @@ struct DevIndex {
 	const uint32_t *ref_jg;        // [2^32 + 1] jump table over HI32; entry 2^32 = n_ref (sentinel replaces the 0xFFFFFFFF special case)
 	const RefEnt   *ref;           // [n_ref]
 	const uint32_t *ref_aux;       // [n_ref_aux][10]
+	uint32_t aux_dups;             // some auxiliary row (either dictionary) lists a position twice: the wave kernel expands rows column by column
 	uint64_t n_ref;
 	// secondary view of the reference dictionary ordered by (LO32, HI32): every k-mer that shares a chunk's first 16 bases is
 	// adjacent, so the 48 "last 16 bases differ in one base" neighbour queries of qv.cc:1213-1296 become one bucket read.

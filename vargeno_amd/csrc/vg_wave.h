@@ -382,45 +382,65 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				} else if (dup) { VG_OVF(2); ovf = true; }
 			};
 			auto push_row = [&](const uint32_t *row, uint32_t c) {               // a row ends at its first 0
-				// The whole row in one wait.  Then the row against the key table AS A BLOCK: the rows of a read's consecutive chunks list the
-				// same copies of a repeat in the same order (positions 32 apart), so once column 0 has found its key at slot s, column j
-				// is expected at slot s + j -- ten LDS reads in one round trip, one mask update each -- and the first row of a pass
-				// (empty table: a row's positions are distinct, hence its keys) is appended without a search.  What does not line up
-				// (diverged copies) takes the one-by-one path.  r03 / the first key-table build pushed 4 x 10 contexts one by one,
-				// each a search of the table: a third of the kernel's time on the repeat-rich genome (profiles/ab_chr22_repeats30_r04.txt).
+				// The whole row in one wait.  Then EVERY column against EVERY key of the table, four keys per LDS round trip (r04, second
+				// half): the rows of a read's chunks list the copies of a repeat family that share THAT chunk's k-mer -- a different subset
+				// of the family from chunk to chunk, as soon as the copies have diverged anywhere -- so nothing positional survives (the
+				// first key-table build expected column j at slot s + j and searched the table once per column that was not there: 3.4
+				// searches per row, 12 000 cycles per row of a wave in which two or three lanes had one; a third of the kernel's time on
+				// the repeat-rich genome, profiles/rows_census_r04.txt).  Columns that matched set their chunk's bit; the others are new
+				// keys and are appended without a search, at kcnt + their rank among the new ones.  A row's positions are distinct in
+				// every index `vargeno index` writes from distinct records; an index whose rows repeat a position (the same SNP record
+				// three times or more in the list: DevIndex::aux_dups, found at load time) takes the careful way, column by column, where
+				// a chunk that votes twice for a key sends the read down to the lane machine.
 #ifdef VG_DBG_NO_ROWS
 				return;                                                 // timing experiment only (wrong results): what do the rows cost?
 #endif
 				uint32_t rw[AUX_COLS];
 				load_row10(row, rw);
-				uint32_t todo = 0;                                      // columns left to the one-by-one path
+				uint32_t todo = 0, newk = 0;                            // columns left to the careful path / columns whose keys are new
 				if (!ovf) {
 					uint32_t r = 0;
 					#pragma unroll
 					for (int j = 0; j < AUX_COLS; j++) if (r == (uint32_t)j && rw[j] != 0) r = (uint32_t)j + 1u;      // live columns
 					cur.add(S_CTX, r);
-					const uint32_t bit = 1u << c, back = 32u * c;
-					if (kcnt == 0 && r <= (uint32_t)W_ECAP) {
-						#pragma unroll
-						for (int j = 0; j < AUX_COLS; j++) if ((uint32_t)j < r) { K_idx[j][col] = rw[j] - back; K_mask[j][col] = (kmask_t)bit; }
-						kcnt = r; hint = 0;
-					} else if (r) {
+					const uint32_t bit = 1u << c, back = 32u * c, live = (1u << r) - 1u;
+					if (d.aux_dups) todo = live;
+					else {
+						uint32_t found = 0;
 						bool dup = false;
-						const uint32_t s0 = key_find(rw[0] - back, c, 0u, kcnt, dup);
-						if (dup) { VG_OVF(2); ovf = true; }
-						else if (s0 == (uint32_t)W_ECAP) todo = (1u << r) - 1u;      // column 0 is new: no anchor
-						else {
-							uint32_t kv[AUX_COLS], km[AUX_COLS];
+						#pragma nounroll
+						for (uint32_t e0 = 0; e0 < kcnt && found != live; e0 += 4) {
+							uint32_t kv[4], km[4];
 							#pragma unroll
-							for (int j = 1; j < AUX_COLS; j++) { const uint32_t e = s0 + (uint32_t)j < (uint32_t)W_ECAP ? s0 + (uint32_t)j : (uint32_t)W_ECAP - 1u; kv[j] = K_idx[e][col]; km[j] = K_mask[e][col]; }
+							for (uint32_t t = 0; t < 4; t++) { const uint32_t e = e0 + t < (uint32_t)W_ECAP ? e0 + t : (uint32_t)W_ECAP - 1u; kv[t] = K_idx[e][col]; km[t] = K_mask[e][col]; }
 							#pragma unroll
-							for (int j = 1; j < AUX_COLS; j++) if ((uint32_t)j < r) {
-								const uint32_t e = s0 + (uint32_t)j;
-								if (e < kcnt && kv[j] == rw[j] - back && !(km[j] & bit)) K_mask[e][col] = (kmask_t)(km[j] | bit);
-								else todo |= 1u << j;
+							for (uint32_t t = 0; t < 4; t++) if (e0 + t < kcnt) {
+								uint32_t h = 0;
+								#pragma unroll
+								for (int j = 0; j < AUX_COLS; j++) h |= (rw[j] - back == kv[t] ? 1u : 0u) << j;
+								h &= live;
+								if (h) {
+									if (km[t] & bit) dup = true;                        // the chunk has voted for this key already
+									else K_mask[e0 + t][col] = (kmask_t)(km[t] | bit);
+									found |= h;
+								}
 							}
-							hint = s0 + r < kcnt ? s0 + r : 0u;
 						}
+						if (dup) { VG_OVF(2); ovf = true; }
+						else newk = live & ~found;
+						hint = 0;
+					}
+				}
+				if (newk && !ovf) {
+					const uint32_t nn = (uint32_t)__popc(newk);
+					if (kcnt + nn > (uint32_t)W_ECAP) { VG_OVF(0); ovf = true; }
+					else {
+						#pragma unroll
+						for (int j = 0; j < AUX_COLS; j++) if ((newk >> j) & 1u) {
+							const uint32_t e = kcnt + (uint32_t)__popc(newk & ((1u << j) - 1u));
+							K_idx[e][col] = rw[j] - 32u * c; K_mask[e][col] = (kmask_t)(1u << c);
+						}
+						kcnt += nn;
 					}
 				}
 				#pragma nounroll
@@ -949,9 +969,16 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						if (q_r || q_s) dual_query(d, hs, qk, q_r, q_s, ri, si);
 					}
 					// is `position` one of the owner's vote keys (the implied read position of one of its exact hits)?
-					auto in_keys = [&](uint32_t position) -> bool {
+					auto in_keys = [&](uint32_t position) -> bool {                 // four keys per LDS round trip
 						bool f = false;
-						for (uint32_t e = 0; e < o_ecnt; e++) f |= K_idx[e][col0 + own] == position;
+						#pragma nounroll
+						for (uint32_t e0 = 0; e0 < o_ecnt; e0 += 4) {
+							uint32_t kv[4];
+							#pragma unroll
+							for (uint32_t t = 0; t < 4; t++) kv[t] = K_idx[e0 + t < (uint32_t)W_ECAP ? e0 + t : (uint32_t)W_ECAP - 1u][col0 + own];
+							#pragma unroll
+							for (uint32_t t = 0; t < 4; t++) f |= e0 + t < o_ecnt && kv[t] == position;
+						}
 						return f;
 					};
 					// acceptance (site / SNP-base tests) + key filter -> bit j: ref candidate j kept, bit 10+j: snp candidate j kept.
@@ -969,7 +996,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						r_aux = r_ok && re.amb != 0; s_aux = s_ok && ((se.key >> 48) & 0xFFu) != 0;
 						rpos = re.pos; spos = se.pos;
 						if (r_ok && !r_aux) {
-							if (!site_loose(d, hs, rpos + mod)) { hs.add(S_CTX, 1); if (in_keys(rpos - 32u * c)) keepm |= 1u; }
+							// (the timed build asks the key table first -- LDS -- and reads the site byte only of a position that is a key)
+							if constexpr (!STATS) { if (in_keys(rpos - 32u * c) && !site_loose(d, hs, rpos + mod)) keepm |= 1u; }
+							else if (!site_loose(d, hs, rpos + mod)) { hs.add(S_CTX, 1); if (in_keys(rpos - 32u * c)) keepm |= 1u; }
 						}
 						if (r_aux) {
 							// the whole row in one wait, then the site bytes of all its positions in a second one (r03 went through the row four
@@ -977,6 +1006,31 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							hs.add(S_AUX_REF, 1);
 							uint32_t v[AUX_COLS], sb[AUX_COLS];
 							load_row10(d.ref_aux + (uint64_t)rpos * AUX_COLS, v);
+							if constexpr (!STATS) {
+								// The timed build asks the key table first (every column against every key, four keys per LDS round trip) and
+								// reads the site byte only of the columns that are keys: ten one-byte gathers, each a line of its own, were most
+								// of what a neighbour k-mer inside a repeat family cost -- for columns the key filter then dropped.
+								uint32_t lv = 0;
+								#pragma unroll
+								for (int j = 0; j < AUX_COLS; j++) if (lv == (uint32_t)j && v[j] != 0) lv = (uint32_t)j + 1u;
+								uint32_t kmm = 0;
+								#pragma nounroll
+								for (uint32_t e0 = 0; e0 < o_ecnt; e0 += 4) {
+									uint32_t kv[4];
+									#pragma unroll
+									for (uint32_t t = 0; t < 4; t++) kv[t] = K_idx[e0 + t < (uint32_t)W_ECAP ? e0 + t : (uint32_t)W_ECAP - 1u][col0 + own];
+									#pragma unroll
+									for (uint32_t t = 0; t < 4; t++) if (e0 + t < o_ecnt) {
+										#pragma unroll
+										for (int j = 0; j < AUX_COLS; j++) kmm |= (v[j] - 32u * c == kv[t] ? 1u : 0u) << j;
+									}
+								}
+								kmm &= (1u << lv) - 1u;
+								#pragma unroll
+								for (int j = 0; j < AUX_COLS; j++) { const uint64_t a = (uint64_t)v[j] + mod; sb[j] = 0; if (((kmm >> j) & 1u) && a < d.pile_len) sb[j] = d.pile[a]; }
+								#pragma unroll
+								for (int j = 0; j < AUX_COLS; j++) if (((kmm >> j) & 1u) && !(sb[j] & 15u)) keepm |= 1u << j;
+							} else {
 							#pragma unroll
 							for (int j = 0; j < AUX_COLS; j++) { const uint64_t a = (uint64_t)v[j] + mod; const bool in = v[j] && a < d.pile_len; sb[j] = d.pile[in ? a : 0]; if (!in) sb[j] = 0; }
 							bool live = true;
@@ -995,6 +1049,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								cand &= cand - 1;
 								const uint32_t pp = j == 0 ? v[0] : j == 1 ? v[1] : j == 2 ? v[2] : j == 3 ? v[3] : j == 4 ? v[4] : j == 5 ? v[5] : j == 6 ? v[6] : j == 7 ? v[7] : j == 8 ? v[8] : v[9];
 								if (in_keys(pp - 32u * c)) keepm |= 1u << j;
+							}
 							}
 						}
 						if (s_ok && !s_aux) {

@@ -636,6 +636,58 @@ def f_quirk(seed=99):
     return {"fasta": fasta, "vcf": vcf, "reads": r, "genome": g, "snps": s}
 
 
+def f_repeated_records(seed=77, genome_len=40_000, n_sites=36):
+    """An SNP list that holds the very same record one to five times (real dbSNP merges leave such lines behind).  `vargeno index`
+    keeps every occurrence (dictgen.c:156-275: a k-mer found k times becomes one entry with an auxiliary row of k positions -- here
+    the SAME position k times, or POS_AMBIGUOUS beyond 10), and `geno` turns every column of that row into a context of its own
+    (qv.cc:913-933): a chunk then votes k times for one position, and each of those contexts walks the pile-up (qv.cc:1444-1494).
+    A repeated record's own position is never a site (all its k-mers are ambiguous, qv.cc:637-659), so every one of them has an
+    ordinary single record five bases further on, inside the same 32-mers: its counters are what the extra contexts change.
+    Reads carry the ALT or the REF allele at either position (exact hits on the repeated SNP k-mers, on both strands) and
+    low-quality chunks over them (neighbour hits on the same rows).
+    Returns a dict like f_quirk(): fasta (bytes), vcf (str), reads (Reads)."""
+    rng = np.random.default_rng(seed)
+    seq = random_bases(rng, genome_len)
+    fa = [b">chr1 repeated-record fixture\n"]
+    for i in range(0, genome_len, 70):
+        fa.append(seq[i:i + 70].tobytes() + b"\n")
+    lines, reads_b, reads_q = [], [], []
+    step = (genome_len - 2000) // n_sites
+    for k in range(n_sites):
+        q = 1000 + k * step + int(rng.integers(0, 50))        # 1-based position
+        ref = chr(seq[q - 1])
+        alt = "ACGT"[("ACGT".index(ref) + 1 + k % 3) % 4]
+        copies = 1 + k % 5
+        for z in range(copies):
+            lines.append("1\t%d\trs%d\t%s\t%s\t.\t.\tCAF=0.6,0.4\n" % (q, k, ref, alt))
+        ref5 = chr(seq[q + 4])
+        alt5 = "ACGT"[("ACGT".index(ref5) + 2) % 4]
+        lines.append("1\t%d\trs%dn\t%s\t%s\t.\t.\tCAF=0.5,0.5\n" % (q + 5, k, ref5, alt5))      # the ordinary neighbour
+        if k % 7 == 3:                                        # ... and another ALT at the same position, twice
+            alt2 = "ACGT"[("ACGT".index(ref) + 1 + (k + 1) % 3) % 4]
+            lines += ["1\t%d\trs%db\t%s\t%s\t.\t.\tCAF=0.7,0.3\n" % (q, k, ref, alt2)] * 2
+        for off in (3, 20, 45, 70, 100, 125, 140):            # the site in every chunk of a 150 bp read, and in the 22-base tail that is cut off
+            st = q - 1 - off
+            for allele, allele5 in ((alt, ref5), (ref, ref5), (alt, alt5), (ref, alt5)):
+                b = seq[st:st + 150].copy()
+                b[off] = ord(allele)
+                b[off + 5] = ord(allele5)
+                for rev in (False, True):
+                    bb = _COMP[b[::-1]] if rev else b
+                    for lowq in (False, True):
+                        qq = np.full(150, ord("I"), dtype=np.uint8)
+                        if lowq:
+                            qq[:4] = ord("#")                 # quality character c gates chunk c (qv.cc:836)
+                        reads_b.append(bb.copy()); reads_q.append(qq)
+    rnd = make_reads(rng, Genome(["chr1"], [seq]), SnpSet(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(0), np.zeros(0), np.zeros(0, np.uint8)),
+                     1500, err=0.01, lowq=0.3) if False else None
+    order = rng.permutation(len(reads_b))
+    bases = np.concatenate([reads_b[i] for i in order])
+    quals = np.concatenate([reads_q[i] for i in order])
+    offsets = (np.arange(len(order) + 1, dtype=np.uint64) * np.uint64(150))
+    return {"fasta": b"".join(fa), "vcf": VCF_HEADER + "".join(lines), "reads": Reads(bases, quals, offsets)}
+
+
 def write_quirk(d, q):
     """The files of f_quirk() in directory d: ref.fa, snps.vcf, reads.fq."""
     with open(os.path.join(d, "ref.fa"), "wb") as f:
