@@ -319,97 +319,143 @@ __global__ void vg_make_snp_entries(const uint64_t *__restrict__ kmer, const uin
 // Streaming pre-pass: ASCII -> chunk k-mers + one flag word per read (gate bits: chunk c is gate-open iff
 // qual[c] < '8', src/qv.cc:836, 943 -- the chunk NUMBER indexes the quality string).  Chunk c of read r
 // lands at pk_kmer[(offsets[r] >> 5) + c]; slots of different reads cannot collide.
-// A workgroup takes 256 consecutive reads: their bases are one contiguous span, copied to LDS with coalesced
-// 16-byte loads (lane-per-read loads at a 150-byte stride fetched every line ~2.5 times), then each lane packs
-// its own read out of LDS.  Only the first n quality characters of a read are ever looked at.
-constexpr uint32_t PACK_T = 64;                 // reads (= lanes) per tile: one wavefront per workgroup (128: 3.5 % fewer reads/s at hg38 scale --
-                                                // smaller tiles keep more workgroups, i.e. more loads, in flight)
-constexpr uint32_t PACK_LDS = PACK_T * 160;     // PACK_T reads of up to 160 bases; longer reads take the direct path
-#ifndef VG_PACK_WPE
-#define VG_PACK_WPE 3
+//
+// r05: the text is packed POSITION by position, not read by read.  A wave takes a tile of 64 consecutive reads: their bases are
+// one contiguous span of text, which the lanes fetch as aligned 16-byte pieces (coalesced, PACK_G per lane in flight), pack to
+// 32 bits each (pack16: v_perm_b32 + v_dot4_u32_u8, ~8 instructions per 4 bases) and lay side by side in LDS -- the tile's text
+// as a 2-bit stream.  A read's k-mers are then 64-bit windows of that stream at bit offset 2 x (its byte offset): five LDS
+// words and four v_alignbit_b32 per pair of chunks.  The r04 kernel staged the ASCII text in LDS and let every lane pack its own
+// read with 64-bit SWAR arithmetic: ~1 500 vector instructions per tile, 147 VGPRs, three waves per SIMD -- its 0.38 ms per
+// 8 M reads were 0.31 ms of vector issue (125 000 tiles x 1 500 instructions over 1 024 SIMDs at one per four cycles), not the
+// memory system.  Pieces that hold a byte other than ACGTacgt are flagged per piece (one ballot per round of 64 pieces); only
+// a read whose chunks touch a flagged piece -- an N run, in practice -- classifies its own text (classify_bad_wide).
+// Workgroups are four INDEPENDENT waves (a CU takes at most 16 workgroups; with ~48 VGPRs the kernel wants 32 waves per CU):
+// no barrier, wave-scope fences only.  Only the first n quality characters of a read are ever looked at.
+constexpr uint32_t PACK_T = 64;                 // reads per tile = lanes of the wave that packs it
+constexpr uint32_t PACK_WPB = 4;                // waves per workgroup
+constexpr uint32_t PACK_MAXLEN = 160;           // tiles whose reads average at most this many bases go through LDS; longer reads take the direct path
+constexpr uint32_t PACK_PIECES = PACK_T * PACK_MAXLEN / 16 + 1;      // aligned 16-byte pieces under a tile (one more than the span needs)
+constexpr uint32_t PACK_ROUNDS = (PACK_PIECES + 63) / 64;
+#ifndef VG_PACK_G
+#define VG_PACK_G 5                             // pieces per lane in flight together (150 bp reads: two groups per tile)
 #endif
 #ifndef VG_PACK_NT
-#define VG_PACK_NT 0                            // `nt` on the pack kernel's loads of the base text, read once
+#define VG_PACK_NT 1                            // `nt` on the loads of the base text, read once
 #endif
-__global__ __launch_bounds__(PACK_T) __attribute__((amdgpu_waves_per_eu(VG_PACK_WPE))) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
+__global__ __launch_bounds__(PACK_T * PACK_WPB) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
                                                       uint64_t n_reads_arg, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta, uint32_t *__restrict__ invalid_reads,
                                                       const uint32_t *__restrict__ n_reads_dev, const uint32_t *__restrict__ gate)
 {
 	// gate != nullptr: the batch comes with one gate word per read (bit c = quality character c < '8') instead of quality strings --
 	// the kernel then streams the bases only.  (With strings it fetches one line per read for the <= 4 characters a 150 bp read's
-	// gate can see: at a 150-byte stride that is every line of the quality array, as much traffic again as the bases.)
-	__shared__ __attribute__((aligned(16))) uint8_t sm[PACK_LDS + 64];
+	// gate can see: at a 150-byte stride that is every line of the quality array, nearly as much traffic again as the bases.)
+	__shared__ uint32_t sm_pk[PACK_WPB][PACK_PIECES + 7];                 // the tile's text, 16 bases per word
+	__shared__ unsigned long long sm_bad[PACK_WPB][PACK_ROUNDS + 1];      // bit p: piece p holds a byte other than ACGTacgt
+	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ln = threadIdx.x & 63u;
 	const uint64_t n_reads = n_reads_dev ? (uint64_t)*n_reads_dev : n_reads_arg;     // a batch framed on the device knows its size there
-	for (uint64_t r0 = (uint64_t)blockIdx.x * PACK_T; r0 < n_reads; r0 += (uint64_t)gridDim.x * PACK_T) {
-		// Two dependent waits per tile: (1) every lane's own offsets -- the tile's span comes out of them by shuffles --, (2) the
-		// tile's bases into LDS together with each read's first four quality characters (all a 150 bp read's gate can see).
-		const uint64_t r = r0 + threadIdx.x;
+	const uint64_t n_tiles = (n_reads + PACK_T - 1) / PACK_T, stride = (uint64_t)gridDim.x * PACK_WPB;
+	uint64_t t = (uint64_t)blockIdx.x * PACK_WPB + wv;
+	// a tile's own offsets (and gate words) are fetched while the tile before it is packed: one dependent wait per tile, not two
+	uint64_t off = 0, off1 = 0;
+	uint32_t gw = 0;
+	auto fetch = [&](uint64_t tile, uint64_t &o, uint64_t &o1, uint32_t &g) {
+		const uint64_t r = tile * PACK_T + ln;
+		o = o1 = 0; g = 0;
+		if (r < n_reads) { o = offsets[r]; o1 = offsets[r + 1]; if (gate) g = gate[r]; }
+	};
+	if (t < n_tiles) fetch(t, off, off1, gw);
+	for (; t < n_tiles; t += stride) {
+		const uint64_t r0 = t * PACK_T, r = r0 + ln;
 		const uint32_t last = (uint32_t)((r0 + PACK_T < n_reads ? r0 + PACK_T : n_reads) - r0) - 1u;     // last live lane of the tile
-		uint64_t off = 0, off1 = 0;
-		if (r < n_reads) { off = offsets[r]; off1 = offsets[r + 1]; }
 		const uint64_t base0 = __shfl(off, 0), span = __shfl(off1, (int)last) - base0;
+		uint64_t noff = 0, noff1 = 0;
+		uint32_t ngw = 0;
+		if (t + stride < n_tiles) fetch(t + stride, noff, noff1, ngw);
 		const uint32_t n = (uint32_t)((off1 - off) >> 5);
 		uint32_t q4 = 0;
-		if (gate) { if (r < n_reads) q4 = gate[r]; }
-		else if (n) __builtin_memcpy(&q4, quals + off, 4);            // 4 <= n + 3 <= the read's own length: never past it
-		const bool staged = span <= PACK_LDS;
-		__syncthreads();                                              // previous tile fully consumed
+		if (!gate && n) __builtin_memcpy(&q4, quals + off, 4);           // 4 <= n + 3 <= the read's own length: never past it
+		// aligned 16-byte pieces: a piece that holds a byte of the text lies in that byte's page, so the first and the last piece
+		// may reach past the text (a batch may start at any byte)
+		const uint64_t a_text = (uint64_t)(bases + base0);
+		const uint32_t shift = (uint32_t)(a_text & 15u);
+		const uint8_t *abase = (const uint8_t *)(a_text - shift);
+		const bool staged = (uint64_t)shift + span <= (uint64_t)PACK_T * PACK_MAXLEN;
+		int cls = 0;
 		if (staged) {
-			// every 16-byte piece of the tile this lane is responsible for goes out before the first is stored to LDS: with one load
-			// in flight per lane (1 KB per wave) the kernel was bound by latency, not by the memory system (0.50 ms per 8 M reads
-			// for 1.5 GB; the quality strings it used to fetch as well had hidden that)
-			constexpr uint32_t NP = PACK_LDS / (PACK_T * 16);              // pieces per lane: 10
-#ifndef VG_PACK_GROUPS
-#define VG_PACK_GROUPS 1                                               // the pieces go out in this many groups (1: all at once)
-#endif
-			constexpr uint32_t NG = NP / VG_PACK_GROUPS;
-			#pragma unroll
-			for (uint32_t q0 = 0; q0 < NP; q0 += NG) {
-				uint4 v[NG];
+			const uint32_t n_pieces = (uint32_t)__builtin_amdgcn_readfirstlane((int)((shift + (uint32_t)span + 15u) >> 4));
+			bool tile_bad = false;                                        // wave-uniform
+			constexpr uint32_t G = VG_PACK_G;
+			for (uint32_t j0 = 0; j0 * 64u < n_pieces; j0 += G) {
+				uint4 v[G];
 				#pragma unroll
-				for (uint32_t q = 0; q < NG; q++) {
-					const uint64_t i = (uint64_t)threadIdx.x * 16 + (uint64_t)(q0 + q) * PACK_T * 16;
-					if (i + 16 <= span) v[q] = load_policy<VG_PACK_NT != 0, uint4, 1>(bases + base0 + i);     // (a batch may start at any byte)
+				for (uint32_t q = 0; q < G; q++) {
+					const uint32_t p = (j0 + q) * 64u + ln;
+					v[q] = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
+					if (p < n_pieces) v[q] = load_policy<VG_PACK_NT != 0, uint4, 16>(abase + 16ull * p);
 				}
 				#pragma unroll
-				for (uint32_t q = 0; q < NG; q++) {
-					const uint64_t i = (uint64_t)threadIdx.x * 16 + (uint64_t)(q0 + q) * PACK_T * 16;
-					if (i + 16 <= span) *reinterpret_cast<uint4 *>(sm + i) = v[q];
-					else if (i < span) for (uint64_t j = i; j < span; j++) sm[j] = bases[base0 + j];
+				for (uint32_t q = 0; q < G; q++) {
+					const uint32_t p = (j0 + q) * 64u + ln;
+					uint32_t br = 0;
+					const uint32_t w = pack16(v[q], br);
+					if (p < n_pieces) sm_pk[wv][p] = w;
+					const unsigned long long bm = __ballot((br & PACK_CASE_MASK) != 0u);
+					tile_bad = tile_bad || bm != 0ull;
+					if (ln == 0 && (j0 + q) * 64u < n_pieces) sm_bad[wv][j0 + q] = bm;
 				}
 			}
-		}
-		__syncthreads();
-		if (r < n_reads) {
-			uint64_t meta = 0, bad = 0;
-			if (staged) {
-				const uint8_t *p = sm + (off - base0);
-				auto enc = [&](uint32_t c) -> uint64_t {
-					uint64_t w[4];
-					__builtin_memcpy(w, p + 32 * c, 32);
-					return (uint64_t)pack8(w[0], bad) | ((uint64_t)pack8(w[1], bad) << 16) | ((uint64_t)pack8(w[2], bad) << 32) | ((uint64_t)pack8(w[3], bad) << 48);
-				};
+			VG_WAVE_SYNC();
+			if (r < n_reads && n) {
+				const uint32_t o = shift + (uint32_t)(off - base0);          // byte offset of the read in the tile's pieces
+				const uint32_t w0 = o >> 4, s = 2u * (o & 15u);
 				uint64_t *dst = pk_kmer + (off >> 5);
+				auto win = [&](uint32_t hi, uint32_t lo) -> uint32_t { return __builtin_amdgcn_alignbit(hi, lo, s); };
 				uint32_t c = 0;
-				for (; c + 2 <= n; c += 2) {                             // a read's k-mers are contiguous: 16-byte stores
-					const ulonglong2 kv = make_ulonglong2(enc(c), enc(c + 1));
+				for (; c + 2 <= n; c += 2) {                               // a read's k-mers are contiguous: 16-byte stores
+					uint32_t d[5];
+					__builtin_memcpy(d, &sm_pk[wv][w0 + 2u * c], 20);
+					const ulonglong2 kv = make_ulonglong2((uint64_t)win(d[1], d[0]) | ((uint64_t)win(d[2], d[1]) << 32), (uint64_t)win(d[3], d[2]) | ((uint64_t)win(d[4], d[3]) << 32));
 					__builtin_memcpy(dst + c, &kv, 16);
 				}
-				if (c < n) dst[c] = enc(c);
-			} else {
-				for (uint32_t c = 0; c < n; c++) pk_kmer[(off >> 5) + c] = encode32(bases + off + 32 * c, bad);
+				if (c < n) {
+					uint32_t d[3];
+					__builtin_memcpy(d, &sm_pk[wv][w0 + 2u * c], 12);
+					dst[c] = (uint64_t)win(d[1], d[0]) | ((uint64_t)win(d[2], d[1]) << 32);
+				}
+				if (tile_bad) {
+					// does one of the pieces under this read's chunks hold an offending byte?  (the flags are per piece: the bases a read's
+					// trim drops, and its neighbours' bases, may be what was seen -- the read's own text decides)
+					bool any = false;
+					for (uint32_t p = w0, left = ((o + 32u * n - 1u) >> 4) - w0 + 1u; left;) {          // (a 150 bp read lies under 9 pieces: one or two words)
+						const uint32_t b = p & 63u, take = 64u - b < left ? 64u - b : left;
+						unsigned long long m = sm_bad[wv][p >> 6] >> b;
+						if (take < 64u) m &= (1ull << take) - 1ull;
+						any = any || m != 0ull;
+						p += take; left -= take;
+					}
+					if (any) cls = classify_bad_wide(bases + off, n);
+				}
 			}
+		} else if (r < n_reads) {
+			uint64_t bad = 0;
+			for (uint32_t c = 0; c < n; c++) pk_kmer[(off >> 5) + c] = encode32(bases + off + 32 * c, bad);
+			if (bad) cls = classify_bad(bases + off, n);
+		}
+		if (r < n_reads) {
 			// quality gate bits (qv.cc:836): character c of the quality line, four characters per gather (the first four are in hand)
-			if (gate) meta = n >= 32 ? q4 : (q4 & ((1u << n) - 1u));
+			uint64_t meta = 0;
+			if (gate) meta = n >= 32 ? gw : (gw & ((1u << n) - 1u));
 			else for (uint32_t c0 = 0; c0 < n && c0 < 32; c0 += 4) {
 				if (c0) __builtin_memcpy(&q4, quals + off + c0, 4);       // c0 + 4 <= n + 3 <= the read's own length
 				for (uint32_t j = 0; j < 4 && c0 + j < n && c0 + j < 32; j++) if ((int)(int8_t)(q4 >> (8 * j)) - '8' < 0) meta |= 1ull << (c0 + j);
 			}
-			if (bad) meta |= classify_bad(bases + off, n) == 1 ? PK_SKIP_N : PK_INVALID;
+			if (cls) meta |= cls == 1 ? PK_SKIP_N : PK_INVALID;
 			if (n > 32) meta |= gate ? PK_INVALID : PK_LONG;            // (a gate word has 32 bits; the reference's line buffer admits 31 chunks)
 			if (meta & PK_INVALID) atomicAdd(invalid_reads, 1u);       // the reference aborts on such a read (util.c:103): the caller is told
 			pk_meta[r] = meta;
 		}
+		VG_WAVE_SYNC();                                                // the tile's LDS words are read: the next tile may overwrite them
+		off = noff; off1 = noff1; gw = ngw;
 	}
 }
 
@@ -445,13 +491,13 @@ __global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
 // One lane = one read: forward pass, then the reverse-complement retry (src/qv.cc:1504-1510).
 // A read touches the counters only at the end of its last pass, so a lane that runs out of scratch
 // simply drops the read onto the overflow list and the same kernel re-runs it with a deep scratch.
-// bases == nullptr: the batch came 2-bit packed (vg_reads_submit_packed, the host-packed FASTQ stream): chunk k-mers and flag words
+// packed: the batch came 2-bit packed (vg_reads_submit_packed, the host-packed FASTQ stream): chunk k-mers and flag words
 // are read from pk_kmer / pk_meta (the layout the pack kernel writes) instead of being encoded from text.
 template <bool STATS>
 __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals,
                                                       const uint64_t *__restrict__ offsets, uint64_t n_reads_arg, const uint32_t *__restrict__ read_ids,
                                                       const uint32_t *__restrict__ n_ids, uint32_t *overflow_list, uint32_t *overflow_count, unsigned long long *stats, uint32_t *invalid_reads,
-                                                      const uint32_t *__restrict__ gate, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta)
+                                                      const uint32_t *__restrict__ gate, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta, const bool packed)
 {
 	const uint64_t n_reads = n_ids ? (uint64_t)*n_ids : n_reads_arg;          // a list launch (or a device-framed batch) is sized on the device: no host round trip
 	const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,8 +505,6 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 	Lane<STATS> L(d, s, gtid);
 	LaneStats<STATS> tot;
 	if constexpr (STATS) for (int i = 0; i < S_COUNT; i++) tot.v[i] = 0;
-	const bool packed = bases == nullptr;
-
 	// entry r of the work goes to lane r / n_waves of wave r % n_waves: a list of a dozen deep reads lands on a dozen waves,
 	// not on twelve lanes of one wave that would run their divergent walks one after the other
 	const uint32_t n_waves = stride >> 6;
@@ -1651,11 +1695,10 @@ static int finish_pending(vg_index *ix)
 // One batch = pack -> wave tier on the main stream, then lane tier (mid scratch) -> lane tier (deep scratch)
 // on the tail stream; the list launches size themselves from device counters, so nothing waits for the host.
 // n_reads: the batch's size, or (d_n_reads given) an upper bound of the size the device holds at d_n_reads
-// d_bases == nullptr: the batch is already packed (sl.pk_kmer / sl.pk_meta hold it, d_offsets = 32 x chunks before each read): no pack kernel
+// packed: the batch is already packed (sl.pk_kmer / sl.pk_meta hold it, d_offsets = 32 x chunks before each read): no pack kernel
 template <bool STATS>
-static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint32_t *d_gate, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on, const uint32_t *d_n_reads)
+static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint32_t *d_gate, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on, const uint32_t *d_n_reads, const bool packed)
 {
-	const bool packed = d_bases == nullptr;
 	uint32_t *ctr = sl.ctr;
 	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
 	if (!ix->force_generic) {
@@ -1669,11 +1712,11 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		}
 		HIP_TRY(hipMemsetAsync(ctr, 0, 64, ps));
 		HIP_TRY(hipEventRecord(sl.e0, ps));
-		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;
-		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T - 1) / PACK_T, (uint64_t)ix->cus * pack_bpc * (256 / PACK_T));
+		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;          // workgroups (of PACK_WPB tiles at a time) per CU
+		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T * PACK_WPB - 1) / (PACK_T * PACK_WPB), (uint64_t)ix->cus * pack_bpc);
 		const bool fused = VG_FUSE_PACK && !packed && !getenv("VG_NO_FUSE");          // the main tier encodes the reads itself (experiment)
 		const FuseIn fin{fused ? d_bases : nullptr, d_quals, d_gate, &ctr[3]}, nofuse{nullptr, nullptr, nullptr, nullptr};
-		if (!packed && !fused) vg_pack_kernel<<<pgrid, PACK_T, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate);
+		if (!packed && !fused) vg_pack_kernel<<<pgrid, PACK_T * PACK_WPB, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate);
 		HIP_TRY(hipEventRecord(sl.e1, ps));
 		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
@@ -1706,13 +1749,13 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
-		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, packed ? nullptr : &ctr[3], d_gate, sl.pk_kmer, sl.pk_meta);
+		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, packed ? nullptr : &ctr[3], d_gate, sl.pk_kmer, sl.pk_meta, packed);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	}
 	// ... then the generic lane machine with the deep HBM scratch for whatever is left
-	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta);
+	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
 	vg_accumulate_counters<<<1, 1, 0, ix->tail>>>(ctr, ix->d_cum);
 	HIP_TRY(hipEventRecord(sl.e3, ix->tail));
 	HIP_TRY(hipGetLastError());
@@ -1753,8 +1796,8 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));
 		sl.list_cap = n_reads;
 	}
-	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads)
-	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads);
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads, false)
+	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads, false);
 }
 
 extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
@@ -1811,8 +1854,8 @@ static int launch_packed(vg_index *ix, Slot &sl, const uint64_t *kmers, const ui
 		HIP_TRY(hipMemcpy(sl.pk_meta, meta, n_reads * 8, hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(sl.st_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice));
 	}
-	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr)
-	                         : enqueue_batch<false>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr);
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr, true)
+	                         : enqueue_batch<false>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr, true);
 }
 
 extern "C" int vg_reads_submit_packed(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads)
@@ -1826,6 +1869,7 @@ extern "C" int vg_reads_submit_packed(vg_index *ix, const uint64_t *kmers, const
 		for (uint64_t i = 0; i < n_reads; i++) {
 			if (chunk_offsets[i + 1] < chunk_offsets[i]) return fail(VG_EINVAL, "chunk offsets not monotone");
 			if (chunk_offsets[i + 1] - chunk_offsets[i] > 31) return fail(VG_EBADREAD, "a packed read of more than 31 chunks (a FASTQ line the reference can read holds at most 1022 bases, qv.cc:700)");
+			if (meta[i] & 0x3FFFFFFF00000000ull) return fail(VG_EINVAL, "a packed read's flag word has reserved bits set (bits 0-31: gate bits, 62: N inside the read, 63: another character; nothing else)");
 			invalid += (meta[i] >> 63) & 1u;
 		}
 		const uint64_t n_chunks = chunk_offsets[n_reads];
