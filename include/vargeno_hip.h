@@ -72,6 +72,12 @@ const char *vg_last_error(void);
 /* sha256 prefix of the sources this library was compiled from (csrc/Makefile): lets a caller refuse a stale build */
 const char *vg_build_id(void);
 int  vg_device_count(void);
+/* Total memory of a device in bytes (0 on failure): what a caller that puts SEVERAL replicas on one device divides into the
+ * budgets it hands to vg_index_open_ex -- without a budget every replica plans for the whole device (less 12 GiB), and the
+ * third or fourth one fails with VG_ENOMEM.  vg_share_budget() is that division as the CLI and the Python binding make it:
+ * (total - 12 GiB) / replicas_on_the_device. */
+uint64_t vg_device_memory(int device);
+uint64_t vg_share_budget(int device, int replicas_on_the_device);
 
 /* Page-locked host buffers for the batches / FASTQ chunks handed to vg_reads_submit / vg_fastq_submit
  * (optional: any host memory works, pinned memory copies at link speed).  NULL on failure. */
@@ -94,6 +100,11 @@ int  vg_index_open_ex(const char *prefix, int device, uint64_t max_device_bytes,
 /* What the budget bought, in words: planned bytes, views kept, views left out with what each costs ("" for a null handle).
  * The string lives as long as the handle. */
 const char *vg_index_plan(const vg_index *ix);
+/* Where the handle's start-up time went (the reference's loader, qv.cc:519-695, takes ~240 s at hg38 scale):
+ * wall seconds of each phase of vg_index_open / vg_index_create with the part spent inside allocation calls, then the memory the
+ * handle ended up with (r05: one arena of 1 GiB chunks taken from the driver once and recycled, vg_arena.h).  "" for a null handle;
+ * the string lives as long as the handle. */
+const char *vg_index_open_report(const vg_index *ix);
 int  vg_index_create(const vg_index_arrays *a, int device, vg_index **out);
 void vg_index_close(vg_index *ix);               /* qv.cc:1775-1786 */
 
@@ -162,8 +173,8 @@ int  vg_fastq_stream_begin(vg_index *ix);
  * quality character for every chunk; anything else refuses the chunk and the rest of the stream), but what crosses the link is
  * the packed form (8 bytes per chunk + 16 per read instead of the text: 6.5 x fewer bytes for 150 bp reads), so a host with cores
  * to spare ingests several times faster than the link can move text.  host_threads > 0: that many; 0: device framing after all
- * (same as vg_fastq_stream_begin); < 0: the library decides (half the hardware threads, at most 96; device framing on hosts with
- * fewer than 16; $VG_PACK_THREADS overrides).  push / end are the calls above and report the same things. */
+ * (same as vg_fastq_stream_begin); < 0: the library decides (half the CPUs the process may use -- a cgroup CPU quota counts --,
+ * at most 96; device framing when that is fewer than 32; $VG_PACK_THREADS overrides).  At most 256 threads are started.  push / end are the calls above and report the same things. */
 int  vg_fastq_stream_begin_packed(vg_index *ix, int host_threads);
 int  vg_fastq_stream_push(vg_index *ix, const uint8_t *text, uint64_t nbytes);
 int  vg_fastq_stream_end(vg_index *ix, uint64_t *n_records, uint64_t *consumed, uint64_t *last_record_start, int *refused);

@@ -14,7 +14,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 CSRC = os.path.join(ROOT, "vargeno_amd", "csrc")
 # the files (in this order) whose sha256 csrc/Makefile compiles into the library / the command-line tool
-LIB_SOURCES = [os.path.join(ROOT, "include", "vargeno_hip.h")] + [os.path.join(CSRC, f) for f in ("vg_device.h", "vg_wave.h", "vargeno_hip.hip", "vg_sort.hip", "vg_hostpack.h", "vg_hostpack.cpp", "vg_allreduce_plan.h", "vg_hostpack_impl.h", "vg_hostpack_impl.inc", "vg_hostpack_avx2.cpp")]
+LIB_SOURCES = [os.path.join(ROOT, "include", "vargeno_hip.h")] + [os.path.join(CSRC, f) for f in ("vg_device.h", "vg_wave.h", "vargeno_hip.hip", "vg_sort.hip", "vg_arena.h", "vg_hostpack.h", "vg_hostpack.cpp", "vg_allreduce_plan.h", "vg_hostpack_impl.h", "vg_hostpack_impl.inc", "vg_hostpack_avx2.cpp")]
 HOST_SOURCES = [os.path.join(ROOT, "include", "vargeno_hip.h"), os.path.join(CSRC, "host", "vg_host.h")] + [
     os.path.join(CSRC, "host", f) for f in ("main.cpp", "index_build.cpp", "fastq.cpp", "caller_vcf.cpp")]
 

@@ -235,3 +235,17 @@ def test_cli_with_eight_replicas_gives_the_golden_vcf(ftiny_dir, tmp_path):
     assert p.returncode == 0, p.stderr
     assert "framed on the host" not in p.stderr, p.stderr            # the eight ranges went through the device-side framing
     assert open(tmp_path / "out.vcf", "rb").read() == gzip.open(os.path.join(GOLDEN, "ftiny.out.vcf.gz"), "rb").read()
+
+
+def test_cli_with_four_full_replicas_sharing_one_device(ftiny_dir, tmp_path):
+    """Replicas that share a device share its memory: without a budget of its own each gets an equal part (vg_share_budget) and
+    plans its views for that -- four replicas with every optional view on used to plan for the whole device each, and the third
+    or fourth one failed with VG_ENOMEM (round 4's advisor).  Same VCF as one replica."""
+    if torch.cuda.device_count() >= 4:
+        pytest.skip("needs replicas that SHARE a device")
+    env = dict(os.environ, VARGENO_GPUS="4", VARGENO_SHARE_DEVICES="1", VARGENO_CHUNK_MB="1", VARGENO_VERBOSE="1")
+    p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), os.path.join(ftiny_dir, "reads.fq"), os.path.join(ftiny_dir, "snps.vcf"), str(tmp_path / "out.vcf")],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr
+    assert "vg_index_open_ex" in p.stderr and "LEFT OUT for the budget" in p.stderr, p.stderr      # each replica planned within its share
+    assert open(tmp_path / "out.vcf", "rb").read() == gzip.open(os.path.join(GOLDEN, "ftiny.out.vcf.gz"), "rb").read()

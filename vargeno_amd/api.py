@@ -31,9 +31,12 @@ class GenoIndex:
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
-    def open(cls, prefix, device=0, max_device_bytes=None):
-        """max_device_bytes: this replica's device-memory budget (vg_index_open_ex); None: vg_index_open (the whole device)."""
+    def open(cls, prefix, device=0, max_device_bytes=None, sharers=1):
+        """max_device_bytes: this replica's device-memory budget (vg_index_open_ex); None: vg_index_open (the whole device) --
+        or, with sharers > 1 replicas / ranks on this device, an equal share of it (vg_share_budget)."""
         h = C.c_void_p()
+        if max_device_bytes is None and sharers > 1:
+            max_device_bytes = int(lib().vg_share_budget(device, int(sharers))) or None
         if max_device_bytes is None:
             check(lib().vg_index_open(os.fsencode(prefix), device, C.byref(h)))
         else:
@@ -45,6 +48,14 @@ class GenoIndex:
         """What the device-memory budget bought (vg_index_plan): views kept, views left out and what each costs."""
         try:
             return lib().vg_index_plan(self._h).decode()
+        except AttributeError:                                   # an older build loaded for an A/B run (VARGENO_HIP_LIB)
+            return ""
+
+    @property
+    def open_report(self):
+        """Where the handle's start-up time went, phase by phase, and the memory it ended up with (vg_index_open_report)."""
+        try:
+            return lib().vg_index_open_report(self._h).decode()
         except AttributeError:                                   # an older build loaded for an A/B run (VARGENO_HIP_LIB)
             return ""
 

@@ -196,12 +196,16 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		std::vector<std::string> errs((size_t)ngpu);
 		const char *bgt = getenv("VARGENO_MAX_DEVICE_GB");
 		const uint64_t budget = bgt && *bgt ? (uint64_t)(atof(bgt) * 1e9) : 0ull;
-		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_index_open_ex(prefix.c_str(), g % have, budget, &ix[(size_t)g]); if (rcs[(size_t)g]) errs[(size_t)g] = vg_last_error(); });
+		// replicas that share a device (VARGENO_SHARE_DEVICES) share its memory too: without a budget of its own each of them gets
+		// an equal part -- planned for the whole device, the third or fourth one would fail where it could have run on fewer views
+		std::vector<uint64_t> budgets((size_t)ngpu, budget);
+		if (!budget && ngpu > have) for (int g = 0; g < ngpu; g++) { int on = 0; for (int k = 0; k < ngpu; k++) on += k % have == g % have; if (on > 1) budgets[(size_t)g] = vg_share_budget(g % have, on); }
+		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_index_open_ex(prefix.c_str(), g % have, budgets[(size_t)g], &ix[(size_t)g]); if (rcs[(size_t)g]) errs[(size_t)g] = vg_last_error(); });
 		for (auto &t : th) t.join();
 		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) { fprintf(stderr, "vargeno: cannot load index %s on GPU %d (%d): %s\n", prefix.c_str(), g, rcs[(size_t)g], errs[(size_t)g].c_str()); return EXIT_FAILURE; }
 	}
 	for (auto *h : ix) VG_CHECK(vg_set_stats(h, env_int("VARGENO_STATS", 0)));
-	if (env_int("VARGENO_VERBOSE", 0)) fprintf(stderr, "index replica: %s\n", vg_index_plan(ix[0]));
+	if (env_int("VARGENO_VERBOSE", 0)) { fprintf(stderr, "index replica: %s\n", vg_index_plan(ix[0])); fprintf(stderr, "index start-up: %s\n", vg_index_open_report(ix[0])); }
 
 	fprintf(stderr, "Processing...\n");
 	struct timespec t_loaded; clock_gettime(CLOCK_MONOTONIC, &t_loaded);

@@ -11,6 +11,7 @@
 #include "vg_wave.h"
 #include "vg_hostpack.h"
 #include "vg_allreduce_plan.h"
+#include "vg_arena.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -26,6 +27,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <chrono>
+#include <map>
 #include <memory>
 #include <string>
 #include <thread>
@@ -77,6 +79,18 @@ extern "C" int vg_device_count(void)
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
 	return n;
+}
+extern "C" uint64_t vg_device_memory(int device)
+{
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return (uint64_t)prop.totalGlobalMem;
+}
+extern "C" uint64_t vg_share_budget(int device, int replicas)
+{
+	const uint64_t total = vg_device_memory(device), reserve = 12ull << 30;
+	if (total == 0 || replicas < 1) return 0;
+	return (total > reserve ? total - reserve : total) / (uint64_t)replicas;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,7 +154,8 @@ __global__ __launch_bounds__(256) void vg_build_jumpgate(const uint64_t *__restr
 	if (blockIdx.x == gridDim.x - 1 && t == 0) jg[n_buckets] = (uint32_t)n;
 }
 
-int vg_dev_sort_pairs_u64_u32(const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, size_t n, hipStream_t stream);   // vg_sort.hip
+size_t vg_dev_sort_pairs_temp_bytes(size_t n);                                                          // vg_sort.hip
+int vg_dev_sort_pairs_u64_u32(uint64_t *keys_a, uint64_t *keys_b, uint32_t *vals_a, uint32_t *vals_b, size_t n, hipStream_t stream, void *tmp, size_t tmp_bytes, bool *result_in_b);
 
 __global__ void vg_make_sec_keys(const uint64_t *__restrict__ kmer, uint64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
 {
@@ -397,7 +412,11 @@ __global__ __launch_bounds__(PACK_T * PACK_WPB) void vg_pack_kernel(const uint8_
 				for (uint32_t q = 0; q < G; q++) {
 					const uint32_t p = (j0 + q) * 64u + ln;
 					uint32_t br = 0;
+#ifdef VG_PACK_DRY
+					const uint32_t w = v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;      // timing experiment only (wrong results): the kernel's traffic without its arithmetic
+#else
 					const uint32_t w = pack16(v[q], br);
+#endif
 					if (p < n_pieces) sm_pk[wv][p] = w;
 					const unsigned long long bm = __ballot((br & PACK_CASE_MASK) != 0u);
 					tile_bad = tile_bad || bm != 0ull;
@@ -711,6 +730,52 @@ __global__ __launch_bounds__(256) void vg_fq_gather(const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // host side of the handle
 // ------------------------------------------------------------------------------------------------
+// the HIP virtual-memory calls behind vg_arena.h
+struct HipVm {
+	typedef hipMemGenericAllocationHandle_t Handle;
+	static hipMemAllocationProp prop(int device)
+	{
+		hipMemAllocationProp p = {};
+		p.type = hipMemAllocationTypePinned;
+		p.location.type = hipMemLocationTypeDevice;
+		p.location.id = device;
+		return p;
+	}
+	static bool granularity_ok(int device, uint64_t chunk)
+	{
+		const hipMemAllocationProp p = prop(device);
+		size_t gran = 0;
+		if (hipMemGetAllocationGranularity(&gran, &p, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || chunk % gran != 0) { (void)hipGetLastError(); return false; }
+		return true;
+	}
+	static uint8_t *reserve(uint64_t bytes)
+	{
+		void *p = nullptr;
+		if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		return (uint8_t *)p;
+	}
+	static void unreserve(uint8_t *va, uint64_t bytes) { (void)hipMemAddressFree(va, bytes); }
+	static bool create(int device, uint64_t bytes, Handle *h)
+	{
+		const hipMemAllocationProp p = prop(device);
+		if (hipMemCreate(h, bytes, &p, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+		return true;
+	}
+	static void release(Handle h) { (void)hipMemRelease(h); }
+	static bool map(uint8_t *at, uint64_t bytes, Handle h, int device)
+	{
+		if (hipMemMap(at, bytes, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+		hipMemAccessDesc acc = {};
+		acc.location.type = hipMemLocationTypeDevice;
+		acc.location.id = device;
+		acc.flags = hipMemAccessFlagsProtReadWrite;
+		if (hipMemSetAccess(at, bytes, &acc, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap(at, bytes); return false; }
+		return true;
+	}
+	static void unmap(uint8_t *at, uint64_t bytes) { (void)hipMemUnmap(at, bytes); }
+};
+typedef DevArenaT<HipVm> DevArena;
+
 struct ScratchBuf {
 	Scratch s{};
 	size_t bytes = 0;
@@ -747,8 +812,10 @@ struct vg_index {
 	                                                // wave kernel's duration then includes the time it spent waiting for the pack kernel (4.18 vs 3.55 ms)
 	bool ingest_stream = true;                      // VG_NO_INGEST_STREAM: FASTQ framing on the main stream too
 	DevIndex d{};
-	std::vector<void *> owned;            // every device allocation of the index
-	uint64_t dev_bytes = 0;
+	DevArena arena;                       // the index's device memory (vg_arena.h): permanent arrays and the temporaries of its construction
+	std::vector<void *> owned;            // device allocations of the index made with hipMalloc (small handle-lifetime buffers; everything, when the arena could not be set up)
+	std::map<void *, uint64_t> owned_bytes;
+	uint64_t dev_bytes = 0;               // device memory of the index: hipMalloc'ed buffers (counted as they are made) + the arena's mapped chunks (counted when construction is over)
 	uint64_t n_sites = 0;
 	bool cnt4_dirty = false;                           // base-indexed counters hold increments not yet folded into d.cnt
 	std::vector<uint32_t> site_pos;
@@ -771,23 +838,50 @@ struct vg_index {
 	uint64_t max_device_bytes = 0;        // the caller's budget for this replica (vg_index_open_ex; 0: the whole device)
 	std::string plan_text;                // what the budget bought: views kept / left out (vg_index_plan)
 	std::string aux_note;                 // ... and what the loader found in the auxiliary rows, if anything
+	std::string open_report;              // where vg_index_open's time went, phase by phase
 	vgp::Packer *packer = nullptr;        // host-side framing + packing (vg_fastq_stream_begin_packed)
 	bool fq_packed = false;               // the open FASTQ stream is framed + packed on the host
 	uint64_t host_invalid = 0;            // reads with a character other than ACGTN found by the host packer since the last reset
 };
 
+// The index handle a thread is constructing (vg_index_open / vg_index_create run on the caller's thread; the CLI opens its replicas
+// on one thread each): where TempDev finds the arena and the stream.
+static thread_local vg_index *g_building = nullptr;
+static thread_local double g_alloc_s = 0;                  // seconds spent inside allocation calls since the last lap (VG_VERBOSE)
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// a permanent array of the index: out of the arena's bottom half; hipMalloc when the arena is not there (or `plain`: buffers that
+// other libraries get to see -- RCCL reduces the counters in place)
 template <class T>
-static int dev_alloc(vg_index *ix, T **p, uint64_t count, bool zero = false)
+static int dev_alloc(vg_index *ix, T **p, uint64_t count, bool zero = false, bool plain = false)
 {
 	void *q = nullptr;
 	const size_t bytes = (size_t)(count ? count : 1) * sizeof(T);
-	hipError_t e = hipMalloc(&q, bytes);
-	if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(%s bytes): %s", std::to_string(bytes).c_str(), hipGetErrorString(e));
-	if (zero) { e = hipMemsetAsync(q, 0, bytes, ix->stream); if (e != hipSuccess) return fail(VG_ENODEV, "hipMemset: %s", hipGetErrorString(e)); }
-	ix->owned.push_back(q);
-	ix->dev_bytes += bytes;
+	const double t0 = now_s();
+	if (!plain) q = ix->arena.take(bytes, false);
+	if (!q) {
+		hipError_t e = hipMalloc(&q, bytes);
+		if (e != hipSuccess) { (void)hipGetLastError(); return fail(VG_ENOMEM, "hipMalloc(%s bytes): %s", std::to_string(bytes).c_str(), hipGetErrorString(e)); }
+		ix->owned.push_back(q);
+		ix->owned_bytes[q] = bytes;
+		ix->dev_bytes += bytes;
+	}
+	g_alloc_s += now_s() - t0;
+	if (zero) { hipError_t e = hipMemsetAsync(q, 0, bytes, ix->stream); if (e != hipSuccess) return fail(VG_ENODEV, "hipMemset: %s", hipGetErrorString(e)); }
 	*p = (T *)q;
 	return VG_OK;
+}
+// ... and one that is not needed any more (a jump table that a wider table has replaced); the device must be done with it
+static void dev_release(vg_index *ix, const void *cp)
+{
+	void *p = const_cast<void *>(cp);
+	if (!p) return;
+	(void)hipStreamSynchronize(ix->stream);
+	if (ix->arena.give(p)) return;
+	for (size_t z = 0; z < ix->owned.size(); z++) if (ix->owned[z] == p) { ix->owned.erase(ix->owned.begin() + (long)z); break; }
+	auto it = ix->owned_bytes.find(p);
+	if (it != ix->owned_bytes.end()) { ix->dev_bytes -= it->second; ix->owned_bytes.erase(it); }
+	(void)hipFree(p);
 }
 template <class T>
 static int dev_upload(vg_index *ix, T **p, const T *src, uint64_t count)
@@ -797,15 +891,24 @@ static int dev_upload(vg_index *ix, T **p, const T *src, uint64_t count)
 	if (count) HIP_TRY(hipMemcpy(*p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
 	return VG_OK;
 }
-// temporary device copy of a host array, freed when it goes out of scope
+// a temporary of the construction, given back when it goes out of scope (or released earlier): out of the arena's top half while a
+// handle is being built on this thread, hipMalloc otherwise.  Giving it back waits for the stream first, as hipFree does.
 template <class T>
 struct TempDev {
 	T *p = nullptr;
-	~TempDev() { if (p) (void)hipFree(p); }
+	vg_index *ix = nullptr;                        // the handle whose arena holds p (nullptr: hipMalloc)
+	~TempDev() { release(); }
 	int alloc(uint64_t count)
 	{
-		hipError_t e = hipMalloc((void **)&p, (size_t)(count ? count : 1) * sizeof(T));
-		if (e != hipSuccess) return fail(VG_ENOMEM, "hipMalloc(staging): %s", hipGetErrorString(e));
+		release();
+		const size_t bytes = (size_t)(count ? count : 1) * sizeof(T);
+		const double t0 = now_s();
+		if (g_building) { p = (T *)g_building->arena.take(bytes, true); if (p) ix = g_building; }
+		if (!p) {
+			hipError_t e = hipMalloc((void **)&p, bytes);
+			if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return fail(VG_ENOMEM, "hipMalloc(staging): %s", hipGetErrorString(e)); }
+		}
+		g_alloc_s += now_s() - t0;
 		return VG_OK;
 	}
 	int upload(const T *src, uint64_t count)
@@ -815,13 +918,20 @@ struct TempDev {
 		if (count) HIP_TRY(hipMemcpy(p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
 		return VG_OK;
 	}
-	void release() { if (p) (void)hipFree(p); p = nullptr; }
+	void release()
+	{
+		if (!p) return;
+		const double t0 = now_s();
+		if (ix) { (void)hipStreamSynchronize(ix->stream); (void)ix->arena.give(p); }
+		else (void)hipFree(p);
+		g_alloc_s += now_s() - t0;
+		p = nullptr; ix = nullptr;
+	}
 };
 
 static int alloc_scratch(vg_index *ix, ScratchBuf &b, uint32_t nlanes, uint32_t cap, uint32_t kcap)
 {
 	b.s.nlanes = nlanes; b.s.cap = cap; b.s.kcap = kcap;
-	const uint64_t before = ix->dev_bytes;
 	int rc;
 	if ((rc = dev_alloc(ix, &b.s.ctx_kmer, (uint64_t)cap * nlanes))) return rc;
 	if ((rc = dev_alloc(ix, &b.s.ctx_kpos, (uint64_t)cap * nlanes))) return rc;
@@ -829,7 +939,7 @@ static int alloc_scratch(vg_index *ix, ScratchBuf &b, uint32_t nlanes, uint32_t 
 	if ((rc = dev_alloc(ix, &b.s.key_index, (uint64_t)kcap * nlanes))) return rc;
 	if ((rc = dev_alloc(ix, &b.s.key_first, (uint64_t)kcap * nlanes))) return rc;
 	if ((rc = dev_alloc(ix, &b.s.key_fm, (uint64_t)kcap * nlanes))) return rc;
-	b.bytes = ix->dev_bytes - before;
+	b.bytes = ((uint64_t)cap * 16 + (uint64_t)kcap * 12) * nlanes;
 	return VG_OK;
 }
 
@@ -841,6 +951,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (ix->tail) (void)hipStreamSynchronize(ix->tail);
 	if (ix->ingest) (void)hipStreamSynchronize(ix->ingest);
 	for (void *p : ix->owned) (void)hipFree(p);
+	ix->arena.destroy();
 	for (Slot &sl : ix->slot) {
 		void *extra[] = {sl.listA, sl.listB, sl.listC, sl.st_bases, sl.st_quals, sl.st_gate, sl.st_offsets, sl.pk_kmer, sl.pk_meta, sl.fq_text, sl.fq_lines, sl.fq_tiles, sl.fq_tmp, sl.fq_chunk};
 		for (void *p : extra) if (p) (void)hipFree(p);
@@ -856,16 +967,23 @@ extern "C" void vg_index_close(vg_index *ix)
 	delete ix;
 }
 
-// VG_VERBOSE=1: wall time of the phases of vg_index_open / vg_index_create on stderr (start-up is §8f-4)
+// Wall time of the phases of vg_index_open / vg_index_create (start-up is SURVEY.md §8f-4): kept in the handle (vg_index_open_report),
+// and on stderr under VG_VERBOSE=1.  Every lap also says how much of it was spent inside allocation calls.
 struct PhaseClock {
+	vg_index *ix;
 	const bool on = getenv("VG_VERBOSE") != nullptr;
 	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	explicit PhaseClock(vg_index *h) : ix(h) { g_alloc_s = 0; }
 	void lap(const char *what)
 	{
-		if (!on) return;
 		(void)hipDeviceSynchronize();
 		const auto n = std::chrono::steady_clock::now();
-		fprintf(stderr, "[vargeno_hip] %-44s %.2f s\n", what, std::chrono::duration<double>(n - t).count());
+		const double sec = std::chrono::duration<double>(n - t).count();
+		char line[200];
+		snprintf(line, sizeof line, "%s%s %.2f s (allocation calls %.2f s)", ix->open_report.empty() ? "" : "; ", what, sec, g_alloc_s);
+		ix->open_report += line;
+		if (on) fprintf(stderr, "[vargeno_hip] %-44s %.2f s  (allocation calls %.2f s)\n", what, sec, g_alloc_s);
+		g_alloc_s = 0;
 		t = n;
 	}
 };
@@ -1054,6 +1172,12 @@ static int init_handle(vg_index *ix, int device)
 	if (device < 0 || device >= ndev) return fail(VG_EINVAL, "device index out of range");
 	ix->device = device;
 	HIP_TRY(hipSetDevice(device));
+	{
+		// the handle's device memory (vg_arena.h); VG_NO_ARENA=1: every buffer its own hipMalloc / hipFree, as through round 4
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = 0; }
+		if (!getenv("VG_NO_ARENA")) (void)ix->arena.init(device, (uint64_t)tot);
+	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
 	{
 		// the spill tiers are a few hundred small workgroups that can only start when main-tier workgroups retire: with a
@@ -1135,6 +1259,8 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 }
 
 // From the columns (device) + the two bit vectors (host words) to the resident index.
+// Device memory comes out of the handle's arena (vg_arena.h): permanent arrays with dev_alloc, temporaries as TempDev; one
+// stream (ix->stream) carries every kernel, and a temporary is only given back after the stream has drained.
 static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const uint64_t *ref_bf_words, uint64_t snp_bf_bits, const uint64_t *snp_bf_words, PhaseClock &pc)
 {
 	if (c.n_ref >= 0xFFFFFFFFull || c.n_snp >= 0xFFFFFFFFull) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
@@ -1144,40 +1270,35 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	d.n_ref = c.n_ref; d.n_snp = c.n_snp;
 	d.ref_aux = c.ref_aux; d.snp_aux_pos = c.snp_aux_pos; d.snp_aux_info = c.snp_aux_info;
 	hipStream_t st = ix->stream;
-	// ---- largest position any entry names (needs columns that are released along the way)
+	// ---- largest position any entry names (needs columns that are released along the way), and what a file that `vargeno index`
+	//      did not write could get wrong: one wait for both
 	unsigned long long maxp = 0;
 	{
-		TempDev<unsigned long long> dmax;
-		if ((rc = dmax.alloc(1))) return rc;
-		HIP_TRY(hipMemsetAsync(dmax.p, 0, 8, st));
-		if (c.n_ref) vg_max_pos<<<2048, 256, 0, st>>>(c.ref_pos.p, c.ref_amb.p, c.n_ref, dmax.p);
-		if (c.n_ref_aux) vg_max_pos<<<1024, 256, 0, st>>>(c.ref_aux, nullptr, c.n_ref_aux * AUX_COLS, dmax.p);
-		if (c.n_snp) vg_max_pos<<<2048, 256, 0, st>>>(c.snp_pos.p, c.snp_amb.p, c.n_snp, dmax.p);
-		if (c.n_snp_aux) vg_max_pos<<<1024, 256, 0, st>>>(c.snp_aux_pos, nullptr, c.n_snp_aux * AUX_COLS, dmax.p);
+		TempDev<unsigned long long> dchk;                  // [0] max position, [1] k-mers out of order, [2] wild row indices, [3] rows that repeat a position
+		if ((rc = dchk.alloc(4))) return rc;
+		HIP_TRY(hipMemsetAsync(dchk.p, 0, 32, st));
+		if (c.n_ref) vg_max_pos<<<2048, 256, 0, st>>>(c.ref_pos.p, c.ref_amb.p, c.n_ref, dchk.p);
+		if (c.n_ref_aux) vg_max_pos<<<1024, 256, 0, st>>>(c.ref_aux, nullptr, c.n_ref_aux * AUX_COLS, dchk.p);
+		if (c.n_snp) vg_max_pos<<<2048, 256, 0, st>>>(c.snp_pos.p, c.snp_amb.p, c.n_snp, dchk.p);
+		if (c.n_snp_aux) vg_max_pos<<<1024, 256, 0, st>>>(c.snp_aux_pos, nullptr, c.n_snp_aux * AUX_COLS, dchk.p);
+		if (c.n_ref) vg_check_columns<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, c.n_ref_aux, dchk.p + 1);
+		if (c.n_snp) vg_check_columns<<<2048, 256, 0, st>>>(c.snp_kmer.p, c.snp_pos.p, c.snp_amb.p, c.n_snp, c.n_snp_aux, dchk.p + 1);
+		if (c.n_ref_aux) vg_check_aux_rows<<<1024, 256, 0, st>>>(c.ref_aux, c.n_ref_aux, dchk.p + 3);
+		if (c.n_snp_aux) vg_check_aux_rows<<<1024, 256, 0, st>>>(c.snp_aux_pos, c.n_snp_aux, dchk.p + 3);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(st));
-		HIP_TRY(hipMemcpy(&maxp, dmax.p, 8, hipMemcpyDeviceToHost));
-		// ---- and what a file that `vargeno index` did not write could get wrong
-		TempDev<unsigned long long> dbad;
-		if ((rc = dbad.alloc(3))) return rc;
-		HIP_TRY(hipMemsetAsync(dbad.p, 0, 24, st));
-		if (c.n_ref) vg_check_columns<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, c.n_ref_aux, dbad.p);
-		if (c.n_snp) vg_check_columns<<<2048, 256, 0, st>>>(c.snp_kmer.p, c.snp_pos.p, c.snp_amb.p, c.n_snp, c.n_snp_aux, dbad.p);
-		if (c.n_ref_aux) vg_check_aux_rows<<<1024, 256, 0, st>>>(c.ref_aux, c.n_ref_aux, dbad.p + 2);
-		if (c.n_snp_aux) vg_check_aux_rows<<<1024, 256, 0, st>>>(c.snp_aux_pos, c.n_snp_aux, dbad.p + 2);
-		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(st));
-		unsigned long long bad[3] = {0, 0, 0};
-		HIP_TRY(hipMemcpy(bad, dbad.p, 24, hipMemcpyDeviceToHost));
-		d.aux_dups = bad[2] || getenv("VG_FORCE_AUX_DUPS") ? 1u : 0u;       // (the knob: tests drive the careful path on ordinary indexes)
-		if (bad[2]) {
+		unsigned long long chk[4] = {0, 0, 0, 0};
+		HIP_TRY(hipMemcpy(chk, dchk.p, 32, hipMemcpyDeviceToHost));
+		maxp = chk[0];
+		d.aux_dups = chk[3] || getenv("VG_FORCE_AUX_DUPS") ? 1u : 0u;       // (the knob: tests drive the careful path on ordinary indexes)
+		if (chk[3]) {
 			char msg[200];
-			snprintf(msg, sizeof msg, "%llu auxiliary rows repeat a position (the SNP list holds a record several times): rows are expanded column by column", bad[2]);
+			snprintf(msg, sizeof msg, "%llu auxiliary rows repeat a position (the SNP list holds a record several times): rows are expanded column by column", chk[3]);
 			ix->aux_note = msg;
 		}
-		if (bad[0] || bad[1]) {
+		if (chk[1] || chk[2]) {
 			char msg[200];
-			snprintf(msg, sizeof msg, "k-mers out of order in %llu places, %llu entries naming auxiliary rows the file does not have", bad[0], bad[1]);
+			snprintf(msg, sizeof msg, "k-mers out of order in %llu places, %llu entries naming auxiliary rows the file does not have", chk[1], chk[2]);
 			return fail(VG_EIO, "not an index `vargeno index` wrote: %s", msg);
 		}
 	}
@@ -1191,140 +1312,121 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		d.ref_bf = r; d.ref_bf_bits = ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = snp_bf_bits;
 	}
 	// The merged view's indices are 32 bits wide: an index of 2^32 or more k-mers (hg38 + full dbSNP), or VG_NO_MX, runs on the
-	// layout without it -- and, its own peak being the tighter one (the paired HI32 table), with another order of construction:
-	// pile-up sites first, columns released as soon as their last reader is done.
+	// layout without it.
 	size_t dev_free = 0, dev_total = 0;
-	(void)hipMemGetInfo(&dev_free, &dev_total);
+	if (hipMemGetInfo(&dev_free, &dev_total) != hipSuccess) { (void)hipGetLastError(); dev_total = 0; }
+	if (dev_total == 0 && ix->max_device_bytes == 0) return fail(VG_ENODEV, "hipMemGetInfo failed and no device-memory budget was given (vg_index_open_ex): the views cannot be planned");
 	const ViewPlan plan = plan_views(c, maxp, ref_bf_bits, snp_bf_bits, ix->max_device_bytes, (uint64_t)dev_total, ix->cus);
 	ix->plan_text = plan.text;
 	if (!ix->aux_note.empty()) ix->plan_text += "; " + ix->aux_note;
 	if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] %s\n", plan.text.c_str());
 	if (plan.base > plan.budget) return fail(VG_ENOMEM, "the device-memory budget is below the smallest layout of this index: %s", plan.text.c_str());
 	const bool want_mx = plan.mx;
-	auto build_sites = [&]() -> int {
-		// ---- pile-up sites (src/qv.cc:602-603, 637-659)
+	// the radix sorts' scratch (a few MB: they ping-pong between the caller's two buffer pairs, vg_sort.hip)
+	TempDev<uint8_t> sort_tmp;
+	const size_t sort_tmp_bytes = vg_dev_sort_pairs_temp_bytes((size_t)(c.n_ref + c.n_snp));
+	if ((rc = sort_tmp.alloc(sort_tmp_bytes))) return rc;
+	pc.lap("checks, bit vectors, plan");
+	// ---- pile-up sites (src/qv.cc:602-603, 637-659): first, while little else is resident (their position-wide scratch is 4 bytes
+	//      per genome position), and the SNP dictionary's frequency columns go right after
+	{
+		const uint64_t plen = maxp + 64, nblk = plen / 64 + 1;
+		TempDev<uint32_t> winner; TempDev<uint64_t> blk; TempDev<uint8_t> tmp;
+		if ((rc = winner.alloc(plen)) || (rc = blk.alloc(nblk + 1))) return rc;
+		HIP_TRY(hipMemsetAsync(winner.p, 0, plen * 4, st));
+		uint8_t *dp = nullptr; ulonglong2 *dr = nullptr;
+		if ((rc = dev_alloc(ix, &dp, plen))) return rc;
+		if ((rc = dev_alloc(ix, &dr, nblk))) return rc;
+		if (c.n_snp) vg_site_winner<<<2048, 256, 0, st>>>(c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.n_snp, winner.p);
+		vg_site_blocks<<<ix->cus * 16, 256, 0, st>>>(winner.p, c.snp_kmer.p, c.snp_info.p, plen, dp, dr, blk.p);
+		HIP_TRY(hipMemsetAsync(blk.p + nblk, 0, 8, st));
+		HIP_TRY(hipGetLastError());
 		{
-			const uint64_t plen = maxp + 64, nblk = plen / 64 + 1;
-			TempDev<uint32_t> winner; TempDev<uint64_t> blk; TempDev<uint8_t> tmp;
-			if ((rc = winner.alloc(plen)) || (rc = blk.alloc(nblk + 1))) return rc;
-			HIP_TRY(hipMemsetAsync(winner.p, 0, plen * 4, st));
-			uint8_t *dp = nullptr; ulonglong2 *dr = nullptr;
-			if ((rc = dev_alloc(ix, &dp, plen))) return rc;
-			if ((rc = dev_alloc(ix, &dr, nblk))) return rc;
-			if (c.n_snp) vg_site_winner<<<2048, 256, 0, st>>>(c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.n_snp, winner.p);
-			vg_site_blocks<<<ix->cus * 16, 256, 0, st>>>(winner.p, c.snp_kmer.p, c.snp_info.p, plen, dp, dr, blk.p);
-			HIP_TRY(hipMemsetAsync(blk.p + nblk, 0, 8, st));
-			HIP_TRY(hipGetLastError());
-			{
-				const size_t need = vg_dev_scan_temp_bytes(1, nblk + 1);
-				if ((rc = tmp.alloc(need))) return rc;
-				const int se = vg_dev_exclusive_scan_u64(blk.p, blk.p, nblk + 1, st, tmp.p, need);
-				if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
-			}
-			HIP_TRY(hipStreamSynchronize(st));
-			uint64_t nsites = 0;
-			HIP_TRY(hipMemcpy(&nsites, blk.p + nblk, 8, hipMemcpyDeviceToHost));
-			if (nsites >= (1ull << 31)) return fail(VG_ETOOBIG, "more than 2^31 SNP sites");
-			ix->n_sites = nsites;
-			TempDev<uint32_t> s_pos; TempDev<uint8_t> s_ref, s_alt, s_rf, s_af;
-			uint8_t *dba = nullptr;
-			if ((rc = s_pos.alloc(nsites)) || (rc = s_ref.alloc(nsites)) || (rc = s_alt.alloc(nsites)) || (rc = s_rf.alloc(nsites)) || (rc = s_af.alloc(nsites))) return rc;
-			if ((rc = dev_alloc(ix, &dba, nsites + 1, true))) return rc;
-			vg_site_tables<<<ix->cus * 16, 256, 0, st>>>(winner.p, dp, c.snp_rf.p, c.snp_af.p, plen, dr, blk.p, s_pos.p, s_ref.p, s_alt.p, s_rf.p, s_af.p, dba);
-			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(st));
-			ix->site_pos.resize(nsites); ix->site_ref.resize(nsites); ix->site_alt.resize(nsites); ix->site_rf.resize(nsites); ix->site_af.resize(nsites);
-			if (nsites) {
-				HIP_TRY(hipMemcpy(ix->site_pos.data(), s_pos.p, nsites * 4, hipMemcpyDeviceToHost));
-				HIP_TRY(hipMemcpy(ix->site_ref.data(), s_ref.p, nsites, hipMemcpyDeviceToHost));
-				HIP_TRY(hipMemcpy(ix->site_alt.data(), s_alt.p, nsites, hipMemcpyDeviceToHost));
-				HIP_TRY(hipMemcpy(ix->site_rf.data(), s_rf.p, nsites, hipMemcpyDeviceToHost));
-				HIP_TRY(hipMemcpy(ix->site_af.data(), s_af.p, nsites, hipMemcpyDeviceToHost));
-			}
-			uint32_t *dc = nullptr, *dc4 = nullptr;
-			if ((rc = dev_alloc(ix, &dc, 2 * nsites + 2, true))) return rc;
-			if ((rc = dev_alloc(ix, &dc4, 4 * nsites + 4, true))) return rc;
-			d.srank = dr; d.pile = dp; d.pile_len = plen; d.cnt = dc; d.site_ba = dba; d.cnt4 = dc4;
-			c.snp_rf.release(); c.snp_af.release();
+			const size_t need = vg_dev_scan_temp_bytes(1, nblk + 1);
+			if ((rc = tmp.alloc(need))) return rc;
+			const int se = vg_dev_exclusive_scan_u64(blk.p, blk.p, nblk + 1, st, tmp.p, need);
+			if (se != 0) return fail(VG_ENODEV, "device scan failed: %s", hipGetErrorString((hipError_t)se));
 		}
-		return VG_OK;
-	};
-	if (!want_mx) { if ((rc = build_sites())) return rc; pc.lap("pile-up sites"); }
-	// ---- reference dictionary: jump table + 16-byte entries
+		HIP_TRY(hipStreamSynchronize(st));
+		uint64_t nsites = 0;
+		HIP_TRY(hipMemcpy(&nsites, blk.p + nblk, 8, hipMemcpyDeviceToHost));
+		if (nsites >= (1ull << 31)) return fail(VG_ETOOBIG, "more than 2^31 SNP sites");
+		ix->n_sites = nsites;
+		TempDev<uint32_t> s_pos; TempDev<uint8_t> s_ref, s_alt, s_rf, s_af;
+		uint8_t *dba = nullptr;
+		if ((rc = s_pos.alloc(nsites)) || (rc = s_ref.alloc(nsites)) || (rc = s_alt.alloc(nsites)) || (rc = s_rf.alloc(nsites)) || (rc = s_af.alloc(nsites))) return rc;
+		if ((rc = dev_alloc(ix, &dba, nsites + 1, true))) return rc;
+		vg_site_tables<<<ix->cus * 16, 256, 0, st>>>(winner.p, dp, c.snp_rf.p, c.snp_af.p, plen, dr, blk.p, s_pos.p, s_ref.p, s_alt.p, s_rf.p, s_af.p, dba);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipStreamSynchronize(st));
+		ix->site_pos.resize(nsites); ix->site_ref.resize(nsites); ix->site_alt.resize(nsites); ix->site_rf.resize(nsites); ix->site_af.resize(nsites);
+		if (nsites) {
+			HIP_TRY(hipMemcpy(ix->site_pos.data(), s_pos.p, nsites * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ix->site_ref.data(), s_ref.p, nsites, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ix->site_alt.data(), s_alt.p, nsites, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ix->site_rf.data(), s_rf.p, nsites, hipMemcpyDeviceToHost));
+			HIP_TRY(hipMemcpy(ix->site_af.data(), s_af.p, nsites, hipMemcpyDeviceToHost));
+		}
+		uint32_t *dc = nullptr, *dc4 = nullptr;
+		if ((rc = dev_alloc(ix, &dc, 2 * nsites + 2, true, true))) return rc;       // (plain hipMalloc: RCCL reduces these in place)
+		if ((rc = dev_alloc(ix, &dc4, 4 * nsites + 4, true))) return rc;
+		d.srank = dr; d.pile = dp; d.pile_len = plen; d.cnt = dc; d.site_ba = dba; d.cnt4 = dc4;
+		c.snp_rf.release(); c.snp_af.release();
+	}
+	pc.lap("pile-up sites");
+	// ---- reference dictionary: jump table + 16-byte entries.  With the paired HI32 table in the plan the jump table is only
+	//      needed until that table is filled: a temporary.
+	TempDev<uint32_t> ref_jg_tmp;
 	{
 		uint32_t *jg = nullptr; RefEnt *ent = nullptr;
-		if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
+		if (plan.hx) { if ((rc = ref_jg_tmp.alloc((1ull << 32) + 1))) return rc; jg = ref_jg_tmp.p; }
+		else if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
 		if ((rc = dev_alloc(ix, &ent, c.n_ref))) return rc;
 		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.ref_kmer.p, c.n_ref, jg, 1ull << 32, 32);
 		vg_make_ref_entries<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, ent);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(st));
 		d.ref_jg = jg; d.ref = ent;
+		// without the merged view nothing reads the position / ambiguity columns any more
+		if (!want_mx) { c.ref_pos.release(); c.ref_amb.release(); }
 		// secondary view ordered by (LO32, HI32): device radix sort of the swapped k-mers + a jump table over LO32's top bits
 		if (plan.sec) {
 			uint32_t bits = 14;
 			while (bits < 30 && (1ull << bits) < c.n_ref) bits++;          // ~1-3 entries per bucket
-			TempDev<uint64_t> kin; TempDev<uint32_t> vin;
-			if ((rc = kin.alloc(c.n_ref))) return rc;
-			if ((rc = vin.alloc(c.n_ref))) return rc;
-			TempDev<uint64_t> skey; TempDev<uint32_t> sidx;
+			TempDev<uint64_t> ka, kb; TempDev<uint32_t> va, vb;
+			if ((rc = ka.alloc(c.n_ref)) || (rc = va.alloc(c.n_ref)) || (rc = kb.alloc(c.n_ref)) || (rc = vb.alloc(c.n_ref))) return rc;
 			uint32_t *sjg = nullptr, *sec3 = nullptr;
-			if ((rc = skey.alloc(c.n_ref)) || (rc = sidx.alloc(c.n_ref))) return rc;
 			if ((rc = dev_alloc(ix, &sjg, (1ull << bits) + 1))) return rc;
-			vg_make_sec_keys<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.n_ref, kin.p, vin.p);
+			vg_make_sec_keys<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.n_ref, ka.p, va.p);
 			HIP_TRY(hipGetLastError());
-			const int se = vg_dev_sort_pairs_u64_u32(kin.p, skey.p, vin.p, sidx.p, c.n_ref, st);
+			bool in_b = false;
+			const int se = vg_dev_sort_pairs_u64_u32(ka.p, kb.p, va.p, vb.p, c.n_ref, st, sort_tmp.p, sort_tmp_bytes, &in_b);
 			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
-			kin.release(); vin.release();
+			if (in_b) { ka.release(); va.release(); } else { kb.release(); vb.release(); }
+			const uint64_t *skey = in_b ? kb.p : ka.p; const uint32_t *sidx = in_b ? vb.p : va.p;
 			if ((rc = dev_alloc(ix, &sec3, 3 * c.n_ref + 4))) return rc;
-			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, st>>>(skey.p, c.n_ref, sjg, 1ull << bits, (int)(64 - bits));
-			vg_make_sec3<<<2048, 256, 0, st>>>(skey.p, sidx.p, ent, c.n_ref, sec3);
+			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, st>>>(skey, c.n_ref, sjg, 1ull << bits, (int)(64 - bits));
+			vg_make_sec3<<<2048, 256, 0, st>>>(skey, sidx, ent, c.n_ref, sec3);
 			// the reference bit vector against the dictionary: when they name the same LO32 values, the view answers qv.cc:955 too
 			unsigned long long chk[3] = {1, 0, 0};
 			if (ref_bf_bits >= (1ull << 32) && !getenv("VG_NO_BF_FROM_SEC")) {
 				TempDev<unsigned long long> dchk;
 				if ((rc = dchk.alloc(3))) return rc;
 				HIP_TRY(hipMemsetAsync(dchk.p, 0, 24, st));
-				vg_sec_bf_check<<<2048, 256, 0, st>>>(skey.p, c.n_ref, d.ref_bf, dchk.p);
+				vg_sec_bf_check<<<2048, 256, 0, st>>>(skey, c.n_ref, d.ref_bf, dchk.p);
 				vg_popcount_words<<<2048, 256, 0, st>>>(d.ref_bf, (1ull << 32) / 64, dchk.p + 2);
 				HIP_TRY(hipGetLastError());
 				HIP_TRY(hipStreamSynchronize(st));
 				HIP_TRY(hipMemcpy(chk, dchk.p, 24, hipMemcpyDeviceToHost));
 			}
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(st));
 			d.sec3 = sec3; d.sec_jg = sjg; d.sec_bits = bits;
 			d.sec_is_bf = (chk[0] == 0 && chk[1] == chk[2]) ? 1u : 0u;
 		}
 	}
-	// the merged view is the last user of the reference dictionary's columns: without it (2^32 or more k-mers in the two
-	// dictionaries together -- hg38 + full dbSNP --, or VG_NO_MX) they go now, 37 GB at hg38 scale
-	if (!want_mx) { c.ref_kmer.release(); c.ref_pos.release(); c.ref_amb.release(); }
+	// the merged view is the last user of the reference dictionary's k-mer column: without it (2^32 or more k-mers in the two
+	// dictionaries together -- hg38 + full dbSNP --, or VG_NO_MX) it goes now, 23 GB at hg38 scale
+	if (!want_mx) c.ref_kmer.release();
 	pc.lap("reference dictionary + LO32-ordered view");
-	// ---- paired HI32 table in place of the two HI32 jump tables (an index without merged view): built in two passes so that only
-	// one 16 GiB jump table is alive next to it; without the room (or with VG_NO_HX) the jump tables stay
-	uint4 *hx = nullptr;
-	if (plan.hx) {
-		const uint64_t hx_bytes = ((1ull << 32) + 1) * 16ull;
-		if (hipMalloc((void **)&hx, hx_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(VG_ENOMEM, "hipMalloc(paired HI32 table) failed although the plan had the room -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str()); }
-		{
-			uint32_t *rjg = const_cast<uint32_t *>(d.ref_jg);
-			vg_hx_fill_ref<<<ix->cus * 32, 256, 0, st>>>(rjg, d.ref, hx);
-			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(st));
-			for (size_t z = 0; z < ix->owned.size(); z++) if (ix->owned[z] == (void *)rjg) { ix->owned.erase(ix->owned.begin() + (long)z); break; }
-			(void)hipFree(rjg); ix->dev_bytes -= ((1ull << 32) + 1) * 4;
-			d.ref_jg = nullptr;
-			TempDev<uint32_t> j32;
-			if ((rc = j32.alloc((1ull << 32) + 1))) { (void)hipFree(hx); return rc; }
-			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, j32.p, 1ull << 32, 32);
-			vg_hx_fill_snp<<<ix->cus * 32, 256, 0, st>>>(j32.p, c.snp_kmer.p, hx);
-			if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(hx); return fail(VG_ENODEV, "building the paired HI32 table failed"); }
-			ix->owned.push_back(hx); ix->dev_bytes += hx_bytes;
-			d.hx = hx;
-		}
-		pc.lap("paired HI32 table");
-	}
 	// ---- SNP dictionary
 	{
 		uint32_t *jg = nullptr; SnpEnt *ent = nullptr;
@@ -1333,9 +1435,9 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		vg_build_jumpgate<<<(unsigned)((1ull << 24) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, jg, 1ull << 24, 40);
 		vg_make_snp_entries<<<2048, 256, 0, st>>>(c.snp_kmer.p, c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.n_snp, ent);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipStreamSynchronize(st));
 		d.snp_jg = jg; d.snp = ent;
-		if (!want_mx) { c.snp_pos.release(); c.snp_info.release(); c.snp_amb.release(); }     // (the sites are built: the entries were their last reader)
+		if (!want_mx) { c.snp_pos.release(); c.snp_amb.release(); }
+		c.snp_info.release();                                      // (the sites are built: the entries were its last reader)
 		// the strided scan's view of the SNP dictionary: signatures (2 bytes per entry) by default, the probed values themselves
 		// (8 bytes per entry) under VG_NO_SIG_VIEW, neither under VG_NO_PROBE_VIEW
 		if (plan.sig) {
@@ -1343,14 +1445,12 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			if ((rc = dev_alloc(ix, &sv, c.n_snp + 16))) return rc;
 			vg_make_snp_sig<<<2048, 256, 0, st>>>(c.snp_kmer.p, jg, c.n_snp, sv);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(st));
 			d.snp_sig = sv;
 		} else if (plan.probe) {
 			uint64_t *pv = nullptr;
 			if ((rc = dev_alloc(ix, &pv, c.n_snp + 1))) return rc;
 			vg_make_snp_probe<<<2048, 256, 0, st>>>(c.snp_kmer.p, jg, c.n_snp, pv);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(st));
 			d.snp_probe = pv;
 		}
 		// an index too large for the merged view gets a HI32 jump table of the SNP dictionary instead (17 GB): its HI24 buckets hold
@@ -1360,69 +1460,91 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			if ((rc = dev_alloc(ix, &j32, (1ull << 32) + 1))) return rc;
 			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, j32, 1ull << 32, 32);
 			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(st));
 			d.snp_jg32 = j32;
 		}
-		if (!want_mx) c.snp_kmer.release();                        // its last readers (probe view, HI32 tables) are done
-		// merged exact-match view (both dictionaries behind one HI32 jump table); its indices are 32 bits wide
-		const uint64_t nm = c.n_ref + c.n_snp;
-		if (want_mx) {
-			TempDev<uint64_t> kin, kout; TempDev<uint32_t> vin, vout;
-			if ((rc = kin.alloc(nm)) || (rc = kout.alloc(nm)) || (rc = vin.alloc(nm)) || (rc = vout.alloc(nm))) return rc;
-			if (c.n_ref) HIP_TRY(hipMemcpyAsync(kin.p, c.ref_kmer.p, (size_t)c.n_ref * 8, hipMemcpyDeviceToDevice, st));
-			if (c.n_snp) HIP_TRY(hipMemcpyAsync(kin.p + c.n_ref, c.snp_kmer.p, (size_t)c.n_snp * 8, hipMemcpyDeviceToDevice, st));
-			vg_iota_u32<<<2048, 256, 0, st>>>(vin.p, nm);
-			TempDev<uint32_t> strand_bits;
-			if ((rc = strand_bits.alloc(nm / 32 + 2))) return rc;
-			HIP_TRY(hipMemsetAsync(strand_bits.p, 0, (nm / 32 + 2) * 4, st));
-			vg_canon_keys<<<2048, 256, 0, st>>>(kin.p, nm, strand_bits.p);
+	}
+	pc.lap("SNP dictionary, scan view");
+	// ---- paired HI32 table in place of the two HI32 jump tables (an index without merged view): built in two passes so that only
+	//      one 16 GiB jump table is alive next to it
+	if (plan.hx) {
+		uint4 *hx = nullptr;
+		if ((rc = dev_alloc(ix, &hx, (1ull << 32) + 1))) return fail(VG_ENOMEM, "no room for the paired HI32 table although the plan had it -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str());
+		vg_hx_fill_ref<<<ix->cus * 32, 256, 0, st>>>(ref_jg_tmp.p, d.ref, hx);
+		HIP_TRY(hipGetLastError());
+		ref_jg_tmp.release();                                   // (waits for the stream)
+		d.ref_jg = nullptr;
+		TempDev<uint32_t> j32;
+		if ((rc = j32.alloc((1ull << 32) + 1))) return rc;
+		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, j32.p, 1ull << 32, 32);
+		vg_hx_fill_snp<<<ix->cus * 32, 256, 0, st>>>(j32.p, c.snp_kmer.p, hx);
+		if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(VG_ENODEV, "building the paired HI32 table failed");
+		d.hx = hx;
+		pc.lap("paired HI32 table");
+	}
+	if (!want_mx) c.snp_kmer.release();                        // its last readers (scan view, HI32 tables) are done
+	// ---- merged exact-match view (both dictionaries behind one HI32 jump table); its indices are 32 bits wide
+	const uint64_t nm = c.n_ref + c.n_snp;
+	if (want_mx) {
+		TempDev<uint64_t> ka, kb; TempDev<uint32_t> va, vb;
+		if ((rc = ka.alloc(nm))) return rc;
+		if (c.n_ref) HIP_TRY(hipMemcpyAsync(ka.p, c.ref_kmer.p, (size_t)c.n_ref * 8, hipMemcpyDeviceToDevice, st));
+		if (c.n_snp) HIP_TRY(hipMemcpyAsync(ka.p + c.n_ref, c.snp_kmer.p, (size_t)c.n_snp * 8, hipMemcpyDeviceToDevice, st));
+		c.ref_kmer.release(); c.snp_kmer.release();            // 26 GB at hg38 scale: the sort's second buffer pair takes their place
+		if ((rc = kb.alloc(nm)) || (rc = va.alloc(nm)) || (rc = vb.alloc(nm))) return rc;
+		vg_iota_u32<<<2048, 256, 0, st>>>(va.p, nm);
+		TempDev<uint32_t> strand_bits;
+		if ((rc = strand_bits.alloc(nm / 32 + 2))) return rc;
+		HIP_TRY(hipMemsetAsync(strand_bits.p, 0, (nm / 32 + 2) * 4, st));
+		vg_canon_keys<<<2048, 256, 0, st>>>(ka.p, nm, strand_bits.p);
+		HIP_TRY(hipGetLastError());
+		bool in_b = false;
+		const int se = vg_dev_sort_pairs_u64_u32(ka.p, kb.p, va.p, vb.p, nm, st, sort_tmp.p, sort_tmp_bytes, &in_b);     // stable: ref before snp on equal k-mers
+		if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
+		if (in_b) { ka.release(); va.release(); } else { kb.release(); vb.release(); }
+		TempDev<uint64_t> &kout = in_b ? kb : ka; TempDev<uint32_t> &vout = in_b ? vb : va;
+		// with the direct table in the plan the merged jump table only lives until that table is filled: a temporary
+		TempDev<uint32_t> mjg_tmp;
+		uint32_t *mjg = nullptr; uint4 *mx = nullptr;
+		if (plan.dx) { if ((rc = mjg_tmp.alloc((1ull << 32) + 1))) return rc; mjg = mjg_tmp.p; }
+		else if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
+		if ((rc = dev_alloc(ix, &mx, nm))) return rc;
+		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(kout.p, nm, mjg, 1ull << 32, 32);
+		vg_make_mx_entries<<<2048, 256, 0, st>>>(kout.p, vout.p, nm, c.n_ref, c.ref_pos.p, c.ref_amb.p, c.snp_pos.p, c.snp_amb.p, mx, strand_bits.p);
+		HIP_TRY(hipGetLastError());
+		kout.release(); vout.release(); strand_bits.release();
+		c.ref_pos.release(); c.ref_amb.release(); c.snp_pos.release(); c.snp_amb.release();
+		d.mx_jg = mjg; d.mx = mx;
+		// direct table (64 GiB) in place of the merged jump table (16 GiB) when the plan has the room; no bucket may exceed the
+		// 24-bit count field (it would be a >16 M-fold repeated 16-mer)
+		if (plan.dx) {
+			uint4 *dx = nullptr;
+			TempDev<uint32_t> big;
+			if ((rc = big.alloc(1))) return rc;
+			HIP_TRY(hipMemsetAsync(big.p, 0, 4, st));
+			uint32_t too_big = 0;
+			if ((rc = dev_alloc(ix, &dx, 1ull << 32))) return fail(VG_ENOMEM, "no room for the direct table although the plan had it -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str());
+			vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(st));
-			c.ref_kmer.release();                                  // 23 GB at hg38 scale: the sort below needs the room
-			const int se = vg_dev_sort_pairs_u64_u32(kin.p, kout.p, vin.p, vout.p, nm, st);     // stable: ref before snp on equal k-mers
-			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
-			kin.release(); vin.release();                          // make room before the 16 GiB table
-			uint32_t *mjg = nullptr; uint4 *mx = nullptr;
-			if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
-			if ((rc = dev_alloc(ix, &mx, nm))) return rc;
-			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(kout.p, nm, mjg, 1ull << 32, 32);
-			vg_make_mx_entries<<<2048, 256, 0, st>>>(kout.p, vout.p, nm, c.n_ref, c.ref_pos.p, c.ref_amb.p, c.snp_pos.p, c.snp_amb.p, mx, strand_bits.p);
-			HIP_TRY(hipGetLastError());
-			HIP_TRY(hipStreamSynchronize(st));
-			strand_bits.release();
-			d.mx_jg = mjg; d.mx = mx;
-			// direct table (64 GiB) in place of the merged jump table (16 GiB) when the device has the room; no bucket may
-			// exceed the 24-bit count field (it would be a >16 M-fold repeated 16-mer)
-			if (plan.dx) {
-				kout.release(); vout.release(); c.ref_pos.release(); c.ref_amb.release();
-				uint4 *dx = nullptr;
-				TempDev<uint32_t> big;
-				if ((rc = big.alloc(1))) return rc;
-				HIP_TRY(hipMemsetAsync(big.p, 0, 4, st));
-				uint32_t too_big = 0;
-				if (hipMalloc((void **)&dx, (size_t)(1ull << 32) * 16) != hipSuccess) { (void)hipGetLastError(); return fail(VG_ENOMEM, "hipMalloc(direct table) failed although the plan had the room -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str()); }
-				vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
-				HIP_TRY(hipGetLastError());
+			HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
+			if (too_big) {
+				// jump-table form after all: the table moves to a permanent place, the 64 GiB go back
+				dev_release(ix, dx); dx = nullptr;
+				uint32_t *keep = nullptr;
+				if ((rc = dev_alloc(ix, &keep, (1ull << 32) + 1))) return rc;
+				HIP_TRY(hipMemcpyAsync(keep, mjg, ((1ull << 32) + 1) * 4, hipMemcpyDeviceToDevice, st));
 				HIP_TRY(hipStreamSynchronize(st));
-				HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
-				if (too_big) { (void)hipFree(dx); dx = nullptr; ix->plan_text += "; direct table not kept: a bucket of more than 2^24 - 1 entries"; }          // jump-table form
-				if (dx) {
-					vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
-					HIP_TRY(hipGetLastError());
-					HIP_TRY(hipStreamSynchronize(st));
-					ix->owned.push_back(dx); ix->dev_bytes += (uint64_t)(1ull << 32) * 16;
-					d.dx = dx;
-					// the merged jump table is not needed any more
-					for (size_t z = 0; z < ix->owned.size(); z++) if (ix->owned[z] == (void *)mjg) { ix->owned.erase(ix->owned.begin() + (long)z); break; }
-					(void)hipFree(mjg); ix->dev_bytes -= ((1ull << 32) + 1) * 4;
-					d.mx_jg = nullptr;
-				}
+				d.mx_jg = keep;
+				ix->plan_text += "; direct table not kept: a bucket of more than 2^24 - 1 entries";
+			} else {
+				vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
+				HIP_TRY(hipGetLastError());
+				d.dx = dx;
+				d.mx_jg = nullptr;                                  // (the merged jump table is not needed any more: released with mjg_tmp)
 			}
 		}
+		pc.lap("merged view, direct table");
 	}
-	pc.lap("SNP dictionary, scan view, merged view, direct table");
-	if (want_mx && (rc = build_sites())) return rc;
-	pc.lap("bit vectors, pile-up sites");
 	// ---- scratch of the lane tier, overflow counters, stats
 	// VG_SCRATCH_CAP / VG_SCRATCH_KCAP shrink the per-lane scratch so tests can drive every tier
 	uint32_t cap = 64, kcap = 32;
@@ -1430,13 +1552,33 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
-	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 16, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
-	if ((rc = dev_alloc(ix, &ix->d_cum, 8, true))) return rc;
-	if ((rc = dev_alloc(ix, &ix->d_clamped, 2 * ix->n_sites + 2))) return rc;
-	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true))) return rc;
-	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true))) return rc;
+	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 16, true, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
+	if ((rc = dev_alloc(ix, &ix->d_cum, 8, true, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_clamped, 2 * ix->n_sites + 2, false, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true, true))) return rc;
+	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true, true))) return rc;
 	HIP_TRY(hipStreamSynchronize(st));
 	return VG_OK;
+}
+
+// while a handle is under construction on this thread its temporaries come out of its arena
+struct Building {
+	explicit Building(vg_index *ix) { g_building = ix; }
+	~Building() { g_building = nullptr; }
+};
+// construction is over (every temporary has been given back): the arena returns its pooled chunks, the handle's size is final
+static void finish_construction(vg_index *ix)
+{
+	const double t0 = now_s();
+	ix->arena.trim();
+	uint64_t plain = 0;
+	for (const auto &kv : ix->owned_bytes) plain += kv.second;
+	ix->dev_bytes = plain + ix->arena.mapped_bytes();
+	char line[300];
+	snprintf(line, sizeof line, "; memory: %.1f GB in the arena (peak during construction %.1f GB, %llu chunks of 1 GiB taken from the driver, %llu re-mapped from the pool; returning the pool %.2f s) + %.1f GB of hipMalloc'ed buffers",
+	         ix->arena.mapped_bytes() / 1e9, ix->arena.peak_bytes() / 1e9, (unsigned long long)ix->arena.created_chunks(), (unsigned long long)ix->arena.remaps(), now_s() - t0, plain / 1e9);
+	ix->open_report += ix->arena.ready() ? line : "; memory: no arena (hipMalloc / hipFree per buffer)";
+	if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] %s\n", line + 2);
 }
 
 // $VG_MAX_DEVICE_BYTES: the budget of vg_index_open / vg_index_create (vg_index_open_ex takes it as an argument)
@@ -1450,7 +1592,8 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 {
 	int rc = init_handle(ix, device);
 	if (rc) return rc;
-	PhaseClock pc;
+	Building guard(ix);
+	PhaseClock pc(ix);
 	DevCols c;
 	c.n_ref = a->n_ref; c.n_ref_aux = a->n_ref_aux; c.n_snp = a->n_snp; c.n_snp_aux = a->n_snp_aux;
 	if ((rc = c.ref_kmer.upload(a->ref_kmer, a->n_ref)) || (rc = c.ref_pos.upload(a->ref_pos, a->n_ref)) || (rc = c.ref_amb.upload(a->ref_amb, a->n_ref))) return rc;
@@ -1472,6 +1615,7 @@ extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **
 	ix->max_device_bytes = env_budget();
 	int rc = guarded([&] { return create_impl(a, device, ix); });
 	if (rc) { vg_index_close(ix); return rc; }
+	finish_construction(ix);
 	*out = ix;
 	return VG_OK;
 }
@@ -1480,23 +1624,37 @@ extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **
 // A byte range of a file -> device memory: reader threads pread() pieces into a ring of pinned buffers, each piece is copied up
 // as soon as it is complete (the page cache / an NVMe array serve the threads concurrently; one fread of the 43 GB hg38
 // dictionary is a single memcpy stream, and a copy from pageable memory is staged a second time by the runtime).
-static int file_to_device(int fd, uint64_t off, uint64_t bytes, uint8_t *dst, const std::string &path)
+// the page-locked staging of the file reads: made once per vg_index_open (eight 64 MiB buffers take 0.12 s to pin and 0.08 s to
+// release, tools/alloc_probe), shared by both dictionary files
+struct FileRing {
+	static constexpr uint64_t PIECE = 64ull << 20;
+	static constexpr int NBUF = 8;
+	uint8_t *buf[NBUF] = {};
+	hipEvent_t copied[NBUF] = {};
+	hipStream_t cs = nullptr;
+	int init()
+	{
+		for (int i = 0; i < NBUF; i++) {
+			if (hipHostMalloc((void **)&buf[i], PIECE, hipHostMallocDefault) != hipSuccess) return fail(VG_ENOMEM, "hipHostMalloc(staging) failed");
+			if (hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess) return fail(VG_ENODEV, "hipEventCreate failed");
+		}
+		if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return fail(VG_ENODEV, "hipStreamCreate failed");
+		return VG_OK;
+	}
+	~FileRing()
+	{
+		for (auto p : buf) if (p) (void)hipHostFree(p);
+		for (auto e : copied) if (e) (void)hipEventDestroy(e);
+		if (cs) (void)hipStreamDestroy(cs);
+	}
+};
+static int file_to_device(FileRing &R, int fd, uint64_t off, uint64_t bytes, uint8_t *dst, const std::string &path)
 {
 	if (bytes == 0) return VG_OK;
-	const uint64_t PIECE = 64ull << 20;
-	const int NBUF = 8;
+	constexpr uint64_t PIECE = FileRing::PIECE;
+	constexpr int NBUF = FileRing::NBUF;
 	const uint64_t n_pieces = (bytes + PIECE - 1) / PIECE;
-	std::vector<uint8_t *> ring((size_t)NBUF, nullptr);
-	std::vector<hipEvent_t> copied((size_t)NBUF, nullptr);
-	hipStream_t cs = nullptr;
 	int rc = VG_OK;
-	auto cleanup = [&] { for (auto p : ring) if (p) (void)hipHostFree(p); for (auto e : copied) if (e) (void)hipEventDestroy(e); if (cs) (void)hipStreamDestroy(cs); };
-	for (int i = 0; i < NBUF && rc == VG_OK; i++) {
-		if (hipHostMalloc((void **)&ring[(size_t)i], PIECE, hipHostMallocDefault) != hipSuccess) rc = fail(VG_ENOMEM, "hipHostMalloc(staging) failed");
-		else if (hipEventCreateWithFlags(&copied[(size_t)i], hipEventDisableTiming) != hipSuccess) rc = fail(VG_ENODEV, "hipEventCreate failed");
-	}
-	if (rc == VG_OK && hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) rc = fail(VG_ENODEV, "hipStreamCreate failed");
-	if (rc) { cleanup(); return rc; }
 	std::mutex mu; std::condition_variable cv;
 	std::vector<uint8_t> state(n_pieces, 0);                    // 1 = read into its ring slot
 	uint64_t issued = 0;                                        // pieces whose copy has been enqueued AND whose slot is free again once copied[slot] fires
@@ -1513,7 +1671,7 @@ static int file_to_device(int fd, uint64_t off, uint64_t bytes, uint8_t *dst, co
 			const uint64_t o = p * PIECE, n = std::min(PIECE, bytes - o);
 			uint64_t done = 0;
 			while (done < n) {
-				const ssize_t g = pread(fd, ring[(size_t)(p % NBUF)] + done, (size_t)(n - done), (off_t)(off + o + done));
+				const ssize_t g = pread(fd, R.buf[p % NBUF] + done, (size_t)(n - done), (off_t)(off + o + done));
 				if (g <= 0) break;
 				done += (uint64_t)g;
 			}
@@ -1526,20 +1684,19 @@ static int file_to_device(int fd, uint64_t off, uint64_t bytes, uint8_t *dst, co
 	for (uint64_t p = 0; p < n_pieces; p++) {
 		{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return state[p] != 0 || io_error; }); if (io_error) break; }
 		const uint64_t o = p * PIECE, n = std::min(PIECE, bytes - o);
-		if (hipMemcpyAsync(dst + o, ring[(size_t)(p % NBUF)], n, hipMemcpyHostToDevice, cs) != hipSuccess || hipEventRecord(copied[(size_t)(p % NBUF)], cs) != hipSuccess) {
+		if (hipMemcpyAsync(dst + o, R.buf[p % NBUF], n, hipMemcpyHostToDevice, R.cs) != hipSuccess || hipEventRecord(R.copied[p % NBUF], R.cs) != hipSuccess) {
 			std::lock_guard<std::mutex> g(mu); io_error = true; rc = fail(VG_ENODEV, "host-to-device copy failed"); cv.notify_all(); break;
 		}
 		issued = p + 1;
 		// the slot of piece p - NBUF + 1 .. is reusable once its copy has finished: wait for the oldest outstanding one when the ring is full
 		if (issued - freed >= (uint64_t)NBUF - 1) {
-			(void)hipEventSynchronize(copied[(size_t)(freed % NBUF)]);
+			(void)hipEventSynchronize(R.copied[freed % NBUF]);
 			std::lock_guard<std::mutex> g(mu); freed++; cv.notify_all();
 		}
 	}
-	(void)hipStreamSynchronize(cs);
+	(void)hipStreamSynchronize(R.cs);
 	{ std::lock_guard<std::mutex> g(mu); freed = n_pieces + NBUF; cv.notify_all(); }
 	for (auto &t : readers) t.join();
-	cleanup();
 	if (rc) return rc;
 	if (io_error) return fail(VG_EIO, "short read on %s", path.c_str());
 	return VG_OK;
@@ -1596,7 +1753,8 @@ static int open_impl(const char *prefix, int device, vg_index *ix)
 	if ((rc = read_bf(pre + ".ref.bf", 1ull << 32, rbits, rw))) return rc;
 	if ((rc = read_bf(pre + ".snp.bf", ~0ull, sbits, sw))) return rc;
 	if ((rc = init_handle(ix, device))) return rc;
-	PhaseClock pc;
+	Building guard(ix);
+	PhaseClock pc(ix);
 	DevCols c;
 	c.n_ref = n_ref; c.n_ref_aux = n_ref_aux; c.n_snp = n_snp; c.n_snp_aux = n_snp_aux;
 	if ((rc = c.alloc())) return rc;
@@ -1604,10 +1762,13 @@ static int open_impl(const char *prefix, int device, vg_index *ix)
 	if ((rc = dev_alloc(ix, &c.snp_aux_pos, n_snp_aux * AUX_COLS))) return rc;
 	if ((rc = dev_alloc(ix, &c.snp_aux_info, n_snp_aux * AUX_COLS))) return rc;
 	{
+	FileRing ring;
+	if ((rc = ring.init())) return rc;
+	{
 		// the files' bytes, as they are, next to the columns they unpack into (the larger one first; freed right after)
 		TempDev<uint8_t> raw;
 		if ((rc = raw.alloc(rsize - 16 + 64))) return rc;
-		if ((rc = file_to_device(rf.fd, 16, rsize - 16, raw.p, pre + ".ref.dict"))) return rc;
+		if ((rc = file_to_device(ring, rf.fd, 16, rsize - 16, raw.p, pre + ".ref.dict"))) return rc;
 		vg_unpack_ref<<<4096, 256, 0, ix->stream>>>(raw.p, n_ref, c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p);
 		if (n_ref_aux) vg_unpack_ref_aux<<<1024, 256, 0, ix->stream>>>(raw.p + 13 * n_ref, n_ref_aux * AUX_COLS, c.ref_aux);
 		HIP_TRY(hipGetLastError());
@@ -1616,11 +1777,12 @@ static int open_impl(const char *prefix, int device, vg_index *ix)
 	{
 		TempDev<uint8_t> raw;
 		if ((rc = raw.alloc(ssize - 16 + 64))) return rc;
-		if ((rc = file_to_device(sf.fd, 16, ssize - 16, raw.p, pre + ".snp.dict"))) return rc;
+		if ((rc = file_to_device(ring, sf.fd, 16, ssize - 16, raw.p, pre + ".snp.dict"))) return rc;
 		vg_unpack_snp<<<4096, 256, 0, ix->stream>>>(raw.p, n_snp, c.snp_kmer.p, c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.snp_rf.p, c.snp_af.p);
 		if (n_snp_aux) vg_unpack_snp_aux<<<1024, 256, 0, ix->stream>>>(raw.p + 16 * n_snp, n_snp_aux, c.snp_aux_pos, c.snp_aux_info);
 		HIP_TRY(hipGetLastError());
 		HIP_TRY(hipStreamSynchronize(ix->stream));
+	}
 	}
 	pc.lap("dictionary files read, copied up, unpacked");
 	return build_on_device(ix, c, rbits, rw.data(), sbits, sw.data(), pc);
@@ -1633,13 +1795,19 @@ extern "C" int vg_index_open_ex(const char *prefix, int device, uint64_t max_dev
 	vg_index *ix = new (std::nothrow) vg_index();
 	if (!ix) return fail(VG_ENOMEM, "host allocation failed");
 	ix->max_device_bytes = max_device_bytes;
+	const double t0 = now_s();
 	int rc = guarded([&] { return open_impl(prefix, device, ix); });
 	if (rc) { vg_index_close(ix); return rc; }
+	finish_construction(ix);
+	char line[80];
+	snprintf(line, sizeof line, "; vg_index_open %.2f s in all", now_s() - t0);
+	ix->open_report += line;
 	*out = ix;
 	return VG_OK;
 }
 
 extern "C" const char *vg_index_plan(const vg_index *ix) { return ix ? ix->plan_text.c_str() : ""; }
+extern "C" const char *vg_index_open_report(const vg_index *ix) { return ix ? ix->open_report.c_str() : ""; }
 
 extern "C" int vg_index_open(const char *prefix, int device, vg_index **out)
 {
@@ -1982,6 +2150,7 @@ extern "C" int vg_fastq_stream_begin_packed(vg_index *ix, int host_threads)
 	if (!ix) return fail(VG_EINVAL, "null argument");
 	if (host_threads < 0) host_threads = host_pack_threads_default();
 	if (host_threads == 0) return vg_fastq_stream_begin(ix);
+	if (host_threads > 256) host_threads = 256;               // (threads beyond the CPUs there are only spin)
 	return guarded([&]() -> int {
 		HIP_TRY(hipSetDevice(ix->device));
 		if (!ix->packer || ix->packer->threads() != host_threads) { delete ix->packer; ix->packer = nullptr; ix->packer = new vgp::Packer(host_threads); }
@@ -2173,6 +2342,7 @@ extern "C" int vg_packer_create(int host_threads, vg_packer **out)
 	return guarded([&]() -> int {
 		int t = host_threads;
 		if (t <= 0) { t = host_pack_threads_default(); if (t <= 0) t = 1; }
+		if (t > 256) t = 256;
 		*out = new vg_packer(t);
 		(*out)->p.begin();
 		return VG_OK;

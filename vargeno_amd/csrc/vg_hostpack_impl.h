@@ -20,6 +20,9 @@ struct alignas(128) Out {
 	uint64_t last_rec = 0;                 // start (in the aligned text) of the last record framed here
 	uint64_t stop_at = ~0ull;              // start of a record this thread found incomplete (the tail begins there)
 	bool bad = false;
+	Out() = default;
+	Out(const Out &) = delete;                  // owns its arrays: never copied (a vector of them is sized once)
+	Out &operator=(const Out &) = delete;
 	void clear() { kn = rn = 0; n_invalid = 0; last_rec = 0; stop_at = ~0ull; bad = false; }
 	void grow_k(uint64_t need)
 	{
