@@ -1,143 +1,152 @@
 // tests/arena_mock.cpp -- TEST ONLY (compiled and run by tests/test_abi_and_layout.py; never part of the product).
-// The bookkeeping of the index handle's device-memory arena (vargeno_amd/csrc/vg_arena.h, which the library instantiates with
-// the HIP virtual-memory calls) run against a mock of those calls: "physical chunks" are numbered handles, the mock keeps the
-// table of what is mapped where and complains about everything the driver would refuse (mapping over a mapping, mapping one
-// chunk twice, unmapping what is not mapped, touching addresses outside the reservation) and about leaks.  On top of it a
-// shadow model replays the loader's pattern -- permanent arrays growing from the bottom, temporaries of 1 KiB .. 64 GiB taken and
-// given back in any order -- and checks after every step that live allocations do not overlap, that every byte of them is backed
-// by a mapped chunk, that chunks under nothing are back in the pool, and that an out-of-memory device leaves the arena consistent.
-//   usage: arena_mock <seed> [device GiB, default 288]            prints "ok ..." or complaints
+// The index handle's device-memory arena (vargeno_amd/csrc/vg_arena.h: one block, permanent arrays from the bottom, temporaries
+// from the top; the library instantiates it with hipMalloc / hipFree) against a mock block:
+//   fuzz <seed>     random takes and gives; a shadow model checks that live allocations never overlap, lie inside the block, are
+//                   aligned, that a refusal only happens when no free gap could have held the request, and that the block is
+//                   returned exactly once
+//   replay          the loader's own sequence of allocations (vargeno_hip.hip, build_on_device, in its order) with the array
+//                   sizes of BASELINE.json's configurations: in a block the size of the FINISHED index every request must fit --
+//                   that is the property the construction order was chosen for
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <map>
 #include <random>
-#include <set>
+#include <string>
 #include <vector>
 
 #include "../vargeno_amd/csrc/vg_arena.h"
 
 static int errors = 0;
-static void complain(const char *what) { fprintf(stderr, "mock: %s\n", what); errors++; }
+static void complain(const std::string &what) { fprintf(stderr, "mock: %s\n", what.c_str()); errors++; }
 
-struct MockVm {
-	typedef long Handle;
-	static uint8_t *va; static uint64_t va_bytes;
-	static std::set<long> alive;                       // chunks the "driver" has handed out
-	static std::map<uint64_t, long> mapped;            // offset in the reservation -> chunk
-	static std::set<long> in_use;                      // chunks currently mapped somewhere
-	static long next_handle; static uint64_t device_chunks, chunk_bytes;
-	static bool granularity_ok(int, uint64_t chunk) { chunk_bytes = chunk; return true; }
-	static uint8_t *reserve(uint64_t bytes) { va = (uint8_t *)0x100000000000ull; va_bytes = bytes; return va; }
-	static void unreserve(uint8_t *p, uint64_t bytes) { if (p != va || bytes != va_bytes) complain("unreserve of another range"); if (!mapped.empty()) complain("address range freed with chunks still mapped"); va = nullptr; }
-	static bool create(int, uint64_t bytes, Handle *h)
-	{
-		if (bytes != chunk_bytes) complain("chunk of another size");
-		if (alive.size() >= device_chunks) return false;                  // the device is full
-		*h = ++next_handle; alive.insert(*h);
-		return true;
-	}
-	static void release(Handle h) { if (!alive.erase(h)) complain("release of a chunk that is not alive"); if (in_use.count(h)) complain("release of a mapped chunk"); }
-	static bool map(uint8_t *at, uint64_t bytes, Handle h, int)
-	{
-		const uint64_t off = (uint64_t)(at - va);
-		if (at < va || off + bytes > va_bytes || off % chunk_bytes || bytes != chunk_bytes) { complain("map outside the reservation / off the chunk grid"); return false; }
-		if (mapped.count(off)) { complain("map over a mapping"); return false; }
-		if (!alive.count(h)) { complain("map of a dead chunk"); return false; }
-		if (!in_use.insert(h).second) { complain("one chunk mapped twice"); return false; }
-		mapped[off] = h;
-		return true;
-	}
-	static void unmap(uint8_t *at, uint64_t)
-	{
-		const uint64_t off = (uint64_t)(at - va);
-		auto it = mapped.find(off);
-		if (it == mapped.end()) { complain("unmap of an address that is not mapped"); return; }
-		in_use.erase(it->second);
-		mapped.erase(it);
-	}
+struct MockBlock {
+	static int allocs, frees;
+	static uint64_t last_bytes;
+	static void *alloc(uint64_t bytes) { allocs++; last_bytes = bytes; return (void *)0x100000000000ull; }
+	static void free(void *p) { if (p != (void *)0x100000000000ull) complain("free of another pointer"); frees++; }
 };
-uint8_t *MockVm::va = nullptr; uint64_t MockVm::va_bytes = 0;
-std::set<long> MockVm::alive; std::map<uint64_t, long> MockVm::mapped; std::set<long> MockVm::in_use;
-long MockVm::next_handle = 0; uint64_t MockVm::device_chunks = 0, MockVm::chunk_bytes = 0;
+int MockBlock::allocs = 0, MockBlock::frees = 0;
+uint64_t MockBlock::last_bytes = 0;
+typedef vg::DevArenaT<MockBlock> Arena;
+static uint8_t *const BASE = (uint8_t *)0x100000000000ull;
 
-typedef vg::DevArenaT<MockVm> Arena;
-
-struct Live { uint64_t at, bytes; bool temp; };
-
-static void check(const Arena &a, const std::vector<Live> &live)
+static int fuzz(unsigned seed)
 {
-	// no two live allocations overlap; all of them lie on mapped chunks; nothing else is mapped
-	std::map<uint64_t, uint64_t> spans;
-	std::set<uint64_t> needed;
-	for (const Live &l : live) {
-		spans[l.at] = l.bytes;
-		for (uint64_t s = l.at / Arena::CHUNK; s <= (l.at + l.bytes - 1) / Arena::CHUNK; s++) needed.insert(s * Arena::CHUNK);
-	}
-	uint64_t end = 0;
-	for (auto &kv : spans) { if (kv.first < end) complain("two live allocations overlap"); end = kv.first + kv.second; }
-	for (uint64_t off : needed) if (!MockVm::mapped.count(off)) complain("a live allocation lies on an unmapped chunk");
-	if (MockVm::mapped.size() != needed.size()) complain("a chunk is mapped under nothing");
-	if (a.mapped_bytes() != needed.size() * Arena::CHUNK) complain("mapped_bytes() disagrees with the driver's table");
-	if (a.held_bytes() != MockVm::alive.size() * Arena::CHUNK) complain("held_bytes() disagrees with the chunks alive");
-}
-
-int main(int argc, char **argv)
-{
-	const unsigned seed = argc > 1 ? (unsigned)atoi(argv[1]) : 1u;
-	const uint64_t dev_gib = argc > 2 ? (uint64_t)atoll(argv[2]) : 288;
 	std::mt19937_64 rng(seed);
-	MockVm::device_chunks = dev_gib;
-	uint64_t served = 0, refused = 0, peak_live = 0;
+	const uint64_t S = (64ull + rng() % 256) << 30;
 	{
 		Arena a;
-		if (!a.init(0, dev_gib << 30)) { complain("init failed"); return 1; }
-		std::vector<Live> live;
-		uint64_t live_bytes = 0;
-		for (int step = 0; step < 4000; step++) {
-			const unsigned what = (unsigned)(rng() % 100);
-			if (what < 55 || live.empty()) {
-				// sizes like the loader's: mostly large (GiB scale), some tiny
+		if (!a.init(S)) { complain("init failed"); return 1; }
+		std::map<uint64_t, uint64_t> live;                       // offset -> bytes
+		for (int step = 0; step < 20000; step++) {
+			if (rng() % 100 < 55 || live.empty()) {
 				uint64_t bytes;
 				const unsigned k = (unsigned)(rng() % 10);
 				if (k < 3) bytes = 1 + rng() % 4096;
 				else if (k < 8) bytes = (1ull << 20) * (1 + rng() % 8192);
-				else bytes = (1ull << 30) * (8 + rng() % 57);
-				const bool temp = rng() % 4 != 0;
+				else bytes = (1ull << 30) * (1 + rng() % 48);
+				const bool temp = rng() % 3 != 0;
 				uint8_t *p = (uint8_t *)a.take(bytes, temp);
 				if (!p) {
-					refused++;
-					// a refusal must come from the device being full (or the permanent half's address space), and must leave everything as it was
-					if (MockVm::alive.size() + (bytes + Arena::CHUNK - 1) / Arena::CHUNK + 1 < MockVm::device_chunks && live_bytes + bytes < (dev_gib << 30) / 2 && temp) complain("a temporary was refused although the device had room");
-				} else {
-					served++;
-					if (!a.owns(p)) complain("take returned an address outside the reservation");
-					if ((uint64_t)(p - MockVm::va) % 256) complain("allocation not 256-byte aligned");
-					if (bytes >= (2ull << 20) && (uint64_t)(p - MockVm::va) % (2ull << 20)) complain("large allocation not 2 MiB aligned");
-					live.push_back(Live{(uint64_t)(p - MockVm::va), bytes, temp});
-					live_bytes += bytes;
-					if (live_bytes > peak_live) peak_live = live_bytes;
+					// was there really no gap for it?  (gaps of the shadow model, with 2 MiB of slack for the alignment)
+					uint64_t prev = 0, best = 0;
+					for (auto &kv : live) { if (kv.first - prev > best) best = kv.first - prev; prev = kv.first + kv.second; }
+					if (a.size() - prev > best) best = a.size() - prev;
+					if (best >= bytes + (4ull << 20)) complain("a request was refused although a gap could hold it");
+					continue;
 				}
+				const uint64_t at = (uint64_t)(p - BASE), rounded = (bytes + 255) / 256 * 256;
+				if (at + rounded > a.size()) complain("allocation outside the block");
+				if (at % 256) complain("allocation not 256-byte aligned");
+				if (bytes >= (2ull << 20) && at % (2ull << 20)) complain("large allocation not 2 MiB aligned");
+				auto nx = live.lower_bound(at);
+				if (nx != live.end() && nx->first < at + rounded) complain("overlap with the allocation above");
+				if (nx != live.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second > at) complain("overlap with the allocation below"); }
+				live[at] = rounded;
 			} else {
-				const size_t i = (size_t)(rng() % live.size());
-				if (!a.give(MockVm::va + live[i].at)) complain("give refused a live allocation");
-				if (a.give(MockVm::va + live[i].at)) complain("give accepted the same allocation twice");
-				live_bytes -= live[i].bytes;
-				live[i] = live.back(); live.pop_back();
+				auto it = live.begin();
+				std::advance(it, (long)(rng() % live.size()));
+				if (!a.give(BASE + it->first)) complain("give refused a live allocation");
+				if (a.give(BASE + it->first)) complain("give accepted the same allocation twice");
+				live.erase(it);
 			}
-			if (step % 16 == 0) check(a, live);
+			uint64_t sum = 0;
+			if (step % 64 == 0) { for (auto &kv : live) sum += kv.second; if (sum != a.in_use()) complain("in_use() disagrees with the shadow model"); }
 		}
-		check(a, live);
-		// the end of construction: temporaries go back, the pool is returned, permanent arrays stay
-		for (size_t i = 0; i < live.size();) if (live[i].temp) { a.give(MockVm::va + live[i].at); live[i] = live.back(); live.pop_back(); } else i++;
-		a.trim();
-		check(a, live);
-		if (MockVm::alive.size() != MockVm::mapped.size()) complain("chunks left in the pool after trim");
-		if (a.peak_bytes() > (dev_gib << 30)) complain("peak above the device");
+		// everything back: the block must be one free gap again
+		for (auto &kv : live) a.give(BASE + kv.first);
+		if (a.in_use() != 0) complain("bytes in use after everything was given back");
+		if (!a.take(a.size(), false)) complain("the emptied block is fragmented: it cannot be taken whole");
 	}
-	// the arena is gone: nothing may be left with the driver
-	if (!MockVm::alive.empty() || !MockVm::mapped.empty()) complain("the arena's destructor leaked chunks or mappings");
+	if (MockBlock::allocs != 1 || MockBlock::frees != 1) complain("the block was not taken / returned exactly once");
+	return 0;
+}
+
+// the loader's sequence (vargeno_hip.hip: open_impl + build_on_device) for an index of n reference k-mers, m SNP k-mers, plen genome
+// positions; mx: the layout with merged view + direct table, else the one with the paired HI32 table
+static uint64_t replay(const char *name, uint64_t n, uint64_t m, uint64_t aux_r, uint64_t aux_s, uint64_t plen, uint64_t sites, bool mx, uint64_t S)
+{
+	Arena a;
+	a.init(S);
+	std::map<std::string, void *> h;
+	uint64_t misses = 0;
+	auto P = [&](const char *w, uint64_t b) { void *p = a.take(b, false); if (!p) { misses++; if (S < (1ull << 50)) complain(std::string(name) + ": no room for the permanent array " + w); } h[w] = p; };
+	auto T = [&](const char *w, uint64_t b) { void *p = a.take(b, true); if (!p) { misses++; if (S < (1ull << 50)) complain(std::string(name) + ": no room for the temporary " + w); } h[w] = p; };
+	auto g = [&](const char *w) { if (h[w]) a.give(h[w]); h[w] = nullptr; };
+	const uint64_t J32 = ((1ull << 32) + 1) * 4;
+	T("ref_kmer", 8 * n); T("ref_pos", 4 * n); T("ref_amb", n); T("snp_kmer", 8 * m); T("snp_pos", 4 * m);
+	T("snp_info", m); T("snp_amb", m); T("snp_rf", m); T("snp_af", m);
+	P("ref_aux", 40 * aux_r); P("snp_aux_pos", 40 * aux_s); P("snp_aux_info", 10 * aux_s);
+	T("raw", 13 * n + 40 * aux_r + 64); g("raw"); T("raw", 16 * m + 78 * aux_s + 64); g("raw");
+	T("chk", 32); g("chk");
+	P("ref_bf", 1ull << 29); P("snp_bf", 140000000);
+	T("winner", 4 * plen); T("blk", plen / 8); P("pile", plen); P("srank", plen / 4); T("scan_tmp", 1 << 20);
+	T("s_pos", 4 * sites); T("s_ref", sites); T("s_alt", sites); T("s_rf", sites); T("s_af", sites); P("site_ba", sites); P("cnt4", 16 * sites);
+	g("winner"); g("blk"); g("scan_tmp"); g("s_pos"); g("s_ref"); g("s_alt"); g("s_rf"); g("s_af"); g("snp_rf"); g("snp_af");
+	P("snp_jg", ((1ull << 24) + 1) * 4); P("snp", 16 * m); g("snp_pos"); g("snp_info"); g("snp_amb"); P("snp_sig", 2 * (m + 16));
+	if (!mx) g("snp_kmer");
+	if (mx) P("ref_jg", J32);
+	P("ref", 16 * n); g("ref_pos"); g("ref_amb");
+	T("ka", 8 * n); T("va", 4 * n);
+	if (!mx) g("ref_kmer");
+	T("kb", 8 * n); T("vb", 4 * n); T("sort_tmp", 64ull << 20); g("sort_tmp"); g("kb"); g("vb");
+	uint64_t bits = 14; while (bits < 30 && (1ull << bits) < n) bits++;
+	P("sec_jg", ((1ull << bits) + 1) * 4); P("sec3", 12 * n + 16); T("chk", 24); g("chk"); g("ka"); g("va");
+	if (!mx) P("hx", ((1ull << 32) + 1) * 16);
+	else {
+		const uint64_t nm = n + m;
+		T("ka", 8 * nm); g("ref_kmer"); g("snp_kmer"); T("va", 4 * nm); T("strand", nm / 8 + 8); T("kb", 8 * nm); T("vb", 4 * nm); T("sort_tmp", 64ull << 20); g("sort_tmp"); g("kb"); g("vb");
+		P("mx", 16 * nm); g("ka"); g("va"); g("strand");
+		T("big", 4); P("dx", (1ull << 32) * 16); g("big");
+	}
+	P("scratch_mid", 2048ull * 256 * (64 * 16 + 32 * 12)); P("scratch_big", 4096ull * (16384 * 16 + 2048 * 12));
+	const uint64_t used = a.in_use();
+	if (S < (1ull << 50)) printf("replay %-14s block %.1f GB, finished index %.1f GB, at most %.1f GB alive, %llu requests without room\n", name, S / 1e9, used / 1e9, a.peak() / 1e9, (unsigned long long)misses);
+	return used;
+}
+
+int main(int argc, char **argv)
+{
+	if (argc > 2 && !strcmp(argv[1], "fuzz")) fuzz((unsigned)atoi(argv[2]));
+	else {
+		struct Cfg { const char *name; uint64_t n, m, aux_r, aux_s, plen, sites; bool mx; };
+		const Cfg cfgs[] = {
+			{"configs[2]", 2900000000ull, 320000000ull, 25000000ull, 500000ull, 3100000000ull, 10000000ull, true},
+			{"configs[4]", 2900000000ull, 3200000000ull, 25000000ull, 5000000ull, 3100000000ull, 100000000ull, false},
+			{"configs[1]", 40000000ull, 32000000ull, 300000ull, 5000ull, 40000000ull, 1000000ull, true},
+			{"F-tiny", 2200000ull, 9600ull, 100ull, 10ull, 2000000ull, 300ull, true},
+			{"F-tiny, hx", 2200000ull, 9600ull, 100ull, 10ull, 2000000ull, 300ull, false},
+		};
+		for (const Cfg &c : cfgs) {
+			// the finished index's size: what the sequence leaves alive in a block with room to spare; then the same sequence in a
+			// block of that size + 64 MiB of alignment slack (what plan_views gives the arena)
+			const uint64_t fin = replay(c.name, c.n, c.m, c.aux_r, c.aux_s, c.plen, c.sites, c.mx, 1ull << 52);
+			replay(c.name, c.n, c.m, c.aux_r, c.aux_s, c.plen, c.sites, c.mx, fin + (64ull << 20));
+		}
+	}
 	if (errors) { fprintf(stderr, "%d complaints\n", errors); return 1; }
-	printf("ok served %llu refused %llu peak_live_GiB %.1f\n", (unsigned long long)served, (unsigned long long)refused, peak_live / 1073741824.0);
+	printf("ok\n");
 	return 0;
 }

@@ -213,18 +213,21 @@ __global__ void vg_canon_keys(uint64_t *__restrict__ key, uint64_t n, uint32_t *
 		key[i] = fmix64(ck);
 	}
 }
-// merged exact-match view: after the stable sort, val = index into the concatenation [ref | snp]
+// merged exact-match view: after the stable sort, val = index into the concatenation [ref | snp].  Position and ambiguity come
+// from the dictionaries' 16-byte entries (r05: the columns they were unpacked from are long gone by now -- the construction keeps
+// as little alive as it can, vg_arena.h).  The entry's last word carries HI32 of its key, i.e. its bucket, until the direct
+// table has been built from it (vg_make_direct; vg_inline_pairs then puts the word to its real use).
 __global__ void vg_make_mx_entries(const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, uint64_t n_ref,
-                                   const uint32_t *__restrict__ rpos, const uint8_t *__restrict__ ramb, const uint32_t *__restrict__ spos, const uint8_t *__restrict__ samb,
-                                   uint4 *__restrict__ out, const uint32_t *__restrict__ strand_bits)
+                                   const RefEnt *__restrict__ ref, const SnpEnt *__restrict__ snp, uint4 *__restrict__ out, const uint32_t *__restrict__ strand_bits)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t v = val[i];
 		const bool is_snp = v >= n_ref;
-		const uint32_t pos = is_snp ? spos[v - n_ref] : rpos[v];
-		const uint32_t amb = is_snp ? samb[v - n_ref] : ramb[v];
+		uint32_t pos, amb;
+		if (is_snp) { const SnpEnt e = snp[v - n_ref]; pos = e.pos; amb = (uint32_t)(e.key >> 48) & 0xFFu; }
+		else { const RefEnt e = ref[v]; pos = e.pos; amb = e.amb; }
 		const uint32_t strand = (strand_bits[v >> 5] >> (v & 31)) & 1u;                          // flag 8: the dictionary's k-mer is the reverse complement of its canonical form
-		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1) | (strand << 3), 0u);
+		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1) | (strand << 3), (uint32_t)(key[i] >> 32));
 	}
 }
 // An ambiguous k-mer (2-10 copies) points at an auxiliary row; when the row holds exactly two positions -- the usual case --
@@ -238,23 +241,33 @@ __device__ inline bool aux_pair(const uint32_t *__restrict__ aux, uint32_t row, 
 }
 // direct table: the first entry of every HI32 bucket of the merged view, inline.  flags: 1 non-empty, 2 SNP entry, 4 ambiguous,
 // 8 PAIR (single-entry buckets only: a longer bucket needs w for the index of its entries), 16 TIE (the second entry has the
-// first one's k-mer: a query that matches the first entry of a bucket without it needs no further entry), bits 8.. = entries
-__global__ void vg_make_direct(const uint32_t *__restrict__ jg, const uint4 *__restrict__ mx, uint4 *__restrict__ dx,
+// first one's k-mer: a query that matches the first entry of a bucket without it needs no further entry), bits 8.. = entries.
+// r05: built from the entries themselves -- each carries its bucket in its last word (vg_make_mx_entries), the thread of a
+// bucket's first entry writes the record, the table was zeroed before -- so that no 16 GiB jump table has to exist next to the
+// 64 GiB table while it is filled: that was the one moment at which construction held more than the finished index.
+__global__ void vg_make_direct(const uint4 *__restrict__ mx, uint64_t n, uint4 *__restrict__ dx,
                                const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos, uint32_t *__restrict__ too_big)
 {
-	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t lo = jg[h], hi = jg[h + 1];
-		uint4 r = make_uint4(0, 0, 0, 0);
-		if (hi > lo) {
-			const uint4 e = mx[lo];
-			const uint32_t cnt = hi - lo > 0xFFFFFFu ? 0xFFFFFFu : hi - lo;
-			if (hi - lo > 0xFFFFFFu) atomicOr(too_big, 1u);          // the count field is 24 bits wide: the host keeps the jump-table form
-			r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (((e.z >> 3) & 1u) << 5) | (cnt << 8), lo);   // (flag 32: strand)
-			if (cnt > 1u && mx[lo + 1].x == e.x) r.z |= 16u;            // TIE: the second entry carries the same k-mer (reference + SNP dictionary)
-			uint32_t p0, p1;
-			if (cnt == 1u && (e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { r.y = p0; r.w = p1; r.z |= 8u; }
-		}
-		dx[h] = r;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 e = mx[i];
+		if (i && mx[i - 1].w == e.w) continue;                     // not the first of its bucket
+		uint64_t hi = i + 1;
+		while (hi < n && hi - i <= 0xFFFFFFull && mx[hi].w == e.w) hi++;
+		uint32_t cnt = (uint32_t)(hi - i);
+		if (cnt > 0xFFFFFFu) { atomicOr(too_big, 1u); cnt = 0xFFFFFFu; }       // the count field is 24 bits wide: the host keeps the jump-table form
+		uint4 r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (((e.z >> 3) & 1u) << 5) | (cnt << 8), (uint32_t)i);   // (flag 32: strand)
+		if (cnt > 1u && mx[i + 1].x == e.x) r.z |= 16u;            // TIE: the second entry carries the same k-mer (reference + SNP dictionary)
+		uint32_t p0, p1;
+		if (cnt == 1u && (e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { r.y = p0; r.w = p1; r.z |= 8u; }
+		dx[e.w] = r;
+	}
+}
+// the jump table of the merged view from the same bucket words (only when the direct table could not be kept after all)
+__global__ void vg_jumpgate_from_buckets(const uint4 *__restrict__ mx, uint64_t n, uint32_t *__restrict__ jg)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t h1 = i < n ? (uint64_t)mx[i].w : (1ull << 32), h0 = i ? (uint64_t)mx[i - 1].w + 1 : 0ull;     // buckets (previous entry's, this entry's] start here
+		for (uint64_t h = h0; h <= h1; h++) jg[h] = (uint32_t)i;
 	}
 }
 // the same for the entries of the merged view themselves (read for buckets of several entries); mx flags: 1 SNP, 2 ambiguous, 4 PAIR
@@ -263,7 +276,9 @@ __global__ void vg_inline_pairs(uint4 *__restrict__ mx, uint64_t n, const uint32
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		uint4 e = mx[i];
 		uint32_t p0, p1;
-		if ((e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { e.y = p0; e.w = p1; e.z |= 4u; mx[i] = e; }
+		e.w = 0u;                                                   // (the bucket word has done its job)
+		if ((e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { e.y = p0; e.w = p1; e.z |= 4u; }
+		mx[i] = e;
 	}
 }
 // strided-probe view of the SNP dictionary (DevIndex::snp_probe)
@@ -276,33 +291,49 @@ __global__ void vg_make_snp_probe(const uint64_t *__restrict__ kmer, const uint3
 		out[i] = t < n ? (kmer[t] & LO40_MASK) : 0ull;
 	}
 }
-// paired HI32 table (DevIndex::hx) in two passes, so that only one 16 GiB jump table is alive at a time: the reference side
-// writes whole records, the SNP side completes them.  A filter is computed over at most 64 entries; a longer bucket gets the
-// mask that lets everything through.
-__global__ void vg_hx_fill_ref(const uint32_t *__restrict__ jg, const RefEnt *__restrict__ ref, uint4 *__restrict__ hx)
+// paired HI32 table (DevIndex::hx), r05: from the dictionaries' entries, each of which carries its HI32 bucket in its spare word --
+// no jump table is built for it (r03-r04 built two of 16 GiB each, one after the other, next to the 64 GiB table).  The table is
+// zeroed first; the thread of a bucket's first entry writes the bucket's part of the record: the reference side writes whole
+// records, the SNP side completes them.  A filter is computed over at most 64 entries; a longer bucket gets the mask that lets
+// everything through.  Counts saturate at 0xFFFF: the bucket's end is then the NEXT record's start, which the same thread
+// writes too (an empty bucket has no thread of its own; a non-empty one writes the same value).
+__global__ void vg_hx_fill_ref(const RefEnt *__restrict__ ref, uint64_t n, uint4 *__restrict__ hx)
 {
-	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h <= (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t lo = jg[h], hi = h < (1ull << 32) ? jg[h + 1] : lo, cnt = hi - lo;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t h = ref[i].pad;
+		if (i && ref[i - 1].pad == h) continue;
+		uint64_t hi = i + 1;
+		while (hi < n && ref[hi].pad == h) hi++;
+		const uint64_t cnt = hi - i;
 		uint32_t f = 0;
-		if (cnt == 1u) f = hx_fp16(ref[lo].lo);
+		if (cnt == 1u) f = hx_fp16(ref[i].lo);
 		else if (cnt > 64u) f = 0xFFFFu;
-		else for (uint32_t e = lo; e < hi; e++) f |= hx_bit(ref[e].lo);
-		hx[h] = make_uint4(lo, 0u, cnt < 0xFFFFu ? cnt : 0xFFFFu, f);
+		else for (uint64_t e = i; e < hi; e++) f |= hx_bit(ref[e].lo);
+		hx[h] = make_uint4((uint32_t)i, 0u, cnt < 0xFFFFu ? (uint32_t)cnt : 0xFFFFu, f);
+		if (cnt >= 0xFFFFu) atomicMax(&hx[(uint64_t)h + 1].x, (uint32_t)hi);      // (atomic: the next bucket's own thread may write its record at the same moment -- with this very start)
 	}
 }
-__global__ void vg_hx_fill_snp(const uint32_t *__restrict__ jg, const uint64_t *__restrict__ kmer, uint4 *__restrict__ hx)
+__global__ void vg_hx_fill_snp(const SnpEnt *__restrict__ snp, uint64_t n, uint4 *__restrict__ hx)
 {
-	for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h <= (1ull << 32); h += (uint64_t)gridDim.x * blockDim.x) {
-		const uint32_t lo = jg[h], hi = h < (1ull << 32) ? jg[h + 1] : lo, cnt = hi - lo;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t h = snp[i].pad;
+		if (i && snp[i - 1].pad == h) continue;
+		uint64_t hi = i + 1;
+		while (hi < n && snp[hi].pad == h) hi++;
+		const uint64_t cnt = hi - i;
 		uint32_t f = 0;
-		if (cnt == 1u) f = hx_fp16((uint32_t)kmer[lo]);
+		if (cnt == 1u) f = hx_fp16((uint32_t)snp[i].key);
 		else if (cnt > 64u) f = 0xFFFFu;
-		else for (uint32_t e = lo; e < hi; e++) f |= hx_bit((uint32_t)kmer[e]);
-		uint4 r = hx[h];
-		r.y = lo; r.z |= (cnt < 0xFFFFu ? cnt : 0xFFFFu) << 16; r.w |= f << 16;
-		hx[h] = r;
+		else for (uint64_t e = i; e < hi; e++) f |= hx_bit((uint32_t)snp[e].key);
+		// (the reference side ran before: its words of the record stand)
+		uint32_t *r = reinterpret_cast<uint32_t *>(hx + h);
+		r[1] = (uint32_t)i;
+		atomicOr(&r[2], (cnt < 0xFFFFu ? (uint32_t)cnt : 0xFFFFu) << 16);
+		atomicOr(&r[3], f << 16);
+		if (cnt >= 0xFFFFu) atomicMax(&hx[(uint64_t)h + 1].y, (uint32_t)hi);
 	}
 }
+__global__ void vg_hx_sentinel(uint4 *__restrict__ hx, uint32_t n_ref, uint32_t n_snp) { hx[1ull << 32] = make_uint4(n_ref, n_snp, 0u, 0u); }
 // signature form of the strided-probe view (DevIndex::snp_sig); 16 zero signatures behind the last entry (items read eight at a time)
 __global__ void vg_make_snp_sig(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ jg, uint64_t n, uint16_t *__restrict__ out)
 {
@@ -319,12 +350,12 @@ __global__ void vg_iota_u32(uint32_t *v, uint64_t n) { for (uint64_t i = (uint64
 __global__ void vg_make_ref_entries(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ pos, const uint8_t *__restrict__ amb, uint64_t n, RefEnt *__restrict__ out)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		out[i] = RefEnt{(uint32_t)kmer[i], pos[i], (uint32_t)amb[i], 0u};
+		out[i] = RefEnt{(uint32_t)kmer[i], pos[i], (uint32_t)amb[i], (uint32_t)(kmer[i] >> 32)};       // (the spare word: HI32, the entry's bucket -- see vg_hx_fill_ref)
 }
 __global__ void vg_make_snp_entries(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ pos, const uint8_t *__restrict__ info, const uint8_t *__restrict__ amb, uint64_t n, SnpEnt *__restrict__ out)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-		out[i] = SnpEnt{(kmer[i] & LO40_MASK) | ((uint64_t)info[i] << 40) | ((uint64_t)amb[i] << 48), pos[i], 0u};
+		out[i] = SnpEnt{(kmer[i] & LO40_MASK) | ((uint64_t)info[i] << 40) | ((uint64_t)amb[i] << 48), pos[i], (uint32_t)(kmer[i] >> 32)};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,51 +761,17 @@ __global__ __launch_bounds__(256) void vg_fq_gather(const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // host side of the handle
 // ------------------------------------------------------------------------------------------------
-// the HIP virtual-memory calls behind vg_arena.h
-struct HipVm {
-	typedef hipMemGenericAllocationHandle_t Handle;
-	static hipMemAllocationProp prop(int device)
-	{
-		hipMemAllocationProp p = {};
-		p.type = hipMemAllocationTypePinned;
-		p.location.type = hipMemLocationTypeDevice;
-		p.location.id = device;
-		return p;
-	}
-	static bool granularity_ok(int device, uint64_t chunk)
-	{
-		const hipMemAllocationProp p = prop(device);
-		size_t gran = 0;
-		if (hipMemGetAllocationGranularity(&gran, &p, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || chunk % gran != 0) { (void)hipGetLastError(); return false; }
-		return true;
-	}
-	static uint8_t *reserve(uint64_t bytes)
+// the driver calls behind vg_arena.h: one hipMalloc per handle
+struct HipBlock {
+	static void *alloc(uint64_t bytes)
 	{
 		void *p = nullptr;
-		if (hipMemAddressReserve(&p, bytes, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-		return (uint8_t *)p;
+		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		return p;
 	}
-	static void unreserve(uint8_t *va, uint64_t bytes) { (void)hipMemAddressFree(va, bytes); }
-	static bool create(int device, uint64_t bytes, Handle *h)
-	{
-		const hipMemAllocationProp p = prop(device);
-		if (hipMemCreate(h, bytes, &p, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-		return true;
-	}
-	static void release(Handle h) { (void)hipMemRelease(h); }
-	static bool map(uint8_t *at, uint64_t bytes, Handle h, int device)
-	{
-		if (hipMemMap(at, bytes, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-		hipMemAccessDesc acc = {};
-		acc.location.type = hipMemLocationTypeDevice;
-		acc.location.id = device;
-		acc.flags = hipMemAccessFlagsProtReadWrite;
-		if (hipMemSetAccess(at, bytes, &acc, 1) != hipSuccess) { (void)hipGetLastError(); (void)hipMemUnmap(at, bytes); return false; }
-		return true;
-	}
-	static void unmap(uint8_t *at, uint64_t bytes) { (void)hipMemUnmap(at, bytes); }
+	static void free(void *p) { (void)hipFree(p); }
 };
-typedef DevArenaT<HipVm> DevArena;
+typedef DevArenaT<HipBlock> DevArena;
 
 struct ScratchBuf {
 	Scratch s{};
@@ -815,6 +812,7 @@ struct vg_index {
 	DevArena arena;                       // the index's device memory (vg_arena.h): permanent arrays and the temporaries of its construction
 	std::vector<void *> owned;            // device allocations of the index made with hipMalloc (small handle-lifetime buffers; everything, when the arena could not be set up)
 	std::map<void *, uint64_t> owned_bytes;
+	uint64_t arena_misses = 0, arena_miss_bytes = 0;      // requests the arena had no room for (served by hipMalloc)
 	uint64_t dev_bytes = 0;               // device memory of the index: hipMalloc'ed buffers (counted as they are made) + the arena's mapped chunks (counted when construction is over)
 	uint64_t n_sites = 0;
 	bool cnt4_dirty = false;                           // base-indexed counters hold increments not yet folded into d.cnt
@@ -858,7 +856,7 @@ static int dev_alloc(vg_index *ix, T **p, uint64_t count, bool zero = false, boo
 	void *q = nullptr;
 	const size_t bytes = (size_t)(count ? count : 1) * sizeof(T);
 	const double t0 = now_s();
-	if (!plain) q = ix->arena.take(bytes, false);
+	if (!plain) { q = ix->arena.take(bytes, false); if (!q && ix->arena.ready()) { ix->arena_misses++; ix->arena_miss_bytes += bytes; } }
 	if (!q) {
 		hipError_t e = hipMalloc(&q, bytes);
 		if (e != hipSuccess) { (void)hipGetLastError(); return fail(VG_ENOMEM, "hipMalloc(%s bytes): %s", std::to_string(bytes).c_str(), hipGetErrorString(e)); }
@@ -903,7 +901,7 @@ struct TempDev {
 		release();
 		const size_t bytes = (size_t)(count ? count : 1) * sizeof(T);
 		const double t0 = now_s();
-		if (g_building) { p = (T *)g_building->arena.take(bytes, true); if (p) ix = g_building; }
+		if (g_building) { p = (T *)g_building->arena.take(bytes, true); if (p) ix = g_building; else if (g_building->arena.ready()) { g_building->arena_misses++; g_building->arena_miss_bytes += bytes; } }
 		if (!p) {
 			hipError_t e = hipMalloc((void **)&p, bytes);
 			if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return fail(VG_ENOMEM, "hipMalloc(staging): %s", hipGetErrorString(e)); }
@@ -1172,12 +1170,6 @@ static int init_handle(vg_index *ix, int device)
 	if (device < 0 || device >= ndev) return fail(VG_EINVAL, "device index out of range");
 	ix->device = device;
 	HIP_TRY(hipSetDevice(device));
-	{
-		// the handle's device memory (vg_arena.h); VG_NO_ARENA=1: every buffer its own hipMalloc / hipFree, as through round 4
-		size_t fr = 0, tot = 0;
-		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = 0; }
-		if (!getenv("VG_NO_ARENA")) (void)ix->arena.init(device, (uint64_t)tot);
-	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
 	{
 		// the spill tiers are a few hundred small workgroups that can only start when main-tier workgroups retire: with a
@@ -1213,7 +1205,9 @@ static int init_handle(vg_index *ix, int device)
 struct ViewPlan {
 	bool mx = false, dx = false, sec = false, sig = false, probe = false, hx = false, jg32 = false;
 	uint64_t base = 0, total = 0, budget = 0;
+	uint64_t arena = 0;                    // bytes of the handle's one block (vg_arena.h): the finished index less what lives outside it
 	std::string text;
+	bool same_views(const ViewPlan &o) const { return mx == o.mx && dx == o.dx && sec == o.sec && sig == o.sig && probe == o.probe && hx == o.hx && jg32 == o.jg32; }
 };
 static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits, uint64_t snp_bf_bits, uint64_t budget_arg, uint64_t device_total, int cus)
 {
@@ -1255,23 +1249,27 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 	if (!kept.empty()) p.text += " + " + kept;
 	p.text += dropped.empty() ? "; nothing left out" : "; LEFT OUT for the budget: " + dropped;
 	if (p.base > p.budget) p.text += "; THE BUDGET IS BELOW THE SMALLEST LAYOUT";
+	// the block holds everything but the batch slots (2 GiB reserved above, allocated with the first batches), the counters that
+	// RCCL reduces in place and the clamped copy the host fetches (10 bytes per site); 64 MiB for the alignment of ~40 arrays
+	p.arena = p.total - 2 * GiB - std::min<uint64_t>(sites * 10, p.total / 2) + (64ull << 20);
 	return p;
 }
 
 // From the columns (device) + the two bit vectors (host words) to the resident index.
 // Device memory comes out of the handle's arena (vg_arena.h): permanent arrays with dev_alloc, temporaries as TempDev; one
-// stream (ix->stream) carries every kernel, and a temporary is only given back after the stream has drained.
-static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const uint64_t *ref_bf_words, uint64_t snp_bf_bits, const uint64_t *snp_bf_words, PhaseClock &pc)
+// stream (ix->stream) carries every kernel, and a temporary is only given back after the stream has drained.  The ORDER below
+// keeps what is alive at any moment -- permanent arrays so far + the temporaries of the step -- within the size of the finished
+// index, which is the size of the arena: every column goes as soon as its last reader is done (the dictionaries' 16-byte entries
+// are built early and serve the later steps in the columns' place), the radix sorts ping-pong between two buffer pairs, and
+// neither wide table needs a jump table beside it (the entries carry their buckets).
+static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint64_t ref_bf_bits, const uint64_t *ref_bf_words, uint64_t snp_bf_bits, const uint64_t *snp_bf_words, PhaseClock &pc)
 {
-	if (c.n_ref >= 0xFFFFFFFFull || c.n_snp >= 0xFFFFFFFFull) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
-	if (ref_bf_bits == 0 || snp_bf_bits == 0) return fail(VG_EINVAL, "empty bit vector");
 	int rc;
 	DevIndex &d = ix->d;
 	d.n_ref = c.n_ref; d.n_snp = c.n_snp;
 	d.ref_aux = c.ref_aux; d.snp_aux_pos = c.snp_aux_pos; d.snp_aux_info = c.snp_aux_info;
 	hipStream_t st = ix->stream;
-	// ---- largest position any entry names (needs columns that are released along the way), and what a file that `vargeno index`
-	//      did not write could get wrong: one wait for both
+	// ---- largest position any entry names, and what a file that `vargeno index` did not write could get wrong: one wait for both
 	unsigned long long maxp = 0;
 	{
 		TempDev<unsigned long long> dchk;                  // [0] max position, [1] k-mers out of order, [2] wild row indices, [3] rows that repeat a position
@@ -1311,22 +1309,38 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		if ((rc = dev_upload(ix, &s2, snp_bf_words, (snp_bf_bits + 63) / 64))) return rc;
 		d.ref_bf = r; d.ref_bf_bits = ref_bf_bits; d.snp_bf = s2; d.snp_bf_bits = snp_bf_bits;
 	}
-	// The merged view's indices are 32 bits wide: an index of 2^32 or more k-mers (hg38 + full dbSNP), or VG_NO_MX, runs on the
-	// layout without it.
-	size_t dev_free = 0, dev_total = 0;
-	if (hipMemGetInfo(&dev_free, &dev_total) != hipSuccess) { (void)hipGetLastError(); dev_total = 0; }
-	if (dev_total == 0 && ix->max_device_bytes == 0) return fail(VG_ENODEV, "hipMemGetInfo failed and no device-memory budget was given (vg_index_open_ex): the views cannot be planned");
-	const ViewPlan plan = plan_views(c, maxp, ref_bf_bits, snp_bf_bits, ix->max_device_bytes, (uint64_t)dev_total, ix->cus);
-	ix->plan_text = plan.text;
-	if (!ix->aux_note.empty()) ix->plan_text += "; " + ix->aux_note;
-	if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] %s\n", plan.text.c_str());
-	if (plan.base > plan.budget) return fail(VG_ENOMEM, "the device-memory budget is below the smallest layout of this index: %s", plan.text.c_str());
+	{
+		// the plan was made before anything was allocated, with the genome length <prefix>.chrlens gives (0 without it); what the
+		// dictionaries really name decides the text -- and must still fit the budget
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = 0; }
+		const ViewPlan real = plan_views(c, maxp, ref_bf_bits, snp_bf_bits, ix->max_device_bytes, (uint64_t)tot, ix->cus);
+		ix->plan_text = real.same_views(plan) ? real.text : plan.text + "; (planned with the genome length of the .chrlens file: the dictionaries name positions beyond it)";
+		if (!ix->aux_note.empty()) ix->plan_text += "; " + ix->aux_note;
+		if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] %s\n", ix->plan_text.c_str());
+		if (real.base > real.budget) return fail(VG_ENOMEM, "the device-memory budget is below the smallest layout of this index: %s", real.text.c_str());
+	}
 	const bool want_mx = plan.mx;
-	// the radix sorts' scratch (a few MB: they ping-pong between the caller's two buffer pairs, vg_sort.hip)
-	TempDev<uint8_t> sort_tmp;
-	const size_t sort_tmp_bytes = vg_dev_sort_pairs_temp_bytes((size_t)(c.n_ref + c.n_snp));
-	if ((rc = sort_tmp.alloc(sort_tmp_bytes))) return rc;
-	pc.lap("checks, bit vectors, plan");
+	// sorted pairs end up in the FIRST buffer pair, the one allocated first and therefore higher in the arena: the pair that is
+	// given back is the one next to the permanent arrays
+	auto sort_into_a = [&](TempDev<uint64_t> &ka, TempDev<uint64_t> &kb, TempDev<uint32_t> &va, TempDev<uint32_t> &vb, uint64_t n) -> int {
+		// (the sorts' own scratch is a few MB -- they ping-pong between the two buffer pairs, vg_sort.hip -- and lives only this long: a
+		// temporary that outlives its step sits in a permanent array's way)
+		TempDev<uint8_t> sort_tmp;
+		const size_t sort_tmp_bytes = vg_dev_sort_pairs_temp_bytes((size_t)n);
+		int rc2 = sort_tmp.alloc(sort_tmp_bytes);
+		if (rc2) return rc2;
+		bool in_b = false;
+		const int se = vg_dev_sort_pairs_u64_u32(ka.p, kb.p, va.p, vb.p, n, st, sort_tmp.p, sort_tmp_bytes, &in_b);
+		if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
+		if (in_b && n) {
+			HIP_TRY(hipMemcpyAsync(ka.p, kb.p, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+			HIP_TRY(hipMemcpyAsync(va.p, vb.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+		}
+		kb.release(); vb.release();
+		return VG_OK;
+	};
+	pc.lap("checks, bit vectors");
 	// ---- pile-up sites (src/qv.cc:602-603, 637-659): first, while little else is resident (their position-wide scratch is 4 bytes
 	//      per genome position), and the SNP dictionary's frequency columns go right after
 	{
@@ -1374,60 +1388,8 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		c.snp_rf.release(); c.snp_af.release();
 	}
 	pc.lap("pile-up sites");
-	// ---- reference dictionary: jump table + 16-byte entries.  With the paired HI32 table in the plan the jump table is only
-	//      needed until that table is filled: a temporary.
-	TempDev<uint32_t> ref_jg_tmp;
-	{
-		uint32_t *jg = nullptr; RefEnt *ent = nullptr;
-		if (plan.hx) { if ((rc = ref_jg_tmp.alloc((1ull << 32) + 1))) return rc; jg = ref_jg_tmp.p; }
-		else if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
-		if ((rc = dev_alloc(ix, &ent, c.n_ref))) return rc;
-		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.ref_kmer.p, c.n_ref, jg, 1ull << 32, 32);
-		vg_make_ref_entries<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, ent);
-		HIP_TRY(hipGetLastError());
-		d.ref_jg = jg; d.ref = ent;
-		// without the merged view nothing reads the position / ambiguity columns any more
-		if (!want_mx) { c.ref_pos.release(); c.ref_amb.release(); }
-		// secondary view ordered by (LO32, HI32): device radix sort of the swapped k-mers + a jump table over LO32's top bits
-		if (plan.sec) {
-			uint32_t bits = 14;
-			while (bits < 30 && (1ull << bits) < c.n_ref) bits++;          // ~1-3 entries per bucket
-			TempDev<uint64_t> ka, kb; TempDev<uint32_t> va, vb;
-			if ((rc = ka.alloc(c.n_ref)) || (rc = va.alloc(c.n_ref)) || (rc = kb.alloc(c.n_ref)) || (rc = vb.alloc(c.n_ref))) return rc;
-			uint32_t *sjg = nullptr, *sec3 = nullptr;
-			if ((rc = dev_alloc(ix, &sjg, (1ull << bits) + 1))) return rc;
-			vg_make_sec_keys<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.n_ref, ka.p, va.p);
-			HIP_TRY(hipGetLastError());
-			bool in_b = false;
-			const int se = vg_dev_sort_pairs_u64_u32(ka.p, kb.p, va.p, vb.p, c.n_ref, st, sort_tmp.p, sort_tmp_bytes, &in_b);
-			if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
-			if (in_b) { ka.release(); va.release(); } else { kb.release(); vb.release(); }
-			const uint64_t *skey = in_b ? kb.p : ka.p; const uint32_t *sidx = in_b ? vb.p : va.p;
-			if ((rc = dev_alloc(ix, &sec3, 3 * c.n_ref + 4))) return rc;
-			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, st>>>(skey, c.n_ref, sjg, 1ull << bits, (int)(64 - bits));
-			vg_make_sec3<<<2048, 256, 0, st>>>(skey, sidx, ent, c.n_ref, sec3);
-			// the reference bit vector against the dictionary: when they name the same LO32 values, the view answers qv.cc:955 too
-			unsigned long long chk[3] = {1, 0, 0};
-			if (ref_bf_bits >= (1ull << 32) && !getenv("VG_NO_BF_FROM_SEC")) {
-				TempDev<unsigned long long> dchk;
-				if ((rc = dchk.alloc(3))) return rc;
-				HIP_TRY(hipMemsetAsync(dchk.p, 0, 24, st));
-				vg_sec_bf_check<<<2048, 256, 0, st>>>(skey, c.n_ref, d.ref_bf, dchk.p);
-				vg_popcount_words<<<2048, 256, 0, st>>>(d.ref_bf, (1ull << 32) / 64, dchk.p + 2);
-				HIP_TRY(hipGetLastError());
-				HIP_TRY(hipStreamSynchronize(st));
-				HIP_TRY(hipMemcpy(chk, dchk.p, 24, hipMemcpyDeviceToHost));
-			}
-			HIP_TRY(hipGetLastError());
-			d.sec3 = sec3; d.sec_jg = sjg; d.sec_bits = bits;
-			d.sec_is_bf = (chk[0] == 0 && chk[1] == chk[2]) ? 1u : 0u;
-		}
-	}
-	// the merged view is the last user of the reference dictionary's k-mer column: without it (2^32 or more k-mers in the two
-	// dictionaries together -- hg38 + full dbSNP --, or VG_NO_MX) it goes now, 23 GB at hg38 scale
-	if (!want_mx) c.ref_kmer.release();
-	pc.lap("reference dictionary + LO32-ordered view");
-	// ---- SNP dictionary
+	// ---- SNP dictionary: jump table over HI24, 16-byte entries, the strided scan's view; then its columns go (the k-mers stay for
+	//      the merged view's keys, or -- an index without one -- for the HI32 jump table, if that is what the plan holds)
 	{
 		uint32_t *jg = nullptr; SnpEnt *ent = nullptr;
 		if ((rc = dev_alloc(ix, &jg, (1ull << 24) + 1))) return rc;
@@ -1436,8 +1398,7 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 		vg_make_snp_entries<<<2048, 256, 0, st>>>(c.snp_kmer.p, c.snp_pos.p, c.snp_info.p, c.snp_amb.p, c.n_snp, ent);
 		HIP_TRY(hipGetLastError());
 		d.snp_jg = jg; d.snp = ent;
-		if (!want_mx) { c.snp_pos.release(); c.snp_amb.release(); }
-		c.snp_info.release();                                      // (the sites are built: the entries were its last reader)
+		c.snp_pos.release(); c.snp_info.release(); c.snp_amb.release();
 		// the strided scan's view of the SNP dictionary: signatures (2 bytes per entry) by default, the probed values themselves
 		// (8 bytes per entry) under VG_NO_SIG_VIEW, neither under VG_NO_PROBE_VIEW
 		if (plan.sig) {
@@ -1453,8 +1414,8 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			HIP_TRY(hipGetLastError());
 			d.snp_probe = pv;
 		}
-		// an index too large for the merged view gets a HI32 jump table of the SNP dictionary instead (17 GB): its HI24 buckets hold
-		// ~190 entries there, 8 dependent bisection probes per look-up
+		// an index too large for the merged view and without the paired table gets a HI32 jump table of the SNP dictionary (17 GB):
+		// its HI24 buckets hold ~190 entries there, 8 dependent bisection probes per look-up
 		if (plan.jg32) {
 			uint32_t *j32 = nullptr;
 			if ((rc = dev_alloc(ix, &j32, (1ull << 32) + 1))) return rc;
@@ -1462,60 +1423,96 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			HIP_TRY(hipGetLastError());
 			d.snp_jg32 = j32;
 		}
+		if (!want_mx) c.snp_kmer.release();
 	}
 	pc.lap("SNP dictionary, scan view");
-	// ---- paired HI32 table in place of the two HI32 jump tables (an index without merged view): built in two passes so that only
-	//      one 16 GiB jump table is alive next to it
+	// ---- reference dictionary: 16-byte entries, and -- unless the paired HI32 table will stand in for it -- the jump table over HI32
+	{
+		uint32_t *jg = nullptr; RefEnt *ent = nullptr;
+		if (!plan.hx) {
+			if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
+			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.ref_kmer.p, c.n_ref, jg, 1ull << 32, 32);
+		}
+		if ((rc = dev_alloc(ix, &ent, c.n_ref))) return rc;
+		vg_make_ref_entries<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, ent);
+		HIP_TRY(hipGetLastError());
+		d.ref_jg = jg; d.ref = ent;
+		c.ref_pos.release(); c.ref_amb.release();
+		// secondary view ordered by (LO32, HI32): device radix sort of the swapped k-mers + a jump table over LO32's top bits
+		if (plan.sec) {
+			uint32_t bits = 14;
+			while (bits < 30 && (1ull << bits) < c.n_ref) bits++;          // ~1-3 entries per bucket
+			TempDev<uint64_t> ka, kb; TempDev<uint32_t> va, vb;
+			if ((rc = ka.alloc(c.n_ref)) || (rc = va.alloc(c.n_ref))) return rc;
+			vg_make_sec_keys<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.n_ref, ka.p, va.p);
+			HIP_TRY(hipGetLastError());
+			if (!want_mx) c.ref_kmer.release();                    // (the merged view's keys are its last reader otherwise)
+			if ((rc = kb.alloc(c.n_ref)) || (rc = vb.alloc(c.n_ref))) return rc;
+			if ((rc = sort_into_a(ka, kb, va, vb, c.n_ref))) return rc;
+			uint32_t *sjg = nullptr, *sec3 = nullptr;
+			if ((rc = dev_alloc(ix, &sjg, (1ull << bits) + 1))) return rc;
+			if ((rc = dev_alloc(ix, &sec3, 3 * c.n_ref + 4))) return rc;
+			vg_build_jumpgate<<<(unsigned)((1ull << bits) / JG_SPAN), 256, 0, st>>>(ka.p, c.n_ref, sjg, 1ull << bits, (int)(64 - bits));
+			vg_make_sec3<<<2048, 256, 0, st>>>(ka.p, va.p, ent, c.n_ref, sec3);
+			// the reference bit vector against the dictionary: when they name the same LO32 values, the view answers qv.cc:955 too
+			unsigned long long chk[3] = {1, 0, 0};
+			if (ref_bf_bits >= (1ull << 32) && !getenv("VG_NO_BF_FROM_SEC")) {
+				TempDev<unsigned long long> dchk;
+				if ((rc = dchk.alloc(3))) return rc;
+				HIP_TRY(hipMemsetAsync(dchk.p, 0, 24, st));
+				vg_sec_bf_check<<<2048, 256, 0, st>>>(ka.p, c.n_ref, d.ref_bf, dchk.p);
+				vg_popcount_words<<<2048, 256, 0, st>>>(d.ref_bf, (1ull << 32) / 64, dchk.p + 2);
+				HIP_TRY(hipGetLastError());
+				HIP_TRY(hipStreamSynchronize(st));
+				HIP_TRY(hipMemcpy(chk, dchk.p, 24, hipMemcpyDeviceToHost));
+			}
+			HIP_TRY(hipGetLastError());
+			d.sec3 = sec3; d.sec_jg = sjg; d.sec_bits = bits;
+			d.sec_is_bf = (chk[0] == 0 && chk[1] == chk[2]) ? 1u : 0u;
+		}
+		if (!want_mx) c.ref_kmer.release();
+	}
+	pc.lap("reference dictionary + LO32-ordered view");
+	// ---- paired HI32 table in place of the two HI32 jump tables (an index without merged view), from the entries' bucket words
 	if (plan.hx) {
 		uint4 *hx = nullptr;
 		if ((rc = dev_alloc(ix, &hx, (1ull << 32) + 1))) return fail(VG_ENOMEM, "no room for the paired HI32 table although the plan had it -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str());
-		vg_hx_fill_ref<<<ix->cus * 32, 256, 0, st>>>(ref_jg_tmp.p, d.ref, hx);
-		HIP_TRY(hipGetLastError());
-		ref_jg_tmp.release();                                   // (waits for the stream)
-		d.ref_jg = nullptr;
-		TempDev<uint32_t> j32;
-		if ((rc = j32.alloc((1ull << 32) + 1))) return rc;
-		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.snp_kmer.p, c.n_snp, j32.p, 1ull << 32, 32);
-		vg_hx_fill_snp<<<ix->cus * 32, 256, 0, st>>>(j32.p, c.snp_kmer.p, hx);
+		HIP_TRY(hipMemsetAsync(hx, 0, ((1ull << 32) + 1) * 16, st));
+		vg_hx_sentinel<<<1, 1, 0, st>>>(hx, (uint32_t)c.n_ref, (uint32_t)c.n_snp);
+		if (c.n_ref) vg_hx_fill_ref<<<ix->cus * 32, 256, 0, st>>>(d.ref, c.n_ref, hx);
+		if (c.n_snp) vg_hx_fill_snp<<<ix->cus * 32, 256, 0, st>>>(d.snp, c.n_snp, hx);
 		if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(VG_ENODEV, "building the paired HI32 table failed");
 		d.hx = hx;
 		pc.lap("paired HI32 table");
 	}
-	if (!want_mx) c.snp_kmer.release();                        // its last readers (scan view, HI32 tables) are done
-	// ---- merged exact-match view (both dictionaries behind one HI32 jump table); its indices are 32 bits wide
+	// ---- merged exact-match view (both dictionaries behind one HI32 table); its indices are 32 bits wide
 	const uint64_t nm = c.n_ref + c.n_snp;
 	if (want_mx) {
 		TempDev<uint64_t> ka, kb; TempDev<uint32_t> va, vb;
 		if ((rc = ka.alloc(nm))) return rc;
 		if (c.n_ref) HIP_TRY(hipMemcpyAsync(ka.p, c.ref_kmer.p, (size_t)c.n_ref * 8, hipMemcpyDeviceToDevice, st));
 		if (c.n_snp) HIP_TRY(hipMemcpyAsync(ka.p + c.n_ref, c.snp_kmer.p, (size_t)c.n_snp * 8, hipMemcpyDeviceToDevice, st));
-		c.ref_kmer.release(); c.snp_kmer.release();            // 26 GB at hg38 scale: the sort's second buffer pair takes their place
-		if ((rc = kb.alloc(nm)) || (rc = va.alloc(nm)) || (rc = vb.alloc(nm))) return rc;
-		vg_iota_u32<<<2048, 256, 0, st>>>(va.p, nm);
+		c.ref_kmer.release(); c.snp_kmer.release();            // 26 GB at hg38 scale: the sort's other buffers take their place
 		TempDev<uint32_t> strand_bits;
-		if ((rc = strand_bits.alloc(nm / 32 + 2))) return rc;
+		if ((rc = va.alloc(nm)) || (rc = strand_bits.alloc(nm / 32 + 2))) return rc;
+		vg_iota_u32<<<2048, 256, 0, st>>>(va.p, nm);
 		HIP_TRY(hipMemsetAsync(strand_bits.p, 0, (nm / 32 + 2) * 4, st));
 		vg_canon_keys<<<2048, 256, 0, st>>>(ka.p, nm, strand_bits.p);
 		HIP_TRY(hipGetLastError());
-		bool in_b = false;
-		const int se = vg_dev_sort_pairs_u64_u32(ka.p, kb.p, va.p, vb.p, nm, st, sort_tmp.p, sort_tmp_bytes, &in_b);     // stable: ref before snp on equal k-mers
-		if (se != 0) return fail(VG_ENODEV, "device radix sort failed: %s", hipGetErrorString((hipError_t)se));
-		if (in_b) { ka.release(); va.release(); } else { kb.release(); vb.release(); }
-		TempDev<uint64_t> &kout = in_b ? kb : ka; TempDev<uint32_t> &vout = in_b ? vb : va;
-		// with the direct table in the plan the merged jump table only lives until that table is filled: a temporary
-		TempDev<uint32_t> mjg_tmp;
+		if ((rc = kb.alloc(nm)) || (rc = vb.alloc(nm))) return rc;
+		if ((rc = sort_into_a(ka, kb, va, vb, nm))) return rc;     // stable: ref before snp on equal k-mers
 		uint32_t *mjg = nullptr; uint4 *mx = nullptr;
-		if (plan.dx) { if ((rc = mjg_tmp.alloc((1ull << 32) + 1))) return rc; mjg = mjg_tmp.p; }
-		else if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
+		if (!plan.dx) {
+			if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
+			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(ka.p, nm, mjg, 1ull << 32, 32);
+		}
 		if ((rc = dev_alloc(ix, &mx, nm))) return rc;
-		vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(kout.p, nm, mjg, 1ull << 32, 32);
-		vg_make_mx_entries<<<2048, 256, 0, st>>>(kout.p, vout.p, nm, c.n_ref, c.ref_pos.p, c.ref_amb.p, c.snp_pos.p, c.snp_amb.p, mx, strand_bits.p);
+		vg_make_mx_entries<<<2048, 256, 0, st>>>(ka.p, va.p, nm, c.n_ref, d.ref, d.snp, mx, strand_bits.p);
 		HIP_TRY(hipGetLastError());
-		kout.release(); vout.release(); strand_bits.release();
-		c.ref_pos.release(); c.ref_amb.release(); c.snp_pos.release(); c.snp_amb.release();
+		ka.release(); va.release(); strand_bits.release();
 		d.mx_jg = mjg; d.mx = mx;
-		// direct table (64 GiB) in place of the merged jump table (16 GiB) when the plan has the room; no bucket may exceed the
-		// 24-bit count field (it would be a >16 M-fold repeated 16-mer)
+		// direct table (64 GiB) in place of the merged jump table (16 GiB) when the plan has the room, from the entries' bucket
+		// words; no bucket may exceed the 24-bit count field (it would be a >16 M-fold repeated 16-mer)
 		if (plan.dx) {
 			uint4 *dx = nullptr;
 			TempDev<uint32_t> big;
@@ -1523,26 +1520,23 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 			HIP_TRY(hipMemsetAsync(big.p, 0, 4, st));
 			uint32_t too_big = 0;
 			if ((rc = dev_alloc(ix, &dx, 1ull << 32))) return fail(VG_ENOMEM, "no room for the direct table although the plan had it -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str());
-			vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mjg, mx, dx, d.ref_aux, d.snp_aux_pos, big.p);
+			HIP_TRY(hipMemsetAsync(dx, 0, (1ull << 32) * 16, st));
+			vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mx, nm, dx, d.ref_aux, d.snp_aux_pos, big.p);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(st));
 			HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
 			if (too_big) {
-				// jump-table form after all: the table moves to a permanent place, the 64 GiB go back
+				// jump-table form after all: the 64 GiB go back, the jump table is made from the same bucket words
 				dev_release(ix, dx); dx = nullptr;
-				uint32_t *keep = nullptr;
-				if ((rc = dev_alloc(ix, &keep, (1ull << 32) + 1))) return rc;
-				HIP_TRY(hipMemcpyAsync(keep, mjg, ((1ull << 32) + 1) * 4, hipMemcpyDeviceToDevice, st));
-				HIP_TRY(hipStreamSynchronize(st));
-				d.mx_jg = keep;
-				ix->plan_text += "; direct table not kept: a bucket of more than 2^24 - 1 entries";
-			} else {
-				vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);      // after the table: it reads the row form
+				if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
+				vg_jumpgate_from_buckets<<<ix->cus * 32, 256, 0, st>>>(mx, nm, mjg);
 				HIP_TRY(hipGetLastError());
-				d.dx = dx;
-				d.mx_jg = nullptr;                                  // (the merged jump table is not needed any more: released with mjg_tmp)
-			}
+				d.mx_jg = mjg;
+				ix->plan_text += "; direct table not kept: a bucket of more than 2^24 - 1 entries";
+			} else d.dx = dx;
 		}
+		vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);          // after the table: it reads the row form and the bucket words
+		HIP_TRY(hipGetLastError());
 		pc.lap("merged view, direct table");
 	}
 	// ---- scratch of the lane tier, overflow counters, stats
@@ -1561,23 +1555,45 @@ static int build_on_device(vg_index *ix, DevCols &c, uint64_t ref_bf_bits, const
 	return VG_OK;
 }
 
+// Before anything is allocated: the plan (which views the budget buys) and the handle's one block of device memory, sized for the
+// finished index.  maxp_est: the largest genome position, as far as it is known up front (0: unknown -- the arrays that are one
+// byte or so per position then find no room in the block and are hipMalloc'ed beside it).
+static int plan_and_arena(vg_index *ix, const DevCols &c, uint64_t maxp_est, uint64_t ref_bf_bits, uint64_t snp_bf_bits, ViewPlan &plan)
+{
+	if (c.n_ref >= 0xFFFFFFFFull || c.n_snp >= 0xFFFFFFFFull) return fail(VG_ETOOBIG, "dictionary too large (limit: 2^32 32-mers)");
+	if (ref_bf_bits == 0 || snp_bf_bits == 0) return fail(VG_EINVAL, "empty bit vector");
+	size_t fr = 0, tot = 0;
+	if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = 0; }
+	if (tot == 0 && ix->max_device_bytes == 0) return fail(VG_ENODEV, "hipMemGetInfo failed and no device-memory budget was given (vg_index_open_ex): the views cannot be planned");
+	plan = plan_views(c, maxp_est, ref_bf_bits, snp_bf_bits, ix->max_device_bytes, (uint64_t)tot, ix->cus);
+	if (plan.base > plan.budget) return fail(VG_ENOMEM, "the device-memory budget is below the smallest layout of this index: %s", plan.text.c_str());
+	// VG_NO_ARENA=1: every buffer its own hipMalloc / hipFree, as through round 4 (A/B runs).  A block that cannot be had (somebody
+	// else holds the memory) is not an error here: the individual allocations will say so if they fail too.
+	if (!getenv("VG_NO_ARENA")) {
+		const double t0 = now_s();
+		(void)ix->arena.init(plan.arena);
+		g_alloc_s += now_s() - t0;
+	}
+	return VG_OK;
+}
+
 // while a handle is under construction on this thread its temporaries come out of its arena
 struct Building {
 	explicit Building(vg_index *ix) { g_building = ix; }
 	~Building() { g_building = nullptr; }
 };
-// construction is over (every temporary has been given back): the arena returns its pooled chunks, the handle's size is final
+// construction is over (every temporary has been given back): the handle's size is final
 static void finish_construction(vg_index *ix)
 {
-	const double t0 = now_s();
-	ix->arena.trim();
 	uint64_t plain = 0;
 	for (const auto &kv : ix->owned_bytes) plain += kv.second;
-	ix->dev_bytes = plain + ix->arena.mapped_bytes();
-	char line[300];
-	snprintf(line, sizeof line, "; memory: %.1f GB in the arena (peak during construction %.1f GB, %llu chunks of 1 GiB taken from the driver, %llu re-mapped from the pool; returning the pool %.2f s) + %.1f GB of hipMalloc'ed buffers",
-	         ix->arena.mapped_bytes() / 1e9, ix->arena.peak_bytes() / 1e9, (unsigned long long)ix->arena.created_chunks(), (unsigned long long)ix->arena.remaps(), now_s() - t0, plain / 1e9);
-	ix->open_report += ix->arena.ready() ? line : "; memory: no arena (hipMalloc / hipFree per buffer)";
+	ix->dev_bytes = plain + ix->arena.size();
+	char line[400];
+	if (ix->arena.ready())
+		snprintf(line, sizeof line, "; memory: one block of %.1f GB (%.1f GB of it in use now, at most %.1f GB during construction; %llu requests = %.1f GB did not fit and went to hipMalloc) + %.1f GB of hipMalloc'ed buffers",
+		         ix->arena.size() / 1e9, ix->arena.in_use() / 1e9, ix->arena.peak() / 1e9, (unsigned long long)ix->arena_misses, ix->arena_miss_bytes / 1e9, plain / 1e9);
+	else snprintf(line, sizeof line, "; memory: no arena (hipMalloc / hipFree per buffer), %.1f GB", plain / 1e9);
+	ix->open_report += line;
 	if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] %s\n", line + 2);
 }
 
@@ -1596,14 +1612,23 @@ static int create_impl(const vg_index_arrays *a, int device, vg_index *ix)
 	PhaseClock pc(ix);
 	DevCols c;
 	c.n_ref = a->n_ref; c.n_ref_aux = a->n_ref_aux; c.n_snp = a->n_snp; c.n_snp_aux = a->n_snp_aux;
+	// the largest position the arrays name (the loader's own rule, vg_max_pos): it sizes the arrays that are per genome position
+	uint64_t maxp_est = 0;
+	{
+		auto scan = [&](const uint32_t *pos, const uint8_t *amb, uint64_t n) { for (uint64_t i = 0; i < n; i++) if ((!amb || amb[i] == 0) && pos[i] != POS_AMBIGUOUS && pos[i] > maxp_est) maxp_est = pos[i]; };
+		scan(a->ref_pos, a->ref_amb, a->n_ref); scan(a->ref_aux, nullptr, a->n_ref_aux * AUX_COLS);
+		scan(a->snp_pos, a->snp_amb, a->n_snp); scan(a->snp_aux_pos, nullptr, a->n_snp_aux * AUX_COLS);
+	}
+	ViewPlan plan;
+	if ((rc = plan_and_arena(ix, c, maxp_est, a->ref_bf_bits, a->snp_bf_bits, plan))) return rc;
 	if ((rc = c.ref_kmer.upload(a->ref_kmer, a->n_ref)) || (rc = c.ref_pos.upload(a->ref_pos, a->n_ref)) || (rc = c.ref_amb.upload(a->ref_amb, a->n_ref))) return rc;
 	if ((rc = c.snp_kmer.upload(a->snp_kmer, a->n_snp)) || (rc = c.snp_pos.upload(a->snp_pos, a->n_snp)) || (rc = c.snp_info.upload(a->snp_info, a->n_snp)) ||
 	    (rc = c.snp_amb.upload(a->snp_amb, a->n_snp)) || (rc = c.snp_rf.upload(a->snp_rf, a->n_snp)) || (rc = c.snp_af.upload(a->snp_af, a->n_snp))) return rc;
 	if ((rc = dev_upload(ix, &c.ref_aux, a->ref_aux, a->n_ref_aux * AUX_COLS))) return rc;
 	if ((rc = dev_upload(ix, &c.snp_aux_pos, a->snp_aux_pos, a->n_snp_aux * AUX_COLS))) return rc;
 	if ((rc = dev_upload(ix, &c.snp_aux_info, a->snp_aux_info, a->n_snp_aux * AUX_COLS))) return rc;
-	pc.lap("columns copied to the device");
-	return build_on_device(ix, c, a->ref_bf_bits, a->ref_bf_words, a->snp_bf_bits, a->snp_bf_words, pc);
+	pc.lap("block allocated, columns copied to the device");
+	return build_on_device(ix, c, plan, a->ref_bf_bits, a->ref_bf_words, a->snp_bf_bits, a->snp_bf_words, pc);
 }
 
 extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **out)
@@ -1757,6 +1782,17 @@ static int open_impl(const char *prefix, int device, vg_index *ix)
 	PhaseClock pc(ix);
 	DevCols c;
 	c.n_ref = n_ref; c.n_ref_aux = n_ref_aux; c.n_snp = n_snp; c.n_snp_aux = n_snp_aux;
+	// the genome's length, from <prefix>.chrlens when `vargeno index` left one ("name length" per line): positions are 1-based over
+	// the concatenated sequences, so their sum bounds every position the dictionaries name
+	uint64_t maxp_est = 0;
+	if (FILE *f = fopen((pre + ".chrlens").c_str(), "r")) {
+		char name[256]; unsigned long long len = 0;
+		while (fscanf(f, "%255s %llu", name, &len) == 2) maxp_est += len;
+		fclose(f);
+		if (maxp_est > (1ull << 32)) maxp_est = 0;
+	}
+	ViewPlan plan;
+	if ((rc = plan_and_arena(ix, c, maxp_est, rbits, sbits, plan))) return rc;
 	if ((rc = c.alloc())) return rc;
 	if ((rc = dev_alloc(ix, &c.ref_aux, n_ref_aux * AUX_COLS))) return rc;
 	if ((rc = dev_alloc(ix, &c.snp_aux_pos, n_snp_aux * AUX_COLS))) return rc;
@@ -1784,8 +1820,8 @@ static int open_impl(const char *prefix, int device, vg_index *ix)
 		HIP_TRY(hipStreamSynchronize(ix->stream));
 	}
 	}
-	pc.lap("dictionary files read, copied up, unpacked");
-	return build_on_device(ix, c, rbits, rw.data(), sbits, sw.data(), pc);
+	pc.lap("block allocated, dictionary files read, copied up, unpacked");
+	return build_on_device(ix, c, plan, rbits, rw.data(), sbits, sw.data(), pc);
 }
 
 extern "C" int vg_index_open_ex(const char *prefix, int device, uint64_t max_device_bytes, vg_index **out)

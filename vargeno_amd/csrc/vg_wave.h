@@ -171,11 +171,14 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	const bool use_mx = !STATS && !NOMX && d.mx != nullptr;
 	const bool use_sig = !STATS && d.snp_sig != nullptr;
 	const bool use_probe = !STATS && !use_sig && d.snp_probe != nullptr;
-	// eight entries of the SNP bucket (their signatures) per stage-B item, in the main tier only: an item with two candidates sends
-	// its read to the next tier, and the deep-list tier must be able to finish such a read itself (the lane tier behind it takes
-	// milliseconds per read)
-	const uint32_t sw_log = WPB > 1 && use_sig ? 3u : 0u;                             // log2 of the entries per item (wave-uniform)
+	// 32 entries of the SNP bucket (their signatures: 64 contiguous bytes) per stage-B item (r05; r03-r04: eight), and four records of a
+	// long LO32 bucket, in the main tier only: an item with two candidates sends its read to the next tier, and the deep-list tier
+	// must be able to finish such a read itself (the lane tier behind it takes milliseconds per read).  Stage B1 is bound by the
+	// instructions it issues per ROUND of 64 items, whatever the items hold (profiles/stageb1_rounds_r04.txt): at hg38 scale a SNP
+	// bucket of ~19 entries is one item instead of three, a 100-record LO32 bucket of a repeat family 25 items instead of 100.
+	const uint32_t sw_log = WPB > 1 && use_sig ? 5u : 0u;                             // log2 of the entries per item (wave-uniform)
 	const uint32_t sw_m1 = (1u << sw_log) - 1u;
+	constexpr uint32_t LW_LOG = WPB > 1 ? 2u : 0u, LW = 1u << LW_LOG;                 // records of a long LO32 bucket per item
 	const uint32_t col0 = wv << 6;                       // first column of this wave (scalar)
 	// lane in the wave / this lane's LDS column: recomputed where they are used (two ALU operations) instead of held in a register
 	// from the first line of the kernel to its last -- the main tier sits exactly at its register budget
@@ -769,7 +772,16 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							}
 						}
 						uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
-						if (longsec) { u_lo = s_lo; nhigh = (b1 - b0) + (s_hi - s_lo); hu = b1 - b0; }      // the bucket's records, then the live SNP slots
+						if (!longsec) {
+							// the (at most four) hits in SLOT order, each byte = slot << 2 | hit number (0xFF: none): sorted here, once per pair, so that
+							// the items of stage B1 -- one round of 64 of them executes every path any of its lanes takes -- only pick a byte
+							uint32_t b0_ = nh > 0u ? ((hu & 0xFFu) << 2) | 0u : 0xFFu, b1_ = nh > 1u ? (((hu >> 8) & 0xFFu) << 2) | 1u : 0xFFu;
+							uint32_t b2_ = nh > 2u ? (((hu >> 16) & 0xFFu) << 2) | 2u : 0xFFu, b3_ = nh > 3u ? (((hu >> 24) & 0xFFu) << 2) | 3u : 0xFFu;
+							auto cx = [](uint32_t &x, uint32_t &y) { const uint32_t lo_ = x < y ? x : y, hi_ = x < y ? y : x; x = lo_; y = hi_; };
+							cx(b0_, b1_); cx(b2_, b3_); cx(b0_, b2_); cx(b1_, b3_); cx(b1_, b2_);
+							hu = b0_ | (b1_ << 8) | (b2_ << 16) | (b3_ << 24);
+						}
+						if (longsec) { u_lo = s_lo; nhigh = (((b1 - b0) + LW - 1u) >> LW_LOG) + (s_hi - s_lo); hu = b1 - b0; }      // the bucket's records (LW per item), then the live SNP slots
 						else if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
 						else if (sec_ok && s_hi == s_lo) { mode = 1; nhigh = nh; }
 						else { u_lo = 0; nhigh = 48; }
@@ -813,32 +825,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					T = (uint32_t)__builtin_amdgcn_readlane((int)ci, 63);
 				}
 				VG_WAVE_SYNC();
-				// ---- B1: rounds of 64 items.  The strided-scan probe of an item (most items at hg38 scale, where a SNP bucket holds
-				// ~19 entries) is fetched one round ahead: while a round is worked on, the next round's probes are in flight.
-				auto scan_probe = [&](uint32_t g2) -> uint4 {
-					uint4 v = make_uint4(0u, 0u, 0u, 0u);
-					if (g2 < T) {
-						uint32_t p = 0;
-						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g2) p += step;
-						const uint32_t t = g2 - P_off[p][wv];
-						if (!((P_meta[p][wv] >> 13) & 1u)) {                     // not a large block
-							const uint32_t lo = P_lo[p][wv], slo = P_slo[p][wv], Lr = P_hi[p][wv] - lo, Lsn = P_shi[p][wv] - slo;
-							const uint32_t L = Lr + ((Lsn + sw_m1) >> sw_log);
-							if (t < L) {
-								const bool isr = t < Lr;
-								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)t * REF_STRIDE : (uint64_t)slo + (uint64_t)(t - Lr) * SNP_STRIDE;
-								if (!isr && use_sig) {
-									if (WPB > 1) v = gather<uint4, 1>(d.snp_sig + ((uint64_t)slo + 8u * (t - Lr)));          // eight signatures
-									else v.x = d.snp_sig[(uint64_t)slo + (t - Lr)];
-								}
-								else if (!isr && use_probe) { const uint2 q = gather<uint2, 8>(d.snp_probe + ((uint64_t)slo + (t - Lr))); v.x = q.x; v.y = q.y; }
-								else if (tt < (isr ? d.n_ref : d.n_snp)) v = gather<uint4>(isr ? (const void *)(d.ref + tt) : (const void *)(d.snp + tt));
-							}
-						}
-					}
-					return v;
-				};
-				uint4 scan_cur = scan_probe(lane);
+				// ---- B1: rounds of 64 items.  (r02-r04 fetched an item's strided-scan probe one round ahead; with 32 signatures or four
+				// records per item the loads are issued in the round itself, all of an item's together: a round is bound by the instructions
+				// it issues, and a row search per round instead of two is worth more than the hidden wait.)
 #ifdef VG_STAGE_CLOCKS
 				dbg_pairs += np; dbg_items += T;
 				{ uint32_t lg = 0, sb = 0; if (lane < np) { const uint32_t mt = P_meta[lane][wv]; lg = (mt >> 13) & 1u; sb = ((mt >> 11) & 1u) && !((mt >> 15) & 1u) ? 1u : 0u; } dbg_large += wave_sum<false>(lg); dbg_secbad += wave_sum<false>(sb); }
@@ -849,7 +838,6 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 #ifdef VG_STAGE_CLOCKS
 					dbg_rounds++;
 #endif
-					const uint4 scan_next = scan_probe(g + 64u);
 					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
 					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
 					uint32_t rdirect = 0;                                     // bit 0: ri holds the entry's POSITION field instead (bit 1: its ambig_flag)
@@ -882,19 +870,27 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								// iterate_ref_dict, qv.cc:316-376 / iterate_snp_dict, qv.cc:413-464   (B1): entry lo + 9u (slo + 11u) is
 								// tested, entry lo + u (slo + u) recorded.  Both dictionaries hold 16-byte entries: one gather site.
 								const bool isr = t < Lr;
-								const uint4 v = scan_cur;                                 // zeros when the probe fell off the array
 								if (!isr && use_sig) {
-									// signatures of up to eight consecutive entries of the SNP bucket: which of them can the scan keep at all?
-									const uint32_t u0 = (t - Lr) << sw_log, ks = sig16(k & LO40_MASK);
-									// per 32-bit word two signatures: y = one bit per base in which a signature differs from the k-mer's
-									const uint32_t kk2 = ks | (ks << 16), live = Lsn - u0;   // entries of the bucket from u0 on (>= 1)
+									// signatures of up to 32 consecutive entries of the SNP bucket (main tier; the deep tier: one): which of them can the
+									// scan keep at all?  Per 32-bit word two signatures; y = one bit per base in which a signature differs from the k-mer's.
+									const uint32_t u0 = (t - Lr) << sw_log, live = Lsn - u0, ks = sig16(k & LO40_MASK);      // live: entries of the bucket from u0 on (>= 1)
 									uint32_t cand = 0;
-									auto two = [&](uint32_t w, uint32_t z) {
-										const uint32_t x = w ^ kk2, y = (x | (x >> 1)) & 0x55555555u, yl = y & 0xFFFFu, yh = y >> 16;
-										if (z < live && z <= sw_m1 && yl && !(yl & (yl - 1u))) cand |= 1u << z;
-										if (z + 1u < live && z + 1u <= sw_m1 && yh && !(yh & (yh - 1u))) cand |= 2u << z;
-									};
-									two(v.x, 0u); two(v.y, 2u); two(v.z, 4u); two(v.w, 6u);
+									if constexpr (WPB > 1) {
+										const uint32_t kk2 = ks | (ks << 16);
+										uint4 sv[4];
+										#pragma unroll
+										for (uint32_t q = 0; q < 4; q++) { sv[q] = make_uint4(0u, 0u, 0u, 0u); if (8u * q < live) sv[q] = gather<uint4, 1>(d.snp_sig + ((uint64_t)slo + u0 + 8u * q)); }
+										auto two = [&](uint32_t w) -> uint32_t {
+											const uint32_t x = w ^ kk2, y = (x | (x >> 1)) & 0x55555555u;
+											return (__popc(y & 0xFFFFu) == 1 ? 1u : 0u) | (__popc(y >> 16) == 1 ? 2u : 0u);
+										};
+										#pragma unroll
+										for (uint32_t q = 0; q < 4; q++) cand |= (two(sv[q].x) | (two(sv[q].y) << 2) | (two(sv[q].z) << 4) | (two(sv[q].w) << 6)) << (8u * q);
+										cand &= live >= 32u ? ~0u : ((1u << live) - 1u);
+									} else {
+										const uint32_t x = (uint32_t)d.snp_sig[(uint64_t)slo + u0] ^ ks, y = (x | (x >> 1)) & 0x5555u;
+										cand = __popc(y) == 1 ? 1u : 0u;
+									}
 									if (cand & (cand - 1u)) N_ovf[col0 + own] = 1;        // two candidates in one item: the read goes to the next tier
 									else if (cand) {
 										// the candidate's probed value itself: entry slo + 11 u of the dictionary (zero beyond its end)
@@ -908,6 +904,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								const uint32_t u = isr ? t : t - Lr;
 								const uint64_t tt = isr ? (uint64_t)lo + (uint64_t)u * REF_STRIDE : (uint64_t)slo + (uint64_t)u * SNP_STRIDE;
 								const bool inr = tt < (isr ? d.n_ref : d.n_snp);
+								uint4 v = make_uint4(0u, 0u, 0u, 0u);                      // zeros when the probe falls off the array
+								if (!isr && use_probe) { const uint2 q = gather<uint2, 8>(d.snp_probe + ((uint64_t)slo + u)); v.x = q.x; v.y = q.y; }
+								else if (inr) v = gather<uint4>(isr ? (const void *)(d.ref + tt) : (const void *)(d.snp + tt));
 								hs.add(S_SCAN_REF, isr ? 1u : 0u);
 								hs.add(S_SCAN_SNP, isr ? 0u : 1u);
 								hs.add(S_SCAN_OOB, inr ? 0u : 1u);
@@ -925,29 +924,30 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							bool have_ri = false, slot_item = true;
 							const bool longsec = (meta >> 31) != 0u;
 							if (longsec) {
-								const uint32_t S = P_hu[p][wv];
-								if (h < S) {
-									// one record of the chunk's LO32 bucket: a dictionary k-mer with the chunk's first half whose last half differs in
-									// exactly one base is a high-half neighbour (qv.cc:1213-1296), and the record carries its position
+								const uint32_t S = P_hu[p][wv], NI = (S + LW - 1u) >> LW_LOG;
+								if (h < NI) {
+									// records h, h + NI, h + 2 NI, h + 3 NI of the chunk's LO32 bucket (adjacent lanes read adjacent records, four gathers
+									// in one wait): a dictionary k-mer with the chunk's first half whose last half differs in exactly one base is a
+									// high-half neighbour (qv.cc:1213-1296), and the record carries its position.  Two such records in one item (the
+									// bucket is sorted by the last half, so neighbours of neighbours sit side by side -- hence the stride): next tier.
 									slot_item = false;
-									const uint3 rec = gather12(d.sec3 + 3ull * ((uint64_t)P_hidx[0][p][wv] + h));
-									if (((rec.z ^ klo) & 0x7FFFFFFFu) == 0u && (bf_from_sec || (fl & 1u))) {
-										const int dd = onebase((uint64_t)(rec.x ^ khi));
-										if (dd >= 0) { ri = rec.y; rdirect = 1u | ((rec.z >> 31) << 1); mod = 16u + (uint32_t)dd; nbase = (rec.x >> (2 * dd)) & 3u; }
+									const uint64_t rb = P_hidx[0][p][wv];
+									uint3 rec[LW];
+									#pragma unroll
+									for (uint32_t j = 0; j < LW; j++) { const uint32_t r_ = h + j * NI; rec[j] = make_uint3(0u, 0u, ~klo); if (r_ < S) rec[j] = gather12(d.sec3 + 3ull * (rb + r_)); }
+									uint32_t hits = 0;
+									#pragma unroll
+									for (uint32_t j = 0; j < LW; j++) if (((rec[j].z ^ klo) & 0x7FFFFFFFu) == 0u && (bf_from_sec || (fl & 1u))) {
+										const int dd = onebase((uint64_t)(rec[j].x ^ khi));
+										if (dd >= 0) { hits++; ri = rec[j].y; rdirect = 1u | ((rec[j].z >> 31) << 1); mod = 16u + (uint32_t)dd; nbase = (rec[j].x >> (2 * dd)) & 3u; }
 									}
-								} else h -= S;
+									if (hits > 1u) { N_ovf[col0 + own] = 1; ri = NOHIT; rdirect = 0u; }
+								} else h -= NI;
 							}
 							if (slot_item) {
 							if (mode == 1) {                                     // the h-th hit in slot order
-								const uint32_t hu = P_hu[p][wv];
-								uint32_t zsel = 0;
-								for (uint32_t z = 0; z < nh; z++) {
-									const uint32_t uz = (hu >> (8 * z)) & 0xFFu;
-									uint32_t rank = 0;
-									for (uint32_t y = 0; y < nh; y++) rank += ((hu >> (8 * y)) & 0xFFu) < uz ? 1u : 0u;
-									if (rank == h) zsel = z;
-								}
-								u = (hu >> (8 * zsel)) & 0xFFu;
+								const uint32_t hb = (P_hu[p][wv] >> (8u * (h & 3u))) & 0xFFu, zsel = hb & 3u;      // (sorted by slot in stage B0)
+								u = hb >> 2;
 								ri = P_hidx[zsel][p][wv];                        // (a hit of the LO32-ordered view comes with its position: no entry to fetch)
 								rdirect = 1u | (((uint32_t)P_hamb[p][wv] >> zsel) & 1u) << 1;
 								have_ri = true;
@@ -957,7 +957,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							mod = pair;
 							qk = (k & ~(3ull << (2 * pair))) | ((uint64_t)nbase << (2 * pair));
 							if (!have_ri && !longsec && 2 * pair < rsb) {
-								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) if (((hu >> (8 * z)) & 0xFFu) == u) { ri = P_hidx[z < (uint32_t)HCAP ? z : 0][p][wv]; rdirect = 1u | (((uint32_t)P_hamb[p][wv] >> z) & 1u) << 1; } }
+								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) { const uint32_t hb = (hu >> (8 * z)) & 0xFFu, zz = hb & 3u; if ((hb >> 2) == u) { ri = P_hidx[zz][p][wv]; rdirect = 1u | (((uint32_t)P_hamb[p][wv] >> zz) & 1u) << 1; } } }
 								else q_r = true;
 							}
 							q_s = (large || 2 * pair >= 40u) && 2 * pair < ssb;
@@ -1126,7 +1126,6 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						}
 						if (valid && fits && seg_total && (int)lane == se_l) N_cnt[col0 + own] = (uint16_t)(curc + seg_total);
 					}
-					scan_cur = scan_next;
 					VG_WAVE_SYNC();
 				}
 				VG_CLK(3);
