@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--snps", type=int, default=None)
     ap.add_argument("--chroms", type=int, default=None, help="number of sequences the genome is split into")
     ap.add_argument("--repeats", type=float, default=0.0, help="fraction of the genome in planted exact repeats (2-10 copies and > 10 copies) -- the repeat-rich stress genome; 0 = the default genome (2 %% diverged repeats)")
+    ap.add_argument("--read-len", type=int, default=150, help="read length in bases (150 = BASELINE.json's reads, 4 chunks of 32; the reference's own experiment used 101 bp reads: 3 chunks, src/vartype.h:12, experiment/experiment.md:20-27)")
+    ap.add_argument("--softmask", type=float, default=0.0, help="fraction of the FASTA written in lower case (soft-masked runs, as in a UCSC download): the index then has a reference bit vector that is not the dictionary's LO32 set (generate_bf.cc:230 does not fold case) and the kernel reads the vector itself")
     ap.add_argument("--lowq", type=float, default=0.08, help="fraction of low-quality (gate-open) characters; 0.5 = the stress profile of SURVEY.md §8d")
     ap.add_argument("--cpu-sample", type=int, default=None, help="reads timed on one host thread of the CPU oracle (0 = skip the CPU legs and the parity check)")
     ap.add_argument("--workdir", default=os.environ.get("VG_BENCH_DIR"), help="where the index files go (default: $VG_BENCH_DIR, else /tmp/vg_bench, else -- when /tmp lacks the room -- /dev/shm/vg_bench)")
@@ -77,6 +79,8 @@ def parse_args():
     ap.add_argument("--gate-words", action="store_true", help="time `value` on the reduced input form (one gate word per read, vg_reads_process_device_gated) and report the quality-string form beside it, instead of the other way round")
     ap.add_argument("--secondary", default="auto", help="secondary configurations measured after the main line: auto (= all, for the default workload at N = 1), none, or a comma list of lowq50,chr22,repeats30,hg38f")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the `sustained` leg: blocks of K steps back to back for at least this long (0 = skip)")
+    ap.add_argument("--job-reads", type=int, default=None, help="the `job` leg: one whole `vargeno geno` run (index open + FASTQ ingest + caller + VCF) on a FASTQ file of this many distinct reads written by this bench "
+                    "(default: 200 000 000 for the default workload at N = 1 -- scaled down to what the work directory's file system holds --, else 0 = skip)")
     ap.add_argument("--cleanup", action="store_true", help="remove this run's index files when done (the secondary legs' child runs do)")
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the secondary end-to-end number (FASTQ text in pinned host memory -> counters)")
@@ -108,7 +112,7 @@ def build_index_files(args, g, s, d, prefix):
         return
     os.makedirs(d, exist_ok=True)
     t0 = time.time()
-    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g, softmask=args.softmask)
     synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
     log("[bench] FASTA + VCF written: %.1fs" % (time.time() - t0))
     t0 = time.time()
@@ -323,13 +327,125 @@ def measure_ingest(gx, batch, log, reps=3):
     return out
 
 
+def job_fastq(src, gx, path, n_reads, batch_reads, lowq, log, read_len=150):
+    """The `job` leg's input: n_reads DISTINCT reads of the workload's stream (batches no other leg uses) as one FASTQ file, written
+    batch by batch (text put together on the device, page-locked copy, positioned writes by four threads) -- and, on the way, the
+    same batches through the resident-batch path of the open index: its counters are what the command line must reproduce from
+    the file.  Returns {"reads", "bytes", "counts": (ref, alt), "first": host copy of the first batches for the oracle, ...}."""
+    import threading
+
+    import torch
+
+    from vargeno_amd import synth
+    from vargeno_amd.api import pinned_buffer
+
+    t_all = time.time()
+    gx.set_stats(False)
+    gx.reset()
+    fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    pin = None
+    off, done, first = 0, 0, []
+    try:
+        b = 0
+        while done < n_reads:
+            n = min(batch_reads, n_reads - done)
+            tb, tq, to = src.batch(500_000 + b, n, length=read_len, lowq=lowq)[:3]
+            gx.process_device(tb, tq, to, n)                            # the resident-batch path, same reads
+            if done < 16_000_000:
+                first.append(synth.reads_to_host(tb, tq, to))
+            L = int(to[1].item())
+            rec = 13 + L + 3 + L + 1                                    # "@r%010d\n" bases "\n+\n" quals "\n"
+            m = torch.empty((n, rec), dtype=torch.uint8, device=tb.device)
+            ids = torch.arange(done, done + n, device=tb.device, dtype=torch.int64)
+            m[:, 0] = 64
+            m[:, 1] = 114
+            for k in range(10):
+                m[:, 2 + k] = (48 + (ids // 10 ** (9 - k)) % 10).to(torch.uint8)
+            m[:, 12] = 10
+            m[:, 13:13 + L] = tb.view(n, L)
+            m[:, 13 + L] = 10
+            m[:, 14 + L] = 43
+            m[:, 15 + L] = 10
+            m[:, 16 + L:16 + 2 * L] = tq.view(n, L)
+            m[:, 16 + 2 * L] = 10
+            nb = n * rec
+            if pin is None or len(pin[0]) < nb:
+                pin = pinned_buffer(nb)
+            torch.as_tensor(pin[0][:nb]).copy_(m.view(-1))              # device -> page-locked host
+            del m, ids, tb, tq, to
+            view = memoryview(pin[0][:nb])
+            parts = [(a, min(nb, a + (nb + 3) // 4)) for a in range(0, nb, (nb + 3) // 4)]
+            ths = [threading.Thread(target=lambda a=a, e=e: os.pwrite(fd, view[a:e], off + a)) for a, e in parts]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            off += nb
+            done += n
+            b += 1
+    finally:
+        os.close(fd)
+    rc, ac = gx.counts()
+    log("[bench] job: FASTQ of %d distinct reads (%.1f GB) written + the same batches through the resident-batch path: %.1fs" % (done, off / 1e9, time.time() - t_all))
+    return {"reads": done, "bytes": off, "counts": (rc, ac), "first": first, "write_s": time.time() - t_all}
+
+
+def job_run(d, job, log):
+    """One whole job through the drop-in command line: `vargeno geno idx job.fq snps.vcf job.vcf` as a child process -- index open,
+    FASTQ ingest (packing starts beside the open), caller, VCF -- timed from outside; its counters (VARGENO_DUMP_COUNTS) against
+    the resident-batch path's on the same reads; calls and GQ histogram out of the VCF it wrote."""
+    import re
+
+    dump = os.path.join(d, "job.counts")
+    env = dict(os.environ, VARGENO_VERBOSE="1", VARGENO_DUMP_COUNTS=dump)
+    t0 = time.time()
+    p = subprocess.run([BIN, "geno", "idx", "job.fq", "snps.vcf", "job.vcf"], cwd=d, env=env, capture_output=True, text=True)
+    wall = time.time() - t0
+    out = {"reads": job["reads"], "fastq_GB": job["bytes"] / 1e9, "wall_s": wall, "whole_job_reads_per_s": job["reads"] / wall, "rc": p.returncode}
+    if p.returncode != 0:
+        out["failed"] = (p.stderr or "")[-600:]
+        return out
+    mt = re.search(r"wall: ([\d.]+) s = index load ([\d.]+) \+ FASTQ->counters ([\d.]+) \(([\d.]+) M reads/s\) \+ call/VCF ([\d.]+)(?: \+ close ([\d.]+))?", p.stderr)
+    if mt:
+        out.update({"cli_wall_s": float(mt.group(1)), "index_open_s": float(mt.group(2)), "ingest_after_open_s": float(mt.group(3)), "call_vcf_s": float(mt.group(5)), "close_s": float(mt.group(6) or 0),
+                    "wall_minus_open_s": wall - float(mt.group(2))})
+    for ln in p.stderr.splitlines():
+        if ln.startswith("ingest, replica 0:"):
+            out["ingest_route"] = ln[len("ingest, replica 0:"):].strip()
+        if ln.startswith("index start-up:"):
+            out["index_open_phases"] = ln[len("index start-up:"):].strip()
+    cnt = np.fromfile(dump, dtype=np.uint8)
+    rc, ac = job["counts"]
+    ns = len(rc)
+    out["counters_equal_resident_batch_path"] = bool(len(cnt) == 2 * ns and np.array_equal(cnt[:ns], rc) and np.array_equal(cnt[ns:], ac))
+    assert out["counters_equal_resident_batch_path"], "the command line's counters differ from the resident-batch path's on the same reads"
+    text = open(os.path.join(d, "job.vcf"), "rb").read()
+    calls = re.findall(rb"\t([01]/[01]):(\d+)\n", text)
+    gq = np.array([int(q) for _, q in calls], dtype=np.int64) if calls else np.zeros(0, np.int64)
+    gts = {}
+    for g_, _ in calls:
+        gts[g_.decode()] = gts.get(g_.decode(), 0) + 1
+    hist, edges = np.histogram(gq, bins=[0, 10, 20, 30, 50, 100, 200, 400, 10 ** 6]) if len(gq) else ([], [])
+    out.update({"called": len(calls), "genotypes": gts, "gq_histogram": {"%d-%d" % (edges[i], edges[i + 1] - 1): int(hist[i]) for i in range(len(hist))}, "gq_median": float(np.median(gq)) if len(gq) else None,
+                "mean_coverage_per_site": float((rc.astype(np.int64).sum() + ac.astype(np.int64).sum()) / max(ns, 1))})
+    for f in ("job.fq", "job.counts", "job.vcf"):
+        try:
+            os.remove(os.path.join(d, f))
+        except OSError:
+            pass
+    log("[bench] job: %d reads, wall %.2f s (open %.2f + ingest %.2f + call/VCF %.2f), %.4g reads/s whole job, %d called, counters equal the resident path's" % (
+        job["reads"], wall, out.get("index_open_s", 0), out.get("ingest_after_open_s", 0), out.get("call_vcf_s", 0), out["whole_job_reads_per_s"], len(calls)))
+    return out
+
+
 T_START = time.time()
 BUDGET_S = float(os.environ.get("VG_BENCH_BUDGET_S", "1500"))
 # (estimated wall seconds, bench.py arguments) of the secondary legs that run as child processes, in this order
 # (measured on the pool's boxes: 15 s, 145 s, 315 s)
 CHILD_LEGS = [("chr22", 60, ["--workload", "chr22", "--steps", "40", "--warmup", "5"]),
               ("repeats30", 240, ["--workload", "hg38", "--repeats", "0.3"]),
-              ("hg38f", 450, ["--workload", "hg38f", "--steps", "20", "--warmup", "3"])]
+              ("hg38f", 450, ["--workload", "hg38f", "--steps", "20", "--warmup", "3"]),
+              ("softmask50", 240, ["--workload", "hg38", "--softmask", "0.5"])]
 
 
 def main_kernel_name(views):
@@ -350,7 +466,8 @@ def traffic_for(args, build_id):
         try:
             tj = json.load(open(path))
             w = dict(tj["workload"])
-            if {k: w.get(k) for k in want} != want or float(w.get("lowq", 0.08)) != args.lowq or float(w.get("repeats", 0.0)) != args.repeats or bool(w.get("gate_words", True)) != bool(args.gate_words):
+            if {k: w.get(k) for k in want} != want or float(w.get("lowq", 0.08)) != args.lowq or float(w.get("repeats", 0.0)) != args.repeats or bool(w.get("gate_words", True)) != bool(args.gate_words) \
+                    or int(w.get("read_len", 150)) != args.read_len or float(w.get("softmask", 0.0)) != args.softmask:
                 continue
             if tj.get("build_id") != build_id:
                 note = "%s was measured on build %s, this is build %s: not quoted" % (os.path.basename(path), tj.get("build_id"), build_id)
@@ -433,7 +550,7 @@ def run_child_leg(name, est, extra, args, ref):
         return {"skipped": "time budget: %.0f s of $VG_BENCH_BUDGET_S = %.0f s left, this leg is estimated at %d s" % (left, BUDGET_S, est)}
     ref.wait_quiet("secondary leg %s" % name)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--secondary", "none", "--no-gather-probe", "--no-ingest", "--cpu-reference", "no", "--sustain-seconds", "0",
-           "--cleanup", "--cpu-sample", "200000"] + extra
+           "--cleanup", "--cpu-sample", "200000", "--job-reads", "0"] + extra
     if args.workdir_given:
         cmd += ["--workdir", args.workdir]
     t0 = time.time()
@@ -470,14 +587,14 @@ def main():
 
     from vargeno_amd import synth
 
-    default_workload = args.workload == "hg38" and args.repeats == 0.0 and args.lowq == 0.08 and args.genome == PRESETS["hg38"]["genome"] and args.snps == PRESETS["hg38"]["snps"] and args.reads == PRESETS["hg38"]["reads"]
+    default_workload = args.workload == "hg38" and args.repeats == 0.0 and args.lowq == 0.08 and args.read_len == 150 and args.softmask == 0.0 and args.genome == PRESETS["hg38"]["genome"] and args.snps == PRESETS["hg38"]["snps"] and args.reads == PRESETS["hg38"]["reads"]
     if args.secondary == "auto":
-        legs = ["lowq50", "chr22", "repeats30", "hg38f"] if (default_workload and world == 1 and args.cpu_sample > 0) else []
+        legs = ["lowq50", "len101", "len250", "chr22", "repeats30", "hg38f", "softmask50"] if (default_workload and world == 1 and args.cpu_sample > 0) else []
     else:
         legs = [x for x in args.secondary.split(",") if x and x != "none"]
 
     # ---- data set + index files: host only (rank 0 builds, the others wait for its marker file) ----------------------------
-    tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms) + ("_r%g" % args.repeats if args.repeats else "")
+    tag = "g%d_s%d_c%d" % (args.genome, args.snps, args.chroms) + ("_r%g" % args.repeats if args.repeats else "") + ("_m%g" % args.softmask if args.softmask else "")
     args.workdir_given = args.workdir is not None
     if args.workdir is None:
         # index files: ~16 bytes per base of the genome + ~550 bytes per SNP (hg38 + 10 M SNPs: 48 GB; + 100 M SNPs: 104 GB).
@@ -537,14 +654,24 @@ def main():
     t0 = time.time()
     src = synth.DeviceReadSource(g, s, dev)
     del g, s
-    batches = [src.batch(rank * 1000 + b, args.reads, lowq=args.lowq) for b in range(args.batches)]
-    common = src.batch(999_999, min(args.reads, 1_000_000), lowq=args.lowq) if world > 1 else None
+    batches = [src.batch(rank * 1000 + b, args.reads, length=args.read_len, lowq=args.lowq) for b in range(args.batches)]
+    common = src.batch(999_999, min(args.reads, 1_000_000), length=args.read_len, lowq=args.lowq) if world > 1 else None
     # the stress profile's batches (50 % low-quality characters) wait on the host until their leg
+    # (likewise the batches of the read-length legs: 101 bp -- the reference's own experiment, 3 chunks -- and 250 bp, 7 chunks)
     lowq_host = None
     if "lowq50" in legs:
-        lowq_host = [tuple(t.cpu() for t in src.batch(700_000 + b, args.reads, lowq=0.5)) for b in range(2)]
-    src.release()
-    del src
+        lowq_host = [tuple(t.cpu() for t in src.batch(700_000 + b, args.reads, length=args.read_len, lowq=0.5)) for b in range(2)]
+    len_host = {}
+    for L_ in (101, 250):
+        if "len%d" % L_ in legs:
+            len_host[L_] = [tuple(t.cpu() for t in src.batch(800_000 + 10 * L_ + b, args.reads, length=L_, lowq=args.lowq)) for b in range(2)]
+    want_job = args.job_reads if args.job_reads is not None else (200_000_000 if (default_workload and world == 1 and rank == 0 and args.cpu_sample > 0) else 0)
+    if world > 1 or rank != 0:
+        want_job = 0
+    if not want_job:
+        src.release()
+        del src
+        src = None
     torch.cuda.synchronize(dev)
     torch.cuda.empty_cache()
     if rank == 0:
@@ -561,6 +688,26 @@ def main():
     if rank == 0:
         log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (t_open, gx.device_bytes / 1e9, gx.num_sites))
         log("[bench] vg_index_open phases: %s" % open_report)
+
+    # ---- the `job` leg's input (N = 1): a FASTQ file of distinct reads, and the same reads through the resident-batch path ----------
+    job = None
+    if src is not None:
+        try:
+            st_fs = os.statvfs(d)
+            room = st_fs.f_bavail * st_fs.f_frsize
+            per_read = 2 * args.read_len + 17
+            n_job = min(want_job, int(0.8 * room / per_read) // args.reads * args.reads)
+            if n_job >= 2 * args.reads:
+                job = job_fastq(src, gx, os.path.join(d, "job.fq"), n_job, args.reads, args.lowq, log, read_len=args.read_len)
+                job["wanted"] = want_job
+            else:
+                job = {"skipped": "the work directory's file system has room for %d reads only" % n_job}
+        except Exception as e:
+            job = {"skipped": "writing the job's FASTQ failed: %r" % (e,)}
+            log("[bench] job leg: %r" % (e,))
+        src.release()
+        del src
+        torch.cuda.empty_cache()
 
     # ---- the reference binary on the host, beside everything that follows (N = 1 only) ------------------------------------------
     ref_timer = None
@@ -653,7 +800,32 @@ def main():
                "all_cores": {"value": r0.n / best_t, "threads": best_nt, "host_cores": ncores, "reads_per_s_by_threads": tried,
                              "sample": "batch 0 (%d reads), %.1f s" % (r0.n, best_t)}}
         del r0, sub
-        if "lowq50" not in legs:
+        # the job leg's first reads (up to 16 M) against the oracle, through the resident-batch path (the command line's counters are
+        # checked against that path's on ALL the job's reads when it has run)
+        if job is not None and job.get("first"):
+            try:
+                fr = job.pop("first")
+                ref.wait_quiet("the oracle's run over the job's first reads")
+                ref.heavy_begin()
+                ox.reset()
+                for r_ in fr:
+                    ox.process(r_.bases, r_.quals, r_.offsets, nthreads=nt)
+                ref.heavy_end()
+                so_j = ox.sites()
+                gx.set_stats(False)
+                gx.reset()
+                for r_ in fr:
+                    gx.submit(r_.bases, r_.quals, r_.offsets)
+                rc_j, ac_j = gx.counts()
+                assert np.array_equal(rc_j, so_j["ref_cnt"]) and np.array_equal(ac_j, so_j["alt_cnt"]), "the job's first reads: HIP counters != oracle"
+                job["first_reads_against_oracle"] = {"equal": True, "reads": int(sum(r_.n for r_ in fr)), "site_counters": int(2 * len(rc_j))}
+                log("[bench] job: the first %d reads' counters identical to the oracle's" % job["first_reads_against_oracle"]["reads"])
+                del fr
+            except AssertionError:
+                raise
+            except Exception as e:
+                job["first_reads_against_oracle"] = {"skipped": repr(e)}
+        if not any(x in legs for x in ("lowq50", "len101", "len250")):
             ox.close()
             ox = None
 
@@ -768,50 +940,68 @@ def main():
     views, dev_bytes, plan_text = gx.views, gx.device_bytes, gx.plan
     kernel = main_kernel_name(views)
 
-    # ---- secondary leg on the open index: the stress profile (50 % low-quality characters: 3 gate-open chunks per read) ------------
+    # ---- secondary legs on the open index: the stress profile (50 % low-quality characters: 3 gate-open chunks per read) and the two
+    #      other read lengths -- each with its own counted pass (algorithmic bytes), parity of 1 M reads against the oracle, K timed steps
     secondary = {}
-    if rank == 0 and "lowq50" in legs and lowq_host is not None and ox is not None:
-        try:
-            t_leg = time.time()
-            del batches[1:]                                    # make room: the main line's batches are done with
-            torch.cuda.empty_cache()
-            lb = [tuple(t.to(dev) for t in hb) for hb in lowq_host]
-            lb = [tuple(b) + (gate_words(b[1], b[2]),) for b in lb]
-            lowq_host = None
-            torch.cuda.synchronize(dev)
-            gx.set_stats(True)
-            gx.reset()
-            run(lb[0])
-            st_l = gx.stats()
-            par_l, _, _ = check_against_oracle(gx, ox, run, lb[0], 1_000_000, st_l, ref)
-            gx.set_stats(False)
-            gx.reset()
-            for i in range(3):
-                run(lb[i % 2])
-            gx.sync()
-            gx.timing()
-            gx.reset()
-            dt = timed_block(gx, run, lb, args.steps)
-            tm_l = gx.timing()
-            roof_l = roofline_of(st_l["alg_bytes"], tm_l["ms_main"], args.reads, kernel)
-            import copy
 
-            a_l = copy.copy(args)
-            a_l.lowq = 0.5
-            roof_l["traffic"], _, roof_l["traffic_source"] = traffic_for(a_l, build_id)
-            secondary["lowq50"] = {"workload": "the main line's index, 50 %% low-quality characters (SURVEY.md §8d stress profile: %.2f gate-open chunks per read), %d x 150 bp reads per step rotating over 2 resident batches" % (st_l["gate_open"] / args.reads, args.reads),
-                                   "value": args.reads * args.steps / dt, "unit": "reads/s", "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps,
-                                   "input_form": "quality strings" if args.ascii_quals else "gate words",
-                                   "roofline": roof_l, "parity": par_l,
-                                   "device_ms_per_step": {"pack": tm_l["ms_pack"], "wave": tm_l["ms_main"], "spill_tiers_overlapped": tm_l["ms_tail"]},
-                                   "reads_per_step_redone_by_deep_list_tier": st_l["overflow_reads"], "wall_s": time.time() - t_leg}
-            log("[bench] secondary lowq50: %.4g reads/s, %.3f ms/step, kernel %.3f ms, frac %.3f" % (secondary["lowq50"]["value"], secondary["lowq50"]["ms_per_step"], tm_l["ms_main"], secondary["lowq50"]["roofline"]["frac"]))
-            del lb
+    def open_index_leg(name, host_batches, lowq, read_len, what):
+        t_leg = time.time()
+        lb = [tuple(t.to(dev) for t in hb) for hb in host_batches]
+        lb = [tuple(b) + (gate_words(b[1], b[2]),) for b in lb]
+        torch.cuda.synchronize(dev)
+        gx.set_stats(True)
+        gx.reset()
+        run(lb[0])
+        st_l = gx.stats()
+        par_l, _, _ = check_against_oracle(gx, ox, run, lb[0], 1_000_000, st_l, ref)
+        gx.set_stats(False)
+        gx.reset()
+        for i in range(3):
+            run(lb[i % 2])
+        gx.sync()
+        gx.timing()
+        gx.reset()
+        dt = timed_block(gx, run, lb, args.steps)
+        tm_l = gx.timing()
+        roof_l = roofline_of(st_l["alg_bytes"], tm_l["ms_main"], args.reads, kernel)
+        import copy
+
+        a_l = copy.copy(args)
+        a_l.lowq, a_l.read_len = lowq, read_len
+        roof_l["traffic"], _, roof_l["traffic_source"] = traffic_for(a_l, build_id)
+        out = {"workload": what % (st_l["gate_open"] / args.reads, args.reads, read_len),
+               "value": args.reads * args.steps / dt, "unit": "reads/s", "bases_per_s": args.reads * args.steps * read_len / dt, "ms_per_step": 1e3 * dt / args.steps, "steps": args.steps,
+               "input_form": "quality strings" if args.ascii_quals else "gate words",
+               "roofline": roof_l, "parity": par_l,
+               "device_ms_per_step": {"pack": tm_l["ms_pack"], "wave": tm_l["ms_main"], "spill_tiers_overlapped": tm_l["ms_tail"]},
+               "events_per_read": {k: st_l[k] / args.reads for k in ("passes", "chunks", "gate_open", "ref_query", "snp_query", "walks")},
+               "reads_per_step_redone_by_deep_list_tier": st_l["overflow_reads"], "wall_s": time.time() - t_leg}
+        log("[bench] secondary %s: %.4g reads/s, %.3f ms/step, kernel %.3f ms, frac %.3f" % (name, out["value"], out["ms_per_step"], tm_l["ms_main"], roof_l["frac"]))
+        del lb
+        torch.cuda.empty_cache()
+        return out
+
+    open_legs = []
+    if "lowq50" in legs:
+        open_legs.append(("lowq50", lowq_host, 0.5, args.read_len, "the main line's index, 50 %% low-quality characters (SURVEY.md §8d stress profile: %.2f gate-open chunks per read), %d x %d bp reads per step rotating over 2 resident batches"))
+    for L_ in (101, 250):
+        if "len%d" % L_ in legs:
+            open_legs.append(("len%d" % L_, len_host.get(L_), args.lowq, L_, "the main line's index, reads of another length (%.2f gate-open chunks per read), %d x %d bp reads per step rotating over 2 resident batches"))
+    if rank == 0 and open_legs:
+        del batches[1:]                                        # make room: the main line's batches are done with
+        torch.cuda.empty_cache()
+    for name, hb, lq, L_, what in open_legs:
+        if rank != 0:
+            continue
+        if hb is None or ox is None:
+            secondary[name] = {"skipped": "needs the oracle (--cpu-sample > 0) at N = 1"}
+            continue
+        try:
+            secondary[name] = open_index_leg(name, hb, lq, L_, what)
         except Exception as e:                                 # a secondary leg never fails the main line
-            secondary["lowq50"] = {"skipped": "failed: %r" % (e,)}
-            log("[bench] secondary lowq50 failed: %r" % (e,))
-    elif rank == 0 and "lowq50" in legs:
-        secondary["lowq50"] = {"skipped": "needs the oracle (--cpu-sample > 0) at N = 1"}
+            secondary[name] = {"skipped": "failed: %r" % (e,)}
+            log("[bench] secondary %s failed: %r" % (name, e))
+    lowq_host, len_host = None, {}
     if ox is not None:
         ox.close()
         ox = None
@@ -836,6 +1026,31 @@ def main():
     gx.close()
     del batches
     torch.cuda.empty_cache()
+
+    # ---- the `job` leg: one whole run of the drop-in command line on the FASTQ file written above, now that this process holds no index
+    job_out = None
+    if rank == 0 and job is not None:
+        if "counts" in job:
+            job.pop("first", None)
+            left = BUDGET_S - (time.time() - T_START)
+            if left < 90:
+                job_out = {"skipped": "time budget: %.0f s left" % left}
+            else:
+                try:
+                    job_out = job_run(d, job, log)
+                    job_out["first_reads_against_oracle"] = job.get("first_reads_against_oracle")
+                    job_out["fastq_written_in_s"] = job.get("write_s")
+                    job_out["reads_wanted"] = job.get("wanted")
+                except AssertionError:
+                    raise
+                except Exception as e:
+                    job_out = {"skipped": "failed: %r" % (e,)}
+            try:
+                os.remove(os.path.join(d, "job.fq"))
+            except OSError:
+                pass
+        else:
+            job_out = job
 
     # ---- secondary legs with an index of their own: child processes, one after the other, now that this one holds no index ------
     if rank == 0:
@@ -871,13 +1086,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "%s: %d bp synthetic genome in %d sequence(s), %d SNPs requested, %d x 150 bp reads per GPU per step rotating over %d "
+            "config": {"workload": "%s: %d bp synthetic genome in %d sequence(s), %d SNPs requested, %d x %d bp reads per GPU per step rotating over %d "
                                    "distinct resident batches of the read stream, 0.5%% error, %g%% low-quality chars, seed 20261002%s" % (
                                        "hg38 + full-dbSNP-scale index (BASELINE.json configs[4], one replica)" if args.snps >= 5 * 10 ** 7 else
                                        "hg38-scale (BASELINE.json configs[2])" if args.genome >= 10 ** 9 else "chr22-scale (BASELINE.json configs[1])",
-                                       args.genome, args.chroms, args.snps, args.reads, args.batches, 100 * args.lowq,
+                                       args.genome, args.chroms, args.snps, args.reads, args.read_len, args.batches, 100 * args.lowq,
                                        "" if not args.repeats else "; REPEAT-RICH genome: %g%% of it in planted families of near-identical copies (2-10 and 11-200 copies), 50 microsatellites per Mbp" % (100 * args.repeats)),
-                       "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps, "lowq": args.lowq, "repeats": args.repeats, "gate_words": bool(args.gate_words),
+                       "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps, "lowq": args.lowq, "repeats": args.repeats, "read_len": args.read_len, "softmask": args.softmask, "gate_words": bool(args.gate_words),
                        "index_bytes_hbm": dev_bytes, "index_views": views, "index_plan": plan_text, "index_open_s": t_open, "index_open_phases": open_report, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
             "roofline": roof,
@@ -893,6 +1108,7 @@ def main():
             "other_input_form": other_form,
             "sustained": sustained,
             "ingest_end_to_end": ingest,
+            "job": job_out,
             "multi_gpu_verification": verification,
             "multi_gpu_per_rank": per_rank,
             "secondary": secondary if legs else None,

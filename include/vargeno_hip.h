@@ -78,6 +78,10 @@ int  vg_device_count(void);
  * (total - 12 GiB) / replicas_on_the_device. */
 uint64_t vg_device_memory(int device);
 uint64_t vg_share_budget(int device, int replicas_on_the_device);
+/* Host -> device rate of page-locked memory over this device's link in bytes per second, measured now (three 64 MiB copies; 0 on
+ * failure): what FASTQ text framed ON the device can arrive at -- the command line compares it with the rate its host threads
+ * frame + pack at (vg_packer_*) and lets the faster route take the file (r05; r04 chose by the number of CPUs). */
+double vg_link_rate(int device);
 
 /* Page-locked host buffers for the batches / FASTQ chunks handed to vg_reads_submit / vg_fastq_submit
  * (optional: any host memory works, pinned memory copies at link speed).  NULL on failure. */

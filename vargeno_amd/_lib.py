@@ -17,7 +17,7 @@ STAT_FIELDS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chun
                "ingest_bytes", "overflow_reads", "overflow_deep", "alg_bytes"]
 
 # every symbol include/vargeno_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
-SYMBOLS = ["vg_last_error", "vg_build_id", "vg_device_count", "vg_device_memory", "vg_share_budget", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_open_ex", "vg_index_plan", "vg_index_open_report", "vg_index_create", "vg_index_close",
+SYMBOLS = ["vg_last_error", "vg_build_id", "vg_device_count", "vg_device_memory", "vg_share_budget", "vg_link_rate", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_open_ex", "vg_index_plan", "vg_index_open_report", "vg_index_create", "vg_index_close",
            "vg_index_device_bytes", "vg_index_views", "vg_reads_submit", "vg_reads_process_device", "vg_reads_process_device_gated", "vg_reads_submit_packed", "vg_fastq_submit", "vg_fastq_stream_begin", "vg_fastq_stream_begin_packed", "vg_fastq_stream_push", "vg_fastq_stream_end",
            "vg_packer_create", "vg_packer_destroy", "vg_packer_begin", "vg_packer_reads_cap", "vg_packer_kmers_cap", "vg_packer_push", "vg_packer_end", "vg_sync", "vg_stats_get",
            "vg_set_stats", "vg_timing_get", "vg_num_sites", "vg_sites_fetch", "vg_counts_fetch", "vg_counts_reset",
@@ -74,6 +74,8 @@ def lib():
             L.vg_device_memory.restype = C.c_uint64
             L.vg_share_budget.argtypes = [C.c_int, C.c_int]
             L.vg_share_budget.restype = C.c_uint64
+            L.vg_link_rate.argtypes = [C.c_int]
+            L.vg_link_rate.restype = C.c_double
         except AttributeError:
             if not os.environ.get("VARGENO_HIP_LIB"):
                 raise

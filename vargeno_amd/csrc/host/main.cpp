@@ -9,13 +9,17 @@
 //   VARGENO_SHARE_DEVICES=1  allow more replicas than GPUs (replica g on device g % GPUs): small indexes, one-GPU test boxes
 //   VARGENO_BATCH=n       reads per batch of the host-framed path (default 4194304)
 //   VARGENO_CHUNK_MB=n    FASTQ bytes per chunk handed to the library (default 64; 256 when the host packs)
-//   VARGENO_PACK_THREADS=n  host threads (per replica) that frame and 2-bit pack the FASTQ text inside the library, so that 48 bytes
-//                         per read cross the link instead of ~315 of text (default: half the CPUs the process may use -- a cgroup
-//                         quota counts --, shared among the replicas, at most 96; 0, or fewer than 32 usable CPUs: the text is
-//                         framed on the device)
+//   VARGENO_PACK_THREADS=n  host threads (per replica) that frame and 2-bit pack the FASTQ text, so that 48 bytes per read cross the
+//                         link instead of ~315 of text (default: the CPUs the process may use -- a cgroup quota counts -- less two,
+//                         shared among the replicas, at most 96).  They start BEFORE the index is opened and pack beside it; when the
+//                         index is ready their measured rate is compared with the link's (vg_link_rate) and the faster route --
+//                         host packing, or the text framed on the device -- takes the rest of the file.  0: device framing only
+//   VARGENO_PREPACK=0     do not pack ahead of the index (and do not measure: host packing if VARGENO_PACK_THREADS > 0, else device framing)
+//   VARGENO_PREPACK_GB=n  page-locked memory the packed-ahead reads may take (default 32, at most a quarter of the host's available memory)
 //   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default: an eighth of the hardware threads, 8 to 32)
 //   VARGENO_MAX_DEVICE_GB=x  device-memory budget per replica (vg_index_open_ex): which re-laid-out views the replica holds follows
 //                         from the index and this number alone (default: the whole device); VARGENO_VERBOSE=1 prints the plan
+//   VARGENO_DUMP_COUNTS=path  also write the per-site counters the caller is given (ref counts then alt counts, one byte per site, site order of the index)
 //   VARGENO_HOST_FASTQ=1  frame the FASTQ on the host (the reference's four fgets per record) instead of on the device
 //   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
 #include <fcntl.h>
@@ -29,6 +33,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -139,6 +144,155 @@ static StreamResult stream_range(vg_index *ix, int fd, uint64_t lo, uint64_t hi,
 	return res;
 }
 
+// ---- packing ahead of the index ------------------------------------------------------------------------------------------------
+// Framing + 2-bit packing need no device (vg_packer_*), and vg_index_open takes seconds during which the host would otherwise
+// idle: bytes [lo, hi) of the FASTQ file are read and packed into page-locked memory WHILE the replica's index is being built,
+// and handed to vg_reads_submit_packed the moment the handle exists (r05; the r04 command line started to pack only then).
+// The packed form is 48 bytes per 150 bp read, so a 30x file (620 M reads) is 30 GB: VARGENO_PREPACK_GB (default 32, and never
+// more than a quarter of the host's available memory) bounds what is held.  The pre-packer also MEASURES its rate (text bytes
+// framed + packed per second with the threads it was given, on this host, now); when the index is ready the caller compares it
+// with the link's rate -- what the device-side framing of the remaining text would run at -- and lets the faster one finish.
+struct PackedBatch {
+	uint64_t *kmers = nullptr, *meta = nullptr, *offs = nullptr;
+	uint64_t n_reads = 0, n_chunks = 0;
+};
+class PrePacker {
+public:
+	PrePacker(int fd, uint64_t lo, uint64_t hi, uint64_t chunk, int n_readers, int pack_threads, uint64_t cap_bytes)
+		: fd_(fd), lo_(lo), hi_(hi), chunk_(chunk), n_readers_(n_readers), pack_threads_(pack_threads), cap_(cap_bytes),
+		  piece_bytes_(std::max<uint64_t>(16ull << 20, std::min<uint64_t>(1ull << 30, (hi - lo) / 4 + (8ull << 20))))          // (packed reads are ~1/6 of their text: a small file gets a small buffer)
+	{
+		th_ = std::thread([this] { run(); });
+	}
+	~PrePacker()
+	{
+		stop();
+		if (th_.joinable()) th_.join();
+		for (void *p : pieces_) vg_host_free_pinned(p);
+	}
+	void stop() { stop_.store(true); std::lock_guard<std::mutex> g(mu_); cv_.notify_all(); }
+	// the next batch in file order; false: there are no more (the pre-packer has finished, stopped, run out of room or been refused)
+	bool pop(PackedBatch &b)
+	{
+		std::unique_lock<std::mutex> g(mu_);
+		cv_.wait(g, [&] { return next_out_ < q_.size() || done_; });
+		if (next_out_ >= q_.size()) return false;
+		b = q_[next_out_++];
+		return true;
+	}
+	void join() { if (th_.joinable()) th_.join(); }
+	// valid after join(): what vg_fastq_stream_end would have said about the bytes [lo, lo + consumed)
+	uint64_t records() const { return records_; }
+	uint64_t consumed() const { return consumed_; }
+	uint64_t last_record_start() const { return last_; }
+	bool refused() const { return refused_; }
+	uint64_t invalid() const { return invalid_; }
+	double text_bytes_per_s() const { const double t = pack_s_.load(); return t > 0 ? (double)packed_text_.load() / t : 0.0; }
+	std::string error;
+private:
+	uint64_t *slab(uint64_t words)                    // page-locked memory for a batch's arrays, out of pieces of up to 1 GiB; nullptr: the cap is reached
+	{
+		const uint64_t bytes = words * 8, PIECE = std::max<uint64_t>(piece_bytes_, (bytes + 63) & ~63ull);
+		if (pieces_.empty() || piece_used_ + bytes > piece_cap_) {
+			if (held_ + PIECE > cap_) return nullptr;
+			void *p = vg_host_alloc_pinned((size_t)PIECE);
+			if (!p) return nullptr;
+			pieces_.push_back(p); piece_used_ = 0; piece_cap_ = PIECE; held_ += PIECE;
+		}
+		uint64_t *r = (uint64_t *)((uint8_t *)pieces_.back() + piece_used_);
+		piece_used_ += (bytes + 63) & ~63ull;
+		return r;
+	}
+	void run()
+	{
+		const uint64_t fsize = hi_ - lo_, n_chunks = (fsize + chunk_ - 1) / chunk_;
+		vg_packer *pk = nullptr;
+		if (vg_packer_create(pack_threads_, &pk) != VG_OK) { error = vg_last_error(); finish(); return; }
+		const uint64_t rcap = vg_packer_reads_cap(chunk_), kcap = vg_packer_kmers_cap(chunk_);
+		std::vector<uint64_t> sk(kcap), sm(rcap), so(rcap);                       // worst-case staging of one chunk
+		const int NBUF = 3;
+		std::vector<std::vector<uint8_t>> text((size_t)NBUF);
+		for (auto &t : text) t.resize((size_t)std::min(chunk_, fsize));
+		// reader threads fill the text buffers piecewise, a chunk ahead of the packer
+		const uint64_t piece = std::min<uint64_t>(chunk_, 8ull << 20), ppc = (chunk_ + piece - 1) / piece;
+		std::vector<uint32_t> left((size_t)n_chunks);
+		for (uint64_t i = 0; i < n_chunks; i++) { const uint64_t len = std::min(chunk_, fsize - i * chunk_); left[(size_t)i] = (uint32_t)((len + piece - 1) / piece); }
+		std::mutex rmu; std::condition_variable rcv;
+		uint64_t packed = 0;                                                     // chunks the packer is done with (their buffers are free)
+		std::atomic<uint64_t> next_piece{0};
+		bool io_error = false, quit = false;
+		std::vector<std::thread> readers;
+		for (int t = 0; t < n_readers_; t++) readers.emplace_back([&] {
+			for (;;) {
+				const uint64_t p = next_piece.fetch_add(1);
+				const uint64_t ci = p / ppc, off = ci * chunk_ + (p % ppc) * piece;
+				if (ci >= n_chunks) return;
+				if (off >= std::min(fsize, (ci + 1) * chunk_)) continue;
+				{ std::unique_lock<std::mutex> g(rmu); rcv.wait(g, [&] { return ci < packed + (uint64_t)NBUF || io_error || quit; }); if (io_error || quit) return; }
+				uint64_t n = std::min(piece, std::min(fsize, (ci + 1) * chunk_) - off), done = 0;
+				uint8_t *dst = text[(size_t)(ci % NBUF)].data() + (off - ci * chunk_);
+				while (done < n) {
+					const ssize_t g = pread(fd_, dst + done, (size_t)(n - done), (off_t)(lo_ + off + done));
+					if (g <= 0) break;
+					done += (uint64_t)g;
+				}
+				std::lock_guard<std::mutex> g(rmu);
+				if (done < n) io_error = true;
+				left[(size_t)ci]--;
+				rcv.notify_all();
+			}
+		});
+		bool out_of_room = false;
+		for (uint64_t i = 0; i < n_chunks && !stop_.load(); i++) {
+			{ std::unique_lock<std::mutex> g(rmu); rcv.wait(g, [&] { return left[(size_t)i] == 0 || io_error; }); if (io_error) break; }
+			const uint64_t len = std::min(chunk_, fsize - i * chunk_);
+			uint64_t nr = 0, nc = 0, ninv = 0;
+			struct timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
+			const int rc = vg_packer_push(pk, text[(size_t)(i % NBUF)].data(), len, sk.data(), kcap, sm.data(), so.data(), rcap, &nr, &nc, &ninv);
+			clock_gettime(CLOCK_MONOTONIC, &b);
+			if (rc != VG_OK) { error = vg_last_error(); break; }
+			pack_s_.store(pack_s_.load() + (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec));
+			packed_text_.fetch_add(len);
+			{ std::lock_guard<std::mutex> g(rmu); packed = i + 1; }
+			rcv.notify_all();
+			if (nr) {
+				PackedBatch pb;
+				pb.kmers = slab(nc + 1); pb.meta = slab(nr); pb.offs = slab(nr + 1);
+				if (!pb.kmers || !pb.meta || !pb.offs) { out_of_room = true; lost_last_ = true; break; }   // (this chunk's records are dropped with it: the stream is re-framed from the last batch that was kept)
+				memcpy(pb.kmers, sk.data(), (size_t)nc * 8); memcpy(pb.meta, sm.data(), (size_t)nr * 8); memcpy(pb.offs, so.data(), (size_t)(nr + 1) * 8);
+				pb.n_reads = nr; pb.n_chunks = nc;
+				invalid_ += ninv;
+				uint64_t rec = 0, cons = 0, last = 0; int ref = 0;
+				(void)vg_packer_end(pk, &rec, &cons, &last, &ref);               // (a query: the stream's totals so far)
+				std::lock_guard<std::mutex> g(mu_);
+				q_.push_back(pb); records_ = rec; consumed_ = cons; last_ = last;
+				cv_.notify_all();
+			}
+			int ref = 0;
+			(void)vg_packer_end(pk, nullptr, nullptr, nullptr, &ref);
+			if (ref) { refused_ = true; break; }
+		}
+		(void)out_of_room;
+		{ std::lock_guard<std::mutex> g(rmu); quit = true; }
+		rcv.notify_all();
+		for (auto &t : readers) t.join();
+		if (io_error && error.empty()) error = "error reading the FASTQ file";
+		vg_packer_destroy(pk);
+		finish();
+	}
+	void finish() { std::lock_guard<std::mutex> g(mu_); done_ = true; cv_.notify_all(); }
+	const int fd_; const uint64_t lo_, hi_, chunk_; const int n_readers_, pack_threads_; const uint64_t cap_, piece_bytes_;
+	uint64_t piece_cap_ = 0, held_ = 0;
+	std::thread th_;
+	std::atomic<bool> stop_{false};
+	std::mutex mu_; std::condition_variable cv_;
+	std::vector<PackedBatch> q_; size_t next_out_ = 0; bool done_ = false;
+	std::vector<void *> pieces_; uint64_t piece_used_ = 0;
+	uint64_t records_ = 0, consumed_ = 0, last_ = 0, invalid_ = 0;
+	bool refused_ = false, lost_last_ = false;
+	std::atomic<double> pack_s_{0.0}; std::atomic<uint64_t> packed_text_{0};
+};
+
 // The first record start at or after `from`: the start of a line that begins with '@' whose next-but-one line begins with '+'
 // (a quality line may begin with '@', but then the line two below it is a sequence line, and no sequence begins with '+').
 // Returns fsize when there is none; UINT64_MAX on a line too long to be a FASTQ line of this tool (the caller falls back).
@@ -175,10 +329,22 @@ static bool range_cuts(int fd, uint64_t fsize, int n, std::vector<uint64_t> &cut
 	return true;
 }
 
+static uint64_t mem_available_bytes()
+{
+	uint64_t kb = 0;
+	if (FILE *f = fopen("/proc/meminfo", "r")) {
+		char line[256];
+		while (fgets(line, sizeof line, f)) if (sscanf(line, "MemAvailable: %lu kB", &kb) == 1) break;
+		fclose(f);
+	}
+	return kb * 1024;
+}
+
 static int run_geno(const std::string &prefix, const std::string &fastq, const std::string &vcf_in, const std::string &vcf_out)
 {
 	const clock_t begin = clock();
 	struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+	auto secs = [](const struct timespec &a, const struct timespec &b) { return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec); };
 	std::vector<vgh::ChrLen> chrlens = vgh::read_chrlens(prefix + ".chrlens");
 	int ngpu = env_int("VARGENO_GPUS", 1);
 	const int have = vg_device_count();
@@ -187,8 +353,37 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	if (ngpu > have && !share) ngpu = have;
 	if (ngpu < 1) ngpu = 1;
 	const uint64_t batch = (uint64_t)env_int("VARGENO_BATCH", 1 << 22);
+	const bool verbose = env_int("VARGENO_VERBOSE", 0) != 0;
 
 	fprintf(stderr, "Initializing...\n");
+	// ---- the FASTQ file first: where the replicas' ranges are cut, and -- what needs no device -- framing + packing of their text on
+	//      host threads, started BEFORE the index is opened and running beside it
+	const bool host_framing = env_int("VARGENO_HOST_FASTQ", 0) != 0;
+	int fd = -1;
+	uint64_t fsize = 0;
+	std::vector<uint64_t> cut;
+	bool cuts_ok = false;
+	const int hw = usable_cpus();
+	// host threads that frame + pack (per replica); 0: the text is framed on the device, nothing is packed ahead
+	int pack_threads = env_int("VARGENO_PACK_THREADS", -1);
+	if (pack_threads < 0) pack_threads = std::max(2, std::min(hw - 2, 96) / ngpu);
+	const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
+	std::vector<std::unique_ptr<PrePacker>> pre((size_t)ngpu);
+	if (!host_framing) {
+		fd = open(fastq.c_str(), O_RDONLY);
+		if (fd < 0) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
+		struct stat sb;
+		if (fstat(fd, &sb) != 0) { close(fd); fprintf(stderr, "vargeno: cannot stat %s\n", fastq.c_str()); return EXIT_FAILURE; }
+		fsize = (uint64_t)sb.st_size;
+		cuts_ok = range_cuts(fd, fsize, ngpu, cut);
+		if (cuts_ok && pack_threads > 0 && env_int("VARGENO_PREPACK", 1)) {
+			const uint64_t want = (uint64_t)std::max(1, env_int("VARGENO_PREPACK_GB", 32)) << 30;
+			const uint64_t cap = std::max<uint64_t>(2ull << 30, std::min(want, mem_available_bytes() / 4)) / (uint64_t)ngpu;
+			const uint64_t pchunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", 256)) << 20;
+			for (int g = 0; g < ngpu; g++)
+				if (cut[(size_t)g] < cut[(size_t)g + 1]) pre[(size_t)g].reset(new PrePacker(fd, cut[(size_t)g], cut[(size_t)g + 1], pchunk, std::max(2, n_readers / ngpu), pack_threads, cap));
+		}
+	}
 	std::vector<vg_index *> ix((size_t)ngpu, nullptr);
 	{
 		std::vector<std::thread> th;
@@ -205,48 +400,73 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) { fprintf(stderr, "vargeno: cannot load index %s on GPU %d (%d): %s\n", prefix.c_str(), g, rcs[(size_t)g], errs[(size_t)g].c_str()); return EXIT_FAILURE; }
 	}
 	for (auto *h : ix) VG_CHECK(vg_set_stats(h, env_int("VARGENO_STATS", 0)));
-	if (env_int("VARGENO_VERBOSE", 0)) { fprintf(stderr, "index replica: %s\n", vg_index_plan(ix[0])); fprintf(stderr, "index start-up: %s\n", vg_index_open_report(ix[0])); }
+	if (verbose) { fprintf(stderr, "index replica: %s\n", vg_index_plan(ix[0])); fprintf(stderr, "index start-up: %s\n", vg_index_open_report(ix[0])); }
 
 	fprintf(stderr, "Processing...\n");
 	struct timespec t_loaded; clock_gettime(CLOCK_MONOTONIC, &t_loaded);
 	uint64_t total = 0; int next_gpu = 0;
-	// Default ingest: the file is read in large chunks and FRAMED ON THE DEVICE; the host only moves bytes.  Whatever the
-	// device refuses (from the first chunk with a line beyond fgets' 1023 characters on), and the (possibly truncated) tail of
-	// the file, go through the host reader, which reproduces the reference's four-fgets framing exactly, stale buffers included.
-	const bool host_framing = env_int("VARGENO_HOST_FASTQ", 0) != 0;
+	// Default ingest: the file is a byte stream to the device(s).  One replica takes all of it; several take one contiguous range
+	// each, cut at record starts, all at once.  A range's text is framed + packed by host threads (what was packed while the index
+	// was being opened is submitted first) or copied up as it is and framed on the device -- whichever runs faster HERE: the
+	// pre-packer has measured its rate, vg_link_rate() the link's.  Whatever the stream refuses (from the first chunk with a line
+	// beyond fgets' 1023 characters on) and the (possibly truncated) tail of the file go through the host reader below, which
+	// reproduces the reference's four-fgets framing exactly, stale buffers included; with several replicas a refusal anywhere but
+	// in the last range means the ranges after it were framed out of step with the reference, so everything is reset and framed
+	// on the host.
 	uint64_t host_from = 0;                    // file offset the host reader takes over from
 	uint64_t prime_from = UINT64_MAX;          // start of the last record the device framed (to prime the stale buffers)
 	if (!host_framing) {
-		// The file is a byte stream to the device(s).  One replica takes all of it; several take one contiguous range each, cut at
-		// record starts, all at once.  What the device refuses (a line beyond fgets' 1023 characters) and the tail of the file go
-		// through the host reader below; with several replicas a refusal anywhere but in the last range means the ranges after it
-		// were framed out of step with the reference, so everything is reset and framed on the host.
-		const int fd = open(fastq.c_str(), O_RDONLY);
-		if (fd < 0) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
-		struct stat sb;
-		if (fstat(fd, &sb) != 0) { close(fd); fprintf(stderr, "vargeno: cannot stat %s\n", fastq.c_str()); return EXIT_FAILURE; }
-		const uint64_t fsize = (uint64_t)sb.st_size;
-		// one thread copies ~2 GB/s out of the page cache: enough of them to keep a 50 GB/s link busy, if the host has the cores
-		const int hw = usable_cpus();
-		// a host with CPUs to spare frames + packs the text itself (6.5 x fewer bytes over the link); otherwise the device frames it
-		// (from 32 usable CPUs on: below that the reader threads and the packing threads only take time from each other)
-		int pack_threads = env_int("VARGENO_PACK_THREADS", -1);
-		if (pack_threads < 0) pack_threads = hw >= 32 ? std::max(2, std::min(hw / 2, 96) / ngpu) : 0;
-		const uint64_t chunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", pack_threads > 0 ? 256 : 64)) << 20;
-		const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
-		std::vector<uint64_t> cut;
-		const bool cuts_ok = range_cuts(fd, fsize, ngpu, cut);
 		if (!cuts_ok) {
 			host_from = 0;                                              // no record start found where one should be: the host reader takes the file
 			fprintf(stderr, "vargeno: no FASTQ record start within 1 MiB of a range boundary: the whole file is framed on the host (slower)\n");
 		} else {
+			const double link = pack_threads > 0 ? vg_link_rate(0) : 0.0;          // bytes/s of text the device-side framing can be fed at
 			std::vector<StreamResult> res((size_t)ngpu);
+			std::vector<std::string> route((size_t)ngpu);
 			std::vector<std::thread> th;
 			for (int g = 0; g < ngpu; g++)
 				if (cut[(size_t)g] < cut[(size_t)g + 1] || g == 0)
-					th.emplace_back([&, g] { res[(size_t)g] = stream_range(ix[(size_t)g], fd, cut[(size_t)g], cut[(size_t)g + 1], chunk, std::max(2, n_readers / ngpu), pack_threads); });
+					th.emplace_back([&, g] {
+						StreamResult &r = res[(size_t)g];
+						uint64_t done_to = 0;                                  // bytes of the range framed so far
+						bool pack_rest = pack_threads > 0;
+						if (pre[(size_t)g]) {
+							PrePacker &pp = *pre[(size_t)g];
+							// what was packed while the index was opening goes first; then the faster route takes what is left
+							bool decided = false;
+							uint64_t submitted = 0;
+							PackedBatch pb;
+							for (;;) {
+								if (!decided) {
+									const double rp = pp.text_bytes_per_s();
+									if (rp > 0 && link > 0) { decided = true; pack_rest = rp >= link; if (!pack_rest) pp.stop(); }
+								}
+								if (!pp.pop(pb)) break;
+								const int rc = vg_reads_submit_packed(ix[(size_t)g], pb.kmers, pb.meta, pb.offs, pb.n_reads);
+								if (rc != VG_OK) { r.error = std::string("vg_reads_submit_packed failed: ") + vg_last_error(); pp.stop(); break; }
+								submitted += pb.n_reads;
+							}
+							pp.join();
+							if (r.error.empty() && !pp.error.empty()) r.error = pp.error;
+							r.nrec = pp.records(); r.used = pp.consumed(); r.last = pp.last_record_start(); r.refused = pp.refused() ? 1 : 0;
+							done_to = pp.consumed();
+							char line[200];
+							snprintf(line, sizeof line, "%lu reads packed ahead of / beside the index (%.1f GB/s of text on %d threads; link %.1f GB/s)", (unsigned long)submitted, pp.text_bytes_per_s() / 1e9, pack_threads, link / 1e9);
+							route[(size_t)g] = line;
+						}
+						const uint64_t lo = cut[(size_t)g] + done_to, hi = cut[(size_t)g + 1];
+						if (r.error.empty() && !r.refused && lo < hi) {
+							const uint64_t chunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", pack_rest ? 256 : 64)) << 20;
+							const StreamResult r2 = stream_range(ix[(size_t)g], fd, lo, hi, chunk, std::max(2, n_readers / ngpu), pack_rest ? pack_threads : 0);
+							route[(size_t)g] += pack_rest ? "; rest of the range: framed + packed by host threads" : "; rest of the range: framed on the device";
+							if (!r2.error.empty()) r.error = r2.error;
+							if (r2.nrec) r.last = done_to + r2.last;
+							r.nrec += r2.nrec; r.used = done_to + r2.used; r.refused = r2.refused;
+						}
+					});
 			for (auto &t : th) t.join();
 			for (int g = 0; g < ngpu; g++) if (!res[(size_t)g].error.empty()) { fprintf(stderr, "vargeno: %s\n", res[(size_t)g].error.c_str()); exit(EXIT_FAILURE); }
+			if (verbose) for (int g = 0; g < ngpu; g++) if (!route[(size_t)g].empty()) fprintf(stderr, "ingest, replica %d: %s\n", g, route[(size_t)g].c_str());
 			int last_range = 0;                                         // the last range that holds bytes
 			for (int g = 0; g < ngpu; g++) if (cut[(size_t)g] < cut[(size_t)g + 1]) last_range = g;
 			bool in_step = true;
@@ -258,12 +478,13 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 				next_gpu = last_range;
 			} else {
 				// (the file has been streamed once already: a 2x or larger slowdown that must not pass silently)
-				fprintf(stderr, "vargeno: a FASTQ range before the last one was refused by the device framing (a line beyond 1023 characters?): "
+				fprintf(stderr, "vargeno: a FASTQ range before the last one was refused by the stream framing (a line beyond 1023 characters?): "
 				                "counters reset, the whole file is framed on the host\n");
 				for (auto *h : ix) VG_CHECK(vg_counts_reset(h));
 				host_from = 0;
 			}
 		}
+		pre.clear();
 		close(fd);
 	}
 	{
@@ -302,15 +523,20 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	sc.pos.resize(ns); sc.ref_freq.resize(ns); sc.alt_freq.resize(ns); sc.ref_cnt.resize(ns); sc.alt_cnt.resize(ns);
 	VG_CHECK(vg_sites_fetch(ix[0], sc.pos.data(), nullptr, nullptr, sc.ref_freq.data(), sc.alt_freq.data()));
 	VG_CHECK(vg_counts_fetch(ix[0], sc.ref_cnt.data(), sc.alt_cnt.data()));
+	if (const char *dump = getenv("VARGENO_DUMP_COUNTS")) {              // the saturated counters as the caller gets them: ref counts, then alt counts, one byte per site
+		FILE *f = fopen(dump, "wb");
+		if (!f || fwrite(sc.ref_cnt.data(), 1, ns, f) != ns || fwrite(sc.alt_cnt.data(), 1, ns, f) != ns) { fprintf(stderr, "vargeno: cannot write %s\n", dump); return EXIT_FAILURE; }
+		fclose(f);
+	}
 	vgh::write_genotyped_vcf(sc, chrlens, vcf_in, vcf_out);
+	struct timespec t_vcf; clock_gettime(CLOCK_MONOTONIC, &t_vcf);
 	for (auto *h : ix) vg_index_close(h);
 	const double cpu = (double)(clock() - begin) / CLOCKS_PER_SEC;
 	printf("Time: %f sec\n", cpu);                                       // qv.cc:1749-1751 prints CPU seconds
-	if (env_int("VARGENO_VERBOSE", 0)) {
+	if (verbose) {
 		struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-		auto secs = [](const struct timespec &a, const struct timespec &b) { return (b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec); };
-		fprintf(stderr, "reads: %lu  gpus: %d  wall: %.3f s = index load %.3f + FASTQ->counters %.3f (%.2f M reads/s) + call/VCF %.3f\n", (unsigned long)total, ngpu,
-		        secs(t0, t1), secs(t0, t_loaded), secs(t_loaded, t_reads), total / secs(t_loaded, t_reads) / 1e6, secs(t_reads, t1));
+		fprintf(stderr, "reads: %lu  gpus: %d  wall: %.3f s = index load %.3f + FASTQ->counters %.3f (%.2f M reads/s) + call/VCF %.3f + close %.3f\n", (unsigned long)total, ngpu,
+		        secs(t0, t1), secs(t0, t_loaded), secs(t_loaded, t_reads), (double)total / secs(t_loaded, t_reads) / 1e6, secs(t_reads, t_vcf), secs(t_vcf, t1));
 	}
 	return EXIT_SUCCESS;
 }

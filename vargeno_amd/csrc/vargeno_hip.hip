@@ -86,6 +86,29 @@ extern "C" uint64_t vg_device_memory(int device)
 	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return 0; }
 	return (uint64_t)prop.totalGlobalMem;
 }
+// host -> device rate of page-locked memory over this device's link, bytes per second (0 on failure): two timed copies of 64 MiB
+extern "C" double vg_link_rate(int device)
+{
+	if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return 0.0; }
+	const size_t n = 64ull << 20;
+	void *h = nullptr, *d = nullptr;
+	hipStream_t s = nullptr;
+	double best = 0.0;
+	if (hipHostMalloc(&h, n, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, n) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) {
+		memset(h, 1, n);
+		for (int it = 0; it < 3; it++) {
+			const auto t0 = std::chrono::steady_clock::now();
+			if (hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
+			const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			if (it && dt > 0 && (double)n / dt > best) best = (double)n / dt;        // (the first copy warms the path up)
+		}
+	}
+	(void)hipGetLastError();
+	if (s) (void)hipStreamDestroy(s);
+	if (d) (void)hipFree(d);
+	if (h) (void)hipHostFree(h);
+	return best;
+}
 extern "C" uint64_t vg_share_budget(int device, int replicas)
 {
 	const uint64_t total = vg_device_memory(device), reserve = 12ull << 30;
@@ -533,11 +556,6 @@ __global__ void vg_clamp_counters(const uint32_t *__restrict__ cnt, uint64_t n_s
 	}
 }
 
-__global__ void vg_accumulate_counters(const uint32_t *ctr, uint32_t *cum)
-{
-	cum[0] += ctr[0]; cum[1] += ctr[1]; cum[2] += ctr[2]; cum[3] += ctr[3];     // wave-tier overflow, lane-tier overflow, lost, reads with a non-ACGTN character
-}
-
 // One lane = one read: forward pass, then the reverse-complement retry (src/qv.cc:1504-1510).
 // A read touches the counters only at the end of its last pass, so a lane that runs out of scratch
 // simply drops the read onto the overflow list and the same kernel re-runs it with a deep scratch.
@@ -784,6 +802,9 @@ constexpr int NSLOT = 3;            // (5 and 8 were measured: no gain at 8 M-re
 struct Slot {
 	uint32_t *listA = nullptr, *listB = nullptr, *listC = nullptr;  uint64_t list_cap = 0;   // spill lists: main -> deep tier (A), deep tier -> lane tier (B), lost (C)
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
+	uint32_t *h_ctr = nullptr;            // page-locked copy of ctr[0..3], made on the tail stream when the batch's tiers are done
+	// what the generic lane tier needs should the deep tier leave reads behind: it is only launched then (harvest), never empty
+	const uint8_t *lt_bases = nullptr, *lt_quals = nullptr; const uint64_t *lt_offsets = nullptr; const uint32_t *lt_gate = nullptr; bool lt_packed = false, lt_stats = false;
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
 	uint32_t *st_gate = nullptr; uint64_t st_gate_cap = 0;                              // gate words of a batch framed on the device
@@ -821,7 +842,7 @@ struct vg_index {
 	ScratchBuf mid, big;                  // lane-tier scratch: every lane x 64 contexts; a few lanes x 16384 contexts
 	Slot slot[NSLOT];
 	int next_slot = 0;
-	uint32_t *d_cum = nullptr;            // since reset: [0] wave-tier overflow, [1] lane-tier overflow, [2] lost
+	uint64_t cum[4] = {0, 0, 0, 0};       // since reset: [0] wave-tier overflow, [1] lane-tier overflow, [2] lost, [3] reads with a character other than ACGTN
 	uint8_t *d_clamped = nullptr;         // [2 * n_sites] staging of vg_counts_fetch: min(63, sum), ref counts then alt counts
 	unsigned long long *d_stats = nullptr;
 	bool stats_enabled = true;
@@ -955,7 +976,7 @@ extern "C" void vg_index_close(vg_index *ix)
 		for (void *p : extra) if (p) (void)hipFree(p);
 		hipEvent_t evs[] = {sl.e0, sl.e1, sl.e2, sl.e3, sl.e4, sl.e5, sl.e_fq, sl.e_in};
 		for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
-		void *host[] = {sl.hp_kmers, sl.hp_meta, sl.hp_offsets};
+		void *host[] = {sl.hp_kmers, sl.hp_meta, sl.hp_offsets, sl.h_ctr};
 		for (void *p : host) if (p) (void)hipHostFree(p);
 	}
 	delete ix->packer;
@@ -1182,6 +1203,7 @@ static int init_handle(vg_index *ix, int device)
 	HIP_TRY(hipStreamCreateWithFlags(&ix->ingest, hipStreamNonBlocking));
 	if (const char *e = getenv("VG_PACK_OVERLAP")) ix->pack_overlap = atoi(e) != 0;
 	ix->ingest_stream = getenv("VG_NO_INGEST_STREAM") == nullptr;
+	for (Slot &sl : ix->slot) HIP_TRY(hipHostMalloc((void **)&sl.h_ctr, 64, hipHostMallocDefault));
 	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); HIP_TRY(hipEventCreateWithFlags(&sl.e_fq, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming)); }
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -1535,7 +1557,9 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 				ix->plan_text += "; direct table not kept: a bucket of more than 2^24 - 1 entries";
 			} else d.dx = dx;
 		}
-		vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);          // after the table: it reads the row form and the bucket words
+		// (after the table: it reads the row form and the bucket words.  Without the table the entries keep the row form -- the
+		// jump-table look-up expands rows itself -- and their bucket words, which nothing reads)
+		if (d.dx) vg_inline_pairs<<<2048, 256, 0, st>>>(mx, nm, d.ref_aux, d.snp_aux_pos);
 		HIP_TRY(hipGetLastError());
 		pc.lap("merged view, direct table");
 	}
@@ -1547,7 +1571,6 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
 	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 16, true, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
-	if ((rc = dev_alloc(ix, &ix->d_cum, 8, true, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_clamped, 2 * ix->n_sites + 2, false, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true, true))) return rc;
@@ -1865,6 +1888,15 @@ static int harvest(vg_index *ix, Slot &sl)
 {
 	if (!sl.busy) return VG_OK;
 	HIP_TRY(hipEventSynchronize(sl.e3));
+	if (sl.h_ctr[1]) {
+		// the deep tier left reads behind (listB): the lane machine with its lists in HBM finishes them now
+		if (sl.lt_stats) vg_lane_kernel<true><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
+		else vg_lane_kernel<false><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipMemcpyAsync(sl.h_ctr, sl.ctr, 16, hipMemcpyDeviceToHost, ix->tail));
+		HIP_TRY(hipStreamSynchronize(ix->tail));
+	}
+	for (int i = 0; i < 4; i++) ix->cum[i] += sl.h_ctr[i];
 	float a = 0, b = 0, c = 0, t = 0;
 	HIP_TRY(hipEventElapsedTime(&a, sl.e0, sl.e1)); HIP_TRY(hipEventElapsedTime(&b, sl.e5, sl.e2));
 	float w2 = 0;
@@ -1890,9 +1922,7 @@ static int finish_pending(vg_index *ix)
 		HIP_TRY(hipStreamSynchronize(ix->stream));
 	}
 	ix->cnt4_dirty = false;
-	uint32_t c[4];
-	HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost));
-	if (c[2]) return fail(VG_ENOMEM, "a read produced more hit contexts than the deep scratch holds (the reference overruns MAX_HITS=2000 long before, qv.cc:709)");
+	if (ix->cum[2]) return fail(VG_ENOMEM, "a read produced more hit contexts than the deep scratch holds (the reference overruns MAX_HITS=2000 long before, qv.cc:709)");
 	return VG_OK;
 }
 
@@ -1958,9 +1988,13 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	}
-	// ... then the generic lane machine with the deep HBM scratch for whatever is left
-	vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
-	vg_accumulate_counters<<<1, 1, 0, ix->tail>>>(ctr, ix->d_cum);
+	// ... and the generic lane machine with the deep HBM scratch for whatever is left -- LATER, and only if anything is (r05): the
+	// batch's counters come to the host behind its tiers, and harvest() launches the lane tier when they say that the deep tier left
+	// reads behind (0-5 reads per 8 M at hg38 scale, mostly none).  Through r04 the kernel was enqueued unconditionally: 64 workgroups
+	// that exit at once, but can only be PLACED when workgroups of the next batch's main tier retire -- 1.7-3.7 ms during which the
+	// batch's slot stayed busy, and 2-4 ms at the end of every job.
+	sl.lt_bases = d_bases; sl.lt_quals = d_quals; sl.lt_offsets = d_offsets; sl.lt_gate = d_gate; sl.lt_packed = packed; sl.lt_stats = STATS;
+	HIP_TRY(hipMemcpyAsync(sl.h_ctr, ctr, 16, hipMemcpyDeviceToHost, ix->tail));
 	HIP_TRY(hipEventRecord(sl.e3, ix->tail));
 	HIP_TRY(hipGetLastError());
 	sl.busy = true;
@@ -2445,7 +2479,7 @@ extern "C" int vg_stats_get(vg_index *ix, vg_stats *out)
 	out->scan_ref = h[S_SCAN_REF]; out->scan_snp = h[S_SCAN_SNP]; out->scan_oob = h[S_SCAN_OOB];
 	out->aux_ref = h[S_AUX_REF]; out->aux_snp = h[S_AUX_SNP]; out->site_test = h[S_SITE_TEST]; out->ctx = h[S_CTX];
 	out->walks = h[S_WALKS]; out->incr = h[S_INCR]; out->ingest_bytes = h[S_INGEST];
-	{ uint32_t c[8]; HIP_TRY(hipMemcpy(c, ix->d_cum, sizeof c, hipMemcpyDeviceToHost)); out->overflow_reads = c[0]; out->overflow_deep = c[1]; out->reads_invalid = c[3] + ix->host_invalid; }
+	out->overflow_reads = ix->cum[0]; out->overflow_deep = ix->cum[1]; out->reads_invalid = ix->cum[3] + ix->host_invalid;
 	const uint64_t scans = out->gate_open - out->large_block;
 	out->alg_bytes = out->ingest_bytes + 8 * (out->ref_query + out->snp_query) + 9 * out->ref_probe + 11 * out->snp_probe
 	               + 16 * out->gate_open + 16 * scans + 9 * out->scan_ref + 11 * out->scan_snp
@@ -2507,7 +2541,7 @@ extern "C" int vg_counts_reset(vg_index *ix)
 	{ int rc = finish_pending(ix); if (rc) return rc; }
 	HIP_TRY(hipMemsetAsync(ix->d.cnt, 0, (2 * ix->n_sites + 2) * 4, ix->stream));
 	HIP_TRY(hipMemsetAsync(ix->d_stats, 0, S_COUNT * sizeof(unsigned long long), ix->stream));
-	HIP_TRY(hipMemsetAsync(ix->d_cum, 0, 32, ix->stream));
+	for (auto &c : ix->cum) c = 0;
 	ix->host_invalid = 0;
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	return VG_OK;

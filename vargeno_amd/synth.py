@@ -262,11 +262,23 @@ def make_reads(rng, genome, snps, n, *, lengths=(150,), err=0.005, lowq=0.08, lo
 
 # ----------------------------------------------------------------------------- writers
 
-def write_fasta(path, genome, width=70):
+def write_fasta(path, genome, width=70, softmask=0.0, seed=20261002):
+    """softmask: fraction of every sequence written in LOWER case, in runs of 300-3 000 bases (what RepeatMasker leaves in a UCSC
+    download).  The dictionary pass of `vargeno index` folds case (fasta_parser.c), its bit-vector pass does not
+    (generate_bf.cc:230): an index from such a file has a reference bit vector that is NOT the set of the dictionary's LO32 values."""
+    rng = np.random.default_rng(seed + 77) if softmask > 0 else None
     with open(path, "wb") as f:
         for name, s in zip(genome.names, genome.seqs):
             f.write(b">" + name.encode() + b"\n")
             n = len(s)
+            if rng is not None and n:
+                k = max(1, int(softmask * n / 1650))
+                starts = rng.integers(0, n, k)
+                lens = rng.integers(300, 3000, k)
+                d = np.zeros(n + 1, np.int32)
+                np.add.at(d, starts, 1)
+                np.add.at(d, np.minimum(starts + lens, n), -1)
+                s = np.where(np.cumsum(d[:n]) > 0, s | 0x20, s).astype(np.uint8)
             full = (n // width) * width
             if full:
                 body = np.empty((full // width, width + 1), dtype=np.uint8)
