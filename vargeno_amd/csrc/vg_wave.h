@@ -176,9 +176,16 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	// must be able to finish such a read itself (the lane tier behind it takes milliseconds per read).  Stage B1 is bound by the
 	// instructions it issues per ROUND of 64 items, whatever the items hold (profiles/stageb1_rounds_r04.txt): at hg38 scale a SNP
 	// bucket of ~19 entries is one item instead of three, a 100-record LO32 bucket of a repeat family 25 items instead of 100.
-	const uint32_t sw_log = WPB > 1 && use_sig ? 5u : 0u;                             // log2 of the entries per item (wave-uniform)
+#ifndef VG_SIG_W
+#define VG_SIG_W 4                                                                    // 16-byte loads of signatures per item: 4 = 32 signatures (1, 2: experiments)
+#endif
+#ifndef VG_LW_LOG
+#define VG_LW_LOG 2                                                                   // log2 of the LO32-bucket records per item
+#endif
+	constexpr uint32_t SIG_W = VG_SIG_W, SIG_LOG = SIG_W == 4 ? 5u : SIG_W == 2 ? 4u : 3u;
+	const uint32_t sw_log = WPB > 1 && use_sig ? SIG_LOG : 0u;                        // log2 of the entries per item (wave-uniform)
 	const uint32_t sw_m1 = (1u << sw_log) - 1u;
-	constexpr uint32_t LW_LOG = WPB > 1 ? 2u : 0u, LW = 1u << LW_LOG;                 // records of a long LO32 bucket per item
+	constexpr uint32_t LW_LOG = WPB > 1 ? VG_LW_LOG : 0u, LW = 1u << LW_LOG;          // records of a long LO32 bucket per item
 	const uint32_t col0 = wv << 6;                       // first column of this wave (scalar)
 	// lane in the wave / this lane's LDS column: recomputed where they are used (two ALU operations) instead of held in a register
 	// from the first line of the kernel to its last -- the main tier sits exactly at its register budget
@@ -838,12 +845,31 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 #ifdef VG_STAGE_CLOCKS
 					dbg_rounds++;
 #endif
+					// An item of LO32-bucket records can hold several neighbours (the diverged copies of a repeat family are one another's
+					// neighbours): the first goes through the round's acceptance and compaction with everybody else's items, the others wait
+					// in `hitmask` and get passes of their own (`extra`), in which only their lanes have anything -- rare, so the round's code
+					// is not duplicated for them, it is run again.  (Sending such a read to the next tier instead -- the first build of the
+					// four-records items did -- doubled the deep tier's work on the repeat-rich genome and cost its main tier 30 %.)
+					uint32_t hitmask = 0, xrec = 0, xNI = 0;
+					for (uint32_t extra = 0u;; extra = 1u) {
 					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
 					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
 					uint32_t rdirect = 0;                                     // bit 0: ri holds the entry's POSITION field instead (bit 1: its ambig_flag)
 					LaneStats<STATS> hs;
 					hs.clear();
-					if (valid) {
+					if (extra) {
+						if (hitmask) {
+							uint32_t p = 0;
+							for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g) p += step;
+							const uint32_t meta = P_meta[p][wv], khi = P_khi[p][wv];
+							own = meta & 63u; c = (meta >> 6) & 31u; o_ecnt = P_ecnt[p][wv];
+							const uint32_t j = (uint32_t)__ffs((int)hitmask) - 1u;
+							hitmask &= hitmask - 1u;
+							const uint3 rec = gather12(d.sec3 + 3ull * ((uint64_t)xrec + (uint64_t)j * xNI));
+							const int dd = onebase((uint64_t)(rec.x ^ khi));      // (a neighbour: the first pass has seen it)
+							ri = rec.y; rdirect = 1u | ((rec.z >> 31) << 1); mod = 16u + (uint32_t)dd; nbase = (rec.x >> (2 * dd)) & 3u;
+						}
+					} else if (valid) {
 						uint32_t p = 0;                                                  // last row with P_off <= g
 						for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g) p += step;
 						const uint32_t t = g - P_off[p][wv];
@@ -877,16 +903,16 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 									uint32_t cand = 0;
 									if constexpr (WPB > 1) {
 										const uint32_t kk2 = ks | (ks << 16);
-										uint4 sv[4];
+										uint4 sv[SIG_W];
 										#pragma unroll
-										for (uint32_t q = 0; q < 4; q++) { sv[q] = make_uint4(0u, 0u, 0u, 0u); if (8u * q < live) sv[q] = gather<uint4, 1>(d.snp_sig + ((uint64_t)slo + u0 + 8u * q)); }
+										for (uint32_t q = 0; q < SIG_W; q++) { sv[q] = make_uint4(0u, 0u, 0u, 0u); if (8u * q < live) sv[q] = gather<uint4, 1>(d.snp_sig + ((uint64_t)slo + u0 + 8u * q)); }
 										auto two = [&](uint32_t w) -> uint32_t {
 											const uint32_t x = w ^ kk2, y = (x | (x >> 1)) & 0x55555555u;
 											return (__popc(y & 0xFFFFu) == 1 ? 1u : 0u) | (__popc(y >> 16) == 1 ? 2u : 0u);
 										};
 										#pragma unroll
-										for (uint32_t q = 0; q < 4; q++) cand |= (two(sv[q].x) | (two(sv[q].y) << 2) | (two(sv[q].z) << 4) | (two(sv[q].w) << 6)) << (8u * q);
-										cand &= live >= 32u ? ~0u : ((1u << live) - 1u);
+										for (uint32_t q = 0; q < SIG_W; q++) cand |= (two(sv[q].x) | (two(sv[q].y) << 2) | (two(sv[q].z) << 4) | (two(sv[q].w) << 6)) << (8u * q);
+										cand &= live >= 8u * SIG_W ? (SIG_W == 4 ? ~0u : (1u << (8u * SIG_W)) - 1u) : ((1u << live) - 1u);
 									} else {
 										const uint32_t x = (uint32_t)d.snp_sig[(uint64_t)slo + u0] ^ ks, y = (x | (x >> 1)) & 0x5555u;
 										cand = __popc(y) == 1 ? 1u : 0u;
@@ -928,20 +954,19 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								if (h < NI) {
 									// records h, h + NI, h + 2 NI, h + 3 NI of the chunk's LO32 bucket (adjacent lanes read adjacent records, four gathers
 									// in one wait): a dictionary k-mer with the chunk's first half whose last half differs in exactly one base is a
-									// high-half neighbour (qv.cc:1213-1296), and the record carries its position.  Two such records in one item (the
-									// bucket is sorted by the last half, so neighbours of neighbours sit side by side -- hence the stride): next tier.
+									// high-half neighbour (qv.cc:1213-1296), and the record carries its position.
 									slot_item = false;
 									const uint64_t rb = P_hidx[0][p][wv];
 									uint3 rec[LW];
 									#pragma unroll
 									for (uint32_t j = 0; j < LW; j++) { const uint32_t r_ = h + j * NI; rec[j] = make_uint3(0u, 0u, ~klo); if (r_ < S) rec[j] = gather12(d.sec3 + 3ull * (rb + r_)); }
-									uint32_t hits = 0;
 									#pragma unroll
-									for (uint32_t j = 0; j < LW; j++) if (((rec[j].z ^ klo) & 0x7FFFFFFFu) == 0u && (bf_from_sec || (fl & 1u))) {
+									for (uint32_t j = LW; j-- > 0u;) if (((rec[j].z ^ klo) & 0x7FFFFFFFu) == 0u && (bf_from_sec || (fl & 1u))) {      // (downwards: the lowest hit is the one kept for this pass)
 										const int dd = onebase((uint64_t)(rec[j].x ^ khi));
-										if (dd >= 0) { hits++; ri = rec[j].y; rdirect = 1u | ((rec[j].z >> 31) << 1); mod = 16u + (uint32_t)dd; nbase = (rec[j].x >> (2 * dd)) & 3u; }
+										if (dd >= 0) { hitmask |= 1u << j; ri = rec[j].y; rdirect = 1u | ((rec[j].z >> 31) << 1); mod = 16u + (uint32_t)dd; nbase = (rec[j].x >> (2 * dd)) & 3u; }
 									}
-									if (hits > 1u) { N_ovf[col0 + own] = 1; ri = NOHIT; rdirect = 0u; }
+									hitmask &= hitmask - 1u;                              // the others: passes of their own, below
+									xrec = (uint32_t)rb + h; xNI = NI;
 								} else h -= NI;
 							}
 							if (slot_item) {
@@ -1085,8 +1110,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						}
 					}
 					if constexpr (STATS) {
-						if (valid) for (int i = 0; i < NSH; i++) { const uint32_t v = hs.v[SH_IDS[i]]; if (v) atomicAdd(&S_own[i][col0 + own], v); }
+						if (valid && !extra) for (int i = 0; i < NSH; i++) { const uint32_t v = hs.v[SH_IDS[i]]; if (v) atomicAdd(&S_own[i][col0 + own], v); }
 					}
+					const bool item = extra ? own != 64u : valid;                 // this lane has an item in this pass
 					if (__any(keepm != 0)) {
 						// compaction per owner (a segment of consecutive lanes), canonical order = lane order; ref contexts of an
 						// item before its SNP contexts
@@ -1101,9 +1127,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						const int se_l = above ? (__ffsll((long long)above) - 2) : 63;
 						const uint32_t excl_ss = __shfl(incl - keep, ss);
 						const uint32_t seg_total = __shfl(incl, se_l) - excl_ss;
-						const uint32_t curc = valid ? (uint32_t)N_cnt[col0 + own] : 0u;
+						const uint32_t curc = item ? (uint32_t)N_cnt[col0 + own] : 0u;
 						const bool fits = curc + seg_total <= (uint32_t)W_NCAP;
-						if (valid && keep) {
+						if (item && keep) {
 							if (!fits) N_ovf[col0 + own] = 1;
 							else {
 								uint32_t at = curc + (incl - keep) - excl_ss;
@@ -1124,9 +1150,11 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								}
 							}
 						}
-						if (valid && fits && seg_total && (int)lane == se_l) N_cnt[col0 + own] = (uint16_t)(curc + seg_total);
+						if (item && fits && seg_total && (int)lane == se_l) N_cnt[col0 + own] = (uint16_t)(curc + seg_total);
 					}
 					VG_WAVE_SYNC();
+					if (!__any(hitmask != 0u)) break;
+					}
 				}
 				VG_CLK(3);
 			}
