@@ -858,11 +858,15 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					LaneStats<STATS> hs;
 					hs.clear();
 					if (extra) {
-						if (hitmask) {
-							uint32_t p = 0;
+						// (every lane keeps its item's owner: the compaction below takes runs of lanes with one owner for one segment)
+						uint32_t p = 0, meta = 64u;
+						if (valid) {
 							for (uint32_t step = PCAP / 2; step > 0; step >>= 1) if (p + step < np && P_off[p + step][wv] <= g) p += step;
-							const uint32_t meta = P_meta[p][wv], khi = P_khi[p][wv];
+							meta = P_meta[p][wv];
 							own = meta & 63u; c = (meta >> 6) & 31u; o_ecnt = P_ecnt[p][wv];
+						}
+						if (hitmask) {
+							const uint32_t khi = P_khi[p][wv];
 							const uint32_t j = (uint32_t)__ffs((int)hitmask) - 1u;
 							hitmask &= hitmask - 1u;
 							const uint3 rec = gather12(d.sec3 + 3ull * ((uint64_t)xrec + (uint64_t)j * xNI));
@@ -1112,7 +1116,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					if constexpr (STATS) {
 						if (valid && !extra) for (int i = 0; i < NSH; i++) { const uint32_t v = hs.v[SH_IDS[i]]; if (v) atomicAdd(&S_own[i][col0 + own], v); }
 					}
-					const bool item = extra ? own != 64u : valid;                 // this lane has an item in this pass
+					const bool item = valid;
 					if (__any(keepm != 0)) {
 						// compaction per owner (a segment of consecutive lanes), canonical order = lane order; ref contexts of an
 						// item before its SNP contexts
