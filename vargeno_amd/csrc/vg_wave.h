@@ -354,6 +354,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 
 		// ------------------------------------------------------------------ stage A: exact look-ups
 		uint32_t kcnt = 0, ncnt = 0;                             // vote keys of this pass (slots [0, kcnt)), neighbour contexts
+		uint32_t npend = 0;                                      // auxiliary rows this lane has queued for the wave to expand together (below)
 		bool ovf = false;
 		if (active) {
 			// an exact context of chunk c at k-mer position p (qv.cc:850-937): find its vote key among slots [lo, hi) of the lane's
@@ -556,7 +557,16 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								#pragma unroll
 								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = gather<uint4>(d.mx + (lo + 1u + x)); }
 							}
-							uint32_t ax_r[2] = {NOHIT, NOHIT}, ax_s[2] = {NOHIT, NOHIT};       // auxiliary rows of the pair's chunks still to expand
+							// An auxiliary row (a k-mer with 3-10 copies) is not expanded here but QUEUED -- the neighbour lists' LDS slots are idle
+							// during stage A: row index and chunk per entry -- and the wave expands everybody's rows together after the look-ups
+							// (below).  A pass with a row has exact hits of its own: the reverse-strand block will not be used.  An index whose
+							// rows repeat positions (DevIndex::aux_dups), and a lane whose queue is full, expand the row here, the careful way.
+							auto queue_row = [&](const uint32_t *aux, uint32_t row, uint32_t cc, uint32_t is_snp) {
+								if (d.aux_dups || npend == (uint32_t)W_NCAP) { push_row(aux + (uint64_t)row * AUX_COLS, cc); return; }
+								N_kpos[npend][col] = row; N_meta[npend][col] = (uint16_t)(cc | (is_snp << 5));
+								npend++;
+								rc_top = RC_BAD;
+							};
 							#pragma unroll
 							for (uint32_t y = 0; y < 2; y++) {
 								const uint32_t z = z0 + y;
@@ -610,25 +620,15 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								const bool r_ax = r_ok && (rf & 6u) == 2u, s_ax = s_ok && (sf & 6u) == 2u;   // ambiguous and not a PAIR: read the row
 								if (r_ok) {
 									if (rf & 2u) cur.add(S_AUX_REF, 1);
-									if (r_ax) ax_r[y] = rp;
+									if (r_ax) queue_row(d.ref_aux, rp, c + z, 0u);
 									else { push_exact(rp, c + z); if (rf & 4u) push_exact(rp2, c + z); }
 								}
 								if (s_ok) {
 									if (sf & 2u) cur.add(S_AUX_SNP, 1);
-									if (s_ax) ax_s[y] = sp;
+									if (s_ax) queue_row(d.snp_aux_pos, sp, c + z, 1u);
 									else { push_exact(sp, c + z); if (sf & 4u) push_exact(sp2, c + z); }
 								}
 							}
-							// the auxiliary rows (k-mers with 3-10 copies) after the pair's other contexts, a reference row WHOLE in one wait: a read
-							// inside a repeat waited up to three times per chunk for its row's columns four at a time (the order in which a
-							// pass's contexts reach the key table does not matter)
-							// (two or four rows in flight at once, or the rows of all four chunks collected first and pushed at the end: 48 to 1 100
-							// bytes of scratch per lane -- the register allocation of this kernel does not survive a second copy of the block match)
-							#pragma nounroll
-							for (uint32_t y = 0; y < 2; y++) if (ax_r[y] != NOHIT) push_row(d.ref_aux + (uint64_t)ax_r[y] * AUX_COLS, c + z0 + y);
-							// (an SNP k-mer with several positions is rare -- it takes an SNP inside identical copies: row by row)
-							#pragma unroll
-							for (uint32_t y = 0; y < 2; y++) if (ax_s[y] != NOHIT) push_row(d.snp_aux_pos + (uint64_t)ax_s[y] * AUX_COLS, c + z0 + y);
 						}
 					}
 					// A forward pass without a single exact hit can neither vote nor be walked (the stage-B skip below): the lane goes on as
@@ -681,6 +681,81 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 			}
 		}
 		VG_WAVE_SYNC();
+		// ---- the queued auxiliary rows, expanded by the WAVE (r05).  Through r04 a lane expanded its own rows inside the look-up loop:
+		// the row code -- the whole row against the whole key table -- ran once per chunk for the two or three lanes of 64 that had a
+		// row there, four or five times a pass at ~700 instructions: a third of stage A on a repeat-rich genome, for 5 % of the lanes
+		// (profiles/stage_clocks_r05_repeats30.txt: A = 44 % of the kernel at hg38 scale).  Now round r takes every lane's r-th row, and
+		// a row is the work of TEN lanes, one per column: its position, the owner's keys (LDS broadcast reads), a ballot for the
+		// columns that are new keys and their ranks.  Rows of one owner stay in order (round by round), so a later row finds the keys an
+		// earlier one appended; columns of one row name different positions (the loader has checked: aux_dups), so no two lanes touch
+		// one slot.  Six rows per sub-round of 60 lanes.
+		if constexpr (!STATS && !NOMX) {
+			for (uint32_t r = 0; ; r++) {
+				uint64_t todo = __ballot(active && !ovf && r < npend);
+				if (!todo) break;
+				while (todo) {
+					const uint32_t grp = lane / 10u, j = lane - grp * 10u;                   // lanes 60-63: no group
+					uint64_t m = todo;
+					for (uint32_t i = 0; i < grp && m; i++) m &= m - 1ull;
+					const bool in = lane < 60u && m != 0ull;
+					const uint32_t owner = in ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+					const uint32_t ocol = col0 + owner;
+					const uint32_t kc = __shfl(kcnt, owner);
+					uint32_t pos = 0, cc = 0;
+					if (in) {
+						const uint32_t row = N_kpos[r][ocol], mt = N_meta[r][ocol];
+						cc = mt & 31u;
+						pos = gather<uint32_t>(((mt >> 5) & 1u ? d.snp_aux_pos : d.ref_aux) + ((uint64_t)row * AUX_COLS + j));
+					}
+					// a row ends at its first 0: the group's live columns are the run of non-zero ones from column 0
+					const uint64_t nz = __ballot(in && pos != 0u);
+					const uint32_t gsh = grp * 10u;
+					const uint32_t gnz = in ? (uint32_t)(nz >> gsh) & 0x3FFu : 0u;
+					const uint32_t nlive = (uint32_t)__builtin_ctz(~gnz);                      // (gnz has 10 bits: ctz(~gnz) <= 10)
+					const bool live = in && j < nlive;
+					const uint32_t q = pos - 32u * cc, bit = 1u << cc;
+					uint32_t at = (uint32_t)W_ECAP;
+					bool dup = false;
+					if (live) {
+						#pragma nounroll
+						for (uint32_t e0 = 0; e0 < kc && at == (uint32_t)W_ECAP; e0 += 4) {
+							uint32_t kv[4];
+							#pragma unroll
+							for (uint32_t t = 0; t < 4; t++) kv[t] = K_idx[e0 + t < (uint32_t)W_ECAP ? e0 + t : (uint32_t)W_ECAP - 1u][ocol];
+							#pragma unroll
+							for (uint32_t t = 0; t < 4; t++) if (at == (uint32_t)W_ECAP && e0 + t < kc && kv[t] == q) at = e0 + t;
+						}
+						if (at != (uint32_t)W_ECAP) {
+							const uint32_t km = K_mask[at][ocol];
+							if (km & bit) dup = true; else K_mask[at][ocol] = (kmask_t)(km | bit);   // (the chunk has voted for this key already: next tier)
+						}
+					}
+					const uint64_t newb = __ballot(live && at == (uint32_t)W_ECAP), dupb = __ballot(dup);
+					const uint32_t gnew = (uint32_t)(newb >> gsh) & 0x3FFu, nn = (uint32_t)__popc(gnew);
+					const bool room = kc + nn <= (uint32_t)W_ECAP;
+					if (live && at == (uint32_t)W_ECAP && room) {
+						const uint32_t e = kc + (uint32_t)__popc(gnew & ((1u << j) - 1u));
+						K_idx[e][ocol] = q; K_mask[e][ocol] = (kmask_t)bit;
+					}
+					// the owners take note: new keys, or the reasons to hand the read on
+					const uint32_t done = (uint32_t)__popcll(todo) < 6u ? (uint32_t)__popcll(todo) : 6u;
+					uint64_t mm = todo;
+					for (uint32_t gi = 0; gi < done; gi++) {
+						const uint32_t ow = (uint32_t)__ffsll((long long)mm) - 1u;
+						mm &= mm - 1ull;
+						const uint32_t gn = (uint32_t)(newb >> (gi * 10u)) & 0x3FFu, gd = (uint32_t)(dupb >> (gi * 10u)) & 0x3FFu;
+						if (lane == ow) {
+							const uint32_t add = (uint32_t)__popc(gn);
+							if (gd) { VG_OVF(2); ovf = true; }
+							else if (kcnt + add > (uint32_t)W_ECAP) { VG_OVF(0); ovf = true; }
+							else kcnt += add;
+						}
+					}
+					todo = mm;
+					VG_WAVE_SYNC();
+				}
+			}
+		}
 		VG_CLK(1);
 
 		// ------------------------------------------------------------------ stage B: all gate-open chunks of the wave, flattened
