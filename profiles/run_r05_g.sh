@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, lease g: auxiliary rows expanded by the wave (ten lanes per row).  Parity tests, then hg38 scale: repeat-rich genome (parity on the
+# Round 5, lease g: auxiliary rows dealt to the lanes of the wave (all fetched in one wait, matched in the owners' order).  Parity tests, then hg38 scale: repeat-rich genome (parity on the
 # 8 M-read batch + timing against the r04 library), default genome timing.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r05_g

@@ -681,77 +681,82 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 			}
 		}
 		VG_WAVE_SYNC();
-		// ---- the queued auxiliary rows, expanded by the WAVE (r05).  Through r04 a lane expanded its own rows inside the look-up loop:
-		// the row code -- the whole row against the whole key table -- ran once per chunk for the two or three lanes of 64 that had a
-		// row there, four or five times a pass at ~700 instructions: a third of stage A on a repeat-rich genome, for 5 % of the lanes
-		// (profiles/stage_clocks_r05_repeats30.txt: A = 44 % of the kernel at hg38 scale).  Now round r takes every lane's r-th row, and
-		// a row is the work of TEN lanes, one per column: its position, the owner's keys (LDS broadcast reads), a ballot for the
-		// columns that are new keys and their ranks.  Rows of one owner stay in order (round by round), so a later row finds the keys an
-		// earlier one appended; columns of one row name different positions (the loader has checked: aux_dups), so no two lanes touch
-		// one slot.  Six rows per sub-round of 60 lanes.
+		// ---- the queued auxiliary rows, dealt to the lanes of the WAVE (r05).  Through r04 a lane expanded its own rows inside the look-up
+		// loop: gather the row (one wait), match it against the key table, next chunk -- four or five dependent gathers per pass for the
+		// two or three lanes of 64 that had rows, with the other lanes waiting: a fifth of the kernel on a repeat-rich genome at hg38
+		// scale (profiles/stage_clocks_r05.txt).  Now ALL queued rows of the wave are fetched together -- row i of the wave by lane i,
+		// whoever owns it: one wait for all of them --, and only the matching is done in the owners' order (round r: every owner's r-th
+		// row against its key table, by the lane that holds the row; LDS and arithmetic, no memory wait), so that a later row finds
+		// the keys an earlier one appended.
+		VG_CLK(11);
 		if constexpr (!STATS && !NOMX) {
-			for (uint32_t r = 0; ; r++) {
-				uint64_t todo = __ballot(active && !ovf && r < npend);
-				if (!todo) break;
-				while (todo) {
-					const uint32_t grp = lane / 10u, j = lane - grp * 10u;                   // lanes 60-63: no group
-					uint64_t m = todo;
-					for (uint32_t i = 0; i < grp && m; i++) m &= m - 1ull;
-					const bool in = lane < 60u && m != 0ull;
-					const uint32_t owner = in ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
-					const uint32_t ocol = col0 + owner;
-					const uint32_t kc = __shfl(kcnt, owner);
-					uint32_t pos = 0, cc = 0;
-					if (in) {
-						const uint32_t row = N_kpos[r][ocol], mt = N_meta[r][ocol];
-						cc = mt & 31u;
-						pos = gather<uint32_t>(((mt >> 5) & 1u ? d.snp_aux_pos : d.ref_aux) + ((uint64_t)row * AUX_COLS + j));
-					}
-					// a row ends at its first 0: the group's live columns are the run of non-zero ones from column 0
-					const uint64_t nz = __ballot(in && pos != 0u);
-					const uint32_t gsh = grp * 10u;
-					const uint32_t gnz = in ? (uint32_t)(nz >> gsh) & 0x3FFu : 0u;
-					const uint32_t nlive = (uint32_t)__builtin_ctz(~gnz);                      // (gnz has 10 bits: ctz(~gnz) <= 10)
-					const bool live = in && j < nlive;
-					const uint32_t q = pos - 32u * cc, bit = 1u << cc;
-					uint32_t at = (uint32_t)W_ECAP;
-					bool dup = false;
-					if (live) {
+			const uint32_t mine = (active && !ovf) ? npend : 0u;
+			uint32_t incl = mine;
+			for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((int)lane >= o) incl += y; }
+			const uint32_t base = incl - mine, total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+			uint32_t maxr = mine;
+			for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_xor(maxr, o); maxr = y > maxr ? y : maxr; }
+			maxr = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxr);
+			for (uint32_t it0 = 0; it0 < total; it0 += 64) {
+				const uint32_t item = it0 + lane;
+				const bool has = item < total;
+				uint32_t ow = 0;                                       // the owner: the last lane whose first item is not beyond this one
+				for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t cand = ow + step, bb = __shfl(base, (int)(cand & 63u)); if (cand < 64u && bb <= item) ow = cand; }
+				const uint32_t rr_mine = item - __shfl(base, (int)ow), ocol = col0 + ow;
+				uint32_t rw[AUX_COLS], cc = 0;
+				#pragma unroll
+				for (int j = 0; j < AUX_COLS; j++) rw[j] = 0u;
+				if (has) {
+					const uint32_t row = N_kpos[rr_mine][ocol], mt = N_meta[rr_mine][ocol];
+					cc = mt & 31u;
+					load_row10(((mt >> 5) & 1u ? d.snp_aux_pos : d.ref_aux) + (uint64_t)row * AUX_COLS, rw);
+				}
+				uint32_t nlive = 0;
+				#pragma unroll
+				for (int j = 0; j < AUX_COLS; j++) if (nlive == (uint32_t)j && rw[j] != 0u) nlive = (uint32_t)j + 1u;      // a row ends at its first 0
+				const uint32_t bit = 1u << cc, back = 32u * cc, live = (1u << nlive) - 1u;
+				for (uint32_t rr = 0; rr < maxr; rr++) {
+					const uint32_t kc = __shfl(kcnt, (int)ow);          // the owner's keys as they stand before this round
+					const uint32_t ow_ovf = __shfl((uint32_t)(ovf ? 1u : 0u), (int)ow);
+					uint32_t add = 0, bad = 0;
+					if (has && rr_mine == rr && !ow_ovf) {
+						uint32_t found = 0;
 						#pragma nounroll
-						for (uint32_t e0 = 0; e0 < kc && at == (uint32_t)W_ECAP; e0 += 4) {
-							uint32_t kv[4];
+						for (uint32_t e0 = 0; e0 < kc && found != live; e0 += 4) {
+							uint32_t kv[4], km[4];
 							#pragma unroll
-							for (uint32_t t = 0; t < 4; t++) kv[t] = K_idx[e0 + t < (uint32_t)W_ECAP ? e0 + t : (uint32_t)W_ECAP - 1u][ocol];
+							for (uint32_t t = 0; t < 4; t++) { const uint32_t e = e0 + t < (uint32_t)W_ECAP ? e0 + t : (uint32_t)W_ECAP - 1u; kv[t] = K_idx[e][ocol]; km[t] = K_mask[e][ocol]; }
 							#pragma unroll
-							for (uint32_t t = 0; t < 4; t++) if (at == (uint32_t)W_ECAP && e0 + t < kc && kv[t] == q) at = e0 + t;
+							for (uint32_t t = 0; t < 4; t++) if (e0 + t < kc) {
+								uint32_t h = 0;
+								#pragma unroll
+								for (int j = 0; j < AUX_COLS; j++) h |= (rw[j] - back == kv[t] ? 1u : 0u) << j;
+								h &= live;
+								if (h) {
+									if (km[t] & bit) bad = 2u;                      // the chunk has voted for this key already: next tier
+									else K_mask[e0 + t][ocol] = (kmask_t)(km[t] | bit);
+									found |= h;
+								}
+							}
 						}
-						if (at != (uint32_t)W_ECAP) {
-							const uint32_t km = K_mask[at][ocol];
-							if (km & bit) dup = true; else K_mask[at][ocol] = (kmask_t)(km | bit);   // (the chunk has voted for this key already: next tier)
-						}
-					}
-					const uint64_t newb = __ballot(live && at == (uint32_t)W_ECAP), dupb = __ballot(dup);
-					const uint32_t gnew = (uint32_t)(newb >> gsh) & 0x3FFu, nn = (uint32_t)__popc(gnew);
-					const bool room = kc + nn <= (uint32_t)W_ECAP;
-					if (live && at == (uint32_t)W_ECAP && room) {
-						const uint32_t e = kc + (uint32_t)__popc(gnew & ((1u << j) - 1u));
-						K_idx[e][ocol] = q; K_mask[e][ocol] = (kmask_t)bit;
-					}
-					// the owners take note: new keys, or the reasons to hand the read on
-					const uint32_t done = (uint32_t)__popcll(todo) < 6u ? (uint32_t)__popcll(todo) : 6u;
-					uint64_t mm = todo;
-					for (uint32_t gi = 0; gi < done; gi++) {
-						const uint32_t ow = (uint32_t)__ffsll((long long)mm) - 1u;
-						mm &= mm - 1ull;
-						const uint32_t gn = (uint32_t)(newb >> (gi * 10u)) & 0x3FFu, gd = (uint32_t)(dupb >> (gi * 10u)) & 0x3FFu;
-						if (lane == ow) {
-							const uint32_t add = (uint32_t)__popc(gn);
-							if (gd) { VG_OVF(2); ovf = true; }
-							else if (kcnt + add > (uint32_t)W_ECAP) { VG_OVF(0); ovf = true; }
-							else kcnt += add;
+						const uint32_t newk = live & ~found;
+						add = (uint32_t)__popc(newk);
+						if (!bad && kc + add > (uint32_t)W_ECAP) bad = 1u;
+						if (!bad) {
+							#pragma unroll
+							for (int j = 0; j < AUX_COLS; j++) if ((newk >> j) & 1u) {
+								const uint32_t e = kc + (uint32_t)__popc(newk & ((1u << j) - 1u));
+								K_idx[e][ocol] = rw[j] - back; K_mask[e][ocol] = (kmask_t)bit;
+							}
 						}
 					}
-					todo = mm;
+					// the owner hears from the lane that held its rr-th row (if that row is in this batch of 64)
+					const uint32_t src = base + rr - it0;
+					const uint32_t add_o = __shfl(add, (int)(src & 63u)), bad_o = __shfl(bad, (int)(src & 63u));
+					if (rr < mine && base + rr >= it0 && src < 64u) {
+						if (bad_o) { if (bad_o == 2u) VG_OVF(2); else VG_OVF(0); ovf = true; }
+						else kcnt += add_o;
+					}
 					VG_WAVE_SYNC();
 				}
 			}
