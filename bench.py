@@ -327,7 +327,34 @@ def measure_ingest(gx, batch, log, reps=3):
     return out
 
 
-def job_fastq(src, gx, path, n_reads, batch_reads, lowq, log, read_len=150):
+def big_file_room():
+    """Where a file of tens of GB may go on this host, and how large it may be: (directory, bytes).  /dev/shm when the container's
+    memory limit has the room (its pages are charged to the cgroup: memory.max - memory.current, less 64 GB for everybody else),
+    never the root file system beyond half of what it has free -- a GPU box of this pool has a 79 GB root and a 300 GiB memory
+    limit, and a container that fills either one is killed (round 5 lost a box that way)."""
+    def rd(path):
+        try:
+            v = open(path).read().split()[0]
+            return None if v == "max" else int(v)
+        except Exception:
+            return None
+    best = (None, 0)
+    try:
+        st_ = os.statvfs("/dev/shm")
+        shm_free = st_.f_bavail * st_.f_frsize
+        mx, cur = rd("/sys/fs/cgroup/memory.max"), rd("/sys/fs/cgroup/memory.current")
+        if mx is None:
+            mx = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0]
+            cur = 0
+        room = min(shm_free, mx - (cur or 0) - (64 << 30)) // 2
+        if room > best[1]:
+            best = ("/dev/shm/vg_bench_job", room)
+    except Exception:
+        pass
+    return best
+
+
+def job_fastq(src, gx, path, n_reads, batch_reads, lowq, log, read_len=150, keep_first=0):
     """The `job` leg's input: n_reads DISTINCT reads of the workload's stream (batches no other leg uses) as one FASTQ file, written
     batch by batch (text put together on the device, page-locked copy, positioned writes by four threads) -- and, on the way, the
     same batches through the resident-batch path of the open index: its counters are what the command line must reproduce from
@@ -351,7 +378,7 @@ def job_fastq(src, gx, path, n_reads, batch_reads, lowq, log, read_len=150):
             n = min(batch_reads, n_reads - done)
             tb, tq, to = src.batch(500_000 + b, n, length=read_len, lowq=lowq)[:3]
             gx.process_device(tb, tq, to, n)                            # the resident-batch path, same reads
-            if done < 16_000_000:
+            if done < keep_first:
                 first.append(synth.reads_to_host(tb, tq, to))
             L = int(to[1].item())
             rec = 13 + L + 3 + L + 1                                    # "@r%010d\n" bases "\n+\n" quals "\n"
@@ -390,16 +417,16 @@ def job_fastq(src, gx, path, n_reads, batch_reads, lowq, log, read_len=150):
     return {"reads": done, "bytes": off, "counts": (rc, ac), "first": first, "write_s": time.time() - t_all}
 
 
-def job_run(d, job, log):
+def job_run(d, job_dir, job, log):
     """One whole job through the drop-in command line: `vargeno geno idx job.fq snps.vcf job.vcf` as a child process -- index open,
     FASTQ ingest (packing starts beside the open), caller, VCF -- timed from outside; its counters (VARGENO_DUMP_COUNTS) against
     the resident-batch path's on the same reads; calls and GQ histogram out of the VCF it wrote."""
     import re
 
-    dump = os.path.join(d, "job.counts")
-    env = dict(os.environ, VARGENO_VERBOSE="1", VARGENO_DUMP_COUNTS=dump)
+    dump = os.path.join(job_dir, "job.counts")
+    env = dict(os.environ, VARGENO_VERBOSE="1", VARGENO_DUMP_COUNTS=dump, VARGENO_PREPACK_GB="16")
     t0 = time.time()
-    p = subprocess.run([BIN, "geno", "idx", "job.fq", "snps.vcf", "job.vcf"], cwd=d, env=env, capture_output=True, text=True)
+    p = subprocess.run([BIN, "geno", "idx", os.path.join(job_dir, "job.fq"), "snps.vcf", os.path.join(job_dir, "job.vcf")], cwd=d, env=env, capture_output=True, text=True, timeout=600)
     wall = time.time() - t0
     out = {"reads": job["reads"], "fastq_GB": job["bytes"] / 1e9, "wall_s": wall, "whole_job_reads_per_s": job["reads"] / wall, "rc": p.returncode}
     if p.returncode != 0:
@@ -419,7 +446,7 @@ def job_run(d, job, log):
     ns = len(rc)
     out["counters_equal_resident_batch_path"] = bool(len(cnt) == 2 * ns and np.array_equal(cnt[:ns], rc) and np.array_equal(cnt[ns:], ac))
     assert out["counters_equal_resident_batch_path"], "the command line's counters differ from the resident-batch path's on the same reads"
-    text = open(os.path.join(d, "job.vcf"), "rb").read()
+    text = open(os.path.join(job_dir, "job.vcf"), "rb").read()
     calls = re.findall(rb"\t([01]/[01]):(\d+)\n", text)
     gq = np.array([int(q) for _, q in calls], dtype=np.int64) if calls else np.zeros(0, np.int64)
     gts = {}
@@ -428,11 +455,6 @@ def job_run(d, job, log):
     hist, edges = np.histogram(gq, bins=[0, 10, 20, 30, 50, 100, 200, 400, 10 ** 6]) if len(gq) else ([], [])
     out.update({"called": len(calls), "genotypes": gts, "gq_histogram": {"%d-%d" % (edges[i], edges[i + 1] - 1): int(hist[i]) for i in range(len(hist))}, "gq_median": float(np.median(gq)) if len(gq) else None,
                 "mean_coverage_per_site": float((rc.astype(np.int64).sum() + ac.astype(np.int64).sum()) / max(ns, 1))})
-    for f in ("job.fq", "job.counts", "job.vcf"):
-        try:
-            os.remove(os.path.join(d, f))
-        except OSError:
-            pass
     log("[bench] job: %d reads, wall %.2f s (open %.2f + ingest %.2f + call/VCF %.2f), %.4g reads/s whole job, %d called, counters equal the resident path's" % (
         job["reads"], wall, out.get("index_open_s", 0), out.get("ingest_after_open_s", 0), out.get("call_vcf_s", 0), out["whole_job_reads_per_s"], len(calls)))
     return out
@@ -689,24 +711,11 @@ def main():
         log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (t_open, gx.device_bytes / 1e9, gx.num_sites))
         log("[bench] vg_index_open phases: %s" % open_report)
 
-    # ---- the `job` leg's input (N = 1): a FASTQ file of distinct reads, and the same reads through the resident-batch path ----------
+    # ---- the `job` leg (N = 1): its first 16 M reads now, for the oracle (they are generated again, with all the others, when the
+    #      FASTQ file is written -- late, when the reference binary's processes and the oracle have left the host's memory)
     job = None
     if src is not None:
-        try:
-            st_fs = os.statvfs(d)
-            room = st_fs.f_bavail * st_fs.f_frsize
-            per_read = 2 * args.read_len + 17
-            n_job = min(want_job, int(0.8 * room / per_read) // args.reads * args.reads)
-            if n_job >= 2 * args.reads:
-                job = job_fastq(src, gx, os.path.join(d, "job.fq"), n_job, args.reads, args.lowq, log, read_len=args.read_len)
-                job["wanted"] = want_job
-            else:
-                job = {"skipped": "the work directory's file system has room for %d reads only" % n_job}
-        except Exception as e:
-            job = {"skipped": "writing the job's FASTQ failed: %r" % (e,)}
-            log("[bench] job leg: %r" % (e,))
-        src.release()
-        del src
+        job = {"first": [synth.reads_to_host(*src.batch(500_000 + b, args.reads, length=args.read_len, lowq=args.lowq)[:3]) for b in range(min(2, want_job // args.reads))], "wanted": want_job}
         torch.cuda.empty_cache()
 
     # ---- the reference binary on the host, beside everything that follows (N = 1 only) ------------------------------------------
@@ -805,6 +814,7 @@ def main():
         if job is not None and job.get("first"):
             try:
                 fr = job.pop("first")
+                job["first"] = None
                 ref.wait_quiet("the oracle's run over the job's first reads")
                 ref.heavy_begin()
                 ox.reset()
@@ -1023,34 +1033,48 @@ def main():
     ingest = None
     if rank == 0 and world == 1 and not args.no_ingest:
         ingest = measure_ingest(gx, batches[0], log)
+    # ---- the `job` leg: a FASTQ file of distinct reads (and the same reads through the resident-batch path of the open index), then one
+    #      whole run of the drop-in command line on it, once this process holds no index any more
+    job_out, job_dir = None, None
+    if rank == 0 and job is not None and src is not None:
+        left = BUDGET_S - (time.time() - T_START)
+        job_dir, room = big_file_room()
+        per_read = 2 * args.read_len + 17
+        n_job = min(want_job, int(room / per_read) // args.reads * args.reads)
+        if left < 240:
+            job_out = {"skipped": "time budget: %.0f s left" % left}
+        elif job_dir is None or n_job < 2 * args.reads:
+            job_out = {"skipped": "no room for the job's FASTQ file (memory limit of the container / free space): %d reads would fit" % n_job}
+        else:
+            try:
+                os.makedirs(job_dir, exist_ok=True)
+                first_check = job.get("first_reads_against_oracle")
+                job = job_fastq(src, gx, os.path.join(job_dir, "job.fq"), n_job, args.reads, args.lowq, log, read_len=args.read_len)
+                job["first_reads_against_oracle"] = first_check
+                job["wanted"] = want_job
+            except Exception as e:
+                job_out = {"skipped": "writing the job's FASTQ failed: %r" % (e,)}
+                log("[bench] job leg: %r" % (e,))
+    if src is not None:
+        src.release()
+        del src
     gx.close()
     del batches
     torch.cuda.empty_cache()
+    if rank == 0 and job_out is None and job is not None and "counts" in job:
+        try:
+            job_out = job_run(d, job_dir, job, log)
+            job_out["first_reads_against_oracle"] = job.get("first_reads_against_oracle")
+            job_out["fastq_written_in_s"] = job.get("write_s")
+            job_out["reads_wanted"] = job.get("wanted")
+        except AssertionError:
+            raise
+        except Exception as e:
+            job_out = {"skipped": "failed: %r" % (e,)}
+    if job_dir is not None:
+        import shutil
 
-    # ---- the `job` leg: one whole run of the drop-in command line on the FASTQ file written above, now that this process holds no index
-    job_out = None
-    if rank == 0 and job is not None:
-        if "counts" in job:
-            job.pop("first", None)
-            left = BUDGET_S - (time.time() - T_START)
-            if left < 90:
-                job_out = {"skipped": "time budget: %.0f s left" % left}
-            else:
-                try:
-                    job_out = job_run(d, job, log)
-                    job_out["first_reads_against_oracle"] = job.get("first_reads_against_oracle")
-                    job_out["fastq_written_in_s"] = job.get("write_s")
-                    job_out["reads_wanted"] = job.get("wanted")
-                except AssertionError:
-                    raise
-                except Exception as e:
-                    job_out = {"skipped": "failed: %r" % (e,)}
-            try:
-                os.remove(os.path.join(d, "job.fq"))
-            except OSError:
-                pass
-        else:
-            job_out = job
+        shutil.rmtree(job_dir, ignore_errors=True)
 
     # ---- secondary legs with an index of their own: child processes, one after the other, now that this one holds no index ------
     if rank == 0:
