@@ -1798,11 +1798,19 @@ static int open_impl(const char *prefix, int device, vg_index *ix)
 	if (n_snp > ssize / 16 || n_snp_aux > ssize / 78 || ssize != 16 + 16 * n_snp + 78 * n_snp_aux) return fail(VG_EIO, "%s.snp.dict: size does not match its header", prefix);
 	uint64_t rbits = 0, sbits = 0;
 	std::vector<uint64_t> rw, sw;
+	const double t_bf0 = now_s();
 	if ((rc = read_bf(pre + ".ref.bf", 1ull << 32, rbits, rw))) return rc;
 	if ((rc = read_bf(pre + ".snp.bf", ~0ull, sbits, sw))) return rc;
+	const double t_bf1 = now_s();
 	if ((rc = init_handle(ix, device))) return rc;
 	Building guard(ix);
 	PhaseClock pc(ix);
+	{
+		char line[160];
+		snprintf(line, sizeof line, "bit-vector files read %.2f s; device, streams, events %.2f s", t_bf1 - t_bf0, now_s() - t_bf1);
+		ix->open_report = line;
+		if (pc.on) fprintf(stderr, "[vargeno_hip] %s\n", line);
+	}
 	DevCols c;
 	c.n_ref = n_ref; c.n_ref_aux = n_ref_aux; c.n_snp = n_snp; c.n_snp_aux = n_snp_aux;
 	// the genome's length, from <prefix>.chrlens when `vargeno index` left one ("name length" per line): positions are 1-based over
