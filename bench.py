@@ -425,10 +425,13 @@ def job_run(d, job_dir, job, log):
 
     dump = os.path.join(job_dir, "job.counts")
     env = dict(os.environ, VARGENO_VERBOSE="1", VARGENO_DUMP_COUNTS=dump, VARGENO_PREPACK_GB="16")
+    # the device idle for a while, as a job's would be: this process has just freed 250 GB of it, and memory that another process has
+    # JUST freed is cleared by the driver at allocation (~43 GB/s; vg_index_open 9 s instead of 3: profiles/cold_start_r05.txt)
+    time.sleep(IDLE_BEFORE_CHILD_S)
     t0 = time.time()
     p = subprocess.run([BIN, "geno", "idx", os.path.join(job_dir, "job.fq"), "snps.vcf", os.path.join(job_dir, "job.vcf")], cwd=d, env=env, capture_output=True, text=True, timeout=600)
     wall = time.time() - t0
-    out = {"reads": job["reads"], "fastq_GB": job["bytes"] / 1e9, "wall_s": wall, "whole_job_reads_per_s": job["reads"] / wall, "rc": p.returncode}
+    out = {"reads": job["reads"], "fastq_GB": job["bytes"] / 1e9, "device_idle_before_s": IDLE_BEFORE_CHILD_S, "wall_s": wall, "whole_job_reads_per_s": job["reads"] / wall, "rc": p.returncode}
     if p.returncode != 0:
         out["failed"] = (p.stderr or "")[-600:]
         return out
@@ -460,6 +463,7 @@ def job_run(d, job_dir, job, log):
     return out
 
 
+IDLE_BEFORE_CHILD_S = 20.0        # seconds between this process's release of the device and a child's start (see job_run)
 T_START = time.time()
 BUDGET_S = float(os.environ.get("VG_BENCH_BUDGET_S", "1500"))
 # (estimated wall seconds, bench.py arguments) of the secondary legs that run as child processes, in this order
@@ -575,6 +579,7 @@ def run_child_leg(name, est, extra, args, ref):
            "--cleanup", "--cpu-sample", "200000", "--job-reads", "0"] + extra
     if args.workdir_given:
         cmd += ["--workdir", args.workdir]
+    time.sleep(IDLE_BEFORE_CHILD_S)                        # (the device's memory, just freed by the process before, scrubbed: see job_run)
     t0 = time.time()
     log("[bench] secondary leg %s: %s" % (name, " ".join(cmd[2:])))
     try:
@@ -635,6 +640,11 @@ def main():
     d = os.path.join(args.workdir, tag)
     prefix = os.path.join(d, "idx")
     t0 = time.time()
+    # (the chip's gather ceiling first: a child process whose 16 GiB table is freed -- and scrubbed by the driver -- long before
+    # this process allocates; memory that another process has JUST freed is cleared at allocation, ~43 GB/s: profiles/cold_start_r05.txt)
+    ceiling = None
+    if rank == 0 and not args.no_gather_probe:
+        ceiling = gather_ceiling()
     g, s, _ = synth.genome_and_snps(genome_len=args.genome, n_snps=args.snps, n_chroms=args.chroms, genotypes="hwe" if args.workload == "hg38f" else "uniform", repeats=args.repeats)
     if rank == 0:
         log("[bench] synthetic genome + SNP list: %.1fs (%d bp, %d SNPs)" % (time.time() - t0, g.total_len, len(s.pos)))
@@ -642,10 +652,6 @@ def main():
     else:
         while not os.path.exists(prefix + ".done"):
             time.sleep(1.0)
-    ceiling = None
-    if rank == 0 and not args.no_gather_probe:
-        ceiling = gather_ceiling()                        # child process, before this one holds 240 GB of the device
-
     # ---- GPU from here on --------------------------------------------------------------------------------------------------
     import torch
     import torch.distributed as dist
@@ -671,6 +677,19 @@ def main():
         n_seen = 1
 
     from vargeno_amd.api import GenoIndex, all_reduce_counts, gate_words, shard_range
+
+    # ---- the index first: resident in HBM before this process has allocated (and freed) anything else on the device, and before anything
+    #      loads the host (vg_index_open is part of what a job pays: its time and its phases go into the line; the reference binary's two
+    #      processes -- 48 GB of per-field fread each -- start after it)
+    t0 = time.time()
+    # (ranks that share a device -- the gloo rehearsals on a one-GPU box -- share its memory: each plans for an equal part)
+    sharers = (world + max(ndev, 1) - 1 - dev_index) // max(ndev, 1) if world > max(ndev, 1) else 1
+    gx = GenoIndex.open(prefix, device=dev_index, sharers=sharers)
+    t_open = time.time() - t0
+    open_report = gx.open_report
+    if rank == 0:
+        log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (t_open, gx.device_bytes / 1e9, gx.num_sites))
+        log("[bench] vg_index_open phases: %s" % open_report)
 
     # reads resident in HBM: NB batches of this rank's part of the read stream + (N > 1) one stream every rank knows
     t0 = time.time()
@@ -698,18 +717,6 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0:
         log("[bench] %d batches of %d reads generated on the device: %.1fs" % (args.batches, args.reads, time.time() - t0))
-
-    # ---- the index: resident in HBM before anything else loads the host (vg_index_open is part of what a job pays: its time and
-    #      its phases go into the line; the reference binary's two processes -- 48 GB of per-field fread each -- start after it)
-    t0 = time.time()
-    # (ranks that share a device -- the gloo rehearsals on a one-GPU box -- share its memory: each plans for an equal part)
-    sharers = (world + max(ndev, 1) - 1 - dev_index) // max(ndev, 1) if world > max(ndev, 1) else 1
-    gx = GenoIndex.open(prefix, device=dev_index, sharers=sharers)
-    t_open = time.time() - t0
-    open_report = gx.open_report
-    if rank == 0:
-        log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (t_open, gx.device_bytes / 1e9, gx.num_sites))
-        log("[bench] vg_index_open phases: %s" % open_report)
 
     # ---- the `job` leg (N = 1): its first 16 M reads now, for the oracle (they are generated again, with all the others, when the
     #      FASTQ file is written -- late, when the reference binary's processes and the oracle have left the host's memory)
