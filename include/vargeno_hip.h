@@ -158,6 +158,10 @@ int  vg_reads_process_device_gated(vg_index *ix, const uint8_t *d_bases, const u
  * character outside ACGTacgt, util.c:103) -- 48 bytes per 150 bp read where its FASTQ record has ~315.  Blocking copies: the
  * arrays are free when the call returns; the read loop is only enqueued.  VG_EBADREAD: a read of more than 31 chunks. */
 int  vg_reads_submit_packed(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads);
+/* The same for arrays in PAGE-LOCKED memory (vg_host_alloc_pinned) that the caller leaves untouched until vg_sync: the copies are
+ * asynchronous and the call returns as soon as the batch is enqueued (r05: the command line hands over the hundreds of batches it
+ * packed while the index was being opened). */
+int  vg_reads_submit_packed_async(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads);
 
 /* Same again, starting from raw FASTQ text (host memory): replaces the four fgets() + strlen of qv.cc:760-784.
  *

@@ -119,17 +119,35 @@ class CallBook {
 public:
 	CallBook(const SiteCounts &s, const std::vector<ChrLen> &chrs, CallSummary &sum)
 	{
+		// the calls themselves are independent of one another: threads, a slice of the sites each (r05: 10 M sites at 30-fold coverage
+		// are all genotyped; one thread took 0.3 s of the job's tail for them)
+		const size_t ns = s.pos.size();
+		std::vector<uint8_t> gts(ns);
+		std::vector<int> gqs(ns);
+		{
+			unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 16u));
+			if (ns < (1u << 16)) nt = 1;
+			auto work = [&](unsigned t) {
+				for (size_t i = ns * t / nt; i < ns * (t + 1) / nt; i++) {
+					const Genotype k = call_genotype(s.ref_cnt[i], s.alt_cnt[i], s.ref_freq[i], s.alt_freq[i]);
+					gts[i] = k.gt;
+					gqs[i] = k.gt == GT_NONE ? 0 : genotype_quality(k.confidence);
+				}
+			};
+			if (nt == 1) work(0);
+			else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
+		}
 		// sites ascend over the concatenated genome: walk the chromosome table alongside them
 		size_t c = 0;
 		uint64_t before = 0;                                     // bases in chromosomes 0 .. c-1
-		for (size_t i = 0; i < s.pos.size(); i++) {
+		for (size_t i = 0; i < ns; i++) {
 			const uint64_t g = s.pos[i];
 			while (c < chrs.size() && g - before > chrs[c].len) before += chrs[c++].len;
-			const Genotype k = call_genotype(s.ref_cnt[i], s.alt_cnt[i], s.ref_freq[i], s.alt_freq[i]);
+			struct { uint8_t gt; } k{gts[i]};
 			if (k.gt == GT_NONE) continue;
 			(k.gt == GT_HOM_REF ? sum.ref : k.gt == GT_HOM_ALT ? sum.alt : sum.het)++;
 			if (c == chrs.size()) continue;                      // beyond the last chromosome: no name to print it under
-			by_name_[chrs[c].name].push_back(CalledSite{g - before, (uint32_t)i, (uint8_t)k.gt, genotype_quality(k.confidence)});
+			by_name_[chrs[c].name].push_back(CalledSite{g - before, (uint32_t)i, (uint8_t)k.gt, gqs[i]});
 		}
 		// two chromosomes with one name share a key space; keep, per position, the site that comes last in genome order
 		for (auto &kv : by_name_) {
@@ -320,12 +338,21 @@ static void ordered_lines(const char *&p, const char *end, Layout &lay, const Ca
 	}
 }
 
-CallSummary write_genotyped_vcf(const SiteCounts &s, const std::vector<ChrLen> &chrlens, const std::string &vcf_in, const std::string &vcf_out)
+bool read_whole_file(const std::string &path, std::string &text)
+{
+	bool ok = false;
+	text = slurp(path, ok);
+	return ok;
+}
+
+CallSummary write_genotyped_vcf(const SiteCounts &s, const std::vector<ChrLen> &chrlens, const std::string &vcf_in, const std::string &vcf_out, const std::string *vcf_text)
 {
 	CallSummary sum;
 	const CallBook book(s, chrlens, sum);
-	bool ok = false;
-	const std::string text = slurp(vcf_in, ok);
+	bool ok = vcf_text != nullptr;
+	std::string own;
+	if (!vcf_text) own = slurp(vcf_in, ok);
+	const std::string &text = vcf_text ? *vcf_text : own;
 	if (!ok) { fprintf(stderr, "Error opening: %s . You have failed.\n", vcf_in.c_str()); return sum; }
 	FILE *out = fopen(vcf_out.c_str(), "wb");
 	if (!out) throw Error{"cannot write " + vcf_out};

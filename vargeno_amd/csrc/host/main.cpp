@@ -384,6 +384,11 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 				if (cut[(size_t)g] < cut[(size_t)g + 1]) pre[(size_t)g].reset(new PrePacker(fd, cut[(size_t)g], cut[(size_t)g + 1], pchunk, std::max(2, n_readers / ngpu), pack_threads, cap));
 		}
 	}
+	// the SNP list is read now, beside the index open (the VCF pass at the end of the job starts from its bytes)
+	std::string vcf_text;
+	bool vcf_ok = false;
+	std::thread vcf_reader([&] { vcf_ok = vgh::read_whole_file(vcf_in, vcf_text); });
+	struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } vcf_joiner{vcf_reader};
 	std::vector<vg_index *> ix((size_t)ngpu, nullptr);
 	{
 		std::vector<std::thread> th;
@@ -442,12 +447,13 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 									if (rp > 0 && link > 0) { decided = true; pack_rest = rp >= link; if (!pack_rest) pp.stop(); }
 								}
 								if (!pp.pop(pb)) break;
-								const int rc = vg_reads_submit_packed(ix[(size_t)g], pb.kmers, pb.meta, pb.offs, pb.n_reads);
+								const int rc = vg_reads_submit_packed_async(ix[(size_t)g], pb.kmers, pb.meta, pb.offs, pb.n_reads);       // (the pre-packer's page-locked memory lives until the streams have drained)
 								if (rc != VG_OK) { r.error = std::string("vg_reads_submit_packed failed: ") + vg_last_error(); pp.stop(); break; }
 								submitted += pb.n_reads;
 							}
 							pp.join();
 							if (r.error.empty() && !pp.error.empty()) r.error = pp.error;
+							if (r.error.empty() && vg_sync(ix[(size_t)g]) != VG_OK) r.error = std::string("vg_sync failed: ") + vg_last_error();      // (the copies out of the pre-packer's memory are done)
 							r.nrec = pp.records(); r.used = pp.consumed(); r.last = pp.last_record_start(); r.refused = pp.refused() ? 1 : 0;
 							done_to = pp.consumed();
 							char line[200];
@@ -528,7 +534,8 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		if (!f || fwrite(sc.ref_cnt.data(), 1, ns, f) != ns || fwrite(sc.alt_cnt.data(), 1, ns, f) != ns) { fprintf(stderr, "vargeno: cannot write %s\n", dump); return EXIT_FAILURE; }
 		fclose(f);
 	}
-	vgh::write_genotyped_vcf(sc, chrlens, vcf_in, vcf_out);
+	if (vcf_reader.joinable()) vcf_reader.join();
+	vgh::write_genotyped_vcf(sc, chrlens, vcf_in, vcf_out, vcf_ok ? &vcf_text : nullptr);
 	struct timespec t_vcf; clock_gettime(CLOCK_MONOTONIC, &t_vcf);
 	for (auto *h : ix) vg_index_close(h);
 	const double cpu = (double)(clock() - begin) / CLOCKS_PER_SEC;

@@ -61,7 +61,9 @@ struct SiteCounts {
 };
 // returns {ref calls, alt calls, het calls}
 struct CallSummary { uint64_t ref = 0, alt = 0, het = 0; };
+// vcf_text: the SNP list's bytes if the caller has read them already (the command line reads them while the index is being opened)
 CallSummary write_genotyped_vcf(const SiteCounts &s, const std::vector<ChrLen> &chrlens,
-                                const std::string &vcf_in, const std::string &vcf_out);
+                                const std::string &vcf_in, const std::string &vcf_out, const std::string *vcf_text = nullptr);
+bool read_whole_file(const std::string &path, std::string &text);
 
 }  // namespace vgh

@@ -413,8 +413,10 @@ constexpr uint32_t PACK_ROUNDS = (PACK_PIECES + 63) / 64;
 #endif
 __global__ __launch_bounds__(PACK_T * PACK_WPB) void vg_pack_kernel(const uint8_t *__restrict__ bases, const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
                                                       uint64_t n_reads_arg, uint64_t *__restrict__ pk_kmer, uint64_t *__restrict__ pk_meta, uint32_t *__restrict__ invalid_reads,
-                                                      const uint32_t *__restrict__ n_reads_dev, const uint32_t *__restrict__ gate)
+                                                      const uint32_t *__restrict__ n_reads_dev, const uint32_t *__restrict__ gate, const uint32_t TR)
 {
+	// TR: reads per tile (<= 64; the host picks it from the batch's mean read length so that a tile's text fits the LDS stream:
+	// 64 for reads of up to 160 bases, 40 for 250 bp ...; lanes beyond TR only help to fetch and pack the text)
 	// gate != nullptr: the batch comes with one gate word per read (bit c = quality character c < '8') instead of quality strings --
 	// the kernel then streams the bases only.  (With strings it fetches one line per read for the <= 4 characters a 150 bp read's
 	// gate can see: at a 150-byte stride that is every line of the quality array, nearly as much traffic again as the bases.)
@@ -422,27 +424,28 @@ __global__ __launch_bounds__(PACK_T * PACK_WPB) void vg_pack_kernel(const uint8_
 	__shared__ unsigned long long sm_bad[PACK_WPB][PACK_ROUNDS + 1];      // bit p: piece p holds a byte other than ACGTacgt
 	const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ln = threadIdx.x & 63u;
 	const uint64_t n_reads = n_reads_dev ? (uint64_t)*n_reads_dev : n_reads_arg;     // a batch framed on the device knows its size there
-	const uint64_t n_tiles = (n_reads + PACK_T - 1) / PACK_T, stride = (uint64_t)gridDim.x * PACK_WPB;
+	const uint64_t n_tiles = (n_reads + TR - 1) / TR, stride = (uint64_t)gridDim.x * PACK_WPB;
 	uint64_t t = (uint64_t)blockIdx.x * PACK_WPB + wv;
 	// a tile's own offsets (and gate words) are fetched while the tile before it is packed: one dependent wait per tile, not two
 	uint64_t off = 0, off1 = 0;
 	uint32_t gw = 0;
 	auto fetch = [&](uint64_t tile, uint64_t &o, uint64_t &o1, uint32_t &g) {
-		const uint64_t r = tile * PACK_T + ln;
+		const uint64_t r = tile * TR + ln;
 		o = o1 = 0; g = 0;
-		if (r < n_reads) { o = offsets[r]; o1 = offsets[r + 1]; if (gate) g = gate[r]; }
+		if (ln < TR && r < n_reads) { o = offsets[r]; o1 = offsets[r + 1]; if (gate) g = gate[r]; }
 	};
 	if (t < n_tiles) fetch(t, off, off1, gw);
 	for (; t < n_tiles; t += stride) {
-		const uint64_t r0 = t * PACK_T, r = r0 + ln;
-		const uint32_t last = (uint32_t)((r0 + PACK_T < n_reads ? r0 + PACK_T : n_reads) - r0) - 1u;     // last live lane of the tile
+		const uint64_t r0 = t * TR;
+		const uint64_t r = ln < TR ? r0 + ln : n_reads;                                                    // (lanes beyond the tile have no read)
+		const uint32_t last = (uint32_t)((r0 + TR < n_reads ? r0 + TR : n_reads) - r0) - 1u;               // last live lane of the tile
 		const uint64_t base0 = __shfl(off, 0), span = __shfl(off1, (int)last) - base0;
 		uint64_t noff = 0, noff1 = 0;
 		uint32_t ngw = 0;
 		if (t + stride < n_tiles) fetch(t + stride, noff, noff1, ngw);
 		const uint32_t n = (uint32_t)((off1 - off) >> 5);
 		uint32_t q4 = 0;
-		if (!gate && n) __builtin_memcpy(&q4, quals + off, 4);           // 4 <= n + 3 <= the read's own length: never past it
+		if (!gate && n && r < n_reads) __builtin_memcpy(&q4, quals + off, 4);           // 4 <= n + 3 <= the read's own length: never past it
 		// aligned 16-byte pieces: a piece that holds a byte of the text lies in that byte's page, so the first and the last piece
 		// may reach past the text (a batch may start at any byte)
 		const uint64_t a_text = (uint64_t)(bases + base0);
@@ -1939,7 +1942,7 @@ static int finish_pending(vg_index *ix)
 // n_reads: the batch's size, or (d_n_reads given) an upper bound of the size the device holds at d_n_reads
 // packed: the batch is already packed (sl.pk_kmer / sl.pk_meta hold it, d_offsets = 32 x chunks before each read): no pack kernel
 template <bool STATS>
-static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint32_t *d_gate, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on, const uint32_t *d_n_reads, const bool packed)
+static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const uint8_t *d_quals, const uint32_t *d_gate, const uint64_t *d_offsets, uint64_t n_reads, hipStream_t produced_on, const uint32_t *d_n_reads, const bool packed, const uint64_t total_bases)
 {
 	uint32_t *ctr = sl.ctr;
 	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
@@ -1955,10 +1958,13 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipMemsetAsync(ctr, 0, 64, ps));
 		HIP_TRY(hipEventRecord(sl.e0, ps));
 		static const int pack_bpc = getenv("VG_PACK_BPC") ? std::max(1, atoi(getenv("VG_PACK_BPC"))) : 16;          // workgroups (of PACK_WPB tiles at a time) per CU
-		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + PACK_T * PACK_WPB - 1) / (PACK_T * PACK_WPB), (uint64_t)ix->cus * pack_bpc);
+		// reads per tile of the pack kernel: as many as the mean read length lets fit its LDS stream (64 up to 160 bases)
+		const uint64_t mean_len = n_reads ? (total_bases + n_reads - 1) / n_reads : 1;
+		const uint32_t pack_tr = (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(PACK_T, (uint64_t)PACK_T * PACK_MAXLEN / std::max<uint64_t>(mean_len, 1)));
+		const unsigned pgrid = (unsigned)std::min<uint64_t>((n_reads + (uint64_t)pack_tr * PACK_WPB - 1) / ((uint64_t)pack_tr * PACK_WPB), (uint64_t)ix->cus * pack_bpc);
 		const bool fused = VG_FUSE_PACK && !packed && !getenv("VG_NO_FUSE");          // the main tier encodes the reads itself (experiment)
 		const FuseIn fin{fused ? d_bases : nullptr, d_quals, d_gate, &ctr[3]}, nofuse{nullptr, nullptr, nullptr, nullptr};
-		if (!packed && !fused) vg_pack_kernel<<<pgrid, PACK_T * PACK_WPB, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate);
+		if (!packed && !fused) vg_pack_kernel<<<pgrid, PACK_T * PACK_WPB, 0, ps>>>(d_bases, d_quals, d_offsets, n_reads, sl.pk_kmer, sl.pk_meta, &ctr[3], d_n_reads, d_gate, pack_tr);
 		HIP_TRY(hipEventRecord(sl.e1, ps));
 		if (ps != ix->stream) HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e1, 0));
 		// The previous batch's deep-list tier (tail stream) runs under this batch's pack kernel and, for what is left of it,
@@ -2042,8 +2048,9 @@ static int launch_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const ui
 		for (uint32_t **l : lists) HIP_TRY(hipMalloc((void **)l, (size_t)n_reads * 4));
 		sl.list_cap = n_reads;
 	}
-	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads, false)
-	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads, false);
+	const uint64_t tb = d_n_reads ? 0ull : total;                // (a batch framed on the device: sizes are upper bounds, the mean length is unknown here)
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads, false, tb)
+	                         : enqueue_batch<false>(ix, sl, d_bases, d_quals, d_gate, d_offsets, n_reads, produced_on, d_n_reads, false, tb);
 }
 
 extern "C" int vg_reads_process_device(vg_index *ix, const uint8_t *d_bases, const uint8_t *d_quals, const uint64_t *d_offsets, uint64_t n_reads)
@@ -2100,35 +2107,59 @@ static int launch_packed(vg_index *ix, Slot &sl, const uint64_t *kmers, const ui
 		HIP_TRY(hipMemcpy(sl.pk_meta, meta, n_reads * 8, hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(sl.st_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice));
 	}
-	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr, true)
-	                         : enqueue_batch<false>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr, true);
+	return ix->stats_enabled ? enqueue_batch<true>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr, true, 0)
+	                         : enqueue_batch<false>(ix, sl, nullptr, nullptr, nullptr, sl.st_offsets, n_reads, copy_on, nullptr, true, 0);
 }
 
+// pinned: the caller's arrays are page-locked and stay untouched until vg_sync -- the copies are asynchronous (ingest stream) and
+// the call returns as soon as the batch is enqueued (vg_reads_submit_packed_async: a caller that packed a whole file ahead of the
+// index hands over hundreds of batches; with blocking copies each cost ~10 ms of the host's time)
+static int submit_packed_impl(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads, bool pinned)
+{
+	HIP_TRY(hipSetDevice(ix->device));
+	if (chunk_offsets[0] != 0) return fail(VG_EINVAL, "chunk_offsets[0] must be 0");
+	uint64_t invalid = 0, bad = 0;
+	for (uint64_t i = 0; i < n_reads; i++) {                     // (branch-free: one pass over three arrays, the compiler vectorises it)
+		const uint64_t d = chunk_offsets[i + 1] - chunk_offsets[i];
+		bad |= (chunk_offsets[i + 1] < chunk_offsets[i] ? 1ull : 0ull) | (d > 31 ? 2ull : 0ull) | ((meta[i] & 0x3FFFFFFF00000000ull) ? 4ull : 0ull);
+		invalid += meta[i] >> 63;
+	}
+	if (bad & 1ull) return fail(VG_EINVAL, "chunk offsets not monotone");
+	if (bad & 2ull) return fail(VG_EBADREAD, "a packed read of more than 31 chunks (a FASTQ line the reference can read holds at most 1022 bases, qv.cc:700)");
+	if (bad & 4ull) return fail(VG_EINVAL, "a packed read's flag word has reserved bits set (bits 0-31: gate bits, 62: N inside the read, 63: another character; nothing else)");
+	const uint64_t n_chunks = chunk_offsets[n_reads];
+	if (n_chunks && !kmers) return fail(VG_EINVAL, "null argument");
+	Slot *sl = nullptr;
+	int rc = acquire_slot(ix, &sl);
+	if (rc) return rc;
+	// the flat-batch offsets of the trimmed reads (32 x chunks before each), in the slot's page-locked staging
+	if (n_reads + 1 > sl->hp_reads_cap) {
+		if (sl->hp_meta) (void)hipHostFree(sl->hp_meta);
+		if (sl->hp_offsets) (void)hipHostFree(sl->hp_offsets);
+		sl->hp_meta = sl->hp_offsets = nullptr; sl->hp_reads_cap = 0;
+		const uint64_t cap = (n_reads + 1) * 5 / 4;
+		if (hipHostMalloc((void **)&sl->hp_meta, cap * 8, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&sl->hp_offsets, cap * 8, hipHostMallocDefault) != hipSuccess)
+			return fail(VG_ENOMEM, "hipHostMalloc(packed staging) failed");
+		sl->hp_reads_cap = cap;
+	}
+	for (uint64_t i = 0; i <= n_reads; i++) sl->hp_offsets[i] = 32 * chunk_offsets[i];
+	hipStream_t is = ix->ingest_stream ? ix->ingest : ix->stream;
+	rc = launch_packed(ix, *sl, kmers, meta, sl->hp_offsets, n_reads, n_chunks, is);
+	if (rc == VG_OK && !pinned) HIP_TRY(hipStreamSynchronize(is));          // the caller's arrays are free again
+	if (rc == VG_OK) ix->host_invalid += invalid;
+	return rc;
+}
 extern "C" int vg_reads_submit_packed(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads)
 {
 	if (!ix || !chunk_offsets || (n_reads && !meta)) return fail(VG_EINVAL, "null argument");
 	if (n_reads == 0) return VG_OK;
-	return guarded([&]() -> int {
-		HIP_TRY(hipSetDevice(ix->device));
-		if (chunk_offsets[0] != 0) return fail(VG_EINVAL, "chunk_offsets[0] must be 0");
-		uint64_t invalid = 0;
-		for (uint64_t i = 0; i < n_reads; i++) {
-			if (chunk_offsets[i + 1] < chunk_offsets[i]) return fail(VG_EINVAL, "chunk offsets not monotone");
-			if (chunk_offsets[i + 1] - chunk_offsets[i] > 31) return fail(VG_EBADREAD, "a packed read of more than 31 chunks (a FASTQ line the reference can read holds at most 1022 bases, qv.cc:700)");
-			if (meta[i] & 0x3FFFFFFF00000000ull) return fail(VG_EINVAL, "a packed read's flag word has reserved bits set (bits 0-31: gate bits, 62: N inside the read, 63: another character; nothing else)");
-			invalid += (meta[i] >> 63) & 1u;
-		}
-		const uint64_t n_chunks = chunk_offsets[n_reads];
-		if (n_chunks && !kmers) return fail(VG_EINVAL, "null argument");
-		std::vector<uint64_t> off(n_reads + 1);
-		for (uint64_t i = 0; i <= n_reads; i++) off[i] = 32 * chunk_offsets[i];       // the flat-batch offsets of the trimmed reads
-		Slot *sl = nullptr;
-		int rc = acquire_slot(ix, &sl);
-		if (rc) return rc;
-		rc = launch_packed(ix, *sl, kmers, meta, off.data(), n_reads, n_chunks, nullptr);
-		if (rc == VG_OK) ix->host_invalid += invalid;
-		return rc;
-	});
+	return guarded([&]() -> int { return submit_packed_impl(ix, kmers, meta, chunk_offsets, n_reads, false); });
+}
+extern "C" int vg_reads_submit_packed_async(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads)
+{
+	if (!ix || !chunk_offsets || (n_reads && !meta)) return fail(VG_EINVAL, "null argument");
+	if (n_reads == 0) return VG_OK;
+	return guarded([&]() -> int { return submit_packed_impl(ix, kmers, meta, chunk_offsets, n_reads, true); });
 }
 
 static int submit_impl(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads);
