@@ -168,7 +168,7 @@ public:
 	{
 		stop();
 		if (th_.joinable()) th_.join();
-		for (void *p : pieces_) vg_host_free_pinned(p);
+		if (!keep_) for (void *p : pieces_) vg_host_free_pinned(p);
 	}
 	void stop() { stop_.store(true); std::lock_guard<std::mutex> g(mu_); cv_.notify_all(); }
 	// the next batch in file order; false: there are no more (the pre-packer has finished, stopped, run out of room or been refused)
@@ -188,6 +188,8 @@ public:
 	bool refused() const { return refused_; }
 	uint64_t invalid() const { return invalid_; }
 	double text_bytes_per_s() const { const double t = pack_s_.load(); return t > 0 ? (double)packed_text_.load() / t : 0.0; }
+	uint64_t text_bytes_done() const { return packed_text_.load(); }
+	void keep_memory() { keep_ = true; }             // the process is about to end: releasing gigabytes of page-locked memory piece by piece (~0.15 s per GB) is left to the exit
 	std::string error;
 private:
 	uint64_t *slab(uint64_t words)                    // page-locked memory for a batch's arrays, out of pieces of up to 1 GiB; nullptr: the cap is reached
@@ -289,7 +291,7 @@ private:
 	std::vector<PackedBatch> q_; size_t next_out_ = 0; bool done_ = false;
 	std::vector<void *> pieces_; uint64_t piece_used_ = 0;
 	uint64_t records_ = 0, consumed_ = 0, last_ = 0, invalid_ = 0;
-	bool refused_ = false, lost_last_ = false;
+	bool refused_ = false, lost_last_ = false, keep_ = false;
 	std::atomic<double> pack_s_{0.0}; std::atomic<uint64_t> packed_text_{0};
 };
 
@@ -443,8 +445,15 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 							PackedBatch pb;
 							for (;;) {
 								if (!decided) {
+									// the packer keeps the rest of the range unless the device-side framing would finish it at least a second
+									// earlier (changing horses costs about that much: a new stream, its readers starting cold)
 									const double rp = pp.text_bytes_per_s();
-									if (rp > 0 && link > 0) { decided = true; pack_rest = rp >= link; if (!pack_rest) pp.stop(); }
+									if (rp > 0 && link > 0) {
+										decided = true;
+										const double left = (double)(cut[(size_t)g + 1] - cut[(size_t)g]) - (double)pp.text_bytes_done();
+										pack_rest = rp >= link || left * (1.0 / rp - 1.0 / link) < 1.0;
+										if (!pack_rest) pp.stop();
+									}
 								}
 								if (!pp.pop(pb)) break;
 								const int rc = vg_reads_submit_packed_async(ix[(size_t)g], pb.kmers, pb.meta, pb.offs, pb.n_reads);       // (the pre-packer's page-locked memory lives until the streams have drained)
@@ -490,6 +499,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 				host_from = 0;
 			}
 		}
+		for (auto &pp : pre) if (pp) pp->keep_memory();
 		pre.clear();
 		close(fd);
 	}

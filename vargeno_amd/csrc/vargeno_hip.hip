@@ -807,7 +807,7 @@ struct Slot {
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
 	uint32_t *h_ctr = nullptr;            // page-locked copy of ctr[0..3], made on the tail stream when the batch's tiers are done
 	// what the generic lane tier needs should the deep tier leave reads behind: it is only launched then (harvest), never empty
-	const uint8_t *lt_bases = nullptr, *lt_quals = nullptr; const uint64_t *lt_offsets = nullptr; const uint32_t *lt_gate = nullptr; bool lt_packed = false, lt_stats = false;
+	const uint8_t *lt_bases = nullptr, *lt_quals = nullptr; const uint64_t *lt_offsets = nullptr; const uint32_t *lt_gate = nullptr; bool lt_packed = false, lt_stats = false, lt_enqueued = false;
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
 	uint32_t *st_gate = nullptr; uint64_t st_gate_cap = 0;                              // gate words of a batch framed on the device
@@ -845,6 +845,7 @@ struct vg_index {
 	ScratchBuf mid, big;                  // lane-tier scratch: every lane x 64 contexts; a few lanes x 16384 contexts
 	Slot slot[NSLOT];
 	int next_slot = 0;
+	bool lane_tier_seen = false;          // some batch of this handle left reads for the lane tier: it is enqueued with every batch from then on
 	uint64_t cum[4] = {0, 0, 0, 0};       // since reset: [0] wave-tier overflow, [1] lane-tier overflow, [2] lost, [3] reads with a character other than ACGTN
 	uint8_t *d_clamped = nullptr;         // [2 * n_sites] staging of vg_counts_fetch: min(63, sum), ref counts then alt counts
 	unsigned long long *d_stats = nullptr;
@@ -1899,7 +1900,8 @@ static int harvest(vg_index *ix, Slot &sl)
 {
 	if (!sl.busy) return VG_OK;
 	HIP_TRY(hipEventSynchronize(sl.e3));
-	if (sl.h_ctr[1]) {
+	if (sl.h_ctr[1]) ix->lane_tier_seen = true;
+	if (sl.h_ctr[1] && !sl.lt_enqueued) {
 		// the deep tier left reads behind (listB): the lane machine with its lists in HBM finishes them now
 		if (sl.lt_stats) vg_lane_kernel<true><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
 		else vg_lane_kernel<false><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
@@ -2007,7 +2009,12 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 	// reads behind (0-5 reads per 8 M at hg38 scale, mostly none).  Through r04 the kernel was enqueued unconditionally: 64 workgroups
 	// that exit at once, but can only be PLACED when workgroups of the next batch's main tier retire -- 1.7-3.7 ms during which the
 	// batch's slot stayed busy, and 2-4 ms at the end of every job.
+	// (a workload whose batches DO leave reads for the lane tier -- long reads, tiny list capacities in the tests -- gets the kernel
+	// enqueued behind the deep tier as before, from the first batch that showed it on: a launch at harvest time would stall the host
+	// and the tail stream once per batch)
 	sl.lt_bases = d_bases; sl.lt_quals = d_quals; sl.lt_offsets = d_offsets; sl.lt_gate = d_gate; sl.lt_packed = packed; sl.lt_stats = STATS;
+	sl.lt_enqueued = ix->lane_tier_seen;
+	if (sl.lt_enqueued) vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
 	HIP_TRY(hipMemcpyAsync(sl.h_ctr, ctr, 16, hipMemcpyDeviceToHost, ix->tail));
 	HIP_TRY(hipEventRecord(sl.e3, ix->tail));
 	HIP_TRY(hipGetLastError());
