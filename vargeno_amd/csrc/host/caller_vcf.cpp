@@ -15,6 +15,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <map>
@@ -138,7 +140,8 @@ public:
 			else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t); for (auto &x : th) x.join(); }
 		}
 		// sites ascend over the concatenated genome: walk the chromosome table alongside them
-		size_t c = 0;
+		size_t c = 0, c_of_list = SIZE_MAX;
+		std::vector<CalledSite> *list = nullptr;                 // by_name_[chrs[c].name], looked up once per chromosome
 		uint64_t before = 0;                                     // bases in chromosomes 0 .. c-1
 		for (size_t i = 0; i < ns; i++) {
 			const uint64_t g = s.pos[i];
@@ -147,7 +150,8 @@ public:
 			if (k.gt == GT_NONE) continue;
 			(k.gt == GT_HOM_REF ? sum.ref : k.gt == GT_HOM_ALT ? sum.alt : sum.het)++;
 			if (c == chrs.size()) continue;                      // beyond the last chromosome: no name to print it under
-			by_name_[chrs[c].name].push_back(CalledSite{g - before, (uint32_t)i, (uint8_t)k.gt, gqs[i]});
+			if (c != c_of_list) { list = &by_name_[chrs[c].name]; c_of_list = c; list->reserve(list->size() + (ns - i) / 4); }
+			list->push_back(CalledSite{g - before, (uint32_t)i, (uint8_t)k.gt, gqs[i]});
 		}
 		// two chromosomes with one name share a key space; keep, per position, the site that comes last in genome order
 		for (auto &kv : by_name_) {
@@ -165,7 +169,10 @@ public:
 	// The reference compares the strings  name + "$" + decimal(position)  and  chrom + "$" + POS-column.  A decimal number
 	// holds no '$', so the two are equal exactly when the text after the LAST '$' of the right-hand side is the canonical
 	// decimal form of the position and the text before it is the name.
-	const CalledSite *find(const std::string &key) const
+	// (a SNP list is nearly always sorted: the caller's Hint remembers the list of the last name and the place of the last hit in
+	// it, and the search gallops forward from there; any other order merely falls back to the full search)
+	struct Hint { std::string name; const std::vector<CalledSite> *list = nullptr; size_t at = 0; };
+	const CalledSite *find(const std::string &key, Hint &h) const
 	{
 		const size_t cut = key.rfind('$');
 		const char *d = key.c_str() + cut + 1;
@@ -173,11 +180,26 @@ public:
 		if (nd == 0 || nd > 19 || (d[0] == '0' && nd > 1)) return nullptr;
 		uint64_t v = 0;
 		for (size_t i = 0; i < nd; i++) { if (d[i] < '0' || d[i] > '9') return nullptr; v = v * 10 + (uint64_t)(d[i] - '0'); }
-		const auto it = by_name_.find(key.substr(0, cut));
-		if (it == by_name_.end()) return nullptr;
-		const std::vector<CalledSite> &list = it->second;
-		const auto at = std::lower_bound(list.begin(), list.end(), v, [](const CalledSite &a, uint64_t x) { return a.local < x; });
-		return at != list.end() && at->local == v ? &*at : nullptr;
+		if (!(h.list && h.name.size() == cut && key.compare(0, cut, h.name) == 0)) {
+			h.name.assign(key, 0, cut);
+			const auto it = by_name_.find(h.name);
+			h.list = it == by_name_.end() ? nullptr : &it->second;
+			h.at = 0;
+		}
+		if (!h.list) return nullptr;
+		const std::vector<CalledSite> &list = *h.list;
+		auto lo = list.begin(), hi = list.end();
+		if (h.at < list.size() && list[h.at].local <= v) {
+			// gallop: the answer is at or after the last hit
+			size_t step = 1, a = h.at;
+			while (a + step < list.size() && list[a + step].local < v) { a += step; step *= 2; }
+			lo = list.begin() + (ptrdiff_t)a;
+			hi = list.begin() + (ptrdiff_t)std::min(list.size(), a + step + 1);
+		}
+		const auto at = std::lower_bound(lo, hi, v, [](const CalledSite &a, uint64_t x) { return a.local < x; });
+		if (at == list.end() || at->local != v) return nullptr;
+		h.at = (size_t)(at - list.begin());
+		return &*at;
 	}
 
 private:
@@ -222,17 +244,18 @@ const char *gt_text(uint8_t gt) { return gt == GT_HET ? "0/1" : gt == GT_HOM_ALT
 
 // One data line -> `out` (nothing if its key names no called site).  Returns false if the layout's slots are still open
 // and this record would have to settle them (the caller does that on one thread, in file order).
-bool annotate(Span line, const CallBook &book, const Layout &lay, bool may_settle, Layout *settled, std::string &out)
+struct Scratch { std::string key, fmt, smp; CallBook::Hint hint; };           // one per thread: no allocation per line
+bool annotate(Span line, const CallBook &book, const Layout &lay, bool may_settle, Layout *settled, std::string &out, Scratch &sc)
 {
 	const size_t nf = count_fields(line, '\t');
 	if (nf < 2) return true;
 	const Span chrom = field(line, '\t', 0), pos = field(line, '\t', 1);
-	std::string key;
-	key.reserve(chrom.size() + pos.size() + 4);
+	std::string &key = sc.key;
+	key.clear();
 	if (chrom.size() == 0 || chrom.b[0] != 'c') key = "chr";
 	key.append(chrom.b, chrom.e).push_back('$');
 	key.append(pos.b, pos.e);
-	const CalledSite *site = book.find(key);
+	const CalledSite *site = book.find(key, sc.hint);
 	if (!site) return true;
 
 	const bool in_place = lay.sample_columns && nf >= 10;      // rewrite fields 8 and 9; otherwise append two fields
@@ -251,7 +274,8 @@ bool annotate(Span line, const CallBook &book, const Layout &lay, bool may_settl
 	char gq_text[16];
 	snprintf(gq_text, sizeof gq_text, "%d", site->gq);
 
-	std::string fmt, smp;
+	std::string &fmt = sc.fmt, &smp = sc.smp;
+	fmt.clear(); smp.clear();
 	size_t n_sub = 0;
 	if (in_place) {
 		const Span f8 = field(line, '\t', 8), f9 = field(line, '\t', 9);
@@ -322,7 +346,8 @@ static void ordered_lines(const char *&p, const char *end, Layout &lay, const Ca
 		if (ln.b[0] != '#') {
 			const bool slots_open = (lay.declares_gt && lay.gt_slot < 0) || (lay.declares_gq && lay.gq_slot < 0);
 			if (!slots_open) { p = at; return; }
-			annotate(ln, book, lay, true, &lay, dst);
+			Scratch sc;
+			annotate(ln, book, lay, true, &lay, dst, sc);
 		} else if (ln.size() > 1 && ln.b[1] == '#') {
 			dst.append(ln.b, ln.e).push_back('\n');
 			const std::string meta(ln.b, ln.e);
@@ -348,11 +373,17 @@ bool read_whole_file(const std::string &path, std::string &text)
 CallSummary write_genotyped_vcf(const SiteCounts &s, const std::vector<ChrLen> &chrlens, const std::string &vcf_in, const std::string &vcf_out, const std::string *vcf_text)
 {
 	CallSummary sum;
+	const bool clocks = getenv("VARGENO_VCF_CLOCKS") != nullptr;
+	struct timespec c0, c1, c2; clock_gettime(CLOCK_MONOTONIC, &c0);
+	double t_annot = 0, t_write = 0;
+	auto lap = [](const timespec &a, const timespec &b) { return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec); };
 	const CallBook book(s, chrlens, sum);
+	clock_gettime(CLOCK_MONOTONIC, &c1);
 	bool ok = vcf_text != nullptr;
 	std::string own;
 	if (!vcf_text) own = slurp(vcf_in, ok);
 	const std::string &text = vcf_text ? *vcf_text : own;
+	struct timespec c1b; clock_gettime(CLOCK_MONOTONIC, &c1b);
 	if (!ok) { fprintf(stderr, "Error opening: %s . You have failed.\n", vcf_in.c_str()); return sum; }
 	FILE *out = fopen(vcf_out.c_str(), "wb");
 	if (!out) throw Error{"cannot write " + vcf_out};
@@ -386,8 +417,10 @@ CallSummary write_genotyped_vcf(const SiteCounts &s, const std::vector<ChrLen> &
 		std::vector<std::string> piece(nt), err(nt);
 		auto work = [&](unsigned t) {
 			const char *q = cut[t], *const e = cut[t + 1];
+			piece[t].reserve((size_t)(e - q) + (size_t)(e - q) / 4 + 4096);          // (a line grows by ~":GT:GQ" + the two values)
+			Scratch sc;
 			try {
-				while (q < e) { const Span ln = next_line(q, e); if (ln.size()) annotate(ln, book, lay, false, nullptr, piece[t]); }
+				while (q < e) { const Span ln = next_line(q, e); if (ln.size()) annotate(ln, book, lay, false, nullptr, piece[t], sc); }
 			} catch (const Error &x) { err[t] = x.msg; }
 		};
 		if (nt == 1) work(0);
@@ -397,10 +430,14 @@ CallSummary write_genotyped_vcf(const SiteCounts &s, const std::vector<ChrLen> &
 			for (auto &x : th) x.join();
 		}
 		for (unsigned t = 0; t < nt; t++) if (!err[t].empty()) { fclose(out); throw Error{err[t]}; }
-		for (unsigned t = 0; t < nt; t++) fwrite(piece[t].data(), 1, piece[t].size(), out);
+		clock_gettime(CLOCK_MONOTONIC, &c2);
+		for (unsigned t = 0; t < nt; t++) fwrite(piece[t].data(), 1, piece[t].size(), out);          // (positioned writes by several threads are slower: one inode lock)
+		struct timespec c3; clock_gettime(CLOCK_MONOTONIC, &c3);
+		t_write += lap(c2, c3);
 		p = stop;
 	}
 	if (fclose(out) != 0) throw Error{"cannot write " + vcf_out};
+	if (clocks) { struct timespec c4; clock_gettime(CLOCK_MONOTONIC, &c4); t_annot = lap(c1b, c4) - t_write; fprintf(stderr, "vcf: calls + book %.3f s, SNP list read %.3f s, lines %.3f s, write %.3f s\n", lap(c0, c1), lap(c1, c1b), t_annot, t_write); }
 	return sum;
 }
 
