@@ -424,7 +424,7 @@ def job_run(d, job_dir, job, log):
     import re
 
     dump = os.path.join(job_dir, "job.counts")
-    env = dict(os.environ, VARGENO_VERBOSE="1", VARGENO_DUMP_COUNTS=dump, VARGENO_PREPACK_GB="16")
+    env = dict(os.environ, VARGENO_VERBOSE="1", VARGENO_DUMP_COUNTS=dump, VARGENO_PREPACK_GB="16", VARGENO_VCF_CLOCKS="1")
     # the device idle for a while, as a job's would be: this process has just freed 250 GB of it, and memory that another process has
     # JUST freed is cleared by the driver at allocation (~43 GB/s; vg_index_open 9 s instead of 3: profiles/cold_start_r05.txt)
     time.sleep(IDLE_BEFORE_CHILD_S)
@@ -444,6 +444,14 @@ def job_run(d, job_dir, job, log):
             out["ingest_route"] = ln[len("ingest, replica 0:"):].strip()
         if ln.startswith("index start-up:"):
             out["index_open_phases"] = ln[len("index start-up:"):].strip()
+        if ln.startswith("vcf:"):
+            out["call_vcf_phases"] = ln[4:].strip()
+        if ln.startswith("process: alive for"):
+            # the child's own clocks: before main() (loader, runtime start-up) and after its last line (the operating system
+            # taking the process apart: page-locked memory unpinned, 240 GB of device memory unmapped)
+            alive = float(ln.split()[3])
+            out["before_main_s"] = max(0.0, alive - out.get("cli_wall_s", alive))
+            out["exit_teardown_s"] = max(0.0, wall - alive)
     cnt = np.fromfile(dump, dtype=np.uint8)
     rc, ac = job["counts"]
     ns = len(rc)

@@ -162,15 +162,37 @@ public:
 		: fd_(fd), lo_(lo), hi_(hi), chunk_(chunk), n_readers_(n_readers), pack_threads_(pack_threads), cap_(cap_bytes),
 		  piece_bytes_(std::max<uint64_t>(16ull << 20, std::min<uint64_t>(1ull << 30, (hi - lo) / 4 + (8ull << 20))))          // (packed reads are ~1/6 of their text: a small file gets a small buffer)
 	{
+		clock_gettime(CLOCK_MONOTONIC, &born_);
+		// page-locking memory costs ~0.15 s per GB: a thread of its own gets the pieces ready ahead of the packer (as many as the
+		// file will need: packed reads are ~1/6 of their text), so that the packer's thread never waits for the driver
+		const uint64_t est = std::min<uint64_t>(cap_, (hi - lo) / 6 + piece_bytes_);
+		alloc_th_ = std::thread([this, est] {
+			uint64_t made = 0;
+			for (;;) {
+				{
+					std::unique_lock<std::mutex> g(amu_);
+					acv_.wait(g, [&] { return astop_ || ((made < est || ready_.size() < 1) && held_ + piece_bytes_ <= cap_); });
+					if (astop_) return;
+				}
+				void *p = vg_host_alloc_pinned((size_t)piece_bytes_);
+				std::lock_guard<std::mutex> g(amu_);
+				if (!p) { afail_ = true; acv_.notify_all(); return; }
+				all_pieces_.push_back(p); ready_.push_back(p); held_ += piece_bytes_; made += piece_bytes_;
+				acv_.notify_all();
+			}
+		});
 		th_ = std::thread([this] { run(); });
 	}
 	~PrePacker()
 	{
 		stop();
 		if (th_.joinable()) th_.join();
-		if (!keep_) for (void *p : pieces_) vg_host_free_pinned(p);
+		{ std::lock_guard<std::mutex> g(amu_); astop_ = true; acv_.notify_all(); }
+		if (alloc_th_.joinable()) alloc_th_.join();
+		if (!keep_) for (void *p : all_pieces_) vg_host_free_pinned(p);
 	}
 	void stop() { stop_.store(true); std::lock_guard<std::mutex> g(mu_); cv_.notify_all(); }
+	double finished_after_s() const { return finished_s_.load(); }           // seconds from construction to the last batch (0: still running)
 	// the next batch in file order; false: there are no more (the pre-packer has finished, stopped, run out of room or been refused)
 	bool pop(PackedBatch &b)
 	{
@@ -194,12 +216,27 @@ public:
 private:
 	uint64_t *slab(uint64_t words)                    // page-locked memory for a batch's arrays, out of pieces of up to 1 GiB; nullptr: the cap is reached
 	{
-		const uint64_t bytes = words * 8, PIECE = std::max<uint64_t>(piece_bytes_, (bytes + 63) & ~63ull);
+		const uint64_t bytes = words * 8;
 		if (pieces_.empty() || piece_used_ + bytes > piece_cap_) {
-			if (held_ + PIECE > cap_) return nullptr;
-			void *p = vg_host_alloc_pinned((size_t)PIECE);
-			if (!p) return nullptr;
-			pieces_.push_back(p); piece_used_ = 0; piece_cap_ = PIECE; held_ += PIECE;
+			void *p = nullptr;
+			uint64_t PIECE = piece_bytes_;
+			std::unique_lock<std::mutex> g(amu_);
+			if (bytes > piece_bytes_) {                                      // (an array larger than a piece: a piece of its own, made here)
+				PIECE = (bytes + 63) & ~63ull;
+				if (held_ + PIECE > cap_) return nullptr;
+				g.unlock();
+				p = vg_host_alloc_pinned((size_t)PIECE);
+				if (!p) return nullptr;
+				g.lock();
+				all_pieces_.push_back(p); held_ += PIECE;
+			} else {
+				acv_.notify_all();
+				acv_.wait(g, [&] { return !ready_.empty() || afail_ || held_ + piece_bytes_ > cap_; });
+				if (ready_.empty()) return nullptr;                          // the cap is reached (or the driver refused)
+				p = ready_.front(); ready_.erase(ready_.begin());
+				acv_.notify_all();
+			}
+			pieces_.push_back(p); piece_used_ = 0; piece_cap_ = PIECE;
 		}
 		uint64_t *r = (uint64_t *)((uint8_t *)pieces_.back() + piece_used_);
 		piece_used_ += (bytes + 63) & ~63ull;
@@ -261,7 +298,8 @@ private:
 				PackedBatch pb;
 				pb.kmers = slab(nc + 1); pb.meta = slab(nr); pb.offs = slab(nr + 1);
 				if (!pb.kmers || !pb.meta || !pb.offs) { out_of_room = true; lost_last_ = true; break; }   // (this chunk's records are dropped with it: the stream is re-framed from the last batch that was kept)
-				memcpy(pb.kmers, sk.data(), (size_t)nc * 8); memcpy(pb.meta, sm.data(), (size_t)nr * 8); memcpy(pb.offs, so.data(), (size_t)(nr + 1) * 8);
+				// (one thread copies ~6 GB/s into fresh page-locked memory: a 30x file's 30 GB would take longer than the index's start-up)
+				par_copy(pb.kmers, sk.data(), nc * 8, pb.meta, sm.data(), nr * 8, pb.offs, so.data(), (nr + 1) * 8);
 				pb.n_reads = nr; pb.n_chunks = nc;
 				invalid_ += ninv;
 				uint64_t rec = 0, cons = 0, last = 0; int ref = 0;
@@ -282,10 +320,41 @@ private:
 		vg_packer_destroy(pk);
 		finish();
 	}
-	void finish() { std::lock_guard<std::mutex> g(mu_); done_ = true; cv_.notify_all(); }
+	void finish()
+	{
+		struct timespec now; clock_gettime(CLOCK_MONOTONIC, &now);
+		finished_s_.store((double)(now.tv_sec - born_.tv_sec) + 1e-9 * (double)(now.tv_nsec - born_.tv_nsec));
+		std::lock_guard<std::mutex> g(mu_); done_ = true; cv_.notify_all();
+	}
+	// three arrays copied by a few threads, each taking an equal share of the bytes
+	void par_copy(void *d0, const void *s0, uint64_t n0, void *d1, const void *s1, uint64_t n1, void *d2, const void *s2, uint64_t n2)
+	{
+		const uint64_t total = n0 + n1 + n2;
+		const unsigned nt = total < (8u << 20) ? 1u : (unsigned)std::max(1, std::min(8, pack_threads_));
+		auto part = [&](unsigned t) {
+			uint64_t a = total * t / nt, b = total * (t + 1) / nt;                     // bytes [a, b) of the three arrays laid end to end
+			const uint64_t n[3] = {n0, n1, n2};
+			uint8_t *d[3] = {(uint8_t *)d0, (uint8_t *)d1, (uint8_t *)d2};
+			const uint8_t *s[3] = {(const uint8_t *)s0, (const uint8_t *)s1, (const uint8_t *)s2};
+			uint64_t base = 0;
+			for (int k = 0; k < 3; k++) {
+				const uint64_t lo = std::max(a, base), hi = std::min(b, base + n[k]);
+				if (lo < hi) memcpy(d[k] + (lo - base), s[k] + (lo - base), (size_t)(hi - lo));
+				base += n[k];
+			}
+		};
+		if (nt == 1) { part(0); return; }
+		std::vector<std::thread> th;
+		for (unsigned t = 1; t < nt; t++) th.emplace_back(part, t);
+		part(0);
+		for (auto &x : th) x.join();
+	}
 	const int fd_; const uint64_t lo_, hi_, chunk_; const int n_readers_, pack_threads_; const uint64_t cap_, piece_bytes_;
 	uint64_t piece_cap_ = 0, held_ = 0;
-	std::thread th_;
+	std::thread th_, alloc_th_;
+	std::mutex amu_; std::condition_variable acv_;                     // the piece maker: ready_ / all_pieces_ / held_ / astop_ / afail_
+	std::vector<void *> ready_, all_pieces_; bool astop_ = false, afail_ = false;
+	struct timespec born_; std::atomic<double> finished_s_{0.0};
 	std::atomic<bool> stop_{false};
 	std::mutex mu_; std::condition_variable cv_;
 	std::vector<PackedBatch> q_; size_t next_out_ = 0; bool done_ = false;
@@ -465,8 +534,8 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 							if (r.error.empty() && vg_sync(ix[(size_t)g]) != VG_OK) r.error = std::string("vg_sync failed: ") + vg_last_error();      // (the copies out of the pre-packer's memory are done)
 							r.nrec = pp.records(); r.used = pp.consumed(); r.last = pp.last_record_start(); r.refused = pp.refused() ? 1 : 0;
 							done_to = pp.consumed();
-							char line[200];
-							snprintf(line, sizeof line, "%lu reads packed ahead of / beside the index (%.1f GB/s of text on %d threads; link %.1f GB/s)", (unsigned long)submitted, pp.text_bytes_per_s() / 1e9, pack_threads, link / 1e9);
+							char line[320];
+							snprintf(line, sizeof line, "%lu reads packed ahead of / beside the index (%.1f GB/s of text on %d threads, done %.2f s after the command line started them; link %.1f GB/s)", (unsigned long)submitted, pp.text_bytes_per_s() / 1e9, pack_threads, pp.finished_after_s(), link / 1e9);
 							route[(size_t)g] = line;
 						}
 						const uint64_t lo = cut[(size_t)g] + done_to, hi = cut[(size_t)g + 1];
@@ -559,6 +628,16 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
 		fprintf(stderr, "reads: %lu  gpus: %d  wall: %.3f s = index load %.3f + FASTQ->counters %.3f (%.2f M reads/s) + call/VCF %.3f + close %.3f\n", (unsigned long)total, ngpu,
 		        secs(t0, t1), secs(t0, t_loaded), secs(t_loaded, t_reads), (double)total / secs(t_loaded, t_reads) / 1e6, secs(t_reads, t_vcf), secs(t_vcf, t1));
+		// how long the process has existed (its start time in /proc/self/stat, 10 ms ticks, against the boot clock): what the loader
+		// and the HIP runtime's static start-up took before main() is that minus the wall time above
+		if (FILE *f = fopen("/proc/self/stat", "r")) {
+			char buf[2048]; const size_t n = fread(buf, 1, sizeof buf - 1, f); buf[n] = 0; fclose(f);
+			const char *q = strrchr(buf, ')');
+			unsigned long long start = 0; int field = 2;
+			for (q = q ? q + 1 : buf; q && *q && field < 22; ) { q = strchr(q + 1, ' '); field++; if (field == 21 && q) start = strtoull(q + 1, nullptr, 10); }
+			struct timespec bt; clock_gettime(CLOCK_BOOTTIME, &bt);
+			if (start) fprintf(stderr, "process: alive for %.2f s at this point\n", (double)bt.tv_sec + 1e-9 * (double)bt.tv_nsec - (double)start / (double)sysconf(_SC_CLK_TCK));
+		}
 	}
 	if (!orderly) { fflush(stdout); fflush(stderr); _exit(EXIT_SUCCESS); }
 	return EXIT_SUCCESS;
