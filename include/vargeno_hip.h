@@ -75,7 +75,7 @@ int  vg_device_count(void);
 /* Total memory of a device in bytes (0 on failure): what a caller that puts SEVERAL replicas on one device divides into the
  * budgets it hands to vg_index_open_ex -- without a budget every replica plans for the whole device (less 12 GiB), and the
  * third or fourth one fails with VG_ENOMEM.  vg_share_budget() is that division as the CLI and the Python binding make it:
- * (total - 12 GiB) / replicas_on_the_device. */
+ * (min(total, free at the time of the call) - 12 GiB) / replicas_on_the_device. */
 uint64_t vg_device_memory(int device);
 uint64_t vg_share_budget(int device, int replicas_on_the_device);
 /* Host -> device rate of page-locked memory over this device's link in bytes per second, measured now (three 64 MiB copies; 0 on
@@ -162,6 +162,27 @@ int  vg_reads_submit_packed(vg_index *ix, const uint64_t *kmers, const uint64_t 
  * asynchronous and the call returns as soon as the batch is enqueued (r05: the command line hands over the hundreds of batches it
  * packed while the index was being opened). */
 int  vg_reads_submit_packed_async(vg_index *ix, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads);
+
+/* A read store: packed batches parked in DEVICE memory before an index handle exists on that device -- a job's FASTQ file is framed
+ * and packed (vg_packer_*) while vg_index_open runs, and what is packed goes up the otherwise idle link at once instead of waiting
+ * in page-locked host memory (which costs ~0.15 s per GB to lock and ~0.1 s per GB to give back at exit).  The reference has no
+ * counterpart: it reads the file after load_dict_from_file has returned (qv.cc:1757-1767, then 760-784).
+ *   vg_read_store_create   takes max_bytes of device memory at once (before the index is planned, so that the plan sees what is left)
+ *   vg_read_store_push     validates one batch (the rules of vg_reads_submit_packed) and enqueues its copies; the arrays -- page-locked
+ *                          memory copies at link speed -- must stay untouched until the NEXT vg_read_store_push / _flush on this
+ *                          store returns (a caller alternates between two sets).  VG_ENOMEM: the store is full; the batch was not
+ *                          taken and the caller sends it, and what follows, down another route
+ *   vg_reads_submit_store  every batch of the store through the read loop of an open handle on the same device, in push order,
+ *                          asynchronously (vg_sync); the store must live until then.  A store may be submitted more than once
+ *   vg_read_store_destroy  gives the memory back */
+typedef struct vg_read_store vg_read_store;
+int      vg_read_store_create(int device, uint64_t max_bytes, vg_read_store **out);
+int      vg_read_store_push(vg_read_store *rs, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads);
+int      vg_read_store_flush(vg_read_store *rs);
+uint64_t vg_read_store_reads(const vg_read_store *rs);
+uint64_t vg_read_store_bytes_used(const vg_read_store *rs);
+int      vg_reads_submit_store(vg_index *ix, vg_read_store *rs);
+void     vg_read_store_destroy(vg_read_store *rs);
 
 /* Same again, starting from raw FASTQ text (host memory): replaces the four fgets() + strlen of qv.cc:760-784.
  *

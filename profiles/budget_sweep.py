@@ -49,6 +49,7 @@ def main():
     b1 = int(batches[0][2][n_check].item())
     sub = (batches[0][0][:b1], batches[0][1][:b1], batches[0][2][:n_check + 1].contiguous())
     for gb in budgets:
+        time.sleep(20)                      # (memory a handle has just freed is cleared at its next allocation: profiles/cold_start_r05.txt)
         t0 = time.time()
         try:
             gx = GenoIndex.open(prefix, device=0, max_device_bytes=int(gb * 1e9) if gb else None)
@@ -56,7 +57,10 @@ def main():
             print(json.dumps({"budget_GB": gb, "failed": repr(e)}), flush=True)
             continue
         t_open = time.time() - t0
-        out = {"budget_GB": gb or "whole device", "index_open_s": t_open, "device_GB": gx.device_bytes / 1e9, "views": list(gx.views), "plan": gx.plan}
+        rep_ = gx.open_report
+        out = {"budget_GB": gb or "whole device", "index_open_s": t_open, "device_GB": gx.device_bytes / 1e9, "views": list(gx.views), "plan": gx.plan,
+               "memory": rep_[rep_.find("memory:"):] if "memory:" in rep_ else None}
+        assert not gb or gx.device_bytes <= gb * 1e9, ("the handle holds more than its budget", gb, gx.device_bytes)
         # parity: 1 M reads, timed build (the views) and counting build
         for stats in (True, False):
             gx.set_stats(stats)

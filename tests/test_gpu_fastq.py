@@ -206,6 +206,50 @@ def test_crlf_line_ends_and_named_separator_lines_against_the_reference_binary(f
     assert want.read_bytes().count(b"\n") > 100
 
 
+def test_read_store_filled_before_the_index_is_open(ftiny_dir, ftiny_reads):
+    """vg_read_store_*: batches packed and parked in device memory BEFORE the handle exists (what the command line does while
+    vg_index_open runs), then run through the handle -- twice: the counters of the flat ASCII batch, then twice them (saturating at
+    255 like every counter); a full store refuses the batch and keeps what it has; a store of another device is refused."""
+    from vargeno_amd.api import HostPacker, ReadStore
+
+    prefix = os.path.join(ftiny_dir, "idx")
+    text = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read()
+    (rc0, ac0), st0 = _counts_flat(prefix, ftiny_reads)
+    pk = HostPacker(2)
+    pk.begin()
+    store = ReadStore(0, 64 << 20)
+    small = ReadStore(0, 4096)
+    total = 0
+    for a in range(0, len(text), 555_555):
+        k, m, o, bad = pk.push(text[a:a + 555_555])
+        total += len(m)
+        if len(m):
+            store.push(k, m, o)
+            with pytest.raises(VgError) as e:
+                small.push(k, m, o)
+            assert e.value.code == -3
+    assert total == ftiny_reads.n and store.reads == total and small.reads == 0 and store.bytes_used > 0
+    pk.close()
+    small.close()
+    with GenoIndex.open(prefix) as gx:
+        gx.set_stats(True)
+        gx.submit_store(store)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, rc0) and np.array_equal(ac, ac0)
+        st = gx.stats()
+        for key in ("reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chunks", "gate_open", "ref_query", "snp_query", "ctx", "walks", "incr"):
+            assert st[key] == st0[key], key
+        gx.set_stats(False)
+        gx.submit_store(store)
+        rc2, ac2 = gx.counts()
+        assert np.array_equal(rc2, np.minimum(2 * rc0.astype(np.int64), 255)) and np.array_equal(ac2, np.minimum(2 * ac0.astype(np.int64), 255))
+        # the rules of vg_reads_submit_packed hold at the store's door
+        with pytest.raises(VgError) as e:
+            store.push(np.zeros(32, np.uint64), np.zeros(1, np.uint64), np.array([0, 32], np.uint64))
+        assert e.value.code == -6
+    store.close()
+
+
 @pytest.mark.parametrize("force_generic", ["0", "1"])
 def test_packed_batches_equal_flat_batches_through_every_tier(ftiny_dir, ftiny_reads, monkeypatch, force_generic):
     """vg_reads_submit_packed with batches framed + packed by the library's host packer (vg_packer_*), in odd batch sizes: site

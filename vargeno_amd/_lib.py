@@ -18,7 +18,7 @@ STAT_FIELDS = ["reads", "reads_n", "reads_invalid", "passes", "passes_ok", "chun
 
 # every symbol include/vargeno_hip.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = ["vg_last_error", "vg_build_id", "vg_device_count", "vg_device_memory", "vg_share_budget", "vg_link_rate", "vg_host_alloc_pinned", "vg_host_free_pinned", "vg_index_open", "vg_index_open_ex", "vg_index_plan", "vg_index_open_report", "vg_index_create", "vg_index_close",
-           "vg_index_device_bytes", "vg_index_views", "vg_reads_submit", "vg_reads_process_device", "vg_reads_process_device_gated", "vg_reads_submit_packed", "vg_reads_submit_packed_async", "vg_fastq_submit", "vg_fastq_stream_begin", "vg_fastq_stream_begin_packed", "vg_fastq_stream_push", "vg_fastq_stream_end",
+           "vg_index_device_bytes", "vg_index_views", "vg_reads_submit", "vg_reads_process_device", "vg_reads_process_device_gated", "vg_reads_submit_packed", "vg_reads_submit_packed_async", "vg_read_store_create", "vg_read_store_push", "vg_read_store_flush", "vg_read_store_reads", "vg_read_store_bytes_used", "vg_reads_submit_store", "vg_read_store_destroy", "vg_fastq_submit", "vg_fastq_stream_begin", "vg_fastq_stream_begin_packed", "vg_fastq_stream_push", "vg_fastq_stream_end",
            "vg_packer_create", "vg_packer_destroy", "vg_packer_begin", "vg_packer_reads_cap", "vg_packer_kmers_cap", "vg_packer_push", "vg_packer_end", "vg_sync", "vg_stats_get",
            "vg_set_stats", "vg_timing_get", "vg_num_sites", "vg_sites_fetch", "vg_counts_fetch", "vg_counts_reset",
            "vg_counts_device_ptr", "vg_counts_allreduce", "vg_counts_allreduce_devices"]
@@ -96,6 +96,16 @@ def lib():
             L.vg_fastq_stream_begin_packed.argtypes = [vp, C.c_int]
             L.vg_reads_submit_packed.argtypes = [vp, vp, vp, vp, C.c_uint64]
             L.vg_reads_submit_packed_async.argtypes = [vp, vp, vp, vp, C.c_uint64]
+            L.vg_read_store_create.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp)]
+            L.vg_read_store_push.argtypes = [vp, vp, vp, vp, C.c_uint64]
+            L.vg_read_store_flush.argtypes = [vp]
+            L.vg_read_store_reads.argtypes = [vp]
+            L.vg_read_store_reads.restype = C.c_uint64
+            L.vg_read_store_bytes_used.argtypes = [vp]
+            L.vg_read_store_bytes_used.restype = C.c_uint64
+            L.vg_reads_submit_store.argtypes = [vp, vp]
+            L.vg_read_store_destroy.argtypes = [vp]
+            L.vg_read_store_destroy.restype = None
             L.vg_packer_create.argtypes = [C.c_int, C.POINTER(vp)]
             L.vg_packer_destroy.argtypes = [vp]
             L.vg_packer_destroy.restype = None

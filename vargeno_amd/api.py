@@ -139,6 +139,11 @@ class GenoIndex:
         chunk_offsets = np.ascontiguousarray(chunk_offsets, dtype=np.uint64)
         check(lib().vg_reads_submit_packed(self._h, _ptr(kmers), _ptr(meta), _ptr(chunk_offsets), len(chunk_offsets) - 1))
 
+    def submit_store(self, store):
+        """Every batch of a ReadStore (same device) through the read loop, in push order; asynchronous (sync / counts wait)."""
+        store.flush()
+        check(lib().vg_reads_submit_store(self._h, store._h))
+
     def fastq_stream(self, chunks, host_threads=None):
         """FASTQ text as a stream of byte chunks cut anywhere (numpy uint8 arrays / bytes; pinned host memory copies at link
         speed): records are framed across the cuts -- on the device (host_threads None or 0), or framed and 2-bit packed by
@@ -276,6 +281,46 @@ class HostPacker:
         n, used, last, refused = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int()
         check(lib().vg_packer_end(self._h, C.byref(n), C.byref(used), C.byref(last), C.byref(refused)))
         return int(n.value), int(used.value), int(last.value), bool(refused.value)
+
+
+class ReadStore:
+    """Packed batches parked in device memory before an index handle exists (vg_read_store_*): what the command line packs while
+    vg_index_open runs.  `GenoIndex.submit_store(store)` runs them through an open handle on the same device."""
+
+    def __init__(self, device=0, max_bytes=1 << 30):
+        self._h = C.c_void_p()
+        self._keep = None
+        check(lib().vg_read_store_create(int(device), int(max_bytes), C.byref(self._h)))
+
+    def push(self, kmers, meta, chunk_offsets):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+        meta = np.ascontiguousarray(meta, dtype=np.uint64)
+        chunk_offsets = np.ascontiguousarray(chunk_offsets, dtype=np.uint64)
+        check(lib().vg_read_store_push(self._h, _ptr(kmers), _ptr(meta), _ptr(chunk_offsets), len(chunk_offsets) - 1))
+        self._keep = (kmers, meta, chunk_offsets)          # untouched until the next push / flush returns
+
+    def flush(self):
+        check(lib().vg_read_store_flush(self._h))
+        self._keep = None
+
+    @property
+    def reads(self):
+        return int(lib().vg_read_store_reads(self._h))
+
+    @property
+    def bytes_used(self):
+        return int(lib().vg_read_store_bytes_used(self._h))
+
+    def close(self):
+        if self._h:
+            lib().vg_read_store_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def pinned_buffer(nbytes):

@@ -146,109 +146,56 @@ static StreamResult stream_range(vg_index *ix, int fd, uint64_t lo, uint64_t hi,
 
 // ---- packing ahead of the index ------------------------------------------------------------------------------------------------
 // Framing + 2-bit packing need no device (vg_packer_*), and vg_index_open takes seconds during which the host would otherwise
-// idle: bytes [lo, hi) of the FASTQ file are read and packed into page-locked memory WHILE the replica's index is being built,
-// and handed to vg_reads_submit_packed the moment the handle exists (r05; the r04 command line started to pack only then).
-// The packed form is 48 bytes per 150 bp read, so a 30x file (620 M reads) is 30 GB: VARGENO_PREPACK_GB (default 32, and never
-// more than a quarter of the host's available memory) bounds what is held.  The pre-packer also MEASURES its rate (text bytes
-// framed + packed per second with the threads it was given, on this host, now); when the index is ready the caller compares it
-// with the link's rate -- what the device-side framing of the remaining text would run at -- and lets the faster one finish.
-struct PackedBatch {
-	uint64_t *kmers = nullptr, *meta = nullptr, *offs = nullptr;
-	uint64_t n_reads = 0, n_chunks = 0;
-};
+// idle: bytes [lo, hi) of the FASTQ file are read and packed WHILE the replica's index is being built (r05; the r04 command line
+// started to pack only when the handle existed).  What is packed goes up to the device at once, into a read store
+// (vg_read_store_*: device memory taken before the index is planned; the link is idle two thirds of the open's time), out of two
+// page-locked staging sets -- a first version kept the batches in page-locked HOST memory until the handle existed: 11 GB for
+// 200 M reads, 0.15 s per GB to lock and 0.1 s per GB for the operating system to take back at exit, more than the read loop
+// itself takes (profiles/job_tail_r05.txt).  The packed form is ~56 bytes per 150 bp read, so a 30x file (620 M reads) is 35 GB:
+// VARGENO_PREPACK_GB (default 16) bounds the store; what does not fit is framed after the open like the rest of the range.
+// The pre-packer also MEASURES its rate (text bytes framed + packed per second with the threads it was given, on this host, now);
+// when the index is ready the caller compares it with the link's rate -- what the device-side framing of the remaining text
+// would run at -- and lets the faster one finish.
 class PrePacker {
 public:
-	PrePacker(int fd, uint64_t lo, uint64_t hi, uint64_t chunk, int n_readers, int pack_threads, uint64_t cap_bytes)
-		: fd_(fd), lo_(lo), hi_(hi), chunk_(chunk), n_readers_(n_readers), pack_threads_(pack_threads), cap_(cap_bytes),
-		  piece_bytes_(std::max<uint64_t>(16ull << 20, std::min<uint64_t>(1ull << 30, (hi - lo) / 4 + (8ull << 20))))          // (packed reads are ~1/6 of their text: a small file gets a small buffer)
+	PrePacker(int fd, uint64_t lo, uint64_t hi, uint64_t chunk, int n_readers, int pack_threads, vg_read_store *store)
+		: fd_(fd), lo_(lo), hi_(hi), chunk_(std::min(chunk, std::max<uint64_t>(hi - lo, 1))), n_readers_(n_readers), pack_threads_(pack_threads), store_(store)
 	{
 		clock_gettime(CLOCK_MONOTONIC, &born_);
-		// page-locking memory costs ~0.15 s per GB: a thread of its own gets the pieces ready ahead of the packer (as many as the
-		// file will need: packed reads are ~1/6 of their text), so that the packer's thread never waits for the driver
-		const uint64_t est = std::min<uint64_t>(cap_, (hi - lo) / 6 + piece_bytes_);
-		alloc_th_ = std::thread([this, est] {
-			uint64_t made = 0;
-			for (;;) {
-				{
-					std::unique_lock<std::mutex> g(amu_);
-					acv_.wait(g, [&] { return astop_ || ((made < est || ready_.size() < 1) && held_ + piece_bytes_ <= cap_); });
-					if (astop_) return;
-				}
-				void *p = vg_host_alloc_pinned((size_t)piece_bytes_);
-				std::lock_guard<std::mutex> g(amu_);
-				if (!p) { afail_ = true; acv_.notify_all(); return; }
-				all_pieces_.push_back(p); ready_.push_back(p); held_ += piece_bytes_; made += piece_bytes_;
-				acv_.notify_all();
-			}
-		});
 		th_ = std::thread([this] { run(); });
 	}
 	~PrePacker()
 	{
 		stop();
 		if (th_.joinable()) th_.join();
-		{ std::lock_guard<std::mutex> g(amu_); astop_ = true; acv_.notify_all(); }
-		if (alloc_th_.joinable()) alloc_th_.join();
-		if (!keep_) for (void *p : all_pieces_) vg_host_free_pinned(p);
 	}
-	void stop() { stop_.store(true); std::lock_guard<std::mutex> g(mu_); cv_.notify_all(); }
-	double finished_after_s() const { return finished_s_.load(); }           // seconds from construction to the last batch (0: still running)
-	// the next batch in file order; false: there are no more (the pre-packer has finished, stopped, run out of room or been refused)
-	bool pop(PackedBatch &b)
-	{
-		std::unique_lock<std::mutex> g(mu_);
-		cv_.wait(g, [&] { return next_out_ < q_.size() || done_; });
-		if (next_out_ >= q_.size()) return false;
-		b = q_[next_out_++];
-		return true;
-	}
+	void stop() { stop_.store(true); }
+	bool done() const { return done_.load(); }
 	void join() { if (th_.joinable()) th_.join(); }
-	// valid after join(): what vg_fastq_stream_end would have said about the bytes [lo, lo + consumed)
+	// valid after join(): what vg_fastq_stream_end would have said about the bytes [lo, lo + consumed) -- the batches in the store
 	uint64_t records() const { return records_; }
 	uint64_t consumed() const { return consumed_; }
 	uint64_t last_record_start() const { return last_; }
 	bool refused() const { return refused_; }
-	uint64_t invalid() const { return invalid_; }
+	bool store_full() const { return full_; }
 	double text_bytes_per_s() const { const double t = pack_s_.load(); return t > 0 ? (double)packed_text_.load() / t : 0.0; }
 	uint64_t text_bytes_done() const { return packed_text_.load(); }
-	void keep_memory() { keep_ = true; }             // the process is about to end: releasing gigabytes of page-locked memory piece by piece (~0.15 s per GB) is left to the exit
+	double finished_after_s() const { return finished_s_.load(); }           // seconds from construction to the last batch (0: still running)
 	std::string error;
 private:
-	uint64_t *slab(uint64_t words)                    // page-locked memory for a batch's arrays, out of pieces of up to 1 GiB; nullptr: the cap is reached
-	{
-		const uint64_t bytes = words * 8;
-		if (pieces_.empty() || piece_used_ + bytes > piece_cap_) {
-			void *p = nullptr;
-			uint64_t PIECE = piece_bytes_;
-			std::unique_lock<std::mutex> g(amu_);
-			if (bytes > piece_bytes_) {                                      // (an array larger than a piece: a piece of its own, made here)
-				PIECE = (bytes + 63) & ~63ull;
-				if (held_ + PIECE > cap_) return nullptr;
-				g.unlock();
-				p = vg_host_alloc_pinned((size_t)PIECE);
-				if (!p) return nullptr;
-				g.lock();
-				all_pieces_.push_back(p); held_ += PIECE;
-			} else {
-				acv_.notify_all();
-				acv_.wait(g, [&] { return !ready_.empty() || afail_ || held_ + piece_bytes_ > cap_; });
-				if (ready_.empty()) return nullptr;                          // the cap is reached (or the driver refused)
-				p = ready_.front(); ready_.erase(ready_.begin());
-				acv_.notify_all();
-			}
-			pieces_.push_back(p); piece_used_ = 0; piece_cap_ = PIECE;
-		}
-		uint64_t *r = (uint64_t *)((uint8_t *)pieces_.back() + piece_used_);
-		piece_used_ += (bytes + 63) & ~63ull;
-		return r;
-	}
 	void run()
 	{
 		const uint64_t fsize = hi_ - lo_, n_chunks = (fsize + chunk_ - 1) / chunk_;
 		vg_packer *pk = nullptr;
 		if (vg_packer_create(pack_threads_, &pk) != VG_OK) { error = vg_last_error(); finish(); return; }
+		// two page-locked staging sets of a chunk's worst case (a 256 MiB chunk: 3 x 67 MB each): the store copies out of one
+		// while the packer fills the other
 		const uint64_t rcap = vg_packer_reads_cap(chunk_), kcap = vg_packer_kmers_cap(chunk_);
-		std::vector<uint64_t> sk(kcap), sm(rcap), so(rcap);                       // worst-case staging of one chunk
+		uint64_t *stage[2] = {nullptr, nullptr};
+		for (int k = 0; k < 2; k++) {
+			stage[k] = (uint64_t *)vg_host_alloc_pinned((size_t)(kcap + 2 * rcap + 2) * 8);
+			if (!stage[k]) { error = "page-locked staging for the pre-packer: allocation failed"; if (stage[0]) vg_host_free_pinned(stage[0]); vg_packer_destroy(pk); finish(); return; }
+		}
 		const int NBUF = 3;
 		std::vector<std::vector<uint8_t>> text((size_t)NBUF);
 		for (auto &t : text) t.resize((size_t)std::min(chunk_, fsize));
@@ -281,42 +228,38 @@ private:
 				rcv.notify_all();
 			}
 		});
-		bool out_of_room = false;
 		for (uint64_t i = 0; i < n_chunks && !stop_.load(); i++) {
 			{ std::unique_lock<std::mutex> g(rmu); rcv.wait(g, [&] { return left[(size_t)i] == 0 || io_error; }); if (io_error) break; }
 			const uint64_t len = std::min(chunk_, fsize - i * chunk_);
+			uint64_t *sk = stage[i & 1], *sm = sk + kcap, *so = sm + rcap;
 			uint64_t nr = 0, nc = 0, ninv = 0;
 			struct timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
-			const int rc = vg_packer_push(pk, text[(size_t)(i % NBUF)].data(), len, sk.data(), kcap, sm.data(), so.data(), rcap, &nr, &nc, &ninv);
+			const int rc = vg_packer_push(pk, text[(size_t)(i % NBUF)].data(), len, sk, kcap, sm, so, rcap, &nr, &nc, &ninv);
 			clock_gettime(CLOCK_MONOTONIC, &b);
 			if (rc != VG_OK) { error = vg_last_error(); break; }
 			pack_s_.store(pack_s_.load() + (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec));
-			packed_text_.fetch_add(len);
 			{ std::lock_guard<std::mutex> g(rmu); packed = i + 1; }
 			rcv.notify_all();
 			if (nr) {
-				PackedBatch pb;
-				pb.kmers = slab(nc + 1); pb.meta = slab(nr); pb.offs = slab(nr + 1);
-				if (!pb.kmers || !pb.meta || !pb.offs) { out_of_room = true; lost_last_ = true; break; }   // (this chunk's records are dropped with it: the stream is re-framed from the last batch that was kept)
-				// (one thread copies ~6 GB/s into fresh page-locked memory: a 30x file's 30 GB would take longer than the index's start-up)
-				par_copy(pb.kmers, sk.data(), nc * 8, pb.meta, sm.data(), nr * 8, pb.offs, so.data(), (nr + 1) * 8);
-				pb.n_reads = nr; pb.n_chunks = nc;
-				invalid_ += ninv;
+				// (the push waits for the copies of the chunk before -- the other staging set -- and enqueues this chunk's)
+				const int prc = vg_read_store_push(store_, sk, sm, so, nr);
+				if (prc == VG_ENOMEM) { full_ = true; break; }                      // (this chunk's records are dropped with it: the stream is re-framed from the last batch that was kept)
+				if (prc != VG_OK) { error = vg_last_error(); break; }
 				uint64_t rec = 0, cons = 0, last = 0; int ref = 0;
 				(void)vg_packer_end(pk, &rec, &cons, &last, &ref);               // (a query: the stream's totals so far)
-				std::lock_guard<std::mutex> g(mu_);
-				q_.push_back(pb); records_ = rec; consumed_ = cons; last_ = last;
-				cv_.notify_all();
+				records_ = rec; consumed_ = cons; last_ = last;
 			}
+			packed_text_.fetch_add(len);
 			int ref = 0;
 			(void)vg_packer_end(pk, nullptr, nullptr, nullptr, &ref);
 			if (ref) { refused_ = true; break; }
 		}
-		(void)out_of_room;
 		{ std::lock_guard<std::mutex> g(rmu); quit = true; }
 		rcv.notify_all();
 		for (auto &t : readers) t.join();
 		if (io_error && error.empty()) error = "error reading the FASTQ file";
+		if (vg_read_store_flush(store_) != VG_OK && error.empty()) error = vg_last_error();      // the staging sets are free
+		for (int k = 0; k < 2; k++) vg_host_free_pinned(stage[k]);
 		vg_packer_destroy(pk);
 		finish();
 	}
@@ -324,44 +267,16 @@ private:
 	{
 		struct timespec now; clock_gettime(CLOCK_MONOTONIC, &now);
 		finished_s_.store((double)(now.tv_sec - born_.tv_sec) + 1e-9 * (double)(now.tv_nsec - born_.tv_nsec));
-		std::lock_guard<std::mutex> g(mu_); done_ = true; cv_.notify_all();
+		done_.store(true);
 	}
-	// three arrays copied by a few threads, each taking an equal share of the bytes
-	void par_copy(void *d0, const void *s0, uint64_t n0, void *d1, const void *s1, uint64_t n1, void *d2, const void *s2, uint64_t n2)
-	{
-		const uint64_t total = n0 + n1 + n2;
-		const unsigned nt = total < (8u << 20) ? 1u : (unsigned)std::max(1, std::min(8, pack_threads_));
-		auto part = [&](unsigned t) {
-			uint64_t a = total * t / nt, b = total * (t + 1) / nt;                     // bytes [a, b) of the three arrays laid end to end
-			const uint64_t n[3] = {n0, n1, n2};
-			uint8_t *d[3] = {(uint8_t *)d0, (uint8_t *)d1, (uint8_t *)d2};
-			const uint8_t *s[3] = {(const uint8_t *)s0, (const uint8_t *)s1, (const uint8_t *)s2};
-			uint64_t base = 0;
-			for (int k = 0; k < 3; k++) {
-				const uint64_t lo = std::max(a, base), hi = std::min(b, base + n[k]);
-				if (lo < hi) memcpy(d[k] + (lo - base), s[k] + (lo - base), (size_t)(hi - lo));
-				base += n[k];
-			}
-		};
-		if (nt == 1) { part(0); return; }
-		std::vector<std::thread> th;
-		for (unsigned t = 1; t < nt; t++) th.emplace_back(part, t);
-		part(0);
-		for (auto &x : th) x.join();
-	}
-	const int fd_; const uint64_t lo_, hi_, chunk_; const int n_readers_, pack_threads_; const uint64_t cap_, piece_bytes_;
-	uint64_t piece_cap_ = 0, held_ = 0;
-	std::thread th_, alloc_th_;
-	std::mutex amu_; std::condition_variable acv_;                     // the piece maker: ready_ / all_pieces_ / held_ / astop_ / afail_
-	std::vector<void *> ready_, all_pieces_; bool astop_ = false, afail_ = false;
-	struct timespec born_; std::atomic<double> finished_s_{0.0};
-	std::atomic<bool> stop_{false};
-	std::mutex mu_; std::condition_variable cv_;
-	std::vector<PackedBatch> q_; size_t next_out_ = 0; bool done_ = false;
-	std::vector<void *> pieces_; uint64_t piece_used_ = 0;
-	uint64_t records_ = 0, consumed_ = 0, last_ = 0, invalid_ = 0;
-	bool refused_ = false, lost_last_ = false, keep_ = false;
+	const int fd_; const uint64_t lo_, hi_, chunk_; const int n_readers_, pack_threads_;
+	vg_read_store *const store_;
+	std::thread th_;
+	std::atomic<bool> stop_{false}, done_{false};
+	uint64_t records_ = 0, consumed_ = 0, last_ = 0;
+	bool refused_ = false, full_ = false;
 	std::atomic<double> pack_s_{0.0}; std::atomic<uint64_t> packed_text_{0};
+	struct timespec born_; std::atomic<double> finished_s_{0.0};
 };
 
 // The first record start at or after `from`: the start of a line that begins with '@' whose next-but-one line begins with '+'
@@ -400,7 +315,7 @@ static bool range_cuts(int fd, uint64_t fsize, int n, std::vector<uint64_t> &cut
 	return true;
 }
 
-static uint64_t mem_available_bytes()
+[[maybe_unused]] static uint64_t mem_available_bytes()
 {
 	uint64_t kb = 0;
 	if (FILE *f = fopen("/proc/meminfo", "r")) {
@@ -440,6 +355,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	if (pack_threads < 0) pack_threads = std::max(2, std::min(hw - 2, 96) / ngpu);
 	const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
 	std::vector<std::unique_ptr<PrePacker>> pre((size_t)ngpu);
+	std::vector<vg_read_store *> store((size_t)ngpu, nullptr);
 	if (!host_framing) {
 		fd = open(fastq.c_str(), O_RDONLY);
 		if (fd < 0) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
@@ -448,11 +364,20 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		fsize = (uint64_t)sb.st_size;
 		cuts_ok = range_cuts(fd, fsize, ngpu, cut);
 		if (cuts_ok && pack_threads > 0 && env_int("VARGENO_PREPACK", 1)) {
-			const uint64_t want = (uint64_t)std::max(1, env_int("VARGENO_PREPACK_GB", 32)) << 30;
-			const uint64_t cap = std::max<uint64_t>(2ull << 30, std::min(want, mem_available_bytes() / 4)) / (uint64_t)ngpu;
+			// a read store per replica, on its device, taken NOW (the index is planned with what is left): as large as the range's
+			// packed form (~1/5.5 of its text, and room for a chunk's worst case is not needed: a push that does not fit ends the
+			// pre-packing), at most VARGENO_PREPACK_GB per device and never more than an eighth of the device
+			const uint64_t want = (uint64_t)std::max(1, env_int("VARGENO_PREPACK_GB", 16)) << 30;
 			const uint64_t pchunk = (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", 256)) << 20;
-			for (int g = 0; g < ngpu; g++)
-				if (cut[(size_t)g] < cut[(size_t)g + 1]) pre[(size_t)g].reset(new PrePacker(fd, cut[(size_t)g], cut[(size_t)g + 1], pchunk, std::max(2, n_readers / ngpu), pack_threads, cap));
+			for (int g = 0; g < ngpu; g++) {
+				if (cut[(size_t)g] >= cut[(size_t)g + 1]) continue;
+				int on = 0;
+				for (int k = 0; k < ngpu; k++) on += k % have == g % have;
+				const uint64_t range = cut[(size_t)g + 1] - cut[(size_t)g];
+				const uint64_t bytes = std::min<uint64_t>(std::min<uint64_t>(want, vg_device_memory(g % have) / 8) / (uint64_t)on, range / 5 + (8ull << 20));
+				if (vg_read_store_create(g % have, bytes, &store[(size_t)g]) != VG_OK) { fprintf(stderr, "vargeno: no read store on device %d (%s): its range is framed after the index is open\n", g % have, vg_last_error()); continue; }
+				pre[(size_t)g].reset(new PrePacker(fd, cut[(size_t)g], cut[(size_t)g + 1], pchunk, std::max(2, n_readers / ngpu), pack_threads, store[(size_t)g]));
+			}
 		}
 	}
 	// the SNP list is read now, beside the index open (the VCF pass at the end of the job starts from its bytes)
@@ -508,34 +433,24 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 						bool pack_rest = pack_threads > 0;
 						if (pre[(size_t)g]) {
 							PrePacker &pp = *pre[(size_t)g];
-							// what was packed while the index was opening goes first; then the faster route takes what is left
-							bool decided = false;
-							uint64_t submitted = 0;
-							PackedBatch pb;
-							for (;;) {
-								if (!decided) {
-									// the packer keeps the rest of the range unless the device-side framing would finish it at least a second
-									// earlier (changing horses costs about that much: a new stream, its readers starting cold)
-									const double rp = pp.text_bytes_per_s();
-									if (rp > 0 && link > 0) {
-										decided = true;
-										const double left = (double)(cut[(size_t)g + 1] - cut[(size_t)g]) - (double)pp.text_bytes_done();
-										pack_rest = rp >= link || left * (1.0 / rp - 1.0 / link) < 1.0;
-										if (!pack_rest) pp.stop();
-									}
-								}
-								if (!pp.pop(pb)) break;
-								const int rc = vg_reads_submit_packed_async(ix[(size_t)g], pb.kmers, pb.meta, pb.offs, pb.n_reads);       // (the pre-packer's page-locked memory lives until the streams have drained)
-								if (rc != VG_OK) { r.error = std::string("vg_reads_submit_packed failed: ") + vg_last_error(); pp.stop(); break; }
-								submitted += pb.n_reads;
+							// what was packed while the index was opening is in the read store.  Is the pre-packer still at it?  Then it
+							// keeps the rest of the range unless the device-side framing would finish it at least a second earlier
+							// (changing horses costs about that much: a new stream, its readers starting cold)
+							if (!pp.done()) {
+								const double rp = pp.text_bytes_per_s();
+								const double left = (double)(cut[(size_t)g + 1] - cut[(size_t)g]) - (double)pp.text_bytes_done();
+								if (rp > 0 && link > 0) pack_rest = rp >= link || left * (1.0 / rp - 1.0 / link) < 1.0;
+								if (!pack_rest) pp.stop();
 							}
 							pp.join();
-							if (r.error.empty() && !pp.error.empty()) r.error = pp.error;
-							if (r.error.empty() && vg_sync(ix[(size_t)g]) != VG_OK) r.error = std::string("vg_sync failed: ") + vg_last_error();      // (the copies out of the pre-packer's memory are done)
+							if (!pp.error.empty()) r.error = pp.error;
+							const uint64_t submitted = vg_read_store_reads(store[(size_t)g]);
+							if (r.error.empty() && vg_reads_submit_store(ix[(size_t)g], store[(size_t)g]) != VG_OK) r.error = std::string("vg_reads_submit_store failed: ") + vg_last_error();
 							r.nrec = pp.records(); r.used = pp.consumed(); r.last = pp.last_record_start(); r.refused = pp.refused() ? 1 : 0;
 							done_to = pp.consumed();
 							char line[320];
-							snprintf(line, sizeof line, "%lu reads packed ahead of / beside the index (%.1f GB/s of text on %d threads, done %.2f s after the command line started them; link %.1f GB/s)", (unsigned long)submitted, pp.text_bytes_per_s() / 1e9, pack_threads, pp.finished_after_s(), link / 1e9);
+							snprintf(line, sizeof line, "%lu reads packed ahead of / beside the index into %.1f GB of device memory (%.1f GB/s of text on %d threads, done %.2f s after the command line started them%s; link %.1f GB/s)",
+							         (unsigned long)submitted, (double)vg_read_store_bytes_used(store[(size_t)g]) / 1e9, pp.text_bytes_per_s() / 1e9, pack_threads, pp.finished_after_s(), pp.store_full() ? ", when the store was full" : "", link / 1e9);
 							route[(size_t)g] = line;
 						}
 						const uint64_t lo = cut[(size_t)g] + done_to, hi = cut[(size_t)g + 1];
@@ -568,7 +483,6 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 				host_from = 0;
 			}
 		}
-		for (auto &pp : pre) if (pp) pp->keep_memory();
 		pre.clear();
 		close(fd);
 	}
@@ -621,7 +535,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	// 7 s job at hg38 scale (profiles/job_tail_r05.txt), so the command line ends here unless VARGENO_ORDERLY_EXIT=1 asks for the
 	// full tear-down (tests that look for leaks, sanitizer runs).
 	const bool orderly = env_int("VARGENO_ORDERLY_EXIT", 0) != 0;
-	if (orderly) for (auto *h : ix) vg_index_close(h);
+	if (orderly) { for (auto *h : ix) vg_index_close(h); for (auto *rs : store) vg_read_store_destroy(rs); }
 	const double cpu = (double)(clock() - begin) / CLOCKS_PER_SEC;
 	printf("Time: %f sec\n", cpu);                                       // qv.cc:1749-1751 prints CPU seconds
 	if (verbose) {

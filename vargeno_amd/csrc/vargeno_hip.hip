@@ -111,8 +111,13 @@ extern "C" double vg_link_rate(int device)
 }
 extern "C" uint64_t vg_share_budget(int device, int replicas)
 {
-	const uint64_t total = vg_device_memory(device), reserve = 12ull << 30;
+	uint64_t total = vg_device_memory(device);
+	const uint64_t reserve = 12ull << 30;
 	if (total == 0 || replicas < 1) return 0;
+	// what is free NOW, when that is less (another process on the device, the read stores the command line has just taken)
+	size_t fr = 0, tot = 0;
+	if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) total = std::min<uint64_t>(total, (uint64_t)fr);
+	(void)hipGetLastError();
 	return (total > reserve ? total - reserve : total) / (uint64_t)replicas;
 }
 
@@ -1232,6 +1237,7 @@ struct ViewPlan {
 	bool mx = false, dx = false, sec = false, sig = false, probe = false, hx = false, jg32 = false;
 	uint64_t base = 0, total = 0, budget = 0;
 	uint64_t arena = 0;                    // bytes of the handle's one block (vg_arena.h): the finished index less what lives outside it
+	bool limited = false;                  // views were left out for the budget
 	std::string text;
 	bool same_views(const ViewPlan &o) const { return mx == o.mx && dx == o.dx && sec == o.sec && sig == o.sig && probe == o.probe && hx == o.hx && jg32 == o.jg32; }
 };
@@ -1278,6 +1284,9 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 	// the block holds everything but the batch slots (2 GiB reserved above, allocated with the first batches), the counters that
 	// RCCL reduces in place and the clamped copy the host fetches (10 bytes per site); 64 MiB for the alignment of ~40 arrays
 	p.arena = p.total - 2 * GiB - std::min<uint64_t>(sites * 10, p.total / 2) + (64ull << 20);
+	// with views left out the finished index is smaller than what construction has alive at its peak (the columns beside the
+	// entries, the sorts' buffers): the block then holds the permanent arrays only (vg_arena.h, set_temp_floor)
+	p.limited = !dropped.empty();
 	return p;
 }
 
@@ -1599,6 +1608,7 @@ static int plan_and_arena(vg_index *ix, const DevCols &c, uint64_t maxp_est, uin
 	if (!getenv("VG_NO_ARENA")) {
 		const double t0 = now_s();
 		(void)ix->arena.init(plan.arena);
+		if (plan.limited) ix->arena.set_temp_floor(UINT64_MAX);
 		g_alloc_s += now_s() - t0;
 	}
 	return VG_OK;
@@ -2106,9 +2116,10 @@ static int launch_packed(vg_index *ix, Slot &sl, const uint64_t *kmers, const ui
 		sl.list_cap = n_reads;
 	}
 	if (copy_on) {
-		if (n_chunks) HIP_TRY(hipMemcpyAsync(sl.pk_kmer, kmers, n_chunks * 8, hipMemcpyHostToDevice, copy_on));
-		HIP_TRY(hipMemcpyAsync(sl.pk_meta, meta, n_reads * 8, hipMemcpyHostToDevice, copy_on));
-		HIP_TRY(hipMemcpyAsync(sl.st_offsets, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, copy_on));
+		// (hipMemcpyDefault: the source is page-locked host memory, or -- a read store's batch -- device memory)
+		if (n_chunks) HIP_TRY(hipMemcpyAsync(sl.pk_kmer, kmers, n_chunks * 8, hipMemcpyDefault, copy_on));
+		HIP_TRY(hipMemcpyAsync(sl.pk_meta, meta, n_reads * 8, hipMemcpyDefault, copy_on));
+		HIP_TRY(hipMemcpyAsync(sl.st_offsets, offsets, (n_reads + 1) * 8, hipMemcpyDefault, copy_on));
 	} else {
 		if (n_chunks) HIP_TRY(hipMemcpy(sl.pk_kmer, kmers, n_chunks * 8, hipMemcpyHostToDevice));
 		HIP_TRY(hipMemcpy(sl.pk_meta, meta, n_reads * 8, hipMemcpyHostToDevice));
@@ -2167,6 +2178,118 @@ extern "C" int vg_reads_submit_packed_async(vg_index *ix, const uint64_t *kmers,
 	if (!ix || !chunk_offsets || (n_reads && !meta)) return fail(VG_EINVAL, "null argument");
 	if (n_reads == 0) return VG_OK;
 	return guarded([&]() -> int { return submit_packed_impl(ix, kmers, meta, chunk_offsets, n_reads, true); });
+}
+
+// ---- a read store: packed batches parked in device memory before (or beside) an index handle -------------------------------
+// The command line packs the FASTQ file while vg_index_open runs.  Keeping what it packs in page-locked HOST memory until the
+// handle exists cost 0.15 s per GB to lock and 0.1 s per GB to give back when the process ends (11 GB for 200 M reads: more
+// than the whole read loop), and the copies up only started after the open.  The device has ~45 GB to spare beside an hg38
+// index and the link is idle two thirds of the open's time: the batches go up as they are packed, out of two small staging
+// buffers, and the open handle takes them from device memory.
+struct StoredBatch { const uint64_t *kmers, *meta, *offsets; uint64_t n_reads, n_chunks; };
+struct vg_read_store {
+	int device = 0;
+	uint8_t *block = nullptr;
+	uint64_t bytes = 0, used = 0, reads = 0, invalid = 0;
+	hipStream_t stream = nullptr;
+	std::vector<StoredBatch> batches;
+};
+__global__ void vg_chunk_to_flat_offsets(uint64_t *__restrict__ o, const uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) o[i] <<= 5;
+}
+extern "C" int vg_read_store_create(int device, uint64_t max_bytes, vg_read_store **out)
+{
+	if (!out || max_bytes == 0) return fail(VG_EINVAL, "null argument / a store of no bytes");
+	*out = nullptr;
+	return guarded([&]() -> int {
+		HIP_TRY(hipSetDevice(device));
+		std::unique_ptr<vg_read_store> rs(new vg_read_store);
+		rs->device = device;
+		max_bytes = (max_bytes + 4095) & ~4095ull;
+		hipError_t e = hipMalloc((void **)&rs->block, max_bytes);
+		if (e != hipSuccess) { char t[64]; snprintf(t, sizeof t, "%.1f GB", max_bytes / 1e9); return fail(VG_ENOMEM, "hipMalloc(read store, %s): %s", t, hipGetErrorString(e)); }
+		rs->bytes = max_bytes;
+		if (hipStreamCreateWithFlags(&rs->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(rs->block); return fail(VG_ENODEV, "hipStreamCreate(read store) failed"); }
+		*out = rs.release();
+		return VG_OK;
+	});
+}
+extern "C" void vg_read_store_destroy(vg_read_store *rs)
+{
+	if (!rs) return;
+	(void)hipSetDevice(rs->device);
+	if (rs->stream) { (void)hipStreamSynchronize(rs->stream); (void)hipStreamDestroy(rs->stream); }
+	if (rs->block) (void)hipFree(rs->block);
+	delete rs;
+}
+extern "C" uint64_t vg_read_store_reads(const vg_read_store *rs) { return rs ? rs->reads : 0; }
+extern "C" uint64_t vg_read_store_bytes_used(const vg_read_store *rs) { return rs ? rs->used : 0; }
+extern "C" int vg_read_store_flush(vg_read_store *rs)
+{
+	if (!rs) return fail(VG_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(rs->device));
+	HIP_TRY(hipStreamSynchronize(rs->stream));
+	return VG_OK;
+}
+extern "C" int vg_read_store_push(vg_read_store *rs, const uint64_t *kmers, const uint64_t *meta, const uint64_t *chunk_offsets, uint64_t n_reads)
+{
+	if (!rs || !chunk_offsets || (n_reads && !meta)) return fail(VG_EINVAL, "null argument");
+	return guarded([&]() -> int {
+		HIP_TRY(hipSetDevice(rs->device));
+		HIP_TRY(hipStreamSynchronize(rs->stream));               // the arrays of the push before this one are free again
+		if (n_reads == 0) return VG_OK;
+		if (chunk_offsets[0] != 0) return fail(VG_EINVAL, "chunk_offsets[0] must be 0");
+		uint64_t invalid = 0, bad = 0;
+		for (uint64_t i = 0; i < n_reads; i++) {
+			const uint64_t d = chunk_offsets[i + 1] - chunk_offsets[i];
+			bad |= (chunk_offsets[i + 1] < chunk_offsets[i] ? 1ull : 0ull) | (d > 31 ? 2ull : 0ull) | ((meta[i] & 0x3FFFFFFF00000000ull) ? 4ull : 0ull);
+			invalid += meta[i] >> 63;
+		}
+		if (bad & 1ull) return fail(VG_EINVAL, "chunk offsets not monotone");
+		if (bad & 2ull) return fail(VG_EBADREAD, "a packed read of more than 31 chunks (a FASTQ line the reference can read holds at most 1022 bases, qv.cc:700)");
+		if (bad & 4ull) return fail(VG_EINVAL, "a packed read's flag word has reserved bits set (bits 0-31: gate bits, 62: N inside the read, 63: another character; nothing else)");
+		const uint64_t n_chunks = chunk_offsets[n_reads];
+		if (n_chunks && !kmers) return fail(VG_EINVAL, "null argument");
+		if (n_reads >= (1ull << 32) - (1ull << 24) || n_chunks >= (1ull << 32)) return fail(VG_ETOOBIG, "a batch of 2^32 chunks or more");
+		auto up = [](uint64_t b) { return (b + 255) & ~255ull; };
+		const uint64_t need = up((n_chunks + 2) * 8) + up(n_reads * 8) + up((n_reads + 1) * 8);
+		if (rs->used + need > rs->bytes) { char t[96]; snprintf(t, sizeof t, "%.2f of %.2f GB used, this batch needs %.3f GB", rs->used / 1e9, rs->bytes / 1e9, need / 1e9); return fail(VG_ENOMEM, "the read store is full (%s)", t); }
+		StoredBatch b;
+		uint8_t *at = rs->block + rs->used;
+		b.kmers = (uint64_t *)at; at += up((n_chunks + 2) * 8);
+		b.meta = (uint64_t *)at; at += up(n_reads * 8);
+		b.offsets = (uint64_t *)at;
+		b.n_reads = n_reads; b.n_chunks = n_chunks;
+		if (n_chunks) HIP_TRY(hipMemcpyAsync((void *)b.kmers, kmers, n_chunks * 8, hipMemcpyHostToDevice, rs->stream));
+		HIP_TRY(hipMemcpyAsync((void *)b.meta, meta, n_reads * 8, hipMemcpyHostToDevice, rs->stream));
+		HIP_TRY(hipMemcpyAsync((void *)b.offsets, chunk_offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, rs->stream));
+		vg_chunk_to_flat_offsets<<<(unsigned)((n_reads + 1 + 255) / 256), 256, 0, rs->stream>>>((uint64_t *)b.offsets, n_reads + 1);
+		HIP_TRY(hipGetLastError());
+		rs->used += need; rs->reads += n_reads; rs->invalid += invalid;
+		rs->batches.push_back(b);
+		return VG_OK;
+	});
+}
+extern "C" int vg_reads_submit_store(vg_index *ix, vg_read_store *rs)
+{
+	if (!ix || !rs) return fail(VG_EINVAL, "null argument");
+	if (ix->device != rs->device) return fail(VG_EINVAL, "the read store and the index handle live on different devices");
+	return guarded([&]() -> int {
+		HIP_TRY(hipSetDevice(ix->device));
+		HIP_TRY(hipStreamSynchronize(rs->stream));               // everything pushed is in device memory
+		hipStream_t is = ix->ingest_stream ? ix->ingest : ix->stream;
+		for (const StoredBatch &b : rs->batches) {
+			Slot *sl = nullptr;
+			int rc = acquire_slot(ix, &sl);
+			if (rc) return rc;
+			rc = launch_packed(ix, *sl, b.kmers, b.meta, b.offsets, b.n_reads, b.n_chunks, is);
+			if (rc) return rc;
+		}
+		ix->host_invalid += rs->invalid;
+		return VG_OK;
+	});
 }
 
 static int submit_impl(vg_index *ix, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, uint64_t n_reads);

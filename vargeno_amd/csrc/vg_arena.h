@@ -47,6 +47,11 @@ public:
 		return true;
 	}
 	bool ready() const { return base_ != nullptr; }
+	// Temporaries only at or above this offset (default 0: anywhere).  A block sized for a budget-limited index -- views left out
+	// -- is smaller than what construction has alive at its peak: there the temporaries stay out of the block (the caller's
+	// hipMalloc fallback serves them, transiently) so that every permanent array finds its place and the finished handle holds
+	// exactly what was planned.
+	void set_temp_floor(uint64_t off) { temp_floor_ = off; }
 	uint64_t size() const { return size_; }
 	uint64_t in_use() const { return in_use_; }
 	uint64_t peak() const { return peak_; }
@@ -71,7 +76,7 @@ public:
 				const uint64_t b0 = it->first, b1 = b0 + it->second;
 				if (b1 - b0 < bytes) continue;
 				const uint64_t a = (b1 - bytes) / al * al;
-				if (a >= b0) { at = a; found = true; carve(b0, b1, a, bytes); break; }
+				if (a >= b0 && a >= temp_floor_) { at = a; found = true; carve(b0, b1, a, bytes); break; }
 			}
 		}
 		if (!found) return nullptr;
@@ -103,7 +108,7 @@ public:
 	void destroy()
 	{
 		if (base_) B::free(base_);
-		base_ = nullptr; size_ = 0; free_.clear(); live_.clear(); in_use_ = 0;
+		base_ = nullptr; size_ = 0; free_.clear(); live_.clear(); in_use_ = 0; temp_floor_ = 0;
 	}
 
 private:
@@ -115,7 +120,7 @@ private:
 		if (a + bytes < b1) free_[a + bytes] = b1 - (a + bytes);
 	}
 	uint8_t *base_ = nullptr;
-	uint64_t size_ = 0, in_use_ = 0, peak_ = 0;
+	uint64_t size_ = 0, in_use_ = 0, peak_ = 0, temp_floor_ = 0;
 	std::map<uint64_t, uint64_t> free_, live_;                  // offset -> bytes
 };
 

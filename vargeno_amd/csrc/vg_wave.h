@@ -996,7 +996,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 										};
 										#pragma unroll
 										for (uint32_t q = 0; q < SIG_W; q++) cand |= (two(sv[q].x) | (two(sv[q].y) << 2) | (two(sv[q].z) << 4) | (two(sv[q].w) << 6)) << (8u * q);
-										cand &= live >= 8u * SIG_W ? (SIG_W == 4 ? ~0u : (1u << (8u * SIG_W)) - 1u) : ((1u << live) - 1u);
+										cand &= live >= 8u * SIG_W ? (uint32_t)((1ull << (8u * SIG_W)) - 1ull) : ((1u << live) - 1u);
 									} else {
 										const uint32_t x = (uint32_t)d.snp_sig[(uint64_t)slo + u0] ^ ks, y = (x | (x >> 1)) & 0x5555u;
 										cand = __popc(y) == 1 ? 1u : 0u;
