@@ -29,6 +29,7 @@
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -196,19 +197,28 @@ private:
 			stage[k] = (uint64_t *)vg_host_alloc_pinned((size_t)(kcap + 2 * rcap + 2) * 8);
 			if (!stage[k]) { error = "page-locked staging for the pre-packer: allocation failed"; if (stage[0]) vg_host_free_pinned(stage[0]); vg_packer_destroy(pk); finish(); return; }
 		}
+		// The text: the file mapped (the packer's threads read the page cache / tmpfs pages themselves: no copy into buffers of
+		// ours, which cost as many CPU seconds as the packing itself -- and the job shares a CPU quota with the index's start-up),
+		// the chunks after the current one asked for ahead (MADV_WILLNEED); VARGENO_PREPACK_MMAP=0 or a file that cannot be
+		// mapped: reader threads fill three chunk buffers with pread, a chunk ahead of the packer
+		const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE), map_lo = lo_ / page * page;
+		const uint8_t *map = nullptr;
+		if (env_int("VARGENO_PREPACK_MMAP", 1)) {
+			void *m = mmap(nullptr, (size_t)(hi_ - map_lo), PROT_READ, MAP_SHARED, fd_, (off_t)map_lo);
+			if (m != MAP_FAILED) { map = (const uint8_t *)m; (void)madvise(m, (size_t)(hi_ - map_lo), MADV_SEQUENTIAL); }
+		}
 		const int NBUF = 3;
 		std::vector<std::vector<uint8_t>> text((size_t)NBUF);
-		for (auto &t : text) t.resize((size_t)std::min(chunk_, fsize));
-		// reader threads fill the text buffers piecewise, a chunk ahead of the packer
+		if (!map) for (auto &t : text) t.resize((size_t)std::min(chunk_, fsize));
 		const uint64_t piece = std::min<uint64_t>(chunk_, 8ull << 20), ppc = (chunk_ + piece - 1) / piece;
 		std::vector<uint32_t> left((size_t)n_chunks);
-		for (uint64_t i = 0; i < n_chunks; i++) { const uint64_t len = std::min(chunk_, fsize - i * chunk_); left[(size_t)i] = (uint32_t)((len + piece - 1) / piece); }
+		for (uint64_t i = 0; i < n_chunks; i++) { const uint64_t len = std::min(chunk_, fsize - i * chunk_); left[(size_t)i] = map ? 0u : (uint32_t)((len + piece - 1) / piece); }
 		std::mutex rmu; std::condition_variable rcv;
 		uint64_t packed = 0;                                                     // chunks the packer is done with (their buffers are free)
 		std::atomic<uint64_t> next_piece{0};
 		bool io_error = false, quit = false;
 		std::vector<std::thread> readers;
-		for (int t = 0; t < n_readers_; t++) readers.emplace_back([&] {
+		for (int t = 0; t < (map ? 0 : n_readers_); t++) readers.emplace_back([&] {
 			for (;;) {
 				const uint64_t p = next_piece.fetch_add(1);
 				const uint64_t ci = p / ppc, off = ci * chunk_ + (p % ppc) * piece;
@@ -234,7 +244,10 @@ private:
 			uint64_t *sk = stage[i & 1], *sm = sk + kcap, *so = sm + rcap;
 			uint64_t nr = 0, nc = 0, ninv = 0;
 			struct timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
-			const int rc = vg_packer_push(pk, text[(size_t)(i % NBUF)].data(), len, sk, kcap, sm, so, rcap, &nr, &nc, &ninv);
+			const uint8_t *src = map ? map + (lo_ - map_lo) + i * chunk_ : text[(size_t)(i % NBUF)].data();
+			if (map && i + 1 < n_chunks) (void)madvise((void *)(map + ((lo_ - map_lo) + (i + 1) * chunk_) / page * page), (size_t)std::min(2 * chunk_, hi_ - lo_ - (i + 1) * chunk_), MADV_WILLNEED);
+			const int rc = vg_packer_push(pk, src, len, sk, kcap, sm, so, rcap, &nr, &nc, &ninv);
+			if (map && i > 0) (void)madvise((void *)(map + ((lo_ - map_lo) + (i - 1) * chunk_ + page - 1) / page * page), (size_t)(chunk_ / page * page - page), MADV_DONTNEED);      // (the mapping of the chunk before: its pages stay in the page cache, the page tables go)
 			clock_gettime(CLOCK_MONOTONIC, &b);
 			if (rc != VG_OK) { error = vg_last_error(); break; }
 			pack_s_.store(pack_s_.load() + (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec));
@@ -259,6 +272,7 @@ private:
 		for (auto &t : readers) t.join();
 		if (io_error && error.empty()) error = "error reading the FASTQ file";
 		if (vg_read_store_flush(store_) != VG_OK && error.empty()) error = vg_last_error();      // the staging sets are free
+		if (map) (void)munmap((void *)map, (size_t)(hi_ - map_lo));
 		for (int k = 0; k < 2; k++) vg_host_free_pinned(stage[k]);
 		vg_packer_destroy(pk);
 		finish();

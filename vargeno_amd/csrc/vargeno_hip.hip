@@ -832,7 +832,7 @@ struct vg_index {
 	int device = 0;
 	hipStream_t stream = nullptr, tail = nullptr;   // pack + wave tier | spill tiers of earlier batches
 	hipStream_t ingest = nullptr;                   // FASTQ framing + pack kernel of the next batch, under the current batch's wave kernel
-	bool pack_overlap = false;                      // VG_PACK_OVERLAP=1: the pack kernel of batch k+1 goes to the ingest stream, under batch k's wave kernel.
+	int pack_overlap = -1;                          // the pack kernel of batch k+1 on the ingest stream, under batch k's wave kernel: 1 always, 0 never (VG_PACK_OVERLAP), -1: for small batches.
 	                                                // Off by default: nothing fits beside a full set of main-tier workgroups (4 x 128 VGPRs per SIMD), so the
 	                                                // two kernels only take turns on the CUs -- same reads/s (hg38 scale: 4.21 vs 4.26 ms per 8 M reads), but the
 	                                                // wave kernel's duration then includes the time it spent waiting for the pack kernel (4.18 vs 3.55 ms)
@@ -1210,7 +1210,7 @@ static int init_handle(vg_index *ix, int device)
 		HIP_TRY(hipStreamCreateWithPriority(&ix->tail, hipStreamNonBlocking, hi_p));
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->ingest, hipStreamNonBlocking));
-	if (const char *e = getenv("VG_PACK_OVERLAP")) ix->pack_overlap = atoi(e) != 0;
+	if (const char *e = getenv("VG_PACK_OVERLAP")) ix->pack_overlap = atoi(e) != 0 ? 1 : 0;
 	ix->ingest_stream = getenv("VG_NO_INGEST_STREAM") == nullptr;
 	for (Slot &sl : ix->slot) HIP_TRY(hipHostMalloc((void **)&sl.h_ctr, 64, hipHostMallocDefault));
 	for (Slot &sl : ix->slot) { HIP_TRY(hipEventCreate(&sl.e0)); HIP_TRY(hipEventCreate(&sl.e1)); HIP_TRY(hipEventCreate(&sl.e2)); HIP_TRY(hipEventCreate(&sl.e3)); HIP_TRY(hipEventCreate(&sl.e4)); HIP_TRY(hipEventCreate(&sl.e5)); HIP_TRY(hipEventCreateWithFlags(&sl.e_fq, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming)); }
@@ -1959,10 +1959,12 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 	uint32_t *ctr = sl.ctr;
 	const unsigned g1 = (unsigned)std::min<uint64_t>((n_reads + 255) / 256, (uint64_t)ix->lane_grid_blocks);
 	if (!ix->force_generic) {
-		// main stream: pack, then the wave tier.  (Packing batch k+1 on a third stream under batch k's wave
-		// kernel was measured and lost 12 %: two co-scheduled kernels split the CUs.)
+		// main stream: pack, then the wave tier.  (Packing batch k+1 on a third stream under batch k's wave kernel was measured
+		// with 8 M-read batches and lost 12 %: two co-scheduled kernels split the CUs.  With batches of a million reads the
+		// launch gaps between the dependent kernels of one stream weigh more than that: chr22-scale, 1 M reads per step,
+		// 0.384 -> 0.352 ms per step (profiles/ab_chr22_pack_overlap_r05.txt) -- so small batches do overlap.)
 		hipStream_t ps = ix->stream;
-		if (ix->pack_overlap) ps = ix->ingest;
+		if (ix->ingest && (ix->pack_overlap == 1 || (ix->pack_overlap < 0 && n_reads <= (2u << 20)))) ps = ix->ingest;
 		if (produced_on && produced_on != ps) {                     // a batch gathered by the FASTQ framing on the ingest stream
 			HIP_TRY(hipEventRecord(sl.e_in, produced_on));
 			HIP_TRY(hipStreamWaitEvent(ps, sl.e_in, 0));
