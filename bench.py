@@ -690,10 +690,12 @@ def main():
     #      loads the host (vg_index_open is part of what a job pays: its time and its phases go into the line; the reference binary's two
     #      processes -- 48 GB of per-field fread each -- start after it)
     t0 = time.time()
+    cpu0 = time.process_time()
     # (ranks that share a device -- the gloo rehearsals on a one-GPU box -- share its memory: each plans for an equal part)
     sharers = (world + max(ndev, 1) - 1 - dev_index) // max(ndev, 1) if world > max(ndev, 1) else 1
     gx = GenoIndex.open(prefix, device=dev_index, sharers=sharers)
     t_open = time.time() - t0
+    cpu_open = time.process_time() - cpu0                  # host CPU seconds of this process (all its threads) inside vg_index_open
     open_report = gx.open_report
     if rank == 0:
         log("[bench] index resident in HBM: %.1fs, %.1f GB, %d sites" % (t_open, gx.device_bytes / 1e9, gx.num_sites))
@@ -920,12 +922,15 @@ def main():
         total_after = int(gx.counts_tensor().sum(dtype=torch.int64).item())
         assert total_after == int(local_sum.item()), "reduced counters hold %d increments, the ranks made %d" % (total_after, int(local_sum.item()))
         # what every rank saw, so that a scaling run explains itself: main-tier kernel ms, steps' wall ms, the exchange's ms
-        mine = torch.tensor([tm["ms_main"], 1e3 * (t_steps_done - t0) / args.steps, 1e3 * t_reduce], dtype=torch.float64, device=coll_dev)
+        mine = torch.tensor([tm["ms_main"], 1e3 * (t_steps_done - t0) / args.steps, 1e3 * t_reduce, t_open, cpu_open, gx.device_bytes / 1e9], dtype=torch.float64, device=coll_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         if rank == 0:
             verification["timed_region_increments"] = total_after
             per_rank = {"kernel_ms": [float(x[0]) for x in allr], "ms_per_step_before_exchange": [float(x[1]) for x in allr], "all_reduce_ms": [float(x[2]) for x in allr],
+                        # every replica's start-up as it ran beside the others (they read the same files at the same time): wall seconds, host
+                        # CPU seconds of the rank's process, GB of device memory it holds -- what a first run on real hardware is compared with
+                        "index_open_s": [float(x[3]) for x in allr], "index_open_cpu_s": [float(x[4]) for x in allr], "index_device_GB": [float(x[5]) for x in allr],
                         "all_reduce_bytes": int(gx.counts_tensor().numel()) * 4, "backend": "RCCL (torch.distributed nccl)" if backend == "nccl" else backend,
                         "devices_visible": ndev, "ranks_seen_by_the_collective": n_seen}
 
@@ -1132,7 +1137,7 @@ def main():
                                        args.genome, args.chroms, args.snps, args.reads, args.read_len, args.batches, 100 * args.lowq,
                                        "" if not args.repeats else "; REPEAT-RICH genome: %g%% of it in planted families of near-identical copies (2-10 and 11-200 copies), 50 microsatellites per Mbp" % (100 * args.repeats)),
                        "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps, "lowq": args.lowq, "repeats": args.repeats, "read_len": args.read_len, "softmask": args.softmask, "gate_words": bool(args.gate_words),
-                       "index_bytes_hbm": dev_bytes, "index_views": views, "index_plan": plan_text, "index_open_s": t_open, "index_open_phases": open_report, "lib_build_id": build_id,
+                       "index_bytes_hbm": dev_bytes, "index_views": views, "index_plan": plan_text, "index_open_s": t_open, "index_open_cpu_s": cpu_open, "index_open_phases": open_report, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
             "roofline": roof,
             "cpu_baseline": cpu,
