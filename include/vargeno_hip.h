@@ -98,15 +98,20 @@ int  vg_index_open(const char *prefix, int device, vg_index **out);
  * dictionaries' sizes and the budget alone, in a fixed order, before anything is allocated -- never from what happens to be free at
  * that moment: the same files and the same budget always give the same vg_index_views().  A caller that shares the device must say
  * how much of it is its own; when an allocation the plan had room for fails all the same, the call fails with VG_ENOMEM instead of
- * silently building a slower layout.  VG_ENOMEM also when the budget is below the smallest layout.  While the handle is being
- * built the device holds up to ~20 % more than the final size (sort buffers of the merged view). */
+ * silently building a slower layout.  VG_ENOMEM also when the budget is below the smallest layout.
+ * The budget bounds what the FINISHED handle holds (vg_index_device_bytes <= budget; profiles/budget_sweep_r05.json).  With
+ * every view planned, construction stays inside the handle's one block (vg_arena.h: the order of construction keeps the live set
+ * within the finished size).  With views left out the finished handle is smaller than what construction has alive at its peak --
+ * the dictionaries' columns beside their entries, the sorts' buffers -- and those temporaries are taken from the device beside the
+ * block and given back: up to ~100 GB more than the budget for some hundred milliseconds at hg38 scale.  Replicas that SHARE a
+ * device and open at the same time must leave that room (or open one after the other). */
 int  vg_index_open_ex(const char *prefix, int device, uint64_t max_device_bytes, vg_index **out);
 /* What the budget bought, in words: planned bytes, views kept, views left out with what each costs ("" for a null handle).
  * The string lives as long as the handle. */
 const char *vg_index_plan(const vg_index *ix);
 /* Where the handle's start-up time went (the reference's loader, qv.cc:519-695, takes ~240 s at hg38 scale):
  * wall seconds of each phase of vg_index_open / vg_index_create with the part spent inside allocation calls, then the memory the
- * handle ended up with (r05: one arena of 1 GiB chunks taken from the driver once and recycled, vg_arena.h).  "" for a null handle;
+ * handle ended up with (r05: one block taken from the driver once and carved up, vg_arena.h).  "" for a null handle;
  * the string lives as long as the handle. */
 const char *vg_index_open_report(const vg_index *ix);
 int  vg_index_create(const vg_index_arrays *a, int device, vg_index **out);
