@@ -825,9 +825,12 @@ struct Slot {
 	hipEvent_t e_fq = nullptr; bool fq_tail_wanted = false;          // the NEXT chunk's prepare kernel reads this text's tail: recorded after it
 	uint64_t stage_bytes = 0, stage_quals_bytes = 0, stage_reads = 0;      // capacities of st_bases, st_quals, st_offsets
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
-	// the spill tiers of this slot's batch: a stream and a lane-tier scratch of its own (r05).  One tail stream for all slots made
-	// the tiers of batch k+1 wait for those of batch k: with 250 bp reads a batch's tiers take 13 ms (a handful of reads with
-	// thousands of contexts, latency-bound) against 5 ms per step, and the main stream waited for its slots (6.9 ms per step)
+	// the lane tier of this slot's batch: a stream and a scratch of its own (r05).  One tail stream for everything made the deep
+	// wave tier of batch k+1 wait for the lane tier of batch k: with 250 bp reads a batch's lane tier takes 5-12 ms (a handful of
+	// reads with thousands of contexts, latency-bound) against 5 ms per step, and the main stream waited for its slots (6.9 ms per
+	// step; 5.4 with this).  The deep wave tiers stay on ONE stream: their grids are sized for the worst case (768 single-wave
+	// workgroups of 42 KB of LDS that mostly exit at once), and three of them in flight get in the main tier's way (chr22-scale:
+	// 0.35 -> 0.41 ms per step)
 	hipStream_t tail = nullptr;
 	ScratchBuf big;                       // lane-tier scratch: a few lanes x 16384 contexts
 	bool busy = false;
@@ -835,7 +838,7 @@ struct Slot {
 
 struct vg_index {
 	int device = 0;
-	hipStream_t stream = nullptr;                   // pack + wave tier (the spill tiers of earlier batches run on their slots' streams)
+	hipStream_t stream = nullptr, tail = nullptr;   // pack + wave tier | deep wave tier of earlier batches, one after the other (their lane tiers run on their slots' streams)
 	hipStream_t ingest = nullptr;                   // FASTQ framing + pack kernel of the next batch, under the current batch's wave kernel
 	int pack_overlap = -1;                          // the pack kernel of batch k+1 on the ingest stream, under batch k's wave kernel: 1 always, 0 never (VG_PACK_OVERLAP), -1: for small batches.
 	                                                // Off by default: nothing fits beside a full set of main-tier workgroups (4 x 128 VGPRs per SIMD), so the
@@ -981,6 +984,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	if (!ix) return;
 	(void)hipSetDevice(ix->device);
 	if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+	if (ix->tail) (void)hipStreamSynchronize(ix->tail);
 	for (Slot &sl : ix->slot) if (sl.tail) (void)hipStreamSynchronize(sl.tail);
 	if (ix->ingest) (void)hipStreamSynchronize(ix->ingest);
 	for (void *p : ix->owned) (void)hipFree(p);
@@ -995,6 +999,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	}
 	delete ix->packer;
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
+	if (ix->tail) (void)hipStreamDestroy(ix->tail);
 	for (Slot &sl : ix->slot) if (sl.tail) (void)hipStreamDestroy(sl.tail);
 	if (ix->ingest) (void)hipStreamDestroy(ix->ingest);
 	delete ix;
@@ -1212,6 +1217,7 @@ static int init_handle(vg_index *ix, int device)
 		int lo_p = 0, hi_p = 0;
 		(void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
 		if (getenv("VG_TAIL_PRIO") && atoi(getenv("VG_TAIL_PRIO")) == 0) hi_p = 0;
+		HIP_TRY(hipStreamCreateWithPriority(&ix->tail, hipStreamNonBlocking, hi_p));
 		for (Slot &sl : ix->slot) HIP_TRY(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, hi_p));
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->ingest, hipStreamNonBlocking));
@@ -1939,6 +1945,7 @@ static int finish_pending(vg_index *ix)
 {
 	HIP_TRY(hipSetDevice(ix->device));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
+	HIP_TRY(hipStreamSynchronize(ix->tail));
 	for (Slot &sl : ix->slot) HIP_TRY(hipStreamSynchronize(sl.tail));
 	// (the FASTQ stream's own work -- vg_fastq_stream_begin's reset of the stream state included -- is otherwise only ordered
 	// before the batches it produced: an empty stream has none)
@@ -2002,11 +2009,12 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		// when that kernel's workgroups retired, 2.2 ms later -- the tail stream was busy for a whole step, the handle's batch slots
 		// waited for it and the main stream idled 0.2 ms per step (profiles/timeline_hg38_r04_three_tiers.txt).  With vote keys instead
 		// of context lists the deep tier has 0.005-0.3 % of the reads to do, not 10 %.
-		HIP_TRY(hipStreamWaitEvent(sl.tail, sl.e2, 0));
+		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
 		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
-		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, sl.tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
-		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, sl.tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
-		HIP_TRY(hipEventRecord(sl.e4, sl.tail));
+		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
+		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
+		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
+		HIP_TRY(hipStreamWaitEvent(sl.tail, sl.e4, 0));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream
 			HIP_TRY(hipEventRecord(sl.e_in, produced_on));
