@@ -121,7 +121,7 @@ static uint64_t replay(const char *name, uint64_t n, uint64_t m, uint64_t aux_r,
 		P("mx", 16 * nm); g("ka"); g("va"); g("strand");
 		T("big", 4); P("dx", (1ull << 32) * 16); g("big");
 	}
-	P("scratch_mid", 2048ull * 256 * (64 * 16 + 32 * 12)); for (int k = 0; k < 3; k++) P(k == 0 ? "scratch_big0" : k == 1 ? "scratch_big1" : "scratch_big2", 4096ull * (16384 * 16 + 2048 * 12));
+	P("scratch_mid", 2048ull * 256 * (64 * 16 + 32 * 12)); P("scratch_big", 4096ull * (16384 * 16 + 2048 * 12));
 	const uint64_t used = a.in_use();
 	if (S < (1ull << 50)) printf("replay %-14s block %.1f GB, finished index %.1f GB, at most %.1f GB alive, %llu requests without room\n", name, S / 1e9, used / 1e9, a.peak() / 1e9, (unsigned long long)misses);
 	return used;

@@ -617,9 +617,9 @@ def test_a_device_memory_budget_decides_the_views_and_nothing_else_does(ftiny_di
     _, _, so = _oracle_counts(prefix, r)
     GiB = 1 << 30
     seen = {}
-    # F-tiny: the smallest layout is planned at ~22.6 GiB (the 16 GiB jump table is always there, 4 GiB of lane-tier scratch -- a deep one per batch slot --, 2 GiB
+    # F-tiny: the smallest layout is planned at ~20.5 GiB (the 16 GiB jump table is always there, 1.8 GiB of lane-tier scratch, 2 GiB
     # reserved for batch slots); the LO32 and signature views are tiny here, the merged view adds 16 GiB, the direct table 48 more
-    for budget in (200 * GiB, 60 * GiB, 40 * GiB, 24 * GiB, 200 * GiB, 60 * GiB):
+    for budget in (200 * GiB, 60 * GiB, 40 * GiB, 21 * GiB, 200 * GiB, 60 * GiB):
         hog = torch.empty(6 * GiB, dtype=torch.uint8, device="cuda:0") if len(seen) % 2 else None
         with GenoIndex.open(prefix, max_device_bytes=budget) as gx:
             views, plan = tuple(gx.views), gx.plan
@@ -635,7 +635,7 @@ def test_a_device_memory_budget_decides_the_views_and_nothing_else_does(ftiny_di
         print("budget %3d GiB: %s | %s" % (budget // GiB, ",".join(views), plan))
     assert "dx" in seen[200 * GiB][0] and "mx" in seen[200 * GiB][0] and "nothing left out" in seen[200 * GiB][1]
     assert "dx" not in seen[60 * GiB][0] and "mx" in seen[60 * GiB][0] and "LEFT OUT" in seen[60 * GiB][1] and "direct table" in seen[60 * GiB][1]
-    assert "mx" not in seen[24 * GiB][0] and "sec" in seen[24 * GiB][0]
+    assert "mx" not in seen[21 * GiB][0] and "sec" in seen[21 * GiB][0]
     with pytest.raises(VgError) as e:
         GenoIndex.open(prefix, max_device_bytes=10 * GiB)
     assert e.value.code == -3 and "budget" in str(e.value)

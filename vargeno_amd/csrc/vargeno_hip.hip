@@ -825,20 +825,18 @@ struct Slot {
 	hipEvent_t e_fq = nullptr; bool fq_tail_wanted = false;          // the NEXT chunk's prepare kernel reads this text's tail: recorded after it
 	uint64_t stage_bytes = 0, stage_quals_bytes = 0, stage_reads = 0;      // capacities of st_bases, st_quals, st_offsets
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr, e4 = nullptr, e5 = nullptr;
-	// the lane tier of this slot's batch: a stream and a scratch of its own (r05).  One tail stream for everything made the deep
-	// wave tier of batch k+1 wait for the lane tier of batch k: with 250 bp reads a batch's lane tier takes 5-12 ms (a handful of
-	// reads with thousands of contexts, latency-bound) against 5 ms per step, and the main stream waited for its slots (6.9 ms per
-	// step; 5.4 with this).  The deep wave tiers stay on ONE stream: their grids are sized for the worst case (768 single-wave
-	// workgroups of 42 KB of LDS that mostly exit at once), and three of them in flight get in the main tier's way (chr22-scale:
-	// 0.35 -> 0.41 ms per step)
-	hipStream_t tail = nullptr;
-	ScratchBuf big;                       // lane-tier scratch: a few lanes x 16384 contexts
 	bool busy = false;
 };
 
 struct vg_index {
 	int device = 0;
-	hipStream_t stream = nullptr, tail = nullptr;   // pack + wave tier | deep wave tier of earlier batches, one after the other (their lane tiers run on their slots' streams)
+	hipStream_t stream = nullptr, tail = nullptr;   // pack + wave tier | deep wave tier of earlier batches, one after the other
+	// ... and their lane tiers + the copies of their counters, on a stream of their own (r05).  On the one tail stream the deep wave
+	// tier of batch k+1 waited for the lane tier of batch k: with 250 bp reads a batch's lane tier takes 5-12 ms (a handful of reads
+	// with thousands of contexts, latency-bound) against 5 ms per step, and the main stream waited for its slots (6.9 ms per step).
+	// (A stream per batch slot -- six streams in all -- was tried and cost the DEFAULT workload 6 % and chr22-scale 25 %
+	// (profiles/ab_tail_streams_r05.txt): more streams than hardware queues, and the main stream shares one.)
+	hipStream_t tail2 = nullptr;
 	hipStream_t ingest = nullptr;                   // FASTQ framing + pack kernel of the next batch, under the current batch's wave kernel
 	int pack_overlap = -1;                          // the pack kernel of batch k+1 on the ingest stream, under batch k's wave kernel: 1 always, 0 never (VG_PACK_OVERLAP), -1: for small batches.
 	                                                // Off by default: nothing fits beside a full set of main-tier workgroups (4 x 128 VGPRs per SIMD), so the
@@ -855,7 +853,7 @@ struct vg_index {
 	bool cnt4_dirty = false;                           // base-indexed counters hold increments not yet folded into d.cnt
 	std::vector<uint32_t> site_pos;
 	std::vector<uint8_t> site_ref, site_alt, site_rf, site_af;
-	ScratchBuf mid;                       // lane-tier scratch of VG_FORCE_GENERIC: every lane x 64 contexts (the deep scratch is per slot)
+	ScratchBuf mid, big;                  // lane-tier scratch: every lane x 64 contexts; a few lanes x 16384 contexts
 	Slot slot[NSLOT];
 	int next_slot = 0;
 	bool lane_tier_seen = false;          // some batch of this handle left reads for the lane tier: it is enqueued with every batch from then on
@@ -985,7 +983,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	(void)hipSetDevice(ix->device);
 	if (ix->stream) (void)hipStreamSynchronize(ix->stream);
 	if (ix->tail) (void)hipStreamSynchronize(ix->tail);
-	for (Slot &sl : ix->slot) if (sl.tail) (void)hipStreamSynchronize(sl.tail);
+	if (ix->tail2) (void)hipStreamSynchronize(ix->tail2);
 	if (ix->ingest) (void)hipStreamSynchronize(ix->ingest);
 	for (void *p : ix->owned) (void)hipFree(p);
 	ix->arena.destroy();
@@ -1000,7 +998,7 @@ extern "C" void vg_index_close(vg_index *ix)
 	delete ix->packer;
 	if (ix->stream) (void)hipStreamDestroy(ix->stream);
 	if (ix->tail) (void)hipStreamDestroy(ix->tail);
-	for (Slot &sl : ix->slot) if (sl.tail) (void)hipStreamDestroy(sl.tail);
+	if (ix->tail2) (void)hipStreamDestroy(ix->tail2);
 	if (ix->ingest) (void)hipStreamDestroy(ix->ingest);
 	delete ix;
 }
@@ -1218,7 +1216,7 @@ static int init_handle(vg_index *ix, int device)
 		(void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
 		if (getenv("VG_TAIL_PRIO") && atoi(getenv("VG_TAIL_PRIO")) == 0) hi_p = 0;
 		HIP_TRY(hipStreamCreateWithPriority(&ix->tail, hipStreamNonBlocking, hi_p));
-		for (Slot &sl : ix->slot) HIP_TRY(hipStreamCreateWithPriority(&sl.tail, hipStreamNonBlocking, hi_p));
+		HIP_TRY(hipStreamCreateWithPriority(&ix->tail2, hipStreamNonBlocking, hi_p));
 	}
 	HIP_TRY(hipStreamCreateWithFlags(&ix->ingest, hipStreamNonBlocking));
 	if (const char *e = getenv("VG_PACK_OVERLAP")) ix->pack_overlap = atoi(e) != 0 ? 1 : 0;
@@ -1258,7 +1256,7 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 	const uint64_t GiB = 1ull << 30, n = c.n_ref, m = c.n_snp, J32 = ((1ull << 32) + 1) * 4;
 	p.budget = budget_arg ? budget_arg : (device_total > 12 * GiB ? device_total - 12 * GiB : device_total);
 	const uint64_t plen = maxp + 64, sites = m / 32 + 1;                       // (an SNP seeds at most one site; ~32 k-mers per SNP)
-	const uint64_t scratch = (uint64_t)cus * 8 * 256 * (64 * 16 + 32 * 12) + (uint64_t)NSLOT * 4096ull * (16384 * 16 + 2048 * 12);      // (a deep lane-tier scratch per batch slot)
+	const uint64_t scratch = (uint64_t)cus * 8 * 256 * (64 * 16 + 32 * 12) + 4096ull * (16384 * 16 + 2048 * 12);
 	// what every layout holds: both dictionaries in file order with their jump tables, auxiliary rows, bit vectors, pile-up
 	// sites and counters, lane-tier scratch, and room for three batch slots of a few million reads
 	p.base = J32 + 16 * n + 40 * c.n_ref_aux + ((1ull << 24) + 1) * 4 + 16 * m + 50 * c.n_snp_aux + std::min<uint64_t>(ref_bf_bits, 1ull << 32) / 8 + snp_bf_bits / 8
@@ -1593,7 +1591,7 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 	if (const char *e = getenv("VG_SCRATCH_CAP")) cap = (uint32_t)std::max(1, atoi(e));
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
-	for (Slot &sl : ix->slot) if ((rc = alloc_scratch(ix, sl.big, 64u * 64u, 16384, 2048))) return rc;
+	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
 	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 16, true, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
 	if ((rc = dev_alloc(ix, &ix->d_clamped, 2 * ix->n_sites + 2, false, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true, true))) return rc;
@@ -1924,11 +1922,11 @@ static int harvest(vg_index *ix, Slot &sl)
 	if (sl.h_ctr[1]) ix->lane_tier_seen = true;
 	if (sl.h_ctr[1] && !sl.lt_enqueued) {
 		// the deep tier left reads behind (listB): the lane machine with its lists in HBM finishes them now
-		if (sl.lt_stats) vg_lane_kernel<true><<<sl.big.s.nlanes / 64, 64, 0, sl.tail>>>(ix->d, sl.big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
-		else vg_lane_kernel<false><<<sl.big.s.nlanes / 64, 64, 0, sl.tail>>>(ix->d, sl.big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
+		if (sl.lt_stats) vg_lane_kernel<true><<<ix->big.s.nlanes / 64, 64, 0, ix->tail2>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
+		else vg_lane_kernel<false><<<ix->big.s.nlanes / 64, 64, 0, ix->tail2>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(sl.h_ctr, sl.ctr, 16, hipMemcpyDeviceToHost, sl.tail));
-		HIP_TRY(hipStreamSynchronize(sl.tail));
+		HIP_TRY(hipMemcpyAsync(sl.h_ctr, sl.ctr, 16, hipMemcpyDeviceToHost, ix->tail2));
+		HIP_TRY(hipStreamSynchronize(ix->tail2));
 	}
 	for (int i = 0; i < 4; i++) ix->cum[i] += sl.h_ctr[i];
 	float a = 0, b = 0, c = 0, t = 0;
@@ -1946,7 +1944,7 @@ static int finish_pending(vg_index *ix)
 	HIP_TRY(hipSetDevice(ix->device));
 	HIP_TRY(hipStreamSynchronize(ix->stream));
 	HIP_TRY(hipStreamSynchronize(ix->tail));
-	for (Slot &sl : ix->slot) HIP_TRY(hipStreamSynchronize(sl.tail));
+	HIP_TRY(hipStreamSynchronize(ix->tail2));
 	// (the FASTQ stream's own work -- vg_fastq_stream_begin's reset of the stream state included -- is otherwise only ordered
 	// before the batches it produced: an empty stream has none)
 	if (ix->ingest) HIP_TRY(hipStreamSynchronize(ix->ingest));
@@ -2014,7 +2012,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
-		HIP_TRY(hipStreamWaitEvent(sl.tail, sl.e4, 0));
+		HIP_TRY(hipStreamWaitEvent(ix->tail2, sl.e4, 0));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream
 			HIP_TRY(hipEventRecord(sl.e_in, produced_on));
@@ -2026,8 +2024,8 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
 		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, packed ? nullptr : &ctr[3], d_gate, sl.pk_kmer, sl.pk_meta, packed);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
-		HIP_TRY(hipStreamWaitEvent(sl.tail, sl.e2, 0));
-		HIP_TRY(hipEventRecord(sl.e4, sl.tail));
+		HIP_TRY(hipStreamWaitEvent(ix->tail2, sl.e2, 0));
+		HIP_TRY(hipEventRecord(sl.e4, ix->tail2));
 	}
 	// ... and the generic lane machine with the deep HBM scratch for whatever is left -- LATER, and only if anything is (r05): the
 	// batch's counters come to the host behind its tiers, and harvest() launches the lane tier when they say that the deep tier left
@@ -2039,9 +2037,9 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 	// and the tail stream once per batch)
 	sl.lt_bases = d_bases; sl.lt_quals = d_quals; sl.lt_offsets = d_offsets; sl.lt_gate = d_gate; sl.lt_packed = packed; sl.lt_stats = STATS;
 	sl.lt_enqueued = ix->lane_tier_seen;
-	if (sl.lt_enqueued) vg_lane_kernel<STATS><<<sl.big.s.nlanes / 64, 64, 0, sl.tail>>>(ix->d, sl.big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
-	HIP_TRY(hipMemcpyAsync(sl.h_ctr, ctr, 16, hipMemcpyDeviceToHost, sl.tail));
-	HIP_TRY(hipEventRecord(sl.e3, sl.tail));
+	if (sl.lt_enqueued) vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail2>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
+	HIP_TRY(hipMemcpyAsync(sl.h_ctr, ctr, 16, hipMemcpyDeviceToHost, ix->tail2));
+	HIP_TRY(hipEventRecord(sl.e3, ix->tail2));
 	HIP_TRY(hipGetLastError());
 	sl.busy = true;
 	return VG_OK;
