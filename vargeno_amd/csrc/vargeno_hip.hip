@@ -2012,7 +2012,6 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
-		HIP_TRY(hipStreamWaitEvent(ix->tail2, sl.e4, 0));
 	} else {
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream
 			HIP_TRY(hipEventRecord(sl.e_in, produced_on));
@@ -2024,8 +2023,8 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
 		vg_lane_kernel<STATS><<<g1, 256, 0, ix->stream>>>(ix->d, ix->mid.s, d_bases, d_quals, d_offsets, n_reads, nullptr, d_n_reads, sl.listB, &ctr[1], ix->d_stats, packed ? nullptr : &ctr[3], d_gate, sl.pk_kmer, sl.pk_meta, packed);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
-		HIP_TRY(hipStreamWaitEvent(ix->tail2, sl.e2, 0));
-		HIP_TRY(hipEventRecord(sl.e4, ix->tail2));
+		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
+		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	}
 	// ... and the generic lane machine with the deep HBM scratch for whatever is left -- LATER, and only if anything is (r05): the
 	// batch's counters come to the host behind its tiers, and harvest() launches the lane tier when they say that the deep tier left
@@ -2037,9 +2036,13 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 	// and the tail stream once per batch)
 	sl.lt_bases = d_bases; sl.lt_quals = d_quals; sl.lt_offsets = d_offsets; sl.lt_gate = d_gate; sl.lt_packed = packed; sl.lt_stats = STATS;
 	sl.lt_enqueued = ix->lane_tier_seen;
-	if (sl.lt_enqueued) vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, ix->tail2>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
-	HIP_TRY(hipMemcpyAsync(sl.h_ctr, ctr, 16, hipMemcpyDeviceToHost, ix->tail2));
-	HIP_TRY(hipEventRecord(sl.e3, ix->tail2));
+	// (the lane tiers, once a workload needs them, and the counter copies behind them go to `tail2`; a workload that never does keeps
+	// to the one tail stream -- chr22-scale steps are 3 % slower with the fourth stream in use: profiles/ab_tail_streams_r05.txt)
+	hipStream_t lt = ix->tail;
+	if (sl.lt_enqueued) { lt = ix->tail2; HIP_TRY(hipStreamWaitEvent(lt, sl.e4, 0)); }
+	if (sl.lt_enqueued) vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, lt>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
+	HIP_TRY(hipMemcpyAsync(sl.h_ctr, ctr, 16, hipMemcpyDeviceToHost, lt));
+	HIP_TRY(hipEventRecord(sl.e3, lt));
 	HIP_TRY(hipGetLastError());
 	sl.busy = true;
 	return VG_OK;
