@@ -15,7 +15,10 @@
 //                         index is ready their measured rate is compared with the link's (vg_link_rate) and the faster route --
 //                         host packing, or the text framed on the device -- takes the rest of the file.  0: device framing only
 //   VARGENO_PREPACK=0     do not pack ahead of the index (and do not measure: host packing if VARGENO_PACK_THREADS > 0, else device framing)
-//   VARGENO_PREPACK_GB=n  page-locked memory the packed-ahead reads may take (default 32, at most a quarter of the host's available memory)
+//   VARGENO_PREPACK_GB=n  device memory the packed-ahead reads may take per device (the read store; default 16, at most an eighth of the device)
+//   VARGENO_PREPACK_MMAP=0  the pre-packer reads the file with pread into buffers of its own instead of mapping it
+//   VARGENO_ORDERLY_EXIT=1  close the handles and let the runtime shut down before the process ends (default: it ends when the VCF is closed)
+//   VARGENO_VCF_CLOCKS=1  stderr: the seconds of the caller / VCF pass, phase by phase
 //   VARGENO_READERS=n     threads reading the FASTQ file into pinned chunk buffers (default: an eighth of the hardware threads, 8 to 32)
 //   VARGENO_MAX_DEVICE_GB=x  device-memory budget per replica (vg_index_open_ex): which re-laid-out views the replica holds follows
 //                         from the index and this number alone (default: the whole device); VARGENO_VERBOSE=1 prints the plan
