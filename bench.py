@@ -83,6 +83,7 @@ def parse_args():
                     "(default: 200 000 000 for the default workload at N = 1 -- scaled down to what the work directory's file system holds --, else 0 = skip)")
     ap.add_argument("--cleanup", action="store_true", help="remove this run's index files when done (the secondary legs' child runs do)")
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
+    ap.add_argument("--no-pretouch", action="store_true", help="do not have a child process take the device's free memory once before the genome is generated (see pretouch_start)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the secondary end-to-end number (FASTQ text in pinned host memory -> counters)")
     args = ap.parse_args()
     for k, v in PRESETS[args.workload].items():
@@ -304,8 +305,9 @@ def pretouch_finish(handle, log):
         res = {"bytes": int(size), "hipMalloc_s": float(dt), "rc": int(rc),
                "note": "a child process took the device's free memory once and gave it back before the genome was generated: what the driver had to clear of a previous tenant's memory was cleared there (hipMalloc_s), not inside the timed vg_index_open"}
         # (what the child freed is scrubbed in the background; if it had to wait for a clearing, give the scrub its 20 s)
-        if res["hipMalloc_s"] > 0.5:
-            time.sleep(max(0.0, 20.0 - (time.time() - t_start - res["hipMalloc_s"])))
+        # (what the child freed is scrubbed in the background within ~15 s: an index whose files were already there is opened no
+        # earlier than 20 s after the child gave the memory back)
+        time.sleep(max(0.0, 20.0 - (time.time() - t_start - res["hipMalloc_s"] - 0.5)))
         return res
     except Exception as e:
         log("[bench] device pre-touch failed: %r" % (e,))
@@ -643,7 +645,7 @@ def run_child_leg(name, est, extra, args, ref):
         return {"skipped": "time budget: %.0f s of $VG_BENCH_BUDGET_S = %.0f s left, this leg is estimated at %d s" % (left, BUDGET_S, est)}
     ref.wait_quiet("secondary leg %s" % name)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--secondary", "none", "--no-gather-probe", "--no-ingest", "--cpu-reference", "no", "--sustain-seconds", "0",
-           "--cleanup", "--cpu-sample", "200000", "--job-reads", "0"] + extra
+           "--cleanup", "--cpu-sample", "200000", "--job-reads", "0", "--no-pretouch"] + extra
     if args.workdir_given:
         cmd += ["--workdir", args.workdir]
     time.sleep(IDLE_BEFORE_CHILD_S)                        # (the device's memory, just freed by the process before, scrubbed: see job_run)
@@ -712,7 +714,9 @@ def main():
     ceiling = None
     if rank == 0 and not args.no_gather_probe:
         ceiling = gather_ceiling()
-    pretouch = pretouch_start(local_rank, world)
+    # (hg38-scale indexes only, and not in the child legs: those start on a device that has been idle for 20 s, and a pre-touch
+    # shortly before a small index's open would itself be the process that has just freed the memory)
+    pretouch = pretouch_start(local_rank, world) if (args.genome >= 10 ** 9 and not args.no_pretouch) else (None, time.time())
     g, s, _ = synth.genome_and_snps(genome_len=args.genome, n_snps=args.snps, n_chroms=args.chroms, genotypes="hwe" if args.workload == "hg38f" else "uniform", repeats=args.repeats)
     if rank == 0:
         log("[bench] synthetic genome + SNP list: %.1fs (%d bp, %d SNPs)" % (time.time() - t0, g.total_len, len(s.pos)))

@@ -368,3 +368,53 @@ def test_caller_equals_the_reference_function_over_its_whole_domain(tmp_path):
     names = {1: "0/0", 2: "1/1", 3: "0/1"}
     want = {i: (names[int(t["genotype"][i])], int(t["gq"][i])) for i in range(n) if t["genotype"][i] != 0}
     assert len(want) > 65000 and got == want
+
+
+def test_vcf_pass_finds_every_record_whatever_the_order_of_the_list(tmp_path):
+    """The VCF pass looks a record's site up from where the last hit was (r05: SNP lists are sorted, a search that gallops forward
+    finds the next site in a step or two).  The reference looks every record up on its own (qv.cc:1681-1745: a map keyed
+    "name$position"), so the order of the list must not matter: a list with its records shuffled, chromosomes interleaved, records
+    repeated, positions that name no site and positions in a non-canonical spelling gives, line for line, what the sorted list
+    gives -- with one thread and with eight (the pieces a thread gets start anywhere)."""
+    import random
+
+    rng = random.Random(20261004)
+    chroms = [("chr1", 50_000), ("chr2", 30_000), ("chrX", 20_000)]
+    with open(tmp_path / "chrlens", "w") as f:
+        for name, ln in chroms:
+            f.write("%s %d\n" % (name, ln))
+    sites, before = [], 0
+    for name, ln in chroms:
+        for p in sorted(rng.sample(range(1, ln), 4000)):
+            sites.append((name, p, before + p))
+        before += ln
+    with open(tmp_path / "counts.txt", "w") as f:
+        for _, _, g in sites:
+            rc, ac = rng.choice([(20, 0), (0, 20), (10, 10), (0, 0), (3, 1)])
+            f.write("%d 230 25 %d %d\n" % (g, rc, ac))
+    recs = ["%s\t%d\trs%d\tA\tC\t.\t.\tRS=%d" % (name[3:], p, i, i) for i, (name, p, _) in enumerate(sites)]
+    extra = ["1\t%d\tnone%d\tA\tC\t.\t.\t." % (50_001 + k, k) for k in range(50)]                      # beyond every site of chr1
+    extra += ["2\t0%d\tzero%d\tA\tC\t.\t.\t." % (sites[4000 + k][1], k) for k in range(50)]           # "0123" is not the key "123"
+    extra += ["7\t%d\tother%d\tA\tC\t.\t.\t." % (k + 1, k) for k in range(50)]                        # a sequence the index does not have
+    header = "##fileformat=VCFv4.0\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    # (enough lines that the pass cuts the text into pieces: >= 1 MiB)
+    filler = ["9\t%d\tfill%d\tA\tC\t.\t.\tPADDING=%s" % (k + 1, k, "x" * 60) for k in range(12_000)]
+    sorted_lines = recs + extra + filler
+    shuffled = recs + recs[:500] + extra + filler                                                    # some records twice
+    rng.shuffle(shuffled)
+
+    def run(lines, threads):
+        src, out = tmp_path / "in.vcf", tmp_path / "out.vcf"
+        with open(src, "w") as f:
+            f.write(header + "\n".join(lines) + "\n")
+        subprocess.check_call([BIN, "callvcf", str(tmp_path / "chrlens"), str(tmp_path / "counts.txt"), str(src), str(out)], env=dict(os.environ, VARGENO_THREADS=str(threads)))
+        return [ln for ln in open(out).read().splitlines() if ln and ln[0] != "#"]
+
+    want = run(sorted_lines, 1)
+    by_id = {ln.split("\t")[2]: ln for ln in want}
+    assert 6000 < len(want) < 12_000 and all(i.startswith("rs") for i in by_id)        # the called sites, and nothing that names no site
+    for threads in (1, 8):
+        got = run(shuffled, threads)
+        # every output line is the sorted run's line for that record, in the shuffled list's order, repeated records included
+        expect = [by_id[ln.split("\t")[2]] for ln in shuffled if ln.split("\t")[2] in by_id]
+        assert got == expect, threads
