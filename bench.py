@@ -949,6 +949,12 @@ def main():
             log("[bench] %d ranks, %d reads sharded: all-reduced counters identical to one rank on the whole stream" % (world, n_c))
 
     # ---- timed region: K steps back to back over the rotating batches, then (N > 1) the job's one exchange --------------------
+    # (the CPU legs above ran the oracle on 64 threads inside a container with a 16-CPU quota: a cgroup that has overdrawn its
+    # quota is throttled into the next 100 ms periods, and 40 steps of a chr22-scale batch take 15 ms -- the launching thread
+    # was measured 10 % slow right after those legs (0.406-0.415 against 0.370-0.372 ms per step without them, profiles/run_r05_x.sh).
+    # One second of quiet first.)
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        time.sleep(1.0)
     gx.set_stats(False)
     gx.reset()
     for i in range(args.warmup):
