@@ -537,7 +537,10 @@ T_START = time.time()
 BUDGET_S = float(os.environ.get("VG_BENCH_BUDGET_S", "1500"))
 # (estimated wall seconds, bench.py arguments) of the secondary legs that run as child processes, in this order
 # (measured on the pool's boxes: 15 s, 145 s, 315 s)
-CHILD_LEGS = [("chr22", 60, ["--workload", "chr22", "--steps", "40", "--warmup", "5"]),
+# (chr22: 200 warm-up steps = 75 ms.  Its CPU legs leave the device idle for seconds, five 0.37 ms steps do not bring the clocks back
+# up, and the 15 ms timed region then measured 0.40-0.41 ms per step where the same steps measure 0.36-0.37 on a busy device:
+# profiles/run_r05_x.sh, run_r05_y.sh)
+CHILD_LEGS = [("chr22", 60, ["--workload", "chr22", "--steps", "40", "--warmup", "200"]),
               ("repeats30", 240, ["--workload", "hg38", "--repeats", "0.3"]),
               ("hg38f", 450, ["--workload", "hg38f", "--steps", "20", "--warmup", "3"]),
               ("softmask50", 240, ["--workload", "hg38", "--softmask", "0.5"])]
@@ -949,12 +952,6 @@ def main():
             log("[bench] %d ranks, %d reads sharded: all-reduced counters identical to one rank on the whole stream" % (world, n_c))
 
     # ---- timed region: K steps back to back over the rotating batches, then (N > 1) the job's one exchange --------------------
-    # (the CPU legs above ran the oracle on 64 threads inside a container with a 16-CPU quota: a cgroup that has overdrawn its
-    # quota is throttled into the next 100 ms periods, and 40 steps of a chr22-scale batch take 15 ms -- the launching thread
-    # was measured 10 % slow right after those legs (0.406-0.415 against 0.370-0.372 ms per step without them, profiles/run_r05_x.sh).
-    # One second of quiet first.)
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        time.sleep(1.0)
     gx.set_stats(False)
     gx.reset()
     for i in range(args.warmup):
