@@ -537,10 +537,7 @@ T_START = time.time()
 BUDGET_S = float(os.environ.get("VG_BENCH_BUDGET_S", "1500"))
 # (estimated wall seconds, bench.py arguments) of the secondary legs that run as child processes, in this order
 # (measured on the pool's boxes: 15 s, 145 s, 315 s)
-# (chr22: 200 warm-up steps = 75 ms.  Its CPU legs leave the device idle for seconds, five 0.37 ms steps do not bring the clocks back
-# up, and the 15 ms timed region then measured 0.40-0.41 ms per step where the same steps measure 0.36-0.37 on a busy device:
-# profiles/run_r05_x.sh, run_r05_y.sh)
-CHILD_LEGS = [("chr22", 60, ["--workload", "chr22", "--steps", "40", "--warmup", "200"]),
+CHILD_LEGS = [("chr22", 60, ["--workload", "chr22", "--steps", "40", "--warmup", "5"]),
               ("repeats30", 240, ["--workload", "hg38", "--repeats", "0.3"]),
               ("hg38f", 450, ["--workload", "hg38f", "--steps", "20", "--warmup", "3"]),
               ("softmask50", 240, ["--workload", "hg38", "--softmask", "0.5"])]
