@@ -581,6 +581,7 @@ def timed_block(gx, run, batches, steps, first=0):
     t0 = time.perf_counter()
     for i in range(steps):
         run(batches[(first + i) % len(batches)])
+    timed_block.enqueue_s = time.perf_counter() - t0        # the host's part: K batches handed over (a slot ring of three: it waits when the device is behind)
     fetched = gx.counts(copy=False)
     dt = time.perf_counter() - t0
     del fetched
@@ -964,6 +965,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         run(batches[i % args.batches])
+    t_enqueued = time.perf_counter() - t0               # the host's part of the K steps (a slot ring of three: it waits when the device is behind)
     local_sum, t_reduce = None, None
     if world > 1:
         gx.sync()
@@ -1193,6 +1195,7 @@ def main():
             "unit": "reads/s",
             "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
+            "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -9,13 +9,15 @@ show() { python3 - $1 "$2" <<'PY'
 import json, sys
 j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 d = j["device_ms_per_step"]
-print("%-22s %.4g reads/s ms/step %.3f pack %.3f wave %.3f tail %.3f | gate words %.3f" % (sys.argv[2], j["value"], j["ms_per_step"], d["pack"], d["wave"], d["spill_tiers_overlapped"], (j.get("other_input_form") or {}).get("ms_per_step", 0)))
+print("%-22s %.4g reads/s ms/step %.3f (host enqueue %.3f) pack %.3f wave %.3f tail %.3f | gate words %.3f" % (sys.argv[2], j["value"], j["ms_per_step"], j.get("host_enqueue_ms_per_step", 0), d["pack"], d["wave"], d["spill_tiers_overlapped"], (j.get("other_input_form") or {}).get("ms_per_step", 0)))
 PY
 }
-CHILD="--gpus 1 --secondary none --no-gather-probe --no-ingest --cpu-reference no --sustain-seconds 0 --job-reads 0 --workload chr22 --steps 40 --warmup 200"
-for v in "a_child --cpu-sample 200000" "c_child --cpu-sample 200000"; do
+CHILD="--gpus 1 --secondary none --no-gather-probe --no-ingest --cpu-reference no --sustain-seconds 0 --job-reads 0 --workload chr22 --steps 40 --warmup 5"
+for v in "a_child --cpu-sample 200000" "b_nosample --cpu-sample 0"; do
 	set -- $v
 	tag=$1; shift
 	sleep 20
 	timeout 600 python3 bench.py $CHILD "$@" > $OUT/$tag.json 2> $OUT/$tag.err; show $OUT/$tag.json $tag
 done
+sleep 20
+OMP_WAIT_POLICY=passive timeout 600 python3 bench.py $CHILD --cpu-sample 200000 > $OUT/c_passive.json 2> $OUT/c_passive.err; show $OUT/c_passive.json c_child_omp_passive
