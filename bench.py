@@ -454,7 +454,15 @@ def big_file_room():
         if mx is None:
             mx = [int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0]
             cur = 0
-        room = min(shm_free, mx - (cur or 0) - (64 << 30)) // 2
+        # (page cache -- the index files this process has written and read -- is charged to the container too, but is given up under
+        # pressure: memory.stat's `file` less `shmem` does not count against the room)
+        cache = 0
+        try:
+            stat = dict(ln.split()[:2] for ln in open("/sys/fs/cgroup/memory.stat"))
+            cache = max(0, int(stat.get("file", 0)) - int(stat.get("shmem", 0)))
+        except Exception:
+            pass
+        room = min(shm_free, mx - max(0, (cur or 0) - cache) - (64 << 30)) // 2
         if room > best[1]:
             best = ("/dev/shm/vg_bench_job", room)
     except Exception:
