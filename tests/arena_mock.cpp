@@ -39,6 +39,10 @@ static int fuzz(unsigned seed)
 	{
 		Arena a;
 		if (!a.init(S)) { complain("init failed"); return 1; }
+		// every third seed: temporaries only in the upper part of the block (set_temp_floor: what a budget-limited index does with
+		// the floor at the block's end -- here half-way, so that both kinds of request keep being served)
+		const uint64_t floor = seed % 3 == 0 ? a.size() / 2 : 0;
+		a.set_temp_floor(floor);
 		std::map<uint64_t, uint64_t> live;                       // offset -> bytes
 		for (int step = 0; step < 20000; step++) {
 			if (rng() % 100 < 55 || live.empty()) {
@@ -51,14 +55,18 @@ static int fuzz(unsigned seed)
 				uint8_t *p = (uint8_t *)a.take(bytes, temp);
 				if (!p) {
 					// was there really no gap for it?  (gaps of the shadow model, with 2 MiB of slack for the alignment)
+					// (a temporary may only use the part of a gap at or above the floor)
+					const uint64_t lo_ok = temp ? floor : 0;
 					uint64_t prev = 0, best = 0;
-					for (auto &kv : live) { if (kv.first - prev > best) best = kv.first - prev; prev = kv.first + kv.second; }
-					if (a.size() - prev > best) best = a.size() - prev;
+					auto gap = [&](uint64_t g0, uint64_t g1) { if (g0 < lo_ok) g0 = lo_ok; if (g1 > g0 && g1 - g0 > best) best = g1 - g0; };
+					for (auto &kv : live) { gap(prev, kv.first); prev = kv.first + kv.second; }
+					gap(prev, a.size());
 					if (best >= bytes + (4ull << 20)) complain("a request was refused although a gap could hold it");
 					continue;
 				}
 				const uint64_t at = (uint64_t)(p - BASE), rounded = (bytes + 255) / 256 * 256;
 				if (at + rounded > a.size()) complain("allocation outside the block");
+				if (temp && at < floor) complain("a temporary below the floor");
 				if (at % 256) complain("allocation not 256-byte aligned");
 				if (bytes >= (2ull << 20) && at % (2ull << 20)) complain("large allocation not 2 MiB aligned");
 				auto nx = live.lower_bound(at);

@@ -191,6 +191,6 @@ def test_the_device_memory_arena_against_a_mock_block(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-fsanitize=address,undefined", "-o", exe, os.path.join(here, "arena_mock.cpp")])
     p = subprocess.run([exe, "replay"], capture_output=True, text=True)
     assert p.returncode == 0 and p.stdout.strip().endswith("ok") and p.stdout.count(" 0 requests without room") == 5, (p.stdout, p.stderr)
-    for seed in (1, 2, 3, 4):
+    for seed in (1, 2, 3, 4, 6):                       # (seeds 3 and 6: with a floor under the temporaries, what a budget-limited index sets)
         p = subprocess.run([exe, "fuzz", str(seed)], capture_output=True, text=True)
         assert p.returncode == 0 and p.stdout.strip() == "ok", (seed, p.stdout, p.stderr)
