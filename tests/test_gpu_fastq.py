@@ -284,3 +284,50 @@ def test_packed_batches_equal_flat_batches_through_every_tier(ftiny_dir, ftiny_r
             gx.submit_packed(np.zeros(32, np.uint64), np.zeros(1, np.uint64), np.array([0, 32], np.uint64))
         assert e.value.code == -6
     pk.close()
+
+
+@pytest.mark.parametrize("replicas", ["1", "2"])
+def test_cli_read_store_that_fills_up_in_the_middle_of_the_file(ftiny_dir, tmp_path, replicas):
+    """The command line packs the file ahead of the index into a read store (device memory); a 30x file does not fit the store, so
+    the pre-packer must stop at the last chunk the store took and the rest of the range must be framed after the open, from exactly
+    that record on -- by host threads or on the device, whichever the measurement picks.  F-tiny's reads five times over (6 MB, six
+    1 MiB chunks; with two replicas, three each), the store sized exactly (VARGENO_PREPACK_BYTES): for nothing, for one chunk, for
+    two chunks and a bit, for everything.  Every run must write the VCF of the run that packs nothing ahead (VARGENO_PREPACK=0),
+    and the middle sizes must really have stopped in the middle (the verbose line says how many reads were packed ahead)."""
+    import re
+
+    from vargeno_amd.api import HostPacker
+
+    text = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read() * 5
+    fq = tmp_path / "reads5.fq"
+    fq.write_bytes(text)
+    n_total = text.count(b"\n") // 4
+    # what the first 1 MiB chunk of a range takes in the store: three arrays, each rounded up to 256 bytes
+    pk = HostPacker(1)
+    pk.begin()
+    k, m, o, _ = pk.push(text[:1 << 20])
+    pk.close()
+    up = lambda b: (b + 255) // 256 * 256
+    one_chunk = up((len(k) + 2) * 8) + up(len(m) * 8) + up((len(m) + 1) * 8)
+
+    def run(extra):
+        out = tmp_path / ("out_%s.vcf" % "_".join("%s%s" % kv for kv in sorted(extra.items())))
+        env = dict(os.environ, VARGENO_CHUNK_MB="1", VARGENO_PACK_THREADS="3", VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1", VARGENO_VERBOSE="1", **extra)
+        p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), str(fq), os.path.join(ftiny_dir, "snps.vcf"), str(out)], env=env, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        ahead = [int(x) for x in re.findall(r"ingest, replica \d+: (\d+) reads packed ahead", p.stderr)]
+        return out.read_bytes(), ahead, p.stderr
+
+    want, ahead, _ = run({"VARGENO_PREPACK": "0"})
+    assert ahead == [] and want.count(b"\n") > 100
+    for size, expect in ((4096, "none"), (one_chunk + 1024, "some"), (2 * one_chunk + one_chunk // 2, "some"), (64 << 20, "all")):
+        got, ahead, err = run({"VARGENO_PREPACK_BYTES": str(size)})
+        assert got == want, (size, err)
+        assert len(ahead) == int(replicas), err
+        if expect == "none":
+            assert sum(ahead) == 0, err
+        elif expect == "all":
+            assert sum(ahead) == n_total, err
+        else:
+            assert 0 < sum(ahead) < n_total, (size, ahead, err)
+            assert "when the store was full" in err and "rest of the range" in err, err

@@ -16,6 +16,7 @@
 //                         host packing, or the text framed on the device -- takes the rest of the file.  0: device framing only
 //   VARGENO_PREPACK=0     do not pack ahead of the index (and do not measure: host packing if VARGENO_PACK_THREADS > 0, else device framing)
 //   VARGENO_PREPACK_GB=n  device memory the packed-ahead reads may take per device (the read store; default 16, at most an eighth of the device)
+//   VARGENO_PREPACK_BYTES=n  the read store's size in bytes, exactly (tests: a store that fills up in the middle of a small file)
 //   VARGENO_PREPACK_MMAP=0  the pre-packer reads the file with pread into buffers of its own instead of mapping it
 //   VARGENO_ORDERLY_EXIT=1  close the handles and let the runtime shut down before the process ends (default: it ends when the VCF is closed)
 //   VARGENO_VCF_CLOCKS=1  stderr: the seconds of the caller / VCF pass, phase by phase
@@ -391,7 +392,8 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 				int on = 0;
 				for (int k = 0; k < ngpu; k++) on += k % have == g % have;
 				const uint64_t range = cut[(size_t)g + 1] - cut[(size_t)g];
-				const uint64_t bytes = std::min<uint64_t>(std::min<uint64_t>(want, vg_device_memory(g % have) / 8) / (uint64_t)on, range / 5 + (8ull << 20));
+				uint64_t bytes = std::min<uint64_t>(std::min<uint64_t>(want, vg_device_memory(g % have) / 8) / (uint64_t)on, range / 5 + (8ull << 20));
+				if (const char *e = getenv("VARGENO_PREPACK_BYTES")) if (atoll(e) > 0) bytes = (uint64_t)atoll(e);          // (tests: a store that fills up after a chunk or two)
 				if (vg_read_store_create(g % have, bytes, &store[(size_t)g]) != VG_OK) { fprintf(stderr, "vargeno: no read store on device %d (%s): its range is framed after the index is open\n", g % have, vg_last_error()); continue; }
 				pre[(size_t)g].reset(new PrePacker(fd, cut[(size_t)g], cut[(size_t)g + 1], pchunk, std::max(2, n_readers / ngpu), pack_threads, store[(size_t)g]));
 			}
