@@ -290,9 +290,9 @@ def test_packed_batches_equal_flat_batches_through_every_tier(ftiny_dir, ftiny_r
 def test_cli_read_store_that_fills_up_in_the_middle_of_the_file(ftiny_dir, tmp_path, replicas):
     """The command line packs the file ahead of the index into a read store (device memory); a 30x file does not fit the store, so
     the pre-packer must stop at the last chunk the store took and the rest of the range must be framed after the open, from exactly
-    that record on -- by host threads or on the device, whichever the measurement picks.  F-tiny's reads five times over (6 MB, six
-    1 MiB chunks; with two replicas, three each), the store sized exactly (VARGENO_PREPACK_BYTES): for nothing, for one chunk, for
-    two chunks and a bit, for everything.  Every run must write the VCF of the run that packs nothing ahead (VARGENO_PREPACK=0),
+    that record on -- by host threads or on the device, whichever the measurement picks.  F-tiny's reads five times over (5.2 MB, five
+    1 MiB chunks; with two replicas, two and a half each), the store sized exactly (VARGENO_PREPACK_BYTES): for nothing, for one
+    chunk, for two chunks, for everything.  Every run must write the VCF of the run that packs nothing ahead (VARGENO_PREPACK=0),
     and the middle sizes must really have stopped in the middle (the verbose line says how many reads were packed ahead)."""
     import re
 
@@ -320,7 +320,9 @@ def test_cli_read_store_that_fills_up_in_the_middle_of_the_file(ftiny_dir, tmp_p
 
     want, ahead, _ = run({"VARGENO_PREPACK": "0"})
     assert ahead == [] and want.count(b"\n") > 100
-    for size, expect in ((4096, "none"), (one_chunk + 1024, "some"), (2 * one_chunk + one_chunk // 2, "some"), (64 << 20, "all")):
+    # (reads.fq is just under 1 MiB: `one_chunk` is what ~4 000 reads take, a 1 MiB chunk holds a few more; a replica's range is
+    # five such chunks, or two and a half with two replicas)
+    for size, expect in ((4096, "none"), (one_chunk * 13 // 10, "some"), (one_chunk * 23 // 10, "some"), (64 << 20, "all")):
         got, ahead, err = run({"VARGENO_PREPACK_BYTES": str(size)})
         assert got == want, (size, err)
         assert len(ahead) == int(replicas), err
