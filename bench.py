@@ -85,6 +85,8 @@ def parse_args():
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
     ap.add_argument("--no-pretouch", action="store_true", help="do not have a child process take the device's free memory once before the genome is generated (see pretouch_start)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the secondary end-to-end number (FASTQ text in pinned host memory -> counters)")
+    ap.add_argument("--detail-out", default=None, help="where the run's full record goes (every leg's phases, plans, notes: what used to be on the line before it outgrew the driver's parser); "
+                    "default: bench_detail.json beside the index files, and gpurun_out/bench_detail_<workload>.json when that directory exists.  The LAST stdout line stays a compact object (< 8000 bytes)")
     args = ap.parse_args()
     for k, v in PRESETS[args.workload].items():
         if getattr(args, k) is None:
@@ -694,6 +696,122 @@ def roofline_of(alg_bytes, k_ms, reads, kernel):
             "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_read": alg_bytes / reads}
 
 
+LINE_LIMIT = 8000          # bytes; the driver reads the last ~10 KB of stdout and parses the last line (BENCH_r05: a 25 KB line came back `parsed: null`)
+
+
+def _r(x, sig=5):
+    """a float with `sig` significant digits (the compact line carries numbers, not noise)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.*g" % (sig, float(x)))
+    except Exception:
+        return x
+
+
+def _short(sv, n):
+    sv = "" if sv is None else str(sv)
+    return sv if len(sv) <= n else sv[:n - 1] + "\u2026"
+
+
+def compact_line(out, detail_path):
+    """The one JSON line of the contract: metric/value/.../config/roofline/cpu_baseline in full (short strings), one-line summaries of
+    everything else; the full record is `out` itself, written to `detail_path` and to stderr.  Asserted < LINE_LIMIT bytes (also by
+    tests/test_abi_and_layout.py on a synthetic worst case)."""
+    c = out["config"]
+    rf = out["roofline"] or {}
+    cb = out.get("cpu_baseline")
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _r(out[k], 7) if k in ("value", "ms_per_step") else out[k] for k in keep}
+    line["config"] = {"workload": _short(c["workload"], 140), "reads_per_step_per_gpu": c["reads_per_step_per_gpu"], "resident_batches": c["resident_batches"], "genome_bp": c["genome_bp"],
+                      "snps_requested": c["snps_requested"], "read_len": c["read_len"], "lowq": c["lowq"], "repeats": c["repeats"], "softmask": c["softmask"], "gate_words": c["gate_words"],
+                      "index_bytes_hbm": c["index_bytes_hbm"], "index_views": _short(",".join(c.get("index_views") or []) if isinstance(c.get("index_views"), (list, tuple)) else c.get("index_views"), 80), "index_open_s": _r(c["index_open_s"], 4), "lib_build_id": c["lib_build_id"],
+                      "parallelism": _short(c["parallelism"], 120)}
+    gcl = rf.get("gather_ceiling") or {}
+    line["roofline"] = {"bound": rf.get("bound"), "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": _r(rf.get("frac")), "kernel": rf.get("kernel"),
+                        "kernel_ms": _r(rf.get("kernel_ms")), "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"), "algorithmic_bytes_per_read": _r(rf.get("algorithmic_bytes_per_read"), 6),
+                        "traffic": rf.get("traffic"), "traffic_source": _short(rf.get("traffic_source"), 90),
+                        "random_line_ceiling_GB_per_s": _r(gcl.get("peak_GB_per_s"), 4), "frac_of_random_line_ceiling": _r(gcl.get("frac"), 4)}
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": _short(cb.get("sample"), 200)}
+        if cb.get("binary_sha256"):
+            line["cpu_baseline"]["binary_sha256_16"] = cb["binary_sha256"][:16]
+        if cb.get("port"):
+            line["cpu_baseline"]["port_1_thread"] = _r(cb["port"].get("value"))
+        if cb.get("all_cores"):
+            line["cpu_baseline"]["port_all_cores"] = {"value": _r(cb["all_cores"].get("value")), "threads": cb["all_cores"].get("threads")}
+    else:
+        line["cpu_baseline"] = None
+    par = out.get("parity")
+    line["parity"] = {"equal": par.get("equal"), "reads": par.get("reads"), "site_counters": par.get("site_counters"), "event_counters": par.get("event_counters")} if par else None
+    dm = out.get("device_ms_per_step") or {}
+    line["device_ms_per_step"] = {"pack": _r(dm.get("pack"), 4), "wave": _r(dm.get("wave"), 4), "spill_tiers_overlapped": _r(dm.get("spill_tiers_overlapped"), 4)}
+    line["input_form"] = "quality strings" if "quality strings" in (out.get("input_form") or "") else "gate words"
+    of = out.get("other_input_form")
+    if of:
+        line["other_input_form"] = {"input": "gate words" if "gate word" in of.get("input", "") else "quality strings", "value": _r(of.get("value")), "ms_per_step": _r(of.get("ms_per_step"), 4)}
+    su = out.get("sustained")
+    if su:
+        line["sustained"] = {"value": _r(su.get("value")), "seconds": _r(su.get("seconds"), 3), "steps": su.get("steps"), "ms_per_step_median": _r(su["ms_per_step"].get("median"), 4)}
+    ing = out.get("ingest_end_to_end")
+    if ing:
+        line["ingest_end_to_end"] = {"failed": True} if "failed" in ing else {"value": _r(ing.get("value")), "chosen": ing.get("chosen"),
+                                     "paths": {k: _r(v.get("value")) for k, v in (ing.get("paths") or {}).items()}}
+    jb = out.get("job")
+    if jb:
+        line["job"] = {"skipped": _short(jb["skipped"], 100)} if "skipped" in jb else \
+            {k: _r(jb.get(k), 4) for k in ("reads", "wall_s", "index_open_s", "ingest_after_open_s", "call_vcf_s", "wall_minus_open_s", "whole_job_reads_per_s", "fastq_source_reads_per_s", "called", "gq_median", "counters_equal_resident_batch_path") if k in jb}
+        if "first_reads_against_oracle" in jb and jb["first_reads_against_oracle"]:
+            line["job"]["first_reads_against_oracle"] = {k: jb["first_reads_against_oracle"].get(k) for k in ("equal", "reads") if k in jb["first_reads_against_oracle"]}
+    if out.get("multi_gpu_verification"):
+        line["multi_gpu_verification"] = out["multi_gpu_verification"]
+    pr = out.get("multi_gpu_per_rank")
+    if pr:
+        line["multi_gpu_per_rank"] = {k: ([_r(x, 4) for x in v] if isinstance(v, list) else v) for k, v in pr.items()}
+    sec = out.get("secondary")
+    if sec:
+        line["secondary"] = {}
+        for name, e in sec.items():
+            if "skipped" in e:
+                line["secondary"][name] = {"skipped": _short(e["skipped"], 100)}
+                continue
+            r2 = e.get("roofline") or {}
+            line["secondary"][name] = {"value": _r(e.get("value")), "ms_per_step": _r(e.get("ms_per_step"), 4), "kernel_ms": _r(r2.get("kernel_ms"), 4), "frac": _r(r2.get("frac"), 4),
+                                       "traffic": r2.get("traffic"), "alg_bytes_per_read": _r(r2.get("algorithmic_bytes_per_read"), 5), "index_bytes_hbm": e.get("index_bytes_hbm"),
+                                       "parity": (e.get("parity") or {}).get("equal"), "parity_reads": (e.get("parity") or {}).get("reads")}
+    line["detail"] = detail_path
+    line["bench_wall_s"] = _r(out.get("bench_wall_s"), 4)
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:                                  # never again an unparseable line: shed the optional summaries, largest first
+        for k in ("multi_gpu_per_rank", "ingest_end_to_end", "sustained", "other_input_form", "job", "secondary"):
+            line.pop(k, None)
+            text = json.dumps(line)
+            if len(text) < LINE_LIMIT:
+                break
+    assert len(text) < LINE_LIMIT, "bench line is %d bytes" % len(text)
+    return text
+
+
+def write_detail(out, args, d):
+    """The full record: one file beside the index files (or --detail-out), a copy under gpurun_out/ when that exists (merged back from a
+    gpurun lease), and one `[bench-detail]` line on stderr.  Returns the path reported on the compact line."""
+    paths = [args.detail_out] if args.detail_out else [os.path.join(os.path.dirname(d), "bench_detail_%s.json" % os.path.basename(d))]
+    gdir = os.path.join(ROOT, "gpurun_out")
+    if not args.detail_out and os.path.isdir(gdir):
+        paths.append(os.path.join(gdir, "bench_detail_%s.json" % os.path.basename(d)))
+    text = json.dumps(out)
+    wrote = None
+    for pth in paths:
+        try:
+            with open(pth, "w") as f:
+                f.write(text + "\n")
+            wrote = wrote or pth
+        except OSError:
+            pass
+    log("[bench-detail] " + text)
+    return wrote
+
+
 def run_child_leg(name, est, extra, args, ref):
     """One secondary configuration as a child process of this one (which holds no index any more): its own bench.py line."""
     left = BUDGET_S - (time.time() - T_START)
@@ -702,6 +820,8 @@ def run_child_leg(name, est, extra, args, ref):
     ref.wait_quiet("secondary leg %s" % name)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--secondary", "none", "--no-gather-probe", "--no-ingest", "--cpu-reference", "no", "--sustain-seconds", "0",
            "--cleanup", "--cpu-sample", "200000", "--job-reads", "0", "--no-pretouch"] + extra
+    detail = os.path.join(args.workdir, "bench_detail_child_%s.json" % name)
+    cmd += ["--detail-out", detail]
     if args.workdir_given:
         cmd += ["--workdir", args.workdir]
     time.sleep(IDLE_BEFORE_CHILD_S)                        # (the device's memory, just freed by the process before, scrubbed: see job_run)
@@ -714,7 +834,7 @@ def run_child_leg(name, est, extra, args, ref):
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not lines:
             return {"skipped": "child run failed (rc %d): %s" % (p.returncode, (p.stderr or "").strip().splitlines()[-1:] or ["no output"]), "wall_s": time.time() - t0}
-        j = json.loads(lines[-1])
+        j = json.load(open(detail))                        # the child's full record (its stdout line is the compact one)
         rf = j["roofline"]
         return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "input_form": j["input_form"],
                 "other_input_form": j.get("other_input_form") and {k: j["other_input_form"][k] for k in ("input", "value", "ms_per_step")},
@@ -1289,7 +1409,7 @@ def main():
             "secondary": secondary if legs else None,
             "bench_wall_s": time.time() - T_START,
         }
-        print(json.dumps(out), flush=True)
+        print(compact_line(out, write_detail(out, args, d)), flush=True)
     if args.cleanup and rank == 0:
         import shutil
 

@@ -194,3 +194,47 @@ def test_the_device_memory_arena_against_a_mock_block(tmp_path):
     for seed in (1, 2, 3, 4, 6):                       # (seeds 3 and 6: with a floor under the temporaries, what a budget-limited index sets)
         p = subprocess.run([exe, "fuzz", str(seed)], capture_output=True, text=True)
         assert p.returncode == 0 and p.stdout.strip() == "ok", (seed, p.stdout, p.stderr)
+
+
+def test_bench_line_stays_small_enough_for_the_driver_to_parse():
+    """BENCH_r05.parsed was null: the bench's one stdout line had grown to 25 KB.  The line is now a compact object built by
+    bench.compact_line from the full record (which goes to a side file + stderr): here the round-5 record with every leg present,
+    and a worst case with every string blown up -- both must stay under bench.LINE_LIMIT and keep the contract's keys."""
+    import importlib.util
+    import json
+    import sys
+
+    spec = importlib.util.spec_from_file_location("vg_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    assert bench.LINE_LIMIT <= 8000
+    full = json.load(open(os.path.join(ROOT, "profiles", "bench_default_r05.json")))
+    assert len(json.dumps(full)) > 20000                       # (the record that broke the driver)
+
+    def blow(x):
+        if isinstance(x, str):
+            return x * 20
+        if isinstance(x, dict):
+            return {k: blow(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [blow(v) for v in x]
+        return x
+    worst = blow(full)
+    worst["metric"], worst["unit"] = full["metric"], full["unit"]
+    for rec in (full, worst):
+        text = bench.compact_line(rec, "/tmp/vg_bench/bench_detail.json")
+        assert len(text) < bench.LINE_LIMIT and "\n" not in text
+        line = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in line, k
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"]) and len(line["cpu_baseline"]["sample"]) <= 200
+        assert "workload" in line["config"] and "model" not in line["config"]
+    small = json.loads(bench.compact_line(full, "x"))
+    assert set(small["secondary"]) == set(full["secondary"]) and small["secondary"]["chr22"]["parity"] is True
+    assert abs(small["value"] / full["value"] - 1) < 1e-5 and abs(small["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-3
