@@ -188,6 +188,7 @@ class ReferenceTimer:
         import atexit
 
         self.n = n_reads
+        self.ref_bin = ref_bin
         self.res = {}
         self.threads = []
         self.procs = []
@@ -268,11 +269,17 @@ class ReferenceTimer:
         for l0, l1 in self.loops.values():
             for h0, h1 in self.heavy:
                 contended += max(0.0, min(l1 or time.time(), h1 or time.time()) - max(l0, h0))
+        import hashlib
+
+        sha = hashlib.sha256(open(self.ref_bin, "rb").read()).hexdigest()
+        try:
+            recipe_sha = open(os.path.join(ROOT, "tests", "golden", "ref_binary.sha256")).read().split()[0]
+        except Exception:
+            recipe_sha = None
         return {"value": self.n / loop, "unit": "reads/s", "cores": 1, "kind": "reference", "contended_s": round(contended, 2),
-                "sample": "oracle/_ref/vargeno geno (the reference's own binary, its only mode: one thread) on the first %d reads of batch 0: %.1f s from \"Processing...\" to the "
-                          "output VCF's creation, minus %.1f s of the same span on an empty FASTQ (the calling scan); start-up %.0f s, not counted; the two processes ran "
-                          "side by side, and the bench's host-heavy legs (many-thread oracle runs, index builds) were held back while either was inside that span: "
-                          "%.1f s of such work overlapped it" % (self.n, a["loop_and_scan"], b["loop_and_scan"], a["startup"], contended)}
+                "binary_sha256": sha, "binary_is_what_oracle_Makefile_builds": (sha == recipe_sha) if recipe_sha else None,
+                "sample": "oracle/_ref/vargeno (sha256 %s), 1 thread, first %d reads of batch 0: read loop %.1f s (%.1f s to the VCF's creation - %.1f s on an empty FASTQ); start-up %.0f s not counted; contended %.1f s"
+                          % (sha[:12], self.n, loop, a["loop_and_scan"], b["loop_and_scan"], a["startup"], contended)}
 
 
 class NoRef:

@@ -306,3 +306,29 @@ def test_oracle_reproduces_reference_vcf_on_frepeated(tmp_path):
     assert ix.stats.as_dict()["aux_snp"] > 500
     for fn in ("idx.ref.bf", "idx.snp.bf"):
         os.remove(os.path.join(d, fn))
+
+
+def test_reference_binary_on_disk_is_what_the_committed_recipe_builds():
+    """The reference binary that travels to the GPU box (oracle/_ref/vargeno: the cpu_baseline of record and the comparand of the
+    command-line tests there) is the one `make -C oracle ref` produces from the recipe as committed: its sha256 is recorded in
+    tests/golden/ref_binary.sha256 when the recipe or the reference changes, the recipe lists its own Makefile as a prerequisite
+    (round 5's binary predated a change of -march and was never rebuilt), and bench.py prints the hash in cpu_baseline.sample."""
+    import re
+    import subprocess
+
+    from conftest import ROOT
+
+    mk = open(os.path.join(ROOT, "oracle", "Makefile")).read()
+    for target in (r"\$\(OUT\)/vargeno:", r"\$\(OUT\)/caller_table\.bin:", r"\$\(OUT\)/ref_vote_replay:"):
+        rule = re.search(target + r"[^\n]*", mk).group(0)
+        assert "$(THIS)" in rule, rule
+    binp = os.path.join(ROOT, "oracle", "_ref", "vargeno")
+    want = open(os.path.join(GOLDEN, "ref_binary.sha256")).read().split()[0]
+    if os.path.isdir("/root/reference/src"):                        # the build container: make is a no-op when the binary is current
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    if not os.path.exists(binp):
+        import pytest
+
+        pytest.skip("no oracle/_ref/vargeno here")
+    assert _sha(binp) == want
+    assert open(os.path.join(ROOT, "oracle", "_ref", "vargeno.sha256")).read().split()[0] == want
