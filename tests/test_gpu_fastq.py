@@ -333,3 +333,66 @@ def test_cli_read_store_that_fills_up_in_the_middle_of_the_file(ftiny_dir, tmp_p
         else:
             assert 0 < sum(ahead) < n_total, (size, ahead, err)
             assert "when the store was full" in err and "rest of the range" in err, err
+
+
+@pytest.mark.parametrize("replicas", ["1", "2"])
+def test_cli_reads_a_fastq_that_is_not_a_regular_file(ftiny_dir, tmp_path, replicas):
+    """`vargeno geno idx <(zcat reads.fq.gz) ...` -- the reference fopen()s whatever path it is given and fgets its way through it
+    (qv.cc:2182, 760-763), so a FIFO, /dev/stdin and bash's process substitution all work there.  The drop-in's file routes pread
+    ranges from many threads and re-open the path for the host reader; a path that is not a regular file takes the once-only route
+    instead (PipeIngest: one descriptor, one reader thread, the host packer, batches round robin over the replicas -- into their
+    read stores while the index opens, then straight into the read loop).  F-tiny through a FIFO fed by a writer thread, through
+    /dev/stdin and through <(cat ...), with a read store sized for everything, for about one chunk and for nothing; and the
+    truncated-final-record file (the reference's stale line buffers, qv.cc:761-763): the golden VCFs, byte for byte."""
+    import re
+    import threading
+
+    idx, snps = os.path.join(ftiny_dir, "idx"), os.path.join(ftiny_dir, "snps.vcf")
+    whole = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read()
+    lines = whole.split(b"\n")[:-1]
+    k = int(open(os.path.join(GOLDEN, "ftiny.trunc.k")).read())
+    trunc = b"\n".join(lines[:4 * k + 3])
+    n_whole = len(lines) // 4
+    golden = {"whole": gzip.open(os.path.join(GOLDEN, "ftiny.out.vcf.gz"), "rb").read(), "trunc": gzip.open(os.path.join(GOLDEN, "ftiny.trunc.out.vcf.gz"), "rb").read()}
+    base_env = dict(os.environ, VARGENO_CHUNK_MB="1", VARGENO_PACK_THREADS="2", VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1", VARGENO_VERBOSE="1")
+    n = [0]
+
+    def through_fifo(data, extra):
+        n[0] += 1
+        fifo, out = str(tmp_path / ("in%d.fifo" % n[0])), tmp_path / ("out%d.vcf" % n[0])
+        os.mkfifo(fifo)
+
+        def feed():
+            with open(fifo, "wb", buffering=0) as w:
+                for a in range(0, len(data), 300_000):
+                    w.write(data[a:a + 300_000])
+        t = threading.Thread(target=feed)
+        t.start()
+        p = subprocess.run([BIN, "geno", idx, fifo, snps, str(out)], env=dict(base_env, **extra), capture_output=True, text=True, timeout=300)
+        t.join()
+        assert p.returncode == 0, p.stderr
+        return out.read_bytes(), p.stderr
+
+    for size in ("67108864", "300000", "4096"):                         # the read store: everything fits / about one chunk / nothing
+        got, err = through_fifo(whole, {"VARGENO_PREPACK_BYTES": size})
+        assert got == golden["whole"], (size, err)
+        m = re.search(r"not a regular file: one descriptor read once, (\d+) reads framed \+ packed by \d+ host threads \((\d+) into the read stores while the index opened, (\d+) straight", err)
+        assert m and int(m.group(1)) == n_whole and int(m.group(2)) + int(m.group(3)) == n_whole, err
+        if size == "4096":
+            assert int(m.group(2)) == 0, err
+    got, err = through_fifo(trunc, {})
+    assert got == golden["trunc"], err
+    got, err = through_fifo(whole, {"VARGENO_PREPACK": "0"})
+    assert got == golden["whole"], err
+    # /dev/stdin
+    out = tmp_path / "out_stdin.vcf"
+    p = subprocess.run([BIN, "geno", idx, "/dev/stdin", snps, str(out)], env=base_env, input=trunc, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert out.read_bytes() == golden["trunc"]
+    # bash process substitution
+    fq = tmp_path / "reads.fq"
+    fq.write_bytes(whole)
+    out = tmp_path / "out_subst.vcf"
+    p = subprocess.run(["bash", "-c", "%s geno %s <(cat %s) %s %s" % (str(BIN), idx, fq, snps, out)], env=base_env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert out.read_bytes() == golden["whole"]

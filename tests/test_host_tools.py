@@ -418,3 +418,93 @@ def test_vcf_pass_finds_every_record_whatever_the_order_of_the_list(tmp_path):
         # every output line is the sorted run's line for that record, in the shuffled list's order, repeated records included
         expect = [by_id[ln.split("\t")[2]] for ln in shuffled if ln.split("\t")[2] in by_id]
         assert got == expect, threads
+
+
+def _reduce_fqcheck(out):
+    """`fqcheck` lines (read length, read, quality characters the path can see as hex) in the reduced form `fqpipe` prints: chunks,
+    trimmed upper-case read, gate bits; N / X for a read the reference skips / aborts on (first offending character in its scan order)."""
+    res = []
+    for ln in out.split(b"\n")[:-1]:
+        parts = ln.split(b" ")
+        rlen, read, q = int(parts[0]), parts[1], bytes.fromhex(parts[2].decode()) if len(parts) > 2 and parts[2] else b""
+        nch = rlen // 32
+        verdict = None
+        for c in range(nch):
+            for b in range(31, -1, -1):
+                ch = chr(read[32 * c + b] & 0xDF)
+                if ch not in "ACGT":
+                    verdict = "N" if ch == "N" else "X"
+                    break
+            if verdict:
+                break
+        if verdict:
+            res.append(verdict)
+            continue
+        gate = 0
+        for c in range(min(nch, 32)):
+            v = q[c] if q[c] < 128 else q[c] - 256
+            if v - ord("8") < 0:
+                gate |= 1 << c
+        res.append("%d %s %x" % (nch, read[:32 * nch].decode().upper(), gate))
+    return res
+
+
+def test_fastq_that_can_be_read_only_once(tmp_path):
+    """`vargeno geno` on a FASTQ that is not a regular file (a FIFO, /dev/stdin, bash's <(...)): the reference fopen()s whatever it is
+    given and fgets its way through (qv.cc:2182, 760-763).  The command line's once-only route (PipeIngest: one descriptor, one
+    reader thread, the host packer, then the host reader on the bytes still in memory + the descriptor) is run here without a
+    device through the hidden `fqpipe` command and must frame every stream exactly like the four-fgets reader (`fqcheck` on the
+    same bytes as a file): plain files, a truncated final record (stale line buffers), lines beyond 1023 characters (the packer
+    refuses the chunk: everything from there on through the host reader, including what the reader thread had read ahead), N and
+    invalid characters, CRLF, chunks far smaller than the file, through a FIFO with a slow writer, /dev/stdin and <(cat)."""
+    import random
+    import threading
+
+    rng = random.Random(5)
+
+    def rec(i, n, q=None, bases="ACGT"):
+        s = "".join(rng.choice(bases) for _ in range(n))
+        qq = q if q is not None else "".join(rng.choice("#'5:I") for _ in range(n))
+        return ("@r%d\n%s\n+\n%s\n" % (i, s, qq[:n] if q is None else (q * n)[:n])).encode()
+
+    body = b"".join(rec(i, rng.choice([150, 150, 150, 101, 250, 64, 31, 33])) for i in range(3000))
+    cases = {
+        "plain": body,
+        "empty": b"",
+        "one": rec(0, 150),
+        "truncated_tail": body + b"@rX\n" + b"ACGT" * 40 + b"\n+",
+        "no_final_newline": body[:-1],
+        "n_and_invalid": body[:40000] + rec(1, 150, bases="ACGTN") + rec(2, 150, bases="ACGTacgtn") + b"@r\nACGT*CGTACGTACGTACGTACGTACGTACGTACGT\n+\n" + b"I" * 36 + b"\n" + body[40000:80000],
+        "long_line_in_the_middle": body[:300000] + rec(7, 1500, q="I") + body[300000:],
+        "long_line_first": rec(7, 1023, q="#") + body[:50000],
+        "crlf": body[:30000].replace(b"\n", b"\r\n"),
+    }
+    for name, data in cases.items():
+        f = tmp_path / (name + ".fq")
+        f.write_bytes(data)
+        want = _reduce_fqcheck(subprocess.run([BIN, "fqcheck", str(f)], capture_output=True, check=True).stdout)
+        for chunk, threads in ((1 << 16, 1), (1 << 17, 3), (1 << 22, 2)):
+            # (a) the file itself opened once; (b) a FIFO fed by a writer thread in small uneven pieces
+            got = subprocess.run([BIN, "fqpipe", str(f), str(chunk), str(threads)], capture_output=True, check=True).stdout.decode().split("\n")[:-1]
+            assert got == want, (name, chunk, "file")
+        fifo = str(tmp_path / (name + ".fifo"))
+        os.mkfifo(fifo)
+
+        def feed():
+            with open(fifo, "wb", buffering=0) as w:
+                at = 0
+                while at < len(data):
+                    n = rng.choice([1, 7, 4096, 65536, 100000])
+                    w.write(data[at:at + n])
+                    at += n
+        t = threading.Thread(target=feed)
+        t.start()
+        got = subprocess.run([BIN, "fqpipe", fifo, str(1 << 16), "2"], capture_output=True, check=True).stdout.decode().split("\n")[:-1]
+        t.join()
+        assert got == want, (name, "fifo")
+        # (c) /dev/stdin and bash's process substitution
+        got = subprocess.run([BIN, "fqpipe", "/dev/stdin", str(1 << 16), "2"], input=data, capture_output=True, check=True).stdout.decode().split("\n")[:-1]
+        assert got == want, (name, "stdin")
+    f = tmp_path / "plain.fq"
+    got = subprocess.run(["bash", "-c", "%s fqpipe <(cat %s) 65536 2" % (str(BIN), f)], capture_output=True, check=True).stdout.decode().split("\n")[:-1]
+    assert got == _reduce_fqcheck(subprocess.run([BIN, "fqcheck", str(f)], capture_output=True, check=True).stdout)

@@ -2,8 +2,10 @@
 // of at most 1023 characters per record (id, read, separator, quality); the read length is
 // strlen(read) - 1 whatever the last character is; chunk c is gated by the c-th character of the
 // quality LINE.  Records are packed into the flat batch layout the C-ABI takes.
+#include <errno.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "vg_host.h"
 
@@ -11,10 +13,30 @@ namespace vgh {
 
 struct FastqReader::Impl {
 	FILE *f = nullptr;
+	// a stream that can be read only once (a pipe, qv.cc:2182 fopen()s whatever it is given): bytes [base, base + the spans' lengths) of
+	// it are in the caller's memory, what follows comes from the descriptor
+	int rawfd = -1;
+	uint64_t base = 0;
+	std::vector<std::pair<const uint8_t *, size_t>> spans;
+	size_t span_i = 0;
 	std::vector<char> buf;
+	const char *cur = nullptr;                    // [pos, end) of the bytes at hand
 	size_t pos = 0, end = 0;
 	bool eof = false;
 	char line[4][1024];
+	void refill()
+	{
+		pos = end = 0;
+		if (f) { end = fread(buf.data(), 1, buf.size(), f); cur = buf.data(); return; }
+		while (span_i < spans.size() && spans[span_i].second == 0) span_i++;
+		if (span_i < spans.size()) { cur = (const char *)spans[span_i].first; end = spans[span_i].second; span_i++; return; }
+		if (rawfd >= 0) {
+			ssize_t g;
+			do g = read(rawfd, buf.data(), buf.size()); while (g < 0 && errno == EINTR);
+			end = g > 0 ? (size_t)g : 0;
+			cur = buf.data();
+		}
+	}
 	// fgets(dst, 1024, f): up to 1023 chars, stops after '\n'; false at end of file with nothing read
 	bool gets(char *dst)
 	{
@@ -22,11 +44,10 @@ struct FastqReader::Impl {
 		for (;;) {
 			if (pos == end) {
 				if (eof) break;
-				end = fread(buf.data(), 1, buf.size(), f);
-				pos = 0;
+				refill();
 				if (end == 0) { eof = true; break; }
 			}
-			const char *s = buf.data() + pos;
+			const char *s = cur + pos;
 			const size_t avail = end - pos, room = 1023 - n;
 			const size_t take = avail < room ? avail : room;
 			const char *nl = (const char *)memchr(s, '\n', take);
@@ -48,13 +69,36 @@ FastqReader::FastqReader(const std::string &path) : p(new Impl)
 	p->buf.resize(1 << 24);
 	for (auto &l : p->line) memset(l, 0, sizeof l);
 }
+FastqReader::FastqReader(int fd, uint64_t base, std::vector<std::pair<const uint8_t *, size_t>> spans) : p(new Impl)
+{
+	p->rawfd = fd;
+	p->base = base;
+	p->spans = std::move(spans);
+	p->buf.resize(1 << 22);
+	for (auto &l : p->line) memset(l, 0, sizeof l);
+}
 FastqReader::~FastqReader() { if (p->f) fclose(p->f); delete p; }
 
 void FastqReader::seek(uint64_t off)
 {
-	fseeko(p->f, (off_t)off, SEEK_SET);
 	p->pos = p->end = 0;
 	p->eof = false;
+	if (p->f) { fseeko(p->f, (off_t)off, SEEK_SET); return; }
+	// a once-only stream: only offsets inside the bytes held in memory (or their end) can be gone back to
+	uint64_t at = p->base;
+	p->span_i = 0;
+	if (off < at) throw Error{"FASTQ stream: cannot go back before the bytes kept in memory"};
+	for (; p->span_i < p->spans.size(); p->span_i++) {
+		const uint64_t len = p->spans[p->span_i].second;
+		if (off < at + len) {
+			p->cur = (const char *)p->spans[p->span_i].first;
+			p->pos = (size_t)(off - at); p->end = (size_t)len;
+			p->span_i++;
+			return;
+		}
+		at += len;
+	}
+	if (off != at) throw Error{"FASTQ stream: cannot skip ahead on a stream that is read once"};
 }
 
 uint64_t FastqReader::next(ReadBatch &out, uint64_t max_reads)

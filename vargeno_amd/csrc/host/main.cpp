@@ -26,6 +26,7 @@
 //   VARGENO_DUMP_COUNTS=path  also write the per-site counters the caller is given (ref counts then alt counts, one byte per site, site order of the index)
 //   VARGENO_HOST_FASTQ=1  frame the FASTQ on the host (the reference's four fgets per record) instead of on the device
 //   VARGENO_NO_LITE=1     index: skip <prefix>.ref.bf.lite.bf (2.3 GB, read by nothing in geno)
+#include <errno.h>
 #include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -38,6 +39,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -219,6 +221,7 @@ private:
 		for (uint64_t i = 0; i < n_chunks; i++) { const uint64_t len = std::min(chunk_, fsize - i * chunk_); left[(size_t)i] = map ? 0u : (uint32_t)((len + piece - 1) / piece); }
 		std::mutex rmu; std::condition_variable rcv;
 		uint64_t packed = 0;                                                     // chunks the packer is done with (their buffers are free)
+		uint64_t n_pushes = 0;                                                   // batches handed to the store
 		std::atomic<uint64_t> next_piece{0};
 		bool io_error = false, quit = false;
 		std::vector<std::thread> readers;
@@ -245,7 +248,9 @@ private:
 		for (uint64_t i = 0; i < n_chunks && !stop_.load(); i++) {
 			{ std::unique_lock<std::mutex> g(rmu); rcv.wait(g, [&] { return left[(size_t)i] == 0 || io_error; }); if (io_error) break; }
 			const uint64_t len = std::min(chunk_, fsize - i * chunk_);
-			uint64_t *sk = stage[i & 1], *sm = sk + kcap, *so = sm + rcap;
+			// (the sets alternate on the number of PUSHES: the store waits for the copies of the push before at its next push, so a
+			// chunk that framed nothing -- no push -- must not hand the set of a push still in flight to the chunk after it)
+			uint64_t *sk = stage[n_pushes & 1], *sm = sk + kcap, *so = sm + rcap;
 			uint64_t nr = 0, nc = 0, ninv = 0;
 			struct timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
 			const uint8_t *src = map ? map + (lo_ - map_lo) + i * chunk_ : text[(size_t)(i % NBUF)].data();
@@ -262,6 +267,7 @@ private:
 				const int prc = vg_read_store_push(store_, sk, sm, so, nr);
 				if (prc == VG_ENOMEM) { full_ = true; break; }                      // (this chunk's records are dropped with it: the stream is re-framed from the last batch that was kept)
 				if (prc != VG_OK) { error = vg_last_error(); break; }
+				n_pushes++;
 				uint64_t rec = 0, cons = 0, last = 0; int ref = 0;
 				(void)vg_packer_end(pk, &rec, &cons, &last, &ref);               // (a query: the stream's totals so far)
 				records_ = rec; consumed_ = cons; last_ = last;
@@ -295,6 +301,155 @@ private:
 	bool refused_ = false, full_ = false;
 	std::atomic<double> pack_s_{0.0}; std::atomic<uint64_t> packed_text_{0};
 	struct timespec born_; std::atomic<double> finished_s_{0.0};
+};
+
+// ---- a FASTQ "file" that can be read only once -------------------------------------------------------------------------------
+// The reference fopen()s whatever path it is given and fgets its way through it (qv.cc:2182, 760-763): a FIFO, /dev/stdin, bash's
+// <(zcat reads.fq.gz) all work there by construction.  Here the file routes above pread / mmap ranges of the file from many
+// threads, cut it at record starts per replica, and re-open it for the host reader -- none of which a pipe allows: a FIFO
+// loses its only reader between two open()s, a /dev/fd/N substitution has size 0.  So a path that is not a regular file takes THIS
+// route: the one descriptor is read by one thread (read() of whole chunks into a small ring, from the moment the command line
+// starts -- beside the index open), the chunks are framed + packed by the host packer (vg_packer_*: bytes cut anywhere), and the
+// packed batches go to the replicas round robin -- into their read stores while the index is still opening, straight into the
+// read loop (vg_reads_submit_packed) afterwards.  No ranges, no seek.  What the packer refuses (a line beyond fgets' 1023
+// characters ...) and the possibly truncated tail go through the host reader like on the file routes: it is given the bytes
+// still in memory (from the start of the last framed record on, to prime the reference's stale line buffers) and the descriptor.
+class PipeIngest {
+public:
+	// sink(replica, kmers, meta, chunk_offsets, n_reads): a packed batch for a replica's read loop, once attach() has been called;
+	// blocking (the arrays are free when it returns); returns an error text or ""
+	typedef std::function<std::string(size_t, const uint64_t *, const uint64_t *, const uint64_t *, uint64_t)> Sink;
+	PipeIngest(int fd, uint64_t chunk, int pack_threads, const std::vector<vg_read_store *> &stores, Sink sink)
+		: fd_(fd), chunk_(chunk), pack_threads_(pack_threads < 1 ? 1 : pack_threads), stores_(stores), sink_(std::move(sink))
+	{
+		clock_gettime(CLOCK_MONOTONIC, &born_);
+		for (auto &b : ring_) b.data.resize((size_t)chunk_);
+		reader_ = std::thread([this] { read_loop(); });
+		worker_ = std::thread([this] { work_loop(); });
+	}
+	~PipeIngest() { finish(); }
+	// the handles exist: the stores' batches are submitted by the caller; from now on batches go straight to the handles
+	void attach() { { std::lock_guard<std::mutex> g(mu_); attached_ = true; } cv_.notify_all(); }
+	void finish() { if (worker_.joinable()) worker_.join(); if (reader_.joinable()) reader_.join(); }
+	// valid after finish(): the stream's totals, and what the host reader needs
+	uint64_t records = 0, consumed = 0, last = 0, bytes_read = 0;
+	bool refused = false;
+	uint64_t to_store = 0, direct = 0;                       // reads that went through a read store / straight into the read loop
+	double seconds = 0.0;                                    // from construction to the end of the stream
+	std::string error;
+	// bytes [span_base, span_base + the spans) of the stream are still in memory (every chunk from the one that holds `last` on);
+	// the descriptor continues behind them
+	uint64_t span_base = 0;
+	std::vector<std::pair<const uint8_t *, size_t>> spans;
+private:
+	struct Buf { std::vector<uint8_t> data; uint64_t len = 0, off = 0; bool last = false; };
+	static constexpr int NB = 4;                             // the chunk before the packer's (its tail may hold the last framed record), the packer's, two read ahead
+	void read_loop()
+	{
+		for (uint64_t i = 0;; i++) {
+			{ std::unique_lock<std::mutex> g(mu_); cv_.wait(g, [&] { return i + 2 <= done_ + (uint64_t)NB || stop_reading_; }); if (stop_reading_) break; }
+			Buf &b = ring_[i % NB];
+			uint64_t got = 0;
+			bool eof = false;
+			while (got < chunk_) {
+				const ssize_t g = read(fd_, b.data.data() + got, (size_t)(chunk_ - got));
+				if (g < 0 && errno == EINTR) continue;
+				if (g < 0) { std::lock_guard<std::mutex> l(mu_); io_error_ = true; eof = true; break; }
+				if (g == 0) { eof = true; break; }
+				got += (uint64_t)g;
+				// (a refusal: the packer will read no further -- hand over what has arrived, the host reader reads on from the descriptor)
+				{ std::lock_guard<std::mutex> l(mu_); if (stop_reading_) break; }
+			}
+			{ std::lock_guard<std::mutex> l(mu_); b.len = got; b.off = total_read_; b.last = eof; total_read_ += got; filled_ = i + 1; if (eof) eof_ = true; }
+			cv_.notify_all();
+			if (eof) break;
+		}
+		{ std::lock_guard<std::mutex> l(mu_); reader_done_ = true; }
+		cv_.notify_all();
+	}
+	void work_loop()
+	{
+		vg_packer *pk = nullptr;
+		const uint64_t rcap = vg_packer_reads_cap(chunk_), kcap = vg_packer_kmers_cap(chunk_);
+		uint64_t *stage[2] = {nullptr, nullptr};
+		int set_store[2] = {-1, -1};                         // the store whose copies may still read staging set k
+		auto bail = [&](const std::string &e) { if (error.empty()) error = e; };
+		if (vg_packer_create(pack_threads_, &pk) != VG_OK) bail(vg_last_error());
+		bool pinned[2] = {true, true};                       // (page-locked when a device is there to lock it for; any memory works)
+		for (int k = 0; k < 2 && error.empty(); k++) {
+			stage[k] = (uint64_t *)vg_host_alloc_pinned((size_t)(kcap + 2 * rcap + 2) * 8);
+			if (!stage[k]) { pinned[k] = false; stage[k] = (uint64_t *)malloc((size_t)(kcap + 2 * rcap + 2) * 8); }
+			if (!stage[k]) bail("staging for the FASTQ stream: allocation failed");
+		}
+		const size_t nrep = stores_.size();
+		size_t rr = 0;
+		uint64_t n_sets = 0;
+		uint64_t i = 0;
+		for (; error.empty(); i++) {
+			{ std::unique_lock<std::mutex> g(mu_); cv_.wait(g, [&] { return filled_ > i || reader_done_; }); if (filled_ <= i) break; }
+			Buf &b = ring_[i % NB];
+			if (b.len) {
+				const int k = (int)(n_sets & 1);
+				if (set_store[k] >= 0) { if (vg_read_store_flush(stores_[(size_t)set_store[k]]) != VG_OK) { bail(vg_last_error()); break; } set_store[k] = -1; }
+				uint64_t *sk = stage[k], *sm = sk + kcap, *so = sm + rcap;
+				uint64_t nr = 0, nc = 0, ninv = 0;
+				if (vg_packer_push(pk, b.data.data(), b.len, sk, kcap, sm, so, rcap, &nr, &nc, &ninv) != VG_OK) { bail(vg_last_error()); break; }
+				if (nr) {
+					bool sent = false;
+					bool att; { std::lock_guard<std::mutex> g(mu_); att = attached_; }
+					if (!att && stores_[rr]) {
+						const int prc = vg_read_store_push(stores_[rr], sk, sm, so, nr);
+						if (prc == VG_OK) { sent = true; set_store[k] = (int)rr; n_sets++; to_store += nr; }
+						else if (prc != VG_ENOMEM) { bail(vg_last_error()); break; }
+					}
+					if (!sent) {
+						// the store is full (or there is none): this batch waits here for the handle -- the reader thread keeps filling the ring,
+						// then the pipe's writer waits
+						{ std::unique_lock<std::mutex> g(mu_); cv_.wait(g, [&] { return attached_; }); }
+						const std::string e = sink_(rr, sk, sm, so, nr);
+					if (!e.empty()) { bail(e); break; }
+					direct += nr;
+					}
+					rr = (rr + 1) % nrep;
+				}
+				int ref = 0;
+				(void)vg_packer_end(pk, &records, &consumed, &last, &ref);     // (a query: the stream's totals so far)
+				if (ref) { refused = true; i++; break; }
+			}
+			{ std::lock_guard<std::mutex> g(mu_); done_ = i + 1; }           // (chunk i stays in the ring until chunk i + 1 is done with: the last framed record may begin in it)
+			cv_.notify_all();
+			if (b.last) { i++; break; }
+		}
+		// the end of the stream, a refusal or an error: the reader stops after the read() it is in; every chunk from the one before the
+		// packer's last on is handed to the host reader
+		{ std::lock_guard<std::mutex> g(mu_); stop_reading_ = true; }
+		cv_.notify_all();
+		if (reader_.joinable()) reader_.join();
+		for (int k = 0; k < 2; k++) if (set_store[k] >= 0) (void)vg_read_store_flush(stores_[(size_t)set_store[k]]);
+		{
+			std::lock_guard<std::mutex> g(mu_);
+			if (io_error_) bail("error reading the FASTQ stream");
+			bytes_read = total_read_;
+			// chunks [first, filled_) are intact in the ring: first = the chunk before the last one the packer saw (or 0)
+			const uint64_t seen = i;                                             // chunks the packer has been given
+			const uint64_t first = seen >= 2 ? seen - 2 : 0;
+			span_base = filled_ > first ? ring_[first % NB].off : total_read_;
+			for (uint64_t c = first; c < filled_; c++) spans.emplace_back(ring_[c % NB].data.data(), (size_t)ring_[c % NB].len);
+		}
+		for (int k = 0; k < 2; k++) if (stage[k]) { if (pinned[k]) vg_host_free_pinned(stage[k]); else free(stage[k]); }
+		if (pk) vg_packer_destroy(pk);
+		struct timespec now; clock_gettime(CLOCK_MONOTONIC, &now);
+		seconds = (double)(now.tv_sec - born_.tv_sec) + 1e-9 * (double)(now.tv_nsec - born_.tv_nsec);
+	}
+	const int fd_; const uint64_t chunk_; const int pack_threads_;
+	std::vector<vg_read_store *> stores_;
+	Sink sink_;
+	Buf ring_[NB];
+	std::mutex mu_; std::condition_variable cv_;
+	uint64_t filled_ = 0, done_ = 0, total_read_ = 0;
+	bool eof_ = false, reader_done_ = false, stop_reading_ = false, io_error_ = false, attached_ = false;
+	std::thread reader_, worker_;
+	struct timespec born_;
 };
 
 // The first record start at or after `from`: the start of a line that begins with '@' whose next-but-one line begins with '+'
@@ -374,13 +529,32 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
 	std::vector<std::unique_ptr<PrePacker>> pre((size_t)ngpu);
 	std::vector<vg_read_store *> store((size_t)ngpu, nullptr);
+	std::vector<vg_index *> ix((size_t)ngpu, nullptr);
+	std::unique_ptr<PipeIngest> pipe_in;
+	bool once_only = false;
 	if (!host_framing) {
 		fd = open(fastq.c_str(), O_RDONLY);
 		if (fd < 0) { fprintf(stderr, "vargeno: cannot open %s\n", fastq.c_str()); return EXIT_FAILURE; }
 		struct stat sb;
 		if (fstat(fd, &sb) != 0) { close(fd); fprintf(stderr, "vargeno: cannot stat %s\n", fastq.c_str()); return EXIT_FAILURE; }
 		fsize = (uint64_t)sb.st_size;
-		cuts_ok = range_cuts(fd, fsize, ngpu, cut);
+		once_only = !S_ISREG(sb.st_mode);                               // a FIFO, /dev/stdin, <(...): one descriptor, read once, no ranges (PipeIngest)
+		if (once_only) {
+			(void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);                     // (a pipe: the largest buffer an unprivileged process may ask for; fails harmlessly on anything else)
+			const uint64_t want = (uint64_t)std::max(1, env_int("VARGENO_PREPACK_GB", 16)) << 30;
+			if (env_int("VARGENO_PREPACK", 1)) for (int g = 0; g < ngpu; g++) {
+				int on = 0;
+				for (int k = 0; k < ngpu; k++) on += k % have == g % have;
+				uint64_t bytes = std::min<uint64_t>(want, vg_device_memory(g % have) / 8) / (uint64_t)on;
+				if (const char *e = getenv("VARGENO_PREPACK_BYTES")) if (atoll(e) > 0) bytes = (uint64_t)atoll(e);
+				if (vg_read_store_create(g % have, bytes, &store[(size_t)g]) != VG_OK) store[(size_t)g] = nullptr;      // (no store: its batches wait for the handle)
+			}
+			pipe_in.reset(new PipeIngest(fd, (uint64_t)std::max(1, env_int("VARGENO_CHUNK_MB", 64)) << 20, std::max(1, pack_threads * ngpu), store,
+			                             [&ix](size_t g, const uint64_t *k, const uint64_t *m, const uint64_t *o, uint64_t n) -> std::string {
+				                             return vg_reads_submit_packed(ix[g], k, m, o, n) == VG_OK ? std::string() : std::string("vg_reads_submit_packed failed: ") + vg_last_error();
+			                             }));
+		}
+		cuts_ok = !once_only && range_cuts(fd, fsize, ngpu, cut);
 		if (cuts_ok && pack_threads > 0 && env_int("VARGENO_PREPACK", 1)) {
 			// a read store per replica, on its device, taken NOW (the index is planned with what is left): as large as the range's
 			// packed form (~1/5.5 of its text, and room for a chunk's worst case is not needed: a push that does not fit ends the
@@ -404,7 +578,6 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	bool vcf_ok = false;
 	std::thread vcf_reader([&] { vcf_ok = vgh::read_whole_file(vcf_in, vcf_text); });
 	struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } vcf_joiner{vcf_reader};
-	std::vector<vg_index *> ix((size_t)ngpu, nullptr);
 	{
 		std::vector<std::thread> th;
 		std::vector<int> rcs((size_t)ngpu, 0);
@@ -415,9 +588,18 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		// an equal part -- planned for the whole device, the third or fourth one would fail where it could have run on fewer views
 		std::vector<uint64_t> budgets((size_t)ngpu, budget);
 		if (!budget && ngpu > have) for (int g = 0; g < ngpu; g++) { int on = 0; for (int k = 0; k < ngpu; k++) on += k % have == g % have; if (on > 1) budgets[(size_t)g] = vg_share_budget(g % have, on); }
+		// a read store was taken on the device before the index is planned: the plan must be told, or it plans for the device's TOTAL
+		// less 12 GiB while the store (up to 16 GiB) already holds part of that -- an index whose views fill the budget would then
+		// fail in its allocations where it could have run on fewer views.  vg_share_budget looks at what is free NOW (all budgets are
+		// computed here, before any replica opens)
+		if (!budget) for (int g = 0; g < ngpu; g++) if (!budgets[(size_t)g] && store[(size_t)g]) { int on = 0; for (int k = 0; k < ngpu; k++) on += k % have == g % have; budgets[(size_t)g] = vg_share_budget(g % have, on); }
 		for (int g = 0; g < ngpu; g++) th.emplace_back([&, g] { rcs[(size_t)g] = vg_index_open_ex(prefix.c_str(), g % have, budgets[(size_t)g], &ix[(size_t)g]); if (rcs[(size_t)g]) errs[(size_t)g] = vg_last_error(); });
 		for (auto &t : th) t.join();
-		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) { fprintf(stderr, "vargeno: cannot load index %s on GPU %d (%d): %s\n", prefix.c_str(), g, rcs[(size_t)g], errs[(size_t)g].c_str()); return EXIT_FAILURE; }
+		for (int g = 0; g < ngpu; g++) if (rcs[(size_t)g]) {
+			fprintf(stderr, "vargeno: cannot load index %s on GPU %d (%d): %s\n", prefix.c_str(), g, rcs[(size_t)g], errs[(size_t)g].c_str());
+			if (pipe_in) exit(EXIT_FAILURE);                            // (its threads hold the pipe: no unwinding)
+			return EXIT_FAILURE;
+		}
 	}
 	for (auto *h : ix) VG_CHECK(vg_set_stats(h, env_int("VARGENO_STATS", 0)));
 	if (verbose) { fprintf(stderr, "index replica: %s\n", vg_index_plan(ix[0])); fprintf(stderr, "index start-up: %s\n", vg_index_open_report(ix[0])); }
@@ -435,7 +617,19 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	// on the host.
 	uint64_t host_from = 0;                    // file offset the host reader takes over from
 	uint64_t prime_from = UINT64_MAX;          // start of the last record the device framed (to prime the stale buffers)
-	if (!host_framing) {
+	if (pipe_in) {
+		// a stream that is read once: what went into the read stores while the index opened first, then the packer's batches
+		// straight into the read loops until the stream ends (or is refused)
+		for (int g = 0; g < ngpu; g++) if (store[(size_t)g]) { VG_CHECK(vg_read_store_flush(store[(size_t)g])); }
+		pipe_in->attach();
+		pipe_in->finish();
+		for (int g = 0; g < ngpu; g++) if (store[(size_t)g] && vg_read_store_reads(store[(size_t)g])) VG_CHECK(vg_reads_submit_store(ix[(size_t)g], store[(size_t)g]));
+		if (!pipe_in->error.empty()) { fprintf(stderr, "vargeno: %s\n", pipe_in->error.c_str()); exit(EXIT_FAILURE); }
+		total += pipe_in->records;
+		if (verbose) fprintf(stderr, "ingest, replica 0: the FASTQ is not a regular file: one descriptor read once, %lu reads framed + packed by %d host threads (%lu into the read stores while the index opened, %lu straight into the read loop), "
+		                             "%.2f GB of text in %.2f s (%.2f GB/s)%s\n", (unsigned long)pipe_in->records, std::max(1, pack_threads * ngpu), (unsigned long)pipe_in->to_store, (unsigned long)pipe_in->direct,
+		                     (double)pipe_in->bytes_read / 1e9, pipe_in->seconds, pipe_in->seconds > 0 ? (double)pipe_in->bytes_read / 1e9 / pipe_in->seconds : 0.0, pipe_in->refused ? "; the stream framing refused a chunk: the host reader takes the rest" : "");
+	} else if (!host_framing) {
 		if (!cuts_ok) {
 			host_from = 0;                                              // no record start found where one should be: the host reader takes the file
 			fprintf(stderr, "vargeno: no FASTQ record start within 1 MiB of a range boundary: the whole file is framed on the host (slower)\n");
@@ -506,7 +700,11 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		close(fd);
 	}
 	{
-		vgh::FastqReader rd(fastq);
+		// the host reader: the file from host_from on -- or, for a stream that is read once, the bytes still in memory and then the
+		// descriptor (never a second open: a FIFO has lost its writer by then)
+		if (pipe_in) { host_from = pipe_in->consumed; if (pipe_in->records) prime_from = pipe_in->last; }
+		std::unique_ptr<vgh::FastqReader> rdp(pipe_in ? new vgh::FastqReader(fd, pipe_in->span_base, pipe_in->spans) : new vgh::FastqReader(fastq));
+		vgh::FastqReader &rd = *rdp;
 		vgh::ReadBatch rb;
 		if (!host_framing && prime_from != UINT64_MAX) {   // re-read the last framed record: it only fills the line buffers
 			rd.seek(prime_from);
@@ -609,6 +807,57 @@ int main(int argc, const char *argv[])
 					printf("\n");
 				}
 			}
+			return EXIT_SUCCESS;
+		} else if (opt == "fqpipe") {
+			// hidden: the once-only FASTQ route of `geno` (PipeIngest + the host reader behind it) without a device -- <path> is
+			// opened ONCE, whatever it is (a FIFO, /dev/stdin, a regular file).  One line per record in the form both halves can
+			// produce: "<chunks> <trimmed read, upper case> <gate bits, hex>", "N" / "X" for a read the reference skips / aborts on
+			// (tests/test_host_tools.py compares with `fqcheck` on the same bytes).  [chunk bytes] [threads]
+			if (argc < 3 || argc > 5) { print_help(); return EXIT_FAILURE; }
+			const int fd = open(argv[2], O_RDONLY);
+			if (fd < 0) throw vgh::Error{std::string("cannot open ") + argv[2]};
+			const uint64_t chunk = argc > 3 ? (uint64_t)atoll(argv[3]) : (1ull << 20);
+			std::vector<std::string> lines;
+			auto one = [&](uint64_t nch, const uint64_t *km, uint64_t meta) {
+				if (meta >> 63) { lines.push_back("X"); return; }
+				if ((meta >> 62) & 1u) { lines.push_back("N"); return; }
+				std::string l = std::to_string(nch) + " ";
+				for (uint64_t c = 0; c < nch; c++) for (int b = 0; b < 32; b++) l.push_back("ACGT"[(km[c] >> (2 * b)) & 3u]);
+				char hx[32]; snprintf(hx, sizeof hx, " %x", (unsigned)(meta & 0xFFFFFFFFu));
+				lines.push_back(l + hx);
+			};
+			std::vector<vg_read_store *> none(1, nullptr);
+			PipeIngest pin(fd, chunk, argc > 4 ? atoi(argv[4]) : 2, none, [&](size_t, const uint64_t *k, const uint64_t *m, const uint64_t *o, uint64_t n) -> std::string {
+				for (uint64_t r = 0; r < n; r++) one(o[r + 1] - o[r], k + o[r], m[r]);
+				return std::string();
+			});
+			pin.attach();
+			pin.finish();
+			if (!pin.error.empty()) throw vgh::Error{pin.error};
+			fprintf(stderr, "fqpipe: %lu records framed by the packer, %lu bytes consumed of %lu read, refused %d\n", (unsigned long)pin.records, (unsigned long)pin.consumed, (unsigned long)pin.bytes_read, pin.refused ? 1 : 0);
+			vgh::FastqReader rd(fd, pin.span_base, pin.spans);
+			vgh::ReadBatch rb;
+			if (pin.records) { rd.seek(pin.last); rb.clear(); (void)rd.next(rb, 1); }
+			rd.seek(pin.consumed);
+			for (;;) {
+				rb.clear();
+				if (!rd.next(rb, 1000)) break;
+				for (uint64_t i = 0; i < rb.n(); i++) {
+					const uint64_t o = rb.offsets[i], nch = (rb.offsets[i + 1] - o) / 32;
+					std::vector<uint64_t> km((size_t)nch, 0);
+					uint64_t meta = 0;
+					for (uint64_t c = 0; c < nch && !(meta >> 62); c++)
+						for (int b = 31; b >= 0; b--) {                       // (the reference's scan order: the first offending character decides, qv.cc:815-828)
+							const char ch = (char)(rb.bases[o + 32 * c + (uint64_t)b] & 0xDF);
+							const int code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1;
+							if (code < 0) { meta |= ch == 'N' ? 1ull << 62 : 1ull << 63; break; }
+							km[(size_t)c] |= (uint64_t)code << (2 * b);
+						}
+					for (uint64_t c = 0; c < nch && c < 32; c++) if ((int)(int8_t)rb.quals[o + c] - '8' < 0) meta |= 1ull << c;
+					one(nch, km.data(), meta);
+				}
+			}
+			for (const auto &l : lines) puts(l.c_str());
 			return EXIT_SUCCESS;
 		} else if (opt == "fqcuts") {
 			// hidden: where `geno` with n replicas would cut the FASTQ file (no device needed; tests/test_host_tools.py)

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace vgh {
@@ -32,6 +33,10 @@ struct ReadBatch {
 class FastqReader {
 public:
 	explicit FastqReader(const std::string &path);
+	// a stream that can be read only once (a pipe: the reference fopen()s whatever path it is given and fgets its way through,
+	// qv.cc:2182, 760-763): bytes [base, base + the spans' lengths) of it are in the caller's memory (kept alive by the caller),
+	// everything after them is read from fd.  seek() works inside those bytes only.
+	FastqReader(int fd, uint64_t base, std::vector<std::pair<const uint8_t *, size_t>> spans);
 	~FastqReader();
 	// appends up to max_reads records; returns the number appended (0 at end of file)
 	uint64_t next(ReadBatch &out, uint64_t max_reads);
