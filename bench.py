@@ -947,7 +947,17 @@ def main():
     cpu0 = time.process_time()
     # (ranks that share a device -- the gloo rehearsals on a one-GPU box -- share its memory: each plans for an equal part)
     sharers = (world + max(ndev, 1) - 1 - dev_index) // max(ndev, 1) if world > max(ndev, 1) else 1
-    gx = GenoIndex.open(prefix, device=dev_index, sharers=sharers)
+    budget = None
+    if sharers > 1:
+        # vg_share_budget = (what is free now - 12 GiB) / sharers: the same number for every rank only if every rank asks before any
+        # rank opens (round 5's advisor: a rank that asked after a sibling had taken its block got half a share and failed).  The
+        # collective below is the barrier; the minimum is everybody's budget
+        from vargeno_amd._lib import lib as _l
+
+        b = torch.tensor([int(_l().vg_share_budget(dev_index, int(sharers)))], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(b, op=dist.ReduceOp.MIN)
+        budget = int(b.item()) or None
+    gx = GenoIndex.open(prefix, device=dev_index, max_device_bytes=budget)
     t_open = time.time() - t0
     cpu_open = time.process_time() - cpu0                  # host CPU seconds of this process (all its threads) inside vg_index_open
     open_report = gx.open_report

@@ -74,8 +74,13 @@ const char *vg_build_id(void);
 int  vg_device_count(void);
 /* Total memory of a device in bytes (0 on failure): what a caller that puts SEVERAL replicas on one device divides into the
  * budgets it hands to vg_index_open_ex -- without a budget every replica plans for the whole device (less 12 GiB), and the
- * third or fourth one fails with VG_ENOMEM.  vg_share_budget() is that division as the CLI and the Python binding make it:
- * (min(total, free at the time of the call) - 12 GiB) / replicas_on_the_device. */
+ * third or fourth one fails with VG_ENOMEM.  vg_share_budget() is that division as the CLI makes it:
+ * (min(total, free at the time of the call) - 12 GiB) / replicas_on_the_device.  "Free at the time of the call" makes it ONE
+ * number for all sharers only when it is asked for before any of them has opened: a process that opens its replicas itself calls
+ * it once per device, before the first vg_index_open_ex, and hands every sharer that number (the command line; it also does so
+ * for a single replica when it has taken a read store on the device).  Sharers in different processes must agree on a number
+ * among themselves (bench.py: every rank calls before any opens, the minimum over the ranks is everybody's budget) -- a rank that
+ * calls after a sibling has taken its block would get half a share. */
 uint64_t vg_device_memory(int device);
 uint64_t vg_share_budget(int device, int replicas_on_the_device);
 /* Host -> device rate of page-locked memory over this device's link in bytes per second, measured now (three 64 MiB copies; 0 on

@@ -28,12 +28,16 @@ class GenoIndex:
     def __init__(self, handle, device):
         self._h = handle
         self.device = device
+        self._stores = []                 # read stores whose batches are in flight: they must outlive the next vg_sync
 
     # ---- construction -------------------------------------------------------------------
     @classmethod
     def open(cls, prefix, device=0, max_device_bytes=None, sharers=1):
         """max_device_bytes: this replica's device-memory budget (vg_index_open_ex); None: vg_index_open (the whole device) --
-        or, with sharers > 1 replicas / ranks on this device, an equal share of it (vg_share_budget)."""
+        or, with sharers > 1 replicas on this device, an equal share of it (vg_share_budget).  vg_share_budget divides what is free
+        NOW by the number of sharers: it is only the same number for every sharer when all of them ask BEFORE any of them opens --
+        one process that opens its replicas itself (the command line does).  Sharers in different processes must agree on one number
+        first and pass it as max_device_bytes (bench.py: every rank asks, the minimum over the ranks is everybody's budget)."""
         h = C.c_void_p()
         if max_device_bytes is None and sharers > 1:
             max_device_bytes = int(lib().vg_share_budget(device, int(sharers))) or None
@@ -102,6 +106,7 @@ class GenoIndex:
             lib().vg_index_close(self._h)
             self._h = None
         self._pin = None
+        self._stores = []
 
     def __enter__(self):
         return self
@@ -143,6 +148,7 @@ class GenoIndex:
         """Every batch of a ReadStore (same device) through the read loop, in push order; asynchronous (sync / counts wait)."""
         store.flush()
         check(lib().vg_reads_submit_store(self._h, store._h))
+        self._stores.append(store)        # (released by sync / counts / stats / close: the batches read the store's memory until then)
 
     def fastq_stream(self, chunks, host_threads=None):
         """FASTQ text as a stream of byte chunks cut anywhere (numpy uint8 arrays / bytes; pinned host memory copies at link
@@ -173,6 +179,7 @@ class GenoIndex:
 
     def sync(self):
         check(lib().vg_sync(self._h))
+        self._stores = []
 
     def set_stats(self, enable):
         check(lib().vg_set_stats(self._h, 1 if enable else 0))

@@ -525,6 +525,7 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 	const int hw = usable_cpus();
 	// host threads that frame + pack (per replica); 0: the text is framed on the device, nothing is packed ahead
 	int pack_threads = env_int("VARGENO_PACK_THREADS", -1);
+	const bool pack_threads_given = pack_threads >= 0;
 	if (pack_threads < 0) pack_threads = std::max(2, std::min(hw - 2, 96) / ngpu);
 	const int n_readers = std::max(1, std::min(env_int("VARGENO_READERS", std::max(8, std::min(32, hw / 8))), 64));
 	std::vector<std::unique_ptr<PrePacker>> pre((size_t)ngpu);
@@ -643,17 +644,21 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 					th.emplace_back([&, g] {
 						StreamResult &r = res[(size_t)g];
 						uint64_t done_to = 0;                                  // bytes of the range framed so far
-						bool pack_rest = pack_threads > 0;
+						// the rest of a range (what the pre-packer did not take -- it was stopped, its store filled up, or it never ran): host
+						// packing or device framing, whichever is faster HERE.  With a pre-packer its measured rate decides, whether it is
+						// still running or done (a 30x file overruns a 16 GB store: the larger part of the file is "the rest"); without one
+						// (VARGENO_PREPACK=0, no store) the number of CPUs does, as in r04, unless VARGENO_PACK_THREADS says what is wanted
+						bool pack_rest = pack_threads > 0 && (pack_threads_given || hw >= 32);
 						if (pre[(size_t)g]) {
 							PrePacker &pp = *pre[(size_t)g];
-							// what was packed while the index was opening is in the read store.  Is the pre-packer still at it?  Then it
-							// keeps the rest of the range unless the device-side framing would finish it at least a second earlier
+							pack_rest = pack_threads > 0;
+							// it keeps the rest of the range unless the device-side framing would finish it at least a second earlier
 							// (changing horses costs about that much: a new stream, its readers starting cold)
-							if (!pp.done()) {
+							{
 								const double rp = pp.text_bytes_per_s();
 								const double left = (double)(cut[(size_t)g + 1] - cut[(size_t)g]) - (double)pp.text_bytes_done();
-								if (rp > 0 && link > 0) pack_rest = rp >= link || left * (1.0 / rp - 1.0 / link) < 1.0;
-								if (!pack_rest) pp.stop();
+								if (rp > 0 && link > 0 && left > 0) pack_rest = rp >= link || left * (1.0 / rp - 1.0 / link) < 1.0;
+								if (!pp.done() && !pack_rest) pp.stop();
 							}
 							pp.join();
 							if (!pp.error.empty()) r.error = pp.error;
