@@ -639,3 +639,42 @@ def test_a_device_memory_budget_decides_the_views_and_nothing_else_does(ftiny_di
     with pytest.raises(VgError) as e:
         GenoIndex.open(prefix, max_device_bytes=10 * GiB)
     assert e.value.code == -3 and "budget" in str(e.value)
+
+
+@pytest.mark.parametrize("knob", [{}, {"VG_LATE_READS": "2"}, {"VG_NO_LATE_STORE": "1"}])
+def test_reads_the_deep_tier_leaves_behind_are_finished_late_or_per_batch(tmp_path, monkeypatch, knob):
+    """The few reads that outgrow the deep tier's LDS tables are finished by the lane machine (lists in HBM).  Round 5 ran it per
+    batch -- the batch's slot waited 6-12 ms for a handful of 250 bp reads -- round 6 copies their packed form into a store of the
+    handle (vg_late_collect) and runs the lane machine over the store once, at the next synchronisation.  F-small sends reads all
+    the way down; here in three batches and with a synchronisation in the middle: the store as shipped, a store of two reads (it
+    fills up: the rest takes the per-batch lane launch, as do reads of more than 32 chunks), and no store at all -- counting build
+    and timed build, the oracle's counters and event counts every time."""
+    import subprocess
+    from vargeno_amd import synth
+    g, s, r = synth.f_small()
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "ref.fa"), g)
+    synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
+    subprocess.check_call([BIN, "index", "ref.fa", "snps.vcf", "idx"], cwd=d, env=dict(os.environ, VARGENO_NO_LITE="1"), stdout=subprocess.DEVNULL)
+    prefix = os.path.join(d, "idx")
+    ox, _, so = _oracle_counts(prefix, r)
+    want = ox.stats.as_dict()
+    for k, v in knob.items():
+        monkeypatch.setenv(k, v)
+    cuts = [0, r.n // 3, r.n // 3 + 1000, r.n]
+    with GenoIndex.open(prefix) as gx:
+        for stats in (True, False):
+            gx.reset()
+            gx.set_stats(stats)
+            for i in range(3):
+                part = r.slice(cuts[i], cuts[i + 1])
+                gx.submit(part.bases, part.quals, part.offsets)
+                if i == 0:
+                    gx.sync()                                        # (a run of the store in the middle of the job)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), (knob, stats)
+            st = gx.stats()
+            assert st["overflow_deep"] > 2, st["overflow_deep"]      # (the fixture does reach the lane tier, with more reads than the two-read store holds)
+            if stats:
+                for k in CMP_STATS:
+                    assert st[k] == want[k], (knob, k)

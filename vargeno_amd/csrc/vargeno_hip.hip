@@ -634,6 +634,46 @@ __global__ __launch_bounds__(256) void vg_lane_kernel(DevIndex d, Scratch s, con
 }
 
 
+
+// The reads the deep tier leaves behind (listB: more vote keys or neighbour contexts than its LDS tables hold) are finished by the
+// lane machine, one read per lane with its lists in HBM: 6-12 ms for the handful of 250 bp reads per 8 M that reach it, during
+// which the batch's slot -- and with three slots the main stream -- waited (r05: 6.9 ms per step for 5.1 ms of kernels).  Counters
+// are sums, so WHEN such a read is finished does not matter: this kernel copies the packed form of those reads (chunk k-mers + flag
+// word) out of the batch's slot into a small store that belongs to the handle, the slot is free at once, and the lane machine runs
+// over the store ONCE, when the caller next synchronises (finish_pending).  One 64-bit atomic reserves a read's place and its
+// chunks' (reads << 32 | chunks: both cursors move together, so the offsets stay a prefix sum); what does not fit -- or has more
+// chunks than a flag word has gate bits -- goes to the residual list and takes the per-batch lane launch as before.
+struct LateStore {
+	uint64_t *kmers = nullptr, *meta = nullptr, *offsets = nullptr;      // [cap_chunks + 2], [cap_reads], [cap_reads + 1] (offsets in bases: 32 x chunks before)
+	unsigned long long *state = nullptr;                                 // [0] reads << 32 | chunks reserved so far, [1] reads that fit (a prefix)
+	uint32_t *lost = nullptr, *lost_n = nullptr;                         // reads that outgrew the lane machine's deep scratch too
+	uint32_t cap_reads = 0, cap_chunks = 0;
+};
+__global__ __launch_bounds__(256) void vg_late_collect(LateStore ls, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta, const uint64_t *__restrict__ offsets,
+                                                       const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list, uint32_t *__restrict__ residual, uint32_t *__restrict__ n_residual)
+{
+	const uint32_t n = *n_list;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t rid = list[i];
+		const uint64_t off = offsets[rid];
+		const uint32_t nch = (uint32_t)((offsets[rid + 1] - off) >> 5);
+		bool kept = false;
+		if (nch <= 32u) {
+			const unsigned long long old = atomicAdd(&ls.state[0], (1ull << 32) | (unsigned long long)nch);
+			const uint64_t r = old >> 32, c0 = old & 0xFFFFFFFFull;
+			if (r < ls.cap_reads && c0 + nch <= ls.cap_chunks) {
+				for (uint32_t c = 0; c < nch; c++) ls.kmers[c0 + c] = pk_kmer[(off >> 5) + c];
+				ls.meta[r] = pk_meta[rid];
+				ls.offsets[r] = 32ull * c0;
+				ls.offsets[r + 1] = 32ull * (c0 + nch);
+				atomicMax(&ls.state[1], (unsigned long long)(r + 1));
+				kept = true;
+			}
+		}
+		if (!kept) residual[atomicAdd(n_residual, 1u)] = rid;
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernels: FASTQ framing on the device (reference src/qv.cc:760-784: four fgets() per record)
 //
@@ -812,7 +852,7 @@ struct Slot {
 	uint32_t *ctr = nullptr;              // [0] wave-tier overflow, [1] lane-tier overflow, [2] lost -- this batch
 	uint32_t *h_ctr = nullptr;            // page-locked copy of ctr[0..3], made on the tail stream when the batch's tiers are done
 	// what the generic lane tier needs should the deep tier leave reads behind: it is only launched then (harvest), never empty
-	const uint8_t *lt_bases = nullptr, *lt_quals = nullptr; const uint64_t *lt_offsets = nullptr; const uint32_t *lt_gate = nullptr; bool lt_packed = false, lt_stats = false, lt_enqueued = false;
+	const uint8_t *lt_bases = nullptr, *lt_quals = nullptr; const uint64_t *lt_offsets = nullptr; const uint32_t *lt_gate = nullptr; bool lt_packed = false, lt_stats = false, lt_enqueued = false, lt_late = false;      // lt_late: the deep tier's leftovers went through vg_late_collect (the per-batch lane tier then only has the residual list: listA, ctr[6])
 	uint64_t *pk_kmer = nullptr, *pk_meta = nullptr;  uint64_t pk_kmer_cap = 0, pk_meta_cap = 0;   // packed reads of this batch
 	uint8_t *st_bases = nullptr, *st_quals = nullptr; uint64_t *st_offsets = nullptr;   // staging of vg_reads_submit / vg_fastq_submit
 	uint32_t *st_gate = nullptr; uint64_t st_gate_cap = 0;                              // gate words of a batch framed on the device
@@ -856,7 +896,13 @@ struct vg_index {
 	ScratchBuf mid, big;                  // lane-tier scratch: every lane x 64 contexts; a few lanes x 16384 contexts
 	Slot slot[NSLOT];
 	int next_slot = 0;
-	bool lane_tier_seen = false;          // some batch of this handle left reads for the lane tier: it is enqueued with every batch from then on
+	bool lane_tier_seen = false;          // some batch of this handle left reads for the per-batch lane tier (the late store did not take them): it is enqueued with every batch from then on
+	LateStore late;                       // reads the deep tier left behind, kept for ONE lane-machine run at the next synchronisation (vg_late_collect)
+	uint32_t late_h[4] = {0, 0, 0, 0};    // host copy of the store's counters at the last finish_pending
+	bool late_dirty = false, late_stats = false;     // batches have been enqueued since the store was last run / they were counting-build batches
+	uint64_t late_reads_run = 0;          // reads the late runs have finished since open
+	bool spill_known = false;
+	uint32_t spill_hint = 0;              // the deep tier's list of the last harvested batches (reads): sizes the next batch's deep-tier grid
 	uint64_t cum[4] = {0, 0, 0, 0};       // since reset: [0] wave-tier overflow, [1] lane-tier overflow, [2] lost, [3] reads with a character other than ACGTN
 	uint8_t *d_clamped = nullptr;         // [2 * n_sites] staging of vg_counts_fetch: min(63, sum), ref counts then alt counts
 	unsigned long long *d_stats = nullptr;
@@ -1592,7 +1638,15 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
 	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
-	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 16, true, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers
+	if (!getenv("VG_NO_LATE_STORE")) {
+		// the late store (vg_late_collect): 65 536 reads / 2^20 chunks between two synchronisations (VG_LATE_READS: tests fill it up)
+		LateStore &ls = ix->late;
+		ls.cap_reads = 1u << 16; ls.cap_chunks = 1u << 20;
+		if (const char *e = getenv("VG_LATE_READS")) { ls.cap_reads = (uint32_t)std::max(1, atoi(e)); ls.cap_chunks = std::min<uint32_t>(ls.cap_chunks, 32u * ls.cap_reads); }
+		if ((rc = dev_alloc(ix, &ls.kmers, (uint64_t)ls.cap_chunks + 2, false, true)) || (rc = dev_alloc(ix, &ls.meta, ls.cap_reads, false, true)) || (rc = dev_alloc(ix, &ls.offsets, (uint64_t)ls.cap_reads + 1, false, true)) ||
+		    (rc = dev_alloc(ix, &ls.lost, ls.cap_reads, false, true)) || (rc = dev_alloc(ix, &ls.lost_n, 1, true, true)) || (rc = dev_alloc(ix, &ls.state, 2, true, true))) return rc;
+	}
+	for (Slot &sl : ix->slot) if ((rc = dev_alloc(ix, &sl.ctr, 16, true, true))) return rc;       // [0..2] spill counts, [3] invalid reads, [4],[5] work counters of the two wave tiers, [6] reads left for the per-batch lane tier
 	if ((rc = dev_alloc(ix, &ix->d_clamped, 2 * ix->n_sites + 2, false, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true, true))) return rc;
@@ -1919,22 +1973,52 @@ static int harvest(vg_index *ix, Slot &sl)
 {
 	if (!sl.busy) return VG_OK;
 	HIP_TRY(hipEventSynchronize(sl.e3));
-	if (sl.h_ctr[1]) ix->lane_tier_seen = true;
-	if (sl.h_ctr[1] && !sl.lt_enqueued) {
-		// the deep tier left reads behind (listB): the lane machine with its lists in HBM finishes them now
-		if (sl.lt_stats) vg_lane_kernel<true><<<ix->big.s.nlanes / 64, 64, 0, ix->tail2>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
-		else vg_lane_kernel<false><<<ix->big.s.nlanes / 64, 64, 0, ix->tail2>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, sl.listB, &sl.ctr[1], sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
+	// reads left for the per-batch lane tier: what the late store did not take (ctr[6]), or -- VG_FORCE_GENERIC, VG_NO_LATE_STORE -- all of listB
+	const uint32_t resid = sl.lt_late ? sl.h_ctr[6] : sl.h_ctr[1];
+	uint32_t *const r_list = sl.lt_late ? sl.listA : sl.listB, *const r_cnt = sl.lt_late ? &sl.ctr[6] : &sl.ctr[1];
+	if (resid) ix->lane_tier_seen = true;
+	if (resid && !sl.lt_enqueued) {
+		// the lane machine with its lists in HBM finishes them now
+		if (sl.lt_stats) vg_lane_kernel<true><<<ix->big.s.nlanes / 64, 64, 0, ix->tail2>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, r_list, r_cnt, sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
+		else vg_lane_kernel<false><<<ix->big.s.nlanes / 64, 64, 0, ix->tail2>>>(ix->d, ix->big.s, sl.lt_bases, sl.lt_quals, sl.lt_offsets, 0, r_list, r_cnt, sl.listC, &sl.ctr[2], ix->d_stats, nullptr, sl.lt_gate, sl.pk_kmer, sl.pk_meta, sl.lt_packed);
 		HIP_TRY(hipGetLastError());
-		HIP_TRY(hipMemcpyAsync(sl.h_ctr, sl.ctr, 16, hipMemcpyDeviceToHost, ix->tail2));
+		HIP_TRY(hipMemcpyAsync(sl.h_ctr, sl.ctr, 32, hipMemcpyDeviceToHost, ix->tail2));
 		HIP_TRY(hipStreamSynchronize(ix->tail2));
 	}
 	for (int i = 0; i < 4; i++) ix->cum[i] += sl.h_ctr[i];
+	// the deep tier's grid follows the lists it has been getting (enqueue_batch): the larger of this batch's and half the hint before
+	ix->spill_hint = std::max<uint32_t>(sl.h_ctr[0], ix->spill_hint / 2);
+	ix->spill_known = true;
 	float a = 0, b = 0, c = 0, t = 0;
 	HIP_TRY(hipEventElapsedTime(&a, sl.e0, sl.e1)); HIP_TRY(hipEventElapsedTime(&b, sl.e5, sl.e2));
 	float w2 = 0;
 	HIP_TRY(hipEventElapsedTime(&c, sl.e2, sl.e3)); HIP_TRY(hipEventElapsedTime(&t, sl.e0, sl.e3)); HIP_TRY(hipEventElapsedTime(&w2, sl.e2, sl.e4));
 	ix->t_pack += a; ix->t_main += b; ix->t_tail += c; ix->t_total += t; ix->t_w2 += w2; ix->t_batches++;
 	sl.busy = false;
+	return VG_OK;
+}
+
+// The late store's one lane-machine run (see vg_late_collect): every stream of the handle is idle when this is called.
+static int run_late_store(vg_index *ix)
+{
+	if (!ix->late_dirty || !ix->late.state) return VG_OK;
+	unsigned long long st[2] = {0, 0};
+	HIP_TRY(hipMemcpy(st, ix->late.state, 16, hipMemcpyDeviceToHost));
+	ix->late_dirty = false;
+	const uint64_t n = st[1];
+	if (st[0] == 0) return VG_OK;
+	if (n) {
+		if (ix->late_stats) vg_lane_kernel<true><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, nullptr, nullptr, ix->late.offsets, n, nullptr, nullptr, ix->late.lost, ix->late.lost_n, ix->d_stats, nullptr, nullptr, ix->late.kmers, ix->late.meta, true);
+		else vg_lane_kernel<false><<<ix->big.s.nlanes / 64, 64, 0, ix->tail>>>(ix->d, ix->big.s, nullptr, nullptr, ix->late.offsets, n, nullptr, nullptr, ix->late.lost, ix->late.lost_n, ix->d_stats, nullptr, nullptr, ix->late.kmers, ix->late.meta, true);
+		HIP_TRY(hipGetLastError());
+	}
+	uint32_t lost = 0;
+	HIP_TRY(hipMemcpyAsync(&lost, ix->late.lost_n, 4, hipMemcpyDeviceToHost, ix->tail));
+	HIP_TRY(hipMemsetAsync(ix->late.state, 0, 16, ix->tail));
+	HIP_TRY(hipMemsetAsync(ix->late.lost_n, 0, 4, ix->tail));
+	HIP_TRY(hipStreamSynchronize(ix->tail));
+	ix->cum[2] += lost;
+	ix->late_reads_run += n;
 	return VG_OK;
 }
 
@@ -1949,6 +2033,7 @@ static int finish_pending(vg_index *ix)
 	// before the batches it produced: an empty stream has none)
 	if (ix->ingest) HIP_TRY(hipStreamSynchronize(ix->ingest));
 	for (Slot &sl : ix->slot) { int rc = harvest(ix, sl); if (rc) return rc; }
+	{ int rc = run_late_store(ix); if (rc) return rc; }
 	if (ix->cnt4_dirty && ix->n_sites) {
 		vg_fold_counters<<<(unsigned)std::min<uint64_t>((ix->n_sites + 255) / 256, 4096), 256, 0, ix->stream>>>(ix->d.cnt4, ix->d.site_ba, ix->d.cnt, ix->n_sites);
 		HIP_TRY(hipGetLastError());
@@ -2008,16 +2093,31 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		// waited for it and the main stream idled 0.2 ms per step (profiles/timeline_hg38_r04_three_tiers.txt).  With vote keys instead
 		// of context lists the deep tier has 0.005-0.3 % of the reads to do, not 10 %.
 		HIP_TRY(hipStreamWaitEvent(ix->tail, sl.e2, 0));
-		const unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
+		// The deep tier's grid: single-wave workgroups of 42 KB of LDS that can only be PLACED where a main-tier workgroup has retired --
+		// by then the next batch's kernels want the same CUs.  A full grid (3 per CU) for a list of 20 reads took 0.30 ms beside a
+		// 0.32 ms main kernel at chr22 scale (profiles/rocprof_summary_r05_chr22.txt).  The list's size is only known on the device, but
+		// lists of consecutive batches of one workload are alike: the grid follows the last harvested batches' lists (two reads per
+		// wave's pull, and a floor), the full grid until a batch has been harvested.  A list longer than expected is still finished --
+		// the waves pull their work from a counter and their pulls grow with the list -- just by fewer waves.
+		unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
+		if (ix->spill_known && !getenv("VG_W2_FULL_GRID")) w2grid = std::min<unsigned>(w2grid, std::max<unsigned>(32u, (2u * ix->spill_hint + ix->w2_chunk - 1) / ix->w2_chunk + 16u));
 		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
+		// what the deep tier leaves behind goes to the handle's late store (the lane machine runs over it once, at the next
+		// synchronisation); the slot only keeps what the store cannot take (listA is free again: the deep tier has consumed it)
+		sl.lt_late = ix->late.state != nullptr;
+		if (sl.lt_late) {
+			vg_late_collect<<<4, 256, 0, ix->tail>>>(ix->late, sl.pk_kmer, sl.pk_meta, d_offsets, sl.listB, &ctr[1], sl.listA, &ctr[6]);
+			ix->late_dirty = true; ix->late_stats = STATS;
+		}
 		HIP_TRY(hipEventRecord(sl.e4, ix->tail));
 	} else {
+		sl.lt_late = false;
 		if (produced_on && produced_on != ix->stream) {             // a batch gathered by the FASTQ framing on the ingest stream
 			HIP_TRY(hipEventRecord(sl.e_in, produced_on));
 			HIP_TRY(hipStreamWaitEvent(ix->stream, sl.e_in, 0));
 		}
-		HIP_TRY(hipMemsetAsync(ctr, 0, 16, ix->stream));
+		HIP_TRY(hipMemsetAsync(ctr, 0, 64, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e0, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e1, ix->stream));
 		HIP_TRY(hipEventRecord(sl.e5, ix->stream));
@@ -2040,8 +2140,8 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 	// to the one tail stream -- chr22-scale steps are 3 % slower with the fourth stream in use: profiles/ab_tail_streams_r05.txt)
 	hipStream_t lt = ix->tail;
 	if (sl.lt_enqueued) { lt = ix->tail2; HIP_TRY(hipStreamWaitEvent(lt, sl.e4, 0)); }
-	if (sl.lt_enqueued) vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, lt>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.listB, &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
-	HIP_TRY(hipMemcpyAsync(sl.h_ctr, ctr, 16, hipMemcpyDeviceToHost, lt));
+	if (sl.lt_enqueued) vg_lane_kernel<STATS><<<ix->big.s.nlanes / 64, 64, 0, lt>>>(ix->d, ix->big.s, d_bases, d_quals, d_offsets, 0, sl.lt_late ? sl.listA : sl.listB, sl.lt_late ? &ctr[6] : &ctr[1], sl.listC, &ctr[2], ix->d_stats, nullptr, d_gate, sl.pk_kmer, sl.pk_meta, packed);
+	HIP_TRY(hipMemcpyAsync(sl.h_ctr, ctr, 32, hipMemcpyDeviceToHost, lt));
 	HIP_TRY(hipEventRecord(sl.e3, lt));
 	HIP_TRY(hipGetLastError());
 	sl.busy = true;
@@ -2645,6 +2745,7 @@ extern "C" int vg_sync(vg_index *ix)
 extern "C" int vg_set_stats(vg_index *ix, int enable)
 {
 	if (!ix) return fail(VG_EINVAL, "null argument");
+	if (ix->stats_enabled != (enable != 0)) { int rc = finish_pending(ix); if (rc) return rc; }
 	ix->stats_enabled = enable != 0;
 	return VG_OK;
 }
