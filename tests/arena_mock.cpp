@@ -103,7 +103,9 @@ static uint64_t replay(const char *name, uint64_t n, uint64_t m, uint64_t aux_r,
 	auto P = [&](const char *w, uint64_t b) { void *p = a.take(b, false); if (!p) { misses++; if (S < (1ull << 50)) complain(std::string(name) + ": no room for the permanent array " + w); } h[w] = p; };
 	auto T = [&](const char *w, uint64_t b) { void *p = a.take(b, true); if (!p) { misses++; if (S < (1ull << 50)) complain(std::string(name) + ": no room for the temporary " + w); } h[w] = p; };
 	auto g = [&](const char *w) { if (h[w]) a.give(h[w]); h[w] = nullptr; };
-	const uint64_t J32 = ((1ull << 32) + 1) * 4;
+	// (r06: tables that scale with the index -- plan_views' table_bits_for: the power of two at or above the entry count, 2^32 from 2^31 entries on)
+	auto tbits = [](uint64_t entries) { uint64_t b = 16; while (b < 32 && (1ull << b) < entries) b++; return b >= 31 ? 32ull : b; };
+	const uint64_t Jref = ((1ull << tbits(n)) + 1) * 4;
 	T("ref_kmer", 8 * n); T("ref_pos", 4 * n); T("ref_amb", n); T("snp_kmer", 8 * m); T("snp_pos", 4 * m);
 	T("snp_info", m); T("snp_amb", m); T("snp_rf", m); T("snp_af", m);
 	P("ref_aux", 40 * aux_r); P("snp_aux_pos", 40 * aux_s); P("snp_aux_info", 10 * aux_s);
@@ -115,7 +117,7 @@ static uint64_t replay(const char *name, uint64_t n, uint64_t m, uint64_t aux_r,
 	g("winner"); g("blk"); g("scan_tmp"); g("s_pos"); g("s_ref"); g("s_alt"); g("s_rf"); g("s_af"); g("snp_rf"); g("snp_af");
 	P("snp_jg", ((1ull << 24) + 1) * 4); P("snp", 16 * m); g("snp_pos"); g("snp_info"); g("snp_amb"); P("snp_sig", 2 * (m + 16));
 	if (!mx) g("snp_kmer");
-	if (mx) P("ref_jg", J32);
+	if (mx) P("ref_jg", Jref);
 	P("ref", 16 * n); g("ref_pos"); g("ref_amb");
 	T("ka", 8 * n); T("va", 4 * n);
 	if (!mx) g("ref_kmer");
@@ -127,7 +129,7 @@ static uint64_t replay(const char *name, uint64_t n, uint64_t m, uint64_t aux_r,
 		const uint64_t nm = n + m;
 		T("ka", 8 * nm); g("ref_kmer"); g("snp_kmer"); T("va", 4 * nm); T("strand", nm / 8 + 8); T("kb", 8 * nm); T("vb", 4 * nm); T("sort_tmp", 64ull << 20); g("sort_tmp"); g("kb"); g("vb");
 		P("mx", 16 * nm); g("ka"); g("va"); g("strand");
-		T("big", 4); P("dx", (1ull << 32) * 16); g("big");
+		T("big", 4); P("dx", (1ull << tbits(nm)) * 16); g("big");
 	}
 	P("scratch_mid", 2048ull * 256 * (64 * 16 + 32 * 12)); P("scratch_big", 4096ull * (16384 * 16 + 2048 * 12));
 	const uint64_t used = a.in_use();

@@ -247,7 +247,9 @@ def test_cli_with_four_full_replicas_sharing_one_device(ftiny_dir, tmp_path):
     or fourth one failed with VG_ENOMEM (round 4's advisor).  Same VCF as one replica."""
     if torch.cuda.device_count() >= 4:
         pytest.skip("needs replicas that SHARE a device")
-    env = dict(os.environ, VARGENO_GPUS="4", VARGENO_SHARE_DEVICES="1", VARGENO_CHUNK_MB="1", VARGENO_VERBOSE="1")
+    # (r06: a small index gets small tables -- four F-tiny replicas would all fit whole; the 2^32-entry forms of an hg38-scale index,
+    # ~90 GB per replica, are forced so that the shares bite)
+    env = dict(os.environ, VARGENO_GPUS="4", VARGENO_SHARE_DEVICES="1", VARGENO_CHUNK_MB="1", VARGENO_VERBOSE="1", VG_DX_BITS="32", VG_REF_JG_BITS="32")
     p = subprocess.run([BIN, "geno", os.path.join(ftiny_dir, "idx"), os.path.join(ftiny_dir, "reads.fq"), os.path.join(ftiny_dir, "snps.vcf"), str(tmp_path / "out.vcf")],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr

@@ -76,17 +76,25 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
 
 
 @pytest.mark.parametrize("knob", ["VG_NO_DIRECT", "VG_NO_MX", "VG_NO_MX+VG_NO_HX", "VG_NO_MX+VG_NO_SNP_JG32", "VG_NO_MX+VG_NO_SEC+VG_NO_PROBE_VIEW", "VG_NO_SEC", "VG_PACK_OVERLAP",
-                                  "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW", "VG_NO_SIG_VIEW", "VG_NO_BF_FROM_SEC"])
+                                  "VG_NO_INGEST_STREAM", "VG_NO_PROBE_VIEW", "VG_NO_SIG_VIEW", "VG_NO_BF_FROM_SEC",
+                                  # r06: tables that scale with the index.  A small fixture gets small tables by itself (2^22 buckets here); these force the
+                                  # 2^32-entry forms an hg38-scale index gets (the headline kernel instantiation), a direct table of 2^16 buckets (~35 entries
+                                  # each: the in-bucket bisection) and a 2^16-entry reference jump table (long coarse buckets: ref_bounds' bisection)
+                                  "VG_DX_BITS=32+VG_REF_JG_BITS=32", "VG_DX_BITS=16", "VG_REF_JG_BITS=16", "VG_DX_BITS=19+VG_NO_SEC", "VG_REF_JG_BITS=16+VG_NO_MX+VG_NO_HX"])
 def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
     """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view, strided-probe
     view); the pack kernel can run on the ingest stream.  Each has a fallback / alternative; all must give the reference's bits.
     Several batches, so that slots, streams and the base-indexed counters' fold are exercised too."""
     for k in knob.split("+"):                      # (VG_NO_MX: the kernel of an index too big for the merged view; with
-        monkeypatch.setenv(k, "1")                 # VG_NO_SNP_JG32 it bisects HI24 buckets of the SNP dictionary)
+        monkeypatch.setenv(*(k.split("=") if "=" in k else (k, "1")))      # VG_NO_SNP_JG32 it bisects HI24 buckets of the SNP dictionary)
     prefix = os.path.join(ftiny_dir, "idx")
     r = ftiny_reads
     _, _, so = _oracle_counts(prefix, r)
     with GenoIndex.open(prefix) as gx:
+        if "VG_DX_BITS" in knob:
+            assert "direct table of 2^%s buckets" % knob.split("VG_DX_BITS=")[1][:2] in gx.plan, gx.plan
+        if "VG_REF_JG_BITS" in knob and "VG_NO_MX" not in knob:
+            assert "reference jump table: 2^%s entries" % knob.split("VG_REF_JG_BITS=")[1][:2] in gx.plan, gx.plan
         # (F-tiny's FASTA is upper case: its reference bit vector is the LO32 set of its dictionary, which the loader verifies)
         assert ("sec_is_bf" in gx.views) == ("VG_NO_BF_FROM_SEC" not in knob and "VG_NO_SEC" not in knob), gx.views
         gx.set_stats(False)
@@ -96,6 +104,12 @@ def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, 
             gx.submit(sub.bases, sub.quals, sub.offsets)
         rc, ac = gx.counts()
         assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        if "BITS" in knob:                         # (the counting build and the lane machine walk the reference's jump table: its coarse form too)
+            gx.reset()
+            gx.set_stats(True)
+            gx.submit(r.bases, r.quals, r.offsets)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
 
 
 def test_batching_and_reset_invariance(ftiny_dir, ftiny_reads):
@@ -271,9 +285,13 @@ def test_dense_snp_buckets_parity_all_layouts(tmp_path, monkeypatch):
     want = ox.stats.as_dict()
     assert want["scan_snp"] > 100 * want["gate_open"]
     rows = []
-    for label, env, views in (("all views", {}, ("mx", "dx")), ("no merged view (the > 2^32-entry fallback): paired HI32 table", {"VG_NO_MX": "1"}, ("hx",)),
+    for label, env, views in (("all views", {}, ("mx", "dx")), ("all views, tables of 2^32 entries (the hg38-scale forms)", {"VG_DX_BITS": "32", "VG_REF_JG_BITS": "32"}, ("mx", "dx")),
+                              ("all views, direct table of 2^16 buckets", {"VG_DX_BITS": "16", "VG_REF_JG_BITS": "16"}, ("mx", "dx")),
+                              ("no merged view (the > 2^32-entry fallback): paired HI32 table", {"VG_NO_MX": "1"}, ("hx",)),
                               ("no merged view, HI32 jump tables instead of the paired table", {"VG_NO_MX": "1", "VG_NO_HX": "1"}, ("snp_jg32",)),
                               ("no merged view, no HI32 table of the SNP dictionary at all", {"VG_NO_MX": "1", "VG_NO_HX": "1", "VG_NO_SNP_JG32": "1"}, ())):
+        for k in ("VG_DX_BITS", "VG_REF_JG_BITS"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         with GenoIndex.open(prefix) as gx:
@@ -473,7 +491,7 @@ def _revcomp_keys(k):
     return (k >> np.uint64(32)) | (k << np.uint64(32))
 
 
-@pytest.mark.parametrize("knob", [None, "VG_NO_DIRECT", "VG_NO_MX"])
+@pytest.mark.parametrize("knob", [None, "VG_NO_DIRECT", "VG_NO_MX", "VG_DX_BITS=32"])
 def test_self_complementary_and_both_strand_kmers(tmp_path, monkeypatch, knob):
     """The merged view and the direct table are keyed by min(K, revcomp K) with a strand flag, so that one look-up answers both
     passes of a read.  The corner cases of that: 32-mers that are their own reverse complement (an entry of BOTH strands), at
@@ -503,9 +521,9 @@ def test_self_complementary_and_both_strand_kmers(tmp_path, monkeypatch, knob):
     want = ox.stats.as_dict()
     assert so["ref_cnt"].sum() + so["alt_cnt"].sum() > 10_000 and want["snp_probe"] > 0
     if knob:
-        monkeypatch.setenv(knob, "1")
+        monkeypatch.setenv(*(knob.split("=") if "=" in knob else (knob, "1")))
     with GenoIndex.open(prefix) as gx:
-        assert ("dx" in gx.views) == (knob is None) and ("mx" in gx.views) == (knob != "VG_NO_MX"), gx.views
+        assert ("dx" in gx.views) == (knob is None or "BITS" in knob) and ("mx" in gx.views) == (knob != "VG_NO_MX"), gx.views
         for stats in (True, False):
             gx.reset()
             gx.set_stats(stats)
@@ -617,6 +635,24 @@ def test_a_device_memory_budget_decides_the_views_and_nothing_else_does(ftiny_di
     _, _, so = _oracle_counts(prefix, r)
     GiB = 1 << 30
     seen = {}
+    # r06: a small index gets small tables by itself -- F-tiny's whole layout is ~2 GB and no budget of tens of GiB could bite.
+    # First that: everything planned, tables sized to the dictionary, the handle an order of magnitude below the 2^32-entry forms
+    with GenoIndex.open(prefix) as gx:
+        assert "dx" in gx.views and "nothing left out" in gx.plan and "direct table of 2^22 buckets" in gx.plan and "reference jump table: 2^22 entries" in gx.plan, gx.plan
+        assert gx.device_bytes < 4 * GiB, gx.device_bytes
+        full = gx.device_bytes
+    # ... and a budget just below it buys HALF the buckets (then a quarter) before the table is given up
+    with GenoIndex.open(prefix, max_device_bytes=full + 2 * GiB - (40 << 20)) as gx:      # (the plan reserves 2 GiB for batch slots that the handle does not hold yet)
+        assert "dx" in gx.views and "HALF the buckets" in gx.plan and "direct table of 2^21 buckets" in gx.plan, gx.plan
+        gx.set_stats(False)
+        gx.submit(r.bases, r.quals, r.offsets)
+        rc, ac = gx.counts()
+        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+    # the rest of the test: the 2^32-entry forms of an hg38-scale index, forced on the small fixture (the budgets are theirs)
+    import pytest as _pt
+    mp = _pt.MonkeyPatch()
+    mp.setenv("VG_DX_BITS", "32")
+    mp.setenv("VG_REF_JG_BITS", "32")
     # F-tiny: the smallest layout is planned at ~20.5 GiB (the 16 GiB jump table is always there, 1.8 GiB of lane-tier scratch, 2 GiB
     # reserved for batch slots); the LO32 and signature views are tiny here, the merged view adds 16 GiB, the direct table 48 more
     for budget in (200 * GiB, 60 * GiB, 40 * GiB, 21 * GiB, 200 * GiB, 60 * GiB):
@@ -639,19 +675,20 @@ def test_a_device_memory_budget_decides_the_views_and_nothing_else_does(ftiny_di
     with pytest.raises(VgError) as e:
         GenoIndex.open(prefix, max_device_bytes=10 * GiB)
     assert e.value.code == -3 and "budget" in str(e.value)
+    mp.undo()
 
 
 @pytest.mark.parametrize("knob", [{}, {"VG_LATE_READS": "2"}, {"VG_NO_LATE_STORE": "1"}])
 def test_reads_the_deep_tier_leaves_behind_are_finished_late_or_per_batch(tmp_path, monkeypatch, knob):
     """The few reads that outgrow the deep tier's LDS tables are finished by the lane machine (lists in HBM).  Round 5 ran it per
     batch -- the batch's slot waited 6-12 ms for a handful of 250 bp reads -- round 6 copies their packed form into a store of the
-    handle (vg_late_collect) and runs the lane machine over the store once, at the next synchronisation.  F-small sends reads all
-    the way down; here in three batches and with a synchronisation in the middle: the store as shipped, a store of two reads (it
+    handle (vg_late_collect) and runs the lane machine over the store once, at the next synchronisation.  synth.f_manykeys sends
+    48 reads all the way down; here in three batches and with a synchronisation in the middle: the store as shipped, a store of two reads (it
     fills up: the rest takes the per-batch lane launch, as do reads of more than 32 chunks), and no store at all -- counting build
     and timed build, the oracle's counters and event counts every time."""
     import subprocess
     from vargeno_amd import synth
-    g, s, r = synth.f_small()
+    g, s, r = synth.f_manykeys()          # (reads with 64 vote keys: ten copies of each of their seven chunks' k-mers -- the deep tier holds 48)
     d = str(tmp_path)
     synth.write_fasta(os.path.join(d, "ref.fa"), g)
     synth.write_vcf(os.path.join(d, "snps.vcf"), g, s)
@@ -661,13 +698,13 @@ def test_reads_the_deep_tier_leaves_behind_are_finished_late_or_per_batch(tmp_pa
     want = ox.stats.as_dict()
     for k, v in knob.items():
         monkeypatch.setenv(k, v)
-    cuts = [0, r.n // 3, r.n // 3 + 1000, r.n]
+    parts = [(r.n - 20, r.n), (0, r.n - 48), (r.n - 48, r.n - 20)]       # (the 48 many-key reads are the fixture's last: 20 before the synchronisation, 28 after)
     with GenoIndex.open(prefix) as gx:
         for stats in (True, False):
             gx.reset()
             gx.set_stats(stats)
             for i in range(3):
-                part = r.slice(cuts[i], cuts[i + 1])
+                part = r.slice(*parts[i])
                 gx.submit(part.bases, part.quals, part.offsets)
                 if i == 0:
                     gx.sync()                                        # (a run of the store in the middle of the job)

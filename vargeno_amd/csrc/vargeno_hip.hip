@@ -245,8 +245,9 @@ __global__ void vg_canon_keys(uint64_t *__restrict__ key, uint64_t n, uint32_t *
 // from the dictionaries' 16-byte entries (r05: the columns they were unpacked from are long gone by now -- the construction keeps
 // as little alive as it can, vg_arena.h).  The entry's last word carries HI32 of its key, i.e. its bucket, until the direct
 // table has been built from it (vg_make_direct; vg_inline_pairs then puts the word to its real use).
+// dx_bits < 32 (DevIndex::dx_bits): bits 16-31 of the flags word carry field F, the key's high-word bits below the bucket, left-aligned.
 __global__ void vg_make_mx_entries(const uint64_t *__restrict__ key, const uint32_t *__restrict__ val, uint64_t n, uint64_t n_ref,
-                                   const RefEnt *__restrict__ ref, const SnpEnt *__restrict__ snp, uint4 *__restrict__ out, const uint32_t *__restrict__ strand_bits)
+                                   const RefEnt *__restrict__ ref, const SnpEnt *__restrict__ snp, uint4 *__restrict__ out, const uint32_t *__restrict__ strand_bits, const uint32_t dx_bits)
 {
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint32_t v = val[i];
@@ -255,7 +256,8 @@ __global__ void vg_make_mx_entries(const uint64_t *__restrict__ key, const uint3
 		if (is_snp) { const SnpEnt e = snp[v - n_ref]; pos = e.pos; amb = (uint32_t)(e.key >> 48) & 0xFFu; }
 		else { const RefEnt e = ref[v]; pos = e.pos; amb = e.amb; }
 		const uint32_t strand = (strand_bits[v >> 5] >> (v & 31)) & 1u;                          // flag 8: the dictionary's k-mer is the reverse complement of its canonical form
-		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1) | (strand << 3), (uint32_t)(key[i] >> 32));
+		const uint32_t hi = (uint32_t)(key[i] >> 32), F = dx_bits < 32u ? (hi << dx_bits) & 0xFFFF0000u : 0u;
+		out[i] = make_uint4((uint32_t)key[i], pos, (is_snp ? 1u : 0u) | ((amb & 1u) << 1) | (strand << 3) | F, hi);
 	}
 }
 // An ambiguous k-mer (2-10 copies) points at an auxiliary row; when the row holds exactly two positions -- the usual case --
@@ -274,20 +276,25 @@ __device__ inline bool aux_pair(const uint32_t *__restrict__ aux, uint32_t row, 
 // bucket's first entry writes the record, the table was zeroed before -- so that no 16 GiB jump table has to exist next to the
 // 64 GiB table while it is filled: that was the one moment at which construction held more than the finished index.
 __global__ void vg_make_direct(const uint4 *__restrict__ mx, uint64_t n, uint4 *__restrict__ dx,
-                               const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos, uint32_t *__restrict__ too_big)
+                               const uint32_t *__restrict__ ref_aux, const uint32_t *__restrict__ snp_aux_pos, uint32_t *__restrict__ too_big, const uint32_t dx_bits)
 {
+	// dx_bits < 32: a bucket = the top dx_bits bits of the key's high word; the record's flags word carries the first entry's field F
+	// (copied from the entry, bits 16-31) and an 8-bit count; TIE compares the whole of what is left of the key, (F, lo32)
+	const uint32_t sh = 32u - dx_bits;
+	const uint64_t cmax = dx_bits < 32u ? 0xFFull : 0xFFFFFFull;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
 		const uint4 e = mx[i];
-		if (i && mx[i - 1].w == e.w) continue;                     // not the first of its bucket
+		const uint32_t bkt = e.w >> sh;
+		if (i && (mx[i - 1].w >> sh) == bkt) continue;             // not the first of its bucket
 		uint64_t hi = i + 1;
-		while (hi < n && hi - i <= 0xFFFFFFull && mx[hi].w == e.w) hi++;
+		while (hi < n && hi - i <= cmax && (mx[hi].w >> sh) == bkt) hi++;
 		uint32_t cnt = (uint32_t)(hi - i);
-		if (cnt > 0xFFFFFFu) { atomicOr(too_big, 1u); cnt = 0xFFFFFFu; }       // the count field is 24 bits wide: the host keeps the jump-table form
-		uint4 r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (((e.z >> 3) & 1u) << 5) | (cnt << 8), (uint32_t)i);   // (flag 32: strand)
-		if (cnt > 1u && mx[i + 1].x == e.x) r.z |= 16u;            // TIE: the second entry carries the same k-mer (reference + SNP dictionary)
+		if (cnt > cmax) { atomicOr(too_big, 1u); cnt = (uint32_t)cmax; }        // the count field is 24 (8) bits wide: the host keeps the jump-table form (drops the view)
+		uint4 r = make_uint4(e.x, e.y, 1u | ((e.z & 1u) << 1) | (((e.z >> 1) & 1u) << 2) | (((e.z >> 3) & 1u) << 5) | (cnt << 8) | (e.z & 0xFFFF0000u), (uint32_t)i);   // (flag 32: strand)
+		if (cnt > 1u && mx[i + 1].x == e.x && mx[i + 1].w == e.w) r.z |= 16u;            // TIE: the second entry carries the same k-mer (reference + SNP dictionary)
 		uint32_t p0, p1;
 		if (cnt == 1u && (e.z & 2u) && aux_pair((e.z & 1u) ? snp_aux_pos : ref_aux, e.y, p0, p1)) { r.y = p0; r.w = p1; r.z |= 8u; }
-		dx[e.w] = r;
+		dx[bkt] = r;
 	}
 }
 // the jump table of the merged view from the same bucket words (only when the direct table could not be kept after all)
@@ -1293,19 +1300,37 @@ struct ViewPlan {
 	uint64_t base = 0, total = 0, budget = 0;
 	uint64_t arena = 0;                    // bytes of the handle's one block (vg_arena.h): the finished index less what lives outside it
 	bool limited = false;                  // views were left out for the budget
+	uint32_t dx_bits = 32, ref_jg_bits = 32;   // buckets of the direct table / of the reference dictionary's jump table (DevIndex)
 	std::string text;
-	bool same_views(const ViewPlan &o) const { return mx == o.mx && dx == o.dx && sec == o.sec && sig == o.sig && probe == o.probe && hx == o.hx && jg32 == o.jg32; }
+	bool same_views(const ViewPlan &o) const { return mx == o.mx && dx == o.dx && sec == o.sec && sig == o.sig && probe == o.probe && hx == o.hx && jg32 == o.jg32 && dx_bits == o.dx_bits && ref_jg_bits == o.ref_jg_bits; }
 };
+// Tables that scale with the index (r06).  The reference's jump table has 2^32 entries whatever the genome (qv.cc:539-584), and so
+// had this library's direct table: a chr22-scale index (1 GB of files) took 92 GB of HBM, 99 % of it empty buckets.  A table over
+// the top b bits of the same word finds the same entries as long as what the bucket leaves undecided is compared (ref_bounds,
+// DevIndex::dx_bits): b = the power of two at or above the entry count, i.e. a load of 0.5-1 entry per bucket like hg38's 0.75 in
+// 2^32; from 2^31 entries on that is the 2^32 form itself.  VG_DX_BITS / VG_REF_JG_BITS force a width (tests, A/B runs).
+static uint32_t table_bits_for(uint64_t entries, const char *env)
+{
+	if (const char *e = getenv(env)) { const int b = atoi(e); if (b >= 16 && b <= 32) return (uint32_t)b; }
+	uint32_t b = 16;
+	while (b < 32 && (1ull << b) < entries) b++;
+	return b >= 31 ? 32u : b;
+}
 static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits, uint64_t snp_bf_bits, uint64_t budget_arg, uint64_t device_total, int cus)
 {
 	ViewPlan p;
 	const uint64_t GiB = 1ull << 30, n = c.n_ref, m = c.n_snp, J32 = ((1ull << 32) + 1) * 4;
 	p.budget = budget_arg ? budget_arg : (device_total > 12 * GiB ? device_total - 12 * GiB : device_total);
 	const uint64_t plen = maxp + 64, sites = m / 32 + 1;                       // (an SNP seeds at most one site; ~32 k-mers per SNP)
-	const uint64_t scratch = (uint64_t)cus * 8 * 256 * (64 * 16 + 32 * 12) + 4096ull * (16384 * 16 + 2048 * 12);
+	// lane-tier scratch: the deep one (a few lanes x 16384 contexts) always; the wide shallow one (every lane x 64 contexts) only for
+	// the lane machine as the WHOLE path (VG_FORCE_GENERIC=1: tests compare the tiers) -- it was 0.74 GB that no other run touched
+	const bool lane_only = getenv("VG_FORCE_GENERIC") && atoi(getenv("VG_FORCE_GENERIC")) != 0;
+	const uint64_t scratch = (lane_only ? (uint64_t)cus * 8 * 256 * (64 * 16 + 32 * 12) : 0ull) + 4096ull * (16384 * 16 + 2048 * 12);
+	p.ref_jg_bits = table_bits_for(n, "VG_REF_JG_BITS");
+	const uint64_t Jref = ((1ull << p.ref_jg_bits) + 1) * 4;
 	// what every layout holds: both dictionaries in file order with their jump tables, auxiliary rows, bit vectors, pile-up
 	// sites and counters, lane-tier scratch, and room for three batch slots of a few million reads
-	p.base = J32 + 16 * n + 40 * c.n_ref_aux + ((1ull << 24) + 1) * 4 + 16 * m + 50 * c.n_snp_aux + std::min<uint64_t>(ref_bf_bits, 1ull << 32) / 8 + snp_bf_bits / 8
+	p.base = Jref + 16 * n + 40 * c.n_ref_aux + ((1ull << 24) + 1) * 4 + 16 * m + 50 * c.n_snp_aux + std::min<uint64_t>(ref_bf_bits, 1ull << 32) / 8 + snp_bf_bits / 8
 	       + plen + plen / 4 + sites * 32 + scratch + 2 * GiB;
 	p.total = p.base;
 	const bool can_mx = !getenv("VG_NO_MX") && n + m < (1ull << 32);
@@ -1323,15 +1348,33 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 	take(want_probe && getenv("VG_NO_SIG_VIEW") != nullptr, (m + 1) * 8, "probe view of the strided SNP scan", "the scan reads the dictionary entries themselves", p.probe);
 	take(!getenv("VG_NO_SEC"), 12 * n + 16 + ((1ull << bits) + 1) * 4, "LO32-ordered view", "the 48 high-half neighbour queries of a gate-open chunk are made one by one: ~2 x the stage-B time", p.sec);
 	if (can_mx) {
-		take(true, 16 * (n + m) + J32, "merged exact-match view", "two look-ups per chunk instead of one, no both-strands shortcut: ~+45 % kernel time (r03 A/B)", p.mx);
-		take(p.mx && !getenv("VG_NO_DIRECT"), (1ull << 32) * 16 - J32, "direct table", "a jump-table gather in front of every exact look-up: ~+15 % kernel time (r02 A/B)", p.dx);
+		// merged view + direct table together, the table as wide as the index wants it; under a budget that does not hold that, with
+		// half and a quarter of the buckets (two and four entries' worth of key per bucket: more look-ups read a second line) before
+		// the table is given up for the jump-table form (2^32 entries: the form the look-up without a direct table is written for)
+		const uint32_t nat = table_bits_for(n + m, "VG_DX_BITS");
+		const bool forced = getenv("VG_DX_BITS") != nullptr;
+		if (!getenv("VG_NO_DIRECT")) for (uint32_t step = 0; step < (forced ? 1u : 3u) && !p.dx; step++) {
+			const uint32_t b = nat - step;
+			if (b < 16u) break;
+			const uint64_t bytes = 16 * (n + m) + (1ull << b) * 16;
+			if (p.total + bytes <= p.budget) {
+				p.mx = p.dx = true; p.dx_bits = b; p.total += bytes;
+				snprintf(line, sizeof line, "%smerged exact-match view %.1f GB, direct table of 2^%u buckets %.1f GB%s", kept.empty() ? "" : ", ", 16 * (n + m) / 1e9, b, (double)((1ull << b) * 16) / 1e9,
+				         step ? (step == 1 ? " (HALF the buckets the index wants: the budget)" : " (A QUARTER of the buckets the index wants: the budget)") : "");
+				kept += line;
+			}
+		}
+		if (!p.dx) {
+			take(true, 16 * (n + m) + J32, "merged exact-match view", "two look-ups per chunk instead of one, no both-strands shortcut: ~+45 % kernel time (r03 A/B)", p.mx);
+			if (!getenv("VG_NO_DIRECT")) { snprintf(line, sizeof line, "%sdirect table (%.1f GB at 2^%u buckets; a jump-table gather in front of every exact look-up: ~+15 %% kernel time, r02 A/B)", dropped.empty() ? "" : "; ", (double)((1ull << (nat >= 18u ? nat - 2u : 16u)) * 16) / 1e9, nat >= 18u ? nat - 2u : 16u); dropped += line; }
+		}
 	} else {
 		const bool want32 = !getenv("VG_NO_SNP_JG32");
-		take(want32 && !getenv("VG_NO_HX"), ((1ull << 32) + 1) * 16 - J32, "paired HI32 table", "separate jump tables, no absence filters: +25 % kernel time (r03: 6.34 vs 5.03 ms)", p.hx);
+		take(want32 && !getenv("VG_NO_HX"), ((1ull << 32) + 1) * 16 - (p.ref_jg_bits == 32u ? J32 : 0), "paired HI32 table", "separate jump tables, no absence filters: +25 % kernel time (r03: 6.34 vs 5.03 ms)", p.hx);
 		take(want32 && !p.hx, J32, "HI32 jump table of the SNP dictionary", "SNP look-ups bisect HI24 buckets of ~190 entries: 8 dependent probes", p.jg32);
 	}
-	snprintf(line, sizeof line, "budget %.1f GB (%s): %.1f GB planned = %.1f GB of dictionaries, tables, sites and scratch", p.budget / 1e9,
-	         budget_arg ? "the caller's, vg_index_open_ex" : "the device's memory less 12 GiB", p.total / 1e9, p.base / 1e9);
+	snprintf(line, sizeof line, "budget %.1f GB (%s): %.1f GB planned = %.1f GB of dictionaries, tables (reference jump table: 2^%u entries), sites and scratch", p.budget / 1e9,
+	         budget_arg ? "the caller's, vg_index_open_ex" : "the device's memory less 12 GiB", p.total / 1e9, p.base / 1e9, p.ref_jg_bits);
 	p.text = line;
 	if (!kept.empty()) p.text += " + " + kept;
 	p.text += dropped.empty() ? "; nothing left out" : "; LEFT OUT for the budget: " + dropped;
@@ -1341,7 +1384,7 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 	p.arena = p.total - 2 * GiB - std::min<uint64_t>(sites * 10, p.total / 2) + (64ull << 20);
 	// with views left out the finished index is smaller than what construction has alive at its peak (the columns beside the
 	// entries, the sorts' buffers): the block then holds the permanent arrays only (vg_arena.h, set_temp_floor)
-	p.limited = !dropped.empty();
+	p.limited = !dropped.empty() || (p.dx && p.dx_bits < table_bits_for(n + m, "VG_DX_BITS"));
 	return p;
 }
 
@@ -1357,6 +1400,7 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 	int rc;
 	DevIndex &d = ix->d;
 	d.n_ref = c.n_ref; d.n_snp = c.n_snp;
+	d.dx_bits = 32u; d.ref_jg_bits = 32u;
 	d.ref_aux = c.ref_aux; d.snp_aux_pos = c.snp_aux_pos; d.snp_aux_info = c.snp_aux_info;
 	hipStream_t st = ix->stream;
 	// ---- largest position any entry names, and what a file that `vargeno index` did not write could get wrong: one wait for both
@@ -1520,13 +1564,16 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 	{
 		uint32_t *jg = nullptr; RefEnt *ent = nullptr;
 		if (!plan.hx) {
-			if ((rc = dev_alloc(ix, &jg, (1ull << 32) + 1))) return rc;
-			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(c.ref_kmer.p, c.n_ref, jg, 1ull << 32, 32);
+			// (2^32 entries -- the reference's table, qv.cc:539-584 -- for an hg38-scale dictionary; a coarse table over the top bits of
+			// HI32 for a small one: DevIndex::ref_jg_bits, ref_bounds)
+			const uint32_t rb = plan.ref_jg_bits;
+			if ((rc = dev_alloc(ix, &jg, (1ull << rb) + 1))) return rc;
+			vg_build_jumpgate<<<(unsigned)(((1ull << rb) + JG_SPAN - 1) / JG_SPAN), 256, 0, st>>>(c.ref_kmer.p, c.n_ref, jg, 1ull << rb, (int)(64 - rb));
 		}
 		if ((rc = dev_alloc(ix, &ent, c.n_ref))) return rc;
 		vg_make_ref_entries<<<2048, 256, 0, st>>>(c.ref_kmer.p, c.ref_pos.p, c.ref_amb.p, c.n_ref, ent);
 		HIP_TRY(hipGetLastError());
-		d.ref_jg = jg; d.ref = ent;
+		d.ref_jg = jg; d.ref = ent; d.ref_jg_bits = plan.hx ? 32u : plan.ref_jg_bits;
 		c.ref_pos.release(); c.ref_amb.release();
 		// secondary view ordered by (LO32, HI32): device radix sort of the swapped k-mers + a jump table over LO32's top bits
 		if (plan.sec) {
@@ -1597,7 +1644,8 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 			vg_build_jumpgate<<<(unsigned)((1ull << 32) / JG_SPAN), 256, 0, st>>>(ka.p, nm, mjg, 1ull << 32, 32);
 		}
 		if ((rc = dev_alloc(ix, &mx, nm))) return rc;
-		vg_make_mx_entries<<<2048, 256, 0, st>>>(ka.p, va.p, nm, c.n_ref, d.ref, d.snp, mx, strand_bits.p);
+		const uint32_t dxb = plan.dx ? plan.dx_bits : 32u;
+		vg_make_mx_entries<<<2048, 256, 0, st>>>(ka.p, va.p, nm, c.n_ref, d.ref, d.snp, mx, strand_bits.p, dxb);
 		HIP_TRY(hipGetLastError());
 		ka.release(); va.release(); strand_bits.release();
 		d.mx_jg = mjg; d.mx = mx;
@@ -1609,13 +1657,20 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 			if ((rc = big.alloc(1))) return rc;
 			HIP_TRY(hipMemsetAsync(big.p, 0, 4, st));
 			uint32_t too_big = 0;
-			if ((rc = dev_alloc(ix, &dx, 1ull << 32))) return fail(VG_ENOMEM, "no room for the direct table although the plan had it -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str());
-			HIP_TRY(hipMemsetAsync(dx, 0, (1ull << 32) * 16, st));
-			vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mx, nm, dx, d.ref_aux, d.snp_aux_pos, big.p);
+			if ((rc = dev_alloc(ix, &dx, 1ull << dxb))) return fail(VG_ENOMEM, "no room for the direct table although the plan had it -- is the device shared?  Pass a budget (vg_index_open_ex): %s", plan.text.c_str());
+			HIP_TRY(hipMemsetAsync(dx, 0, (1ull << dxb) * 16, st));
+			vg_make_direct<<<ix->cus * 32, 256, 0, st>>>(mx, nm, dx, d.ref_aux, d.snp_aux_pos, big.p, dxb);
 			HIP_TRY(hipGetLastError());
 			HIP_TRY(hipStreamSynchronize(st));
 			HIP_TRY(hipMemcpy(&too_big, big.p, 4, hipMemcpyDeviceToHost));
-			if (too_big) {
+			if (too_big && dxb < 32u) {
+				// a bucket of more than 255 entries in a table of fewer than 2^32 buckets (the mixed keys spread evenly: not seen): the entries
+				// carry that table's field F, so the merged view goes with it -- the look-up takes both dictionaries' own tables instead
+				dev_release(ix, dx); dx = nullptr;
+				dev_release(ix, mx); mx = nullptr;
+				d.mx = nullptr; d.mx_jg = nullptr;
+				ix->plan_text += "; merged view + direct table not kept: a bucket of more than 255 entries";
+			} else if (too_big) {
 				// jump-table form after all: the 64 GiB go back, the jump table is made from the same bucket words
 				dev_release(ix, dx); dx = nullptr;
 				if ((rc = dev_alloc(ix, &mjg, (1ull << 32) + 1))) return rc;
@@ -1623,7 +1678,7 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 				HIP_TRY(hipGetLastError());
 				d.mx_jg = mjg;
 				ix->plan_text += "; direct table not kept: a bucket of more than 2^24 - 1 entries";
-			} else d.dx = dx;
+			} else { d.dx = dx; d.dx_bits = dxb; }
 		}
 		// (after the table: it reads the row form and the bucket words.  Without the table the entries keep the row form -- the
 		// jump-table look-up expands rows itself -- and their bucket words, which nothing reads)
@@ -1636,7 +1691,7 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 	uint32_t cap = 64, kcap = 32;
 	if (const char *e = getenv("VG_SCRATCH_CAP")) cap = (uint32_t)std::max(1, atoi(e));
 	if (const char *e = getenv("VG_SCRATCH_KCAP")) kcap = (uint32_t)std::max(1, atoi(e));
-	if ((rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
+	if (ix->force_generic && (rc = alloc_scratch(ix, ix->mid, (uint32_t)ix->lane_grid_blocks * 256u, cap, kcap))) return rc;
 	if ((rc = alloc_scratch(ix, ix->big, 64u * 64u, 16384, 2048))) return rc;
 	if (!getenv("VG_NO_LATE_STORE")) {
 		// the late store (vg_late_collect): 65 536 reads / 2^20 chunks between two synchronisations (VG_LATE_READS: tests fill it up)
@@ -2083,7 +2138,9 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		ix->cnt4_dirty = true;
 		const unsigned wgrid = (unsigned)std::min<uint64_t>((n_reads + 64 * W1_WPB - 1) / (64 * W1_WPB), (uint64_t)ix->wave_grid / W1_WPB);
 		const bool big = !STATS && ix->d.mx == nullptr;                // an index without the merged view: the kernel built for it
+		const bool sdx = !STATS && !big && ix->d.dx != nullptr && ix->d.dx_bits < 32u;      // a direct table of fewer than 2^32 buckets: the instantiation that compares (F, lo32)
 		if (big) vg_wave_kernel_big<W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats, fin);
+		else if (sdx) vg_wave_kernel<false, W1_ECAP, W1_NCAP, W1_WPB, true><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats, fin);
 		else vg_wave_kernel<STATS, W1_ECAP, W1_NCAP, W1_WPB><<<wgrid, 64 * W1_WPB, 0, ix->stream>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, n_reads, nullptr, d_n_reads, sl.listA, &ctr[0], &ctr[4], ix->work_chunk, ix->d_stats, fin);
 		HIP_TRY(hipEventRecord(sl.e2, ix->stream));
 		// tail stream, the deep tier: the same kernel with deeper tables over the spill list (single-wave workgroups of 42 KB of LDS).
@@ -2102,6 +2159,7 @@ static int enqueue_batch(vg_index *ix, Slot &sl, const uint8_t *d_bases, const u
 		unsigned w2grid = (unsigned)std::min<uint64_t>((n_reads + 63) / 64, (uint64_t)ix->cus * ix->w2_wpc);
 		if (ix->spill_known && !getenv("VG_W2_FULL_GRID")) w2grid = std::min<unsigned>(w2grid, std::max<unsigned>(32u, (2u * ix->spill_hint + ix->w2_chunk - 1) / ix->w2_chunk + 16u));
 		if (big) vg_wave_kernel_big<W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
+		else if (sdx) vg_wave_kernel<false, W3_ECAP, W3_NCAP, 1, true><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		else vg_wave_kernel<STATS, W3_ECAP, W3_NCAP, 1><<<w2grid, 64, 0, ix->tail>>>(ix->d, sl.pk_kmer, sl.pk_meta, d_offsets, 0, sl.listA, &ctr[0], sl.listB, &ctr[1], &ctr[5], ix->w2_chunk, ix->d_stats, nofuse);
 		// what the deep tier leaves behind goes to the handle's late store (the lane machine runs over it once, at the next
 		// synchronisation); the slot only keeps what the store cannot take (listA is free again: the deep tier has consumed it)

@@ -30,7 +30,12 @@ struct __attribute__((aligned(16))) SnpEnt { uint64_t key; uint32_t pos, pad; };
 // FILE ORDER, which is all the reference's behaviour depends on.
 struct DevIndex {
 	// reference dictionary (src/qv.cc:519-590)
-	const uint32_t *ref_jg;        // [2^32 + 1] jump table over HI32; entry 2^32 = n_ref (sentinel replaces the 0xFFFFFFFF special case)
+	const uint32_t *ref_jg;        // [2^ref_jg_bits + 1] jump table over the top ref_jg_bits bits of HI32; the last entry = n_ref (sentinel replaces the 0xFFFFFFFF special case)
+	// ref_jg_bits = 32: the reference's table, one entry per HI32 value (16 GiB whatever the genome, qv.cc:539-584).  A dictionary of
+	// n k-mers fills 2^32 buckets to n / 2^32 -- 1 % for a 40 Mbp genome -- so a small index gets a COARSE table (r06: ~2 n buckets, the
+	// top bits of HI32): a coarse bucket holds the HI32 bucket asked for and maybe a neighbour or two, and the entries say which is
+	// which -- RefEnt::pad carries HI32 of the entry's k-mer (ref_bounds below).  Same [lo, hi) as the 2^32-entry table gives.
+	uint32_t ref_jg_bits;
 	const RefEnt   *ref;           // [n_ref]
 	const uint32_t *ref_aux;       // [n_ref_aux][10]
 	uint32_t aux_dups;             // some auxiliary row (either dictionary) lists a position twice: the wave kernel expands rows column by column
@@ -60,6 +65,13 @@ struct DevIndex {
 	// entry has the same k-mer), bit 3 = PAIR (single-
 	// entry buckets only: then the last word is the second position), bits 8.. = entries in the bucket.  A bucket with one entry -- the common case -- is settled, hit or miss, by ONE gather.  64 GiB.
 	const uint4 *dx;
+	// dx_bits = 32: the table above.  dx_bits < 32 (r06: an index of n + m k-mers gets ~2 (n + m) buckets instead of 2^32 -- chr22-scale
+	// 2 GB instead of 64 GiB --, and an hg38-scale index under a budget can take 2^31 or 2^30): buckets = the TOP dx_bits bits of the
+	// mixed key; the bits of the key's high word that the bucket does not fix (32 - dx_bits <= 16 of them) travel left-aligned in
+	// bits 16-31 of the flags word of every dx record and mx entry (field F), entries inside a bucket are ordered by (F, lo32) --
+	// i.e. by the key --, and a dx record's count is 8 bits wide (bits 8-15; a bucket of more than 255 entries makes the loader drop
+	// the merged view).  The kernel instantiation for this form compares (F, lo32) where the 2^32 form compares lo32.
+	uint32_t dx_bits;
 	// SNP dictionary (src/qv.cc:606-695)
 	const uint32_t *snp_jg;        // [2^24 + 1]
 	const SnpEnt   *snp;           // [n_snp]
@@ -297,7 +309,25 @@ __device__ inline void ref_bounds(const DevIndex &d, uint64_t h, uint32_t &lo, u
 		const uint32_t c = r.z & 0xFFFFu;
 		lo = r.x;
 		hi = c == 0xFFFFu ? gather<uint32_t>(&d.hx[h + 1].x) : lo + c;
-	} else jg_pair(d.ref_jg, h, lo, hi);
+	} else if (d.ref_jg_bits >= 32u) jg_pair(d.ref_jg, h, lo, hi);
+	else {
+		// coarse table: the bucket of h's top bits, then the run of entries whose k-mer has exactly this HI32 (RefEnt::pad) inside it --
+		// the entries are sorted by the whole k-mer, so by HI32 first.  Mostly zero to two entries: walked; a long bucket: bisected.
+		uint32_t a, e;
+		jg_pair(d.ref_jg, h >> (32u - d.ref_jg_bits), a, e);
+		const uint32_t hh = (uint32_t)h;
+		if (e - a > 8u) {
+			uint32_t x = a, y = e;
+			while (x < y) { const uint32_t m = x + ((y - x) >> 1); if (gather<uint32_t>(&d.ref[m].pad) < hh) x = m + 1; else y = m; }
+			lo = x; y = e;
+			while (x < y) { const uint32_t m = x + ((y - x) >> 1); if (gather<uint32_t>(&d.ref[m].pad) <= hh) x = m + 1; else y = m; }
+			hi = x;
+		} else {
+			uint32_t below = 0, same = 0;
+			for (uint32_t i = a; i < e; i++) { const uint32_t p = gather<uint32_t>(&d.ref[i].pad); below += p < hh ? 1u : 0u; same += p == hh ? 1u : 0u; }
+			lo = a + below; hi = lo + same;
+		}
+	}
 }
 
 // columns [j0, j0 + 4) of an auxiliary-table row (AUX_COLS = 10 positions, rows 8-byte aligned) as two independent 8-byte
@@ -437,7 +467,7 @@ __device__ inline void exact_multi_nomx(const DevIndex &d, const uint64_t (&k)[Z
 		rhit[z] = shit[z] = 0; rpos[z] = spos[z] = 0;
 		if (!want[z]) continue;
 		if (d.hx) { hx_bounds(d, k[z], true, true, ra[z], rb[z], sa[z], sb[z]); continue; }
-		jg_pair(d.ref_jg, k[z] >> 32, ra[z], rb[z]);
+		ref_bounds(d, k[z] >> 32, ra[z], rb[z]);
 		if (d.snp_jg32) jg_pair(d.snp_jg32, k[z] >> 32, sa[z], sb[z]); else jg_pair(d.snp_jg, k[z] >> 40, sa[z], sb[z]);
 	}
 	for (;;) {

@@ -125,7 +125,10 @@ __device__ inline uint32_t wave_sum(uint32_t v)
 // NOMX: the instantiation for an index without the merged view / direct table (2^32 or more k-mers in the two dictionaries
 // together, or VG_NO_MX).  A kernel of its own (vg_wave_kernel_big) rather than a branch: the two exact-look-up stages would
 // otherwise share one register allocation, and the kernel has no register to spare.
-template <bool STATS, int W_ECAP, int W_NCAP, int WPB, bool NOMX>
+// SDX: the instantiation for a direct table of fewer than 2^32 buckets (DevIndex::dx_bits < 32: small indexes, and hg38-scale ones
+// under a budget): the look-up compares (F, lo32) -- the key's bits below the bucket -- where the 2^32-bucket form compares lo32.
+// A kernel of its own for the same reason as NOMX: the headline instantiation keeps its registers and its instruction stream.
+template <bool STATS, int W_ECAP, int W_NCAP, int WPB, bool NOMX, bool SDX = false>
 __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                              const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                              const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
@@ -534,15 +537,25 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							kq[z] = fmix64(ck);
 						}
 						VG_CLKW(9);
+						// what an entry is compared with: lo32 of the key -- and, under SDX, field F above it (the high word's bits below the
+						// bucket, left-aligned; see DevIndex::dx_bits).  ekey() of a record / entry is the same 32 or 64 bits of ITS key.
+						const uint32_t dxb = SDX ? d.dx_bits : 32u;
+						auto ekey = [](const uint4 &e) -> uint64_t { return SDX ? ((uint64_t)(e.z & 0xFFFF0000u) << 32) | e.x : (uint64_t)e.x; };
+						auto ecnt = [](const uint4 &b) -> uint32_t { return SDX ? (b.z >> 8) & 0xFFu : b.z >> 8; };
 						uint4 bq[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) { bq[z] = make_uint4(0, 0, 0, 0); if (z < m) bq[z] = gather<uint4>(d.dx + (kq[z] >> 32)); }
+						for (uint32_t z = 0; z < 4; z++) {
+							bq[z] = make_uint4(0, 0, 0, 0);
+							if (z < m) bq[z] = gather<uint4>(d.dx + (SDX ? kq[z] >> (64u - dxb) : kq[z] >> 32));
+							if constexpr (SDX) kq[z] = ((uint64_t)(((uint32_t)(kq[z] >> 32) << dxb) & 0xFFFF0000u) << 32) | (uint32_t)kq[z];      // (F, lo32): what is left to compare
+							else kq[z] = (uint32_t)kq[z];
+						}
 						VG_CLKW(10);
 						// `more`: the bucket has further entries that may hold the key (entries are sorted by lo: nothing below the first; a
 						// match on the first entry is final unless the table says its successor has the same k-mer -- flag TIE)
 						bool more[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && (bq[z].z >> 8) > 1u && (bq[z].x < (uint32_t)kq[z] || (bq[z].x == (uint32_t)kq[z] && (bq[z].z & 16u)));
+						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && ecnt(bq[z]) > 1u && (ekey(bq[z]) < kq[z] || (ekey(bq[z]) == kq[z] && (bq[z].z & 16u)));
 						// Two chunks at a time: the rest of a small bucket -- up to VG_SCAN_W more entries -- arrives together (one wait;
 						// anything deeper is rare and goes one by one); then each chunk's exact contexts are appended (qv.cc:850-937),
 						// reference hit first, then SNP hit.  An ambiguous k-mer with exactly two positions carries both in its entry
@@ -553,9 +566,9 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							uint4 sv[2][SW];
 							#pragma unroll
 							for (uint32_t y = 0; y < 2; y++) {
-								const uint32_t cnt = bq[z0 + y].z >> 8, lo = bq[z0 + y].w;
+								const uint32_t cnt = ecnt(bq[z0 + y]), lo = bq[z0 + y].w;
 								#pragma unroll
-								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = gather<uint4>(d.mx + (lo + 1u + x)); }
+								for (uint32_t x = 0; x < SW; x++) { sv[y][x] = make_uint4(0xFFFFFFFFu, 0, 0xFFFF0000u, 0); if (more[z0 + y] && x + 1u < cnt) sv[y][x] = gather<uint4>(d.mx + (lo + 1u + x)); }
 							}
 							// An auxiliary row (a k-mer with 3-10 copies) is not expanded here but QUEUED -- the neighbour lists' LDS slots are idle
 							// during stage A: row index and chunk per entry -- and the wave expands everybody's rows together after the look-ups
@@ -573,7 +586,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								if (z >= m) continue;
 								cur.add(S_CHUNKS, 1);
 								const uint4 b = bq[z];
-								const uint32_t key = (uint32_t)kq[z];
+								const uint64_t key = kq[z];                             // (lo32, or (F, lo32) under SDX)
 								// hit state: position (or row index), second position of a PAIR, flags 1 hit, 2 ambiguous, 4 PAIR -- for this pass's
 								// strand, and (x...) for the other strand
 								uint32_t rp = 0, rp2 = 0, rf = 0, sp = 0, sp2 = 0, sf = 0;
@@ -596,22 +609,22 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 										}
 									}
 								};
-								if ((b.z & 1u) && b.x == key)                          // the inline first entry (dx flags: 2 SNP, 4 ambiguous, 8 PAIR, 32 strand)
+								if ((b.z & 1u) && ekey(b) == key)                      // the inline first entry (dx flags: 2 SNP, 4 ambiguous, 8 PAIR, 32 strand)
 									note((b.z & 2u) != 0u, (b.z >> 5) & 1u, b.y, b.w, 1u | (((b.z >> 2) & 1u) << 1) | (((b.z >> 3) & 1u) << 2));
 								if (more[z]) {
-									const uint32_t cnt = b.z >> 8, lo = b.w, hi = lo + cnt;
+									const uint32_t cnt = ecnt(b), lo = b.w, hi = lo + cnt;
 									auto take = [&](const uint4 v) {                     // mx flags: 1 SNP, 2 ambiguous, 4 PAIR, 8 strand
 										note((v.z & 1u) != 0u, (v.z >> 3) & 1u, v.y, v.w, 1u | (v.z & 2u) | (v.z & 4u));
 									};
 									#pragma unroll
-									for (uint32_t x = 0; x < SW; x++) if (x + 1u < cnt && sv[y][x].x == key) take(sv[y][x]);
-									if (cnt > SW + 1u && sv[y][SW - 1].x <= key) {      // the bucket goes on and may still hold the key
+									for (uint32_t x = 0; x < SW; x++) if (x + 1u < cnt && ekey(sv[y][x]) == key) take(sv[y][x]);
+									if (cnt > SW + 1u && ekey(sv[y][SW - 1]) <= key) {  // the bucket goes on and may still hold the key
 										uint32_t e = lo + SW + 1u;
-										if (cnt > 8u) { uint32_t eb = hi; while (e < eb) { const uint32_t mm = e + ((eb - e) >> 1); if (d.mx[mm].x < key) e = mm + 1; else eb = mm; } }
+										if (cnt > 8u) { uint32_t eb = hi; while (e < eb) { const uint32_t mm = e + ((eb - e) >> 1); if (ekey(d.mx[mm]) < key) e = mm + 1; else eb = mm; } }
 										for (; e < hi; e++) {
 											const uint4 v = d.mx[e];
-											if (v.x < key) continue;
-											if (v.x > key) break;
+											if (ekey(v) < key) continue;
+											if (ekey(v) > key) break;
 											take(v);
 										}
 									}
@@ -1392,13 +1405,13 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 #undef lane
 #undef col
 
-template <bool STATS, int W_ECAP, int W_NCAP, int WPB>
+template <bool STATS, int W_ECAP, int W_NCAP, int WPB, bool SDX = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(WPB > 1 ? VG_WPE : 1))) void vg_wave_kernel(DevIndex d, const uint64_t *__restrict__ pk_kmer, const uint64_t *__restrict__ pk_meta,
                                                      const uint64_t *__restrict__ offsets, uint64_t n_reads_arg,
                                                      const uint32_t *__restrict__ read_ids, const uint32_t *__restrict__ n_ids,
                                                      uint32_t *overflow_list, uint32_t *overflow_count, uint32_t *work_next, const uint32_t WORK_CHUNK_ARG, unsigned long long *stats, const FuseIn fuse)
 {
-	vg_wave_body<STATS, W_ECAP, W_NCAP, WPB, false>(d, pk_kmer, pk_meta, offsets, n_reads_arg, read_ids, n_ids, overflow_list, overflow_count, work_next, WORK_CHUNK_ARG, stats, fuse);
+	vg_wave_body<STATS, W_ECAP, W_NCAP, WPB, false, SDX>(d, pk_kmer, pk_meta, offsets, n_reads_arg, read_ids, n_ids, overflow_list, overflow_count, work_next, WORK_CHUNK_ARG, stats, fuse);
 }
 
 // the timed build for an index without the merged view (see vg_wave_body)

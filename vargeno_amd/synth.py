@@ -427,6 +427,46 @@ def f_tiny(seed=7):
     return g, s, r
 
 
+
+def f_manykeys(seed=5, n_homes=6, copies_per_home=8, n_random_reads=4_000):
+    """Reads that outgrow the DEEP wave tier (48 vote keys) and are finished by the lane machine: a 400 kbp genome in which seven
+    unrelated 32-mers A0..A6 stand side by side at a "home" and each of them nine more times at scattered places -- ten copies,
+    the most a dictionary entry lists before it turns POS_AMBIGUOUS (dictgen.c:118) --, so that a 224-base read of the home finds
+    ten positions per chunk: one vote key for the home, 7 x 9 = 63 for the scattered copies.  `n_homes` such homes, every home
+    read `copies_per_home` times (both strands, some with an error in a low-quality chunk), among ordinary reads.
+    Returns (genome, snps, reads)."""
+    rng = np.random.default_rng(seed)
+    g = make_genome(rng, [400_000], ["chr1"], repeats_per_mbp=10.0, microsat_per_mbp=0.0, n_gaps=False)
+    s0 = g.seqs[0]
+    homes = 10_000 + 60_000 * np.arange(n_homes, dtype=np.int64)
+    for hi, H in enumerate(homes):
+        H = int(H)
+        for c in range(7):
+            a = s0[H + 32 * c:H + 32 * c + 32].copy()
+            for j in range(9):
+                at = H + 1_000 + 523 * (9 * c + j) + hi                  # scattered, never side by side with another planted k-mer
+                s0[at:at + 32] = a
+    s = make_snps(rng, g, 4_000)
+    r = make_reads(rng, g, s, n_random_reads, lengths=(150, 250, 224), err=0.01, lowq=0.3)
+    h0, _, _ = haplotypes(g, s)
+    extra_b, extra_q = [], []
+    for H in homes:
+        for k in range(copies_per_home):
+            b = h0[int(H):int(H) + 224].copy()
+            q = rng.integers(ord(":"), ord("I") + 1, size=224, dtype=np.uint8)
+            if k % 4 == 3:                                               # an error in chunk 2, whose quality character says "look for neighbours"
+                b[70] = ACGT[(_CODE[b[70]] + 1) % 4]
+                q[2] = ord("#")
+            if k % 2:
+                b = _COMP[b[::-1]]
+            extra_b.append(b)
+            extra_q.append(q)
+    nb = np.concatenate([r.bases] + extra_b)
+    nq = np.concatenate([r.quals] + extra_q)
+    no = np.concatenate([r.offsets, r.offsets[-1] + np.uint64(224) * np.arange(1, len(extra_b) + 1, dtype=np.uint64)])
+    return g, s, Reads(nb, nq, no.astype(np.uint64))
+
+
 def f_strands(seed=31, n_plants=300, n_random_reads=12_000):
     """Strand corner cases of a canonical-key index (one look-up of min(K, revcomp K) answers both strands): a 300 kbp genome
     with planted 32-mers that ARE their own reverse complement (X + revcomp X; once, and at two positions), and 32-mers whose
