@@ -109,7 +109,12 @@ int  vg_index_open(const char *prefix, int device, vg_index **out);
  * within the finished size).  With views left out the finished handle is smaller than what construction has alive at its peak --
  * the dictionaries' columns beside their entries, the sorts' buffers -- and those temporaries are taken from the device beside the
  * block and given back: up to ~100 GB more than the budget for some hundred milliseconds at hg38 scale.  Replicas that SHARE a
- * device and open at the same time must leave that room (or open one after the other). */
+ * device and open at the same time must leave that room (or open one after the other).  When the device does not have that room
+ * free at the time of the call (a plan limited by the device's own size) the handle is built without the block, one allocation
+ * per buffer: slower to open, same views, same results (r06).
+ * Tables scale with the index (r06): the reference's jump table and the direct table have ~2 entries per k-mer instead of 2^32
+ * (a chr22-scale index holds ~8 GB instead of 92); vg_index_plan() names the widths, and under a budget the direct table is
+ * tried with half and a quarter of its buckets before it is given up. */
 int  vg_index_open_ex(const char *prefix, int device, uint64_t max_device_bytes, vg_index **out);
 /* What the budget bought, in words: planned bytes, views kept, views left out with what each costs ("" for a null handle).
  * The string lives as long as the handle. */

@@ -1,6 +1,7 @@
 """Parity of the HIP path (through the C-ABI) against the oracle and the reference's golden output.
 Bit-exact: this is integer / index work, there is no tolerance anywhere."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -635,19 +636,28 @@ def test_a_device_memory_budget_decides_the_views_and_nothing_else_does(ftiny_di
     _, _, so = _oracle_counts(prefix, r)
     GiB = 1 << 30
     seen = {}
-    # r06: a small index gets small tables by itself -- F-tiny's whole layout is ~2 GB and no budget of tens of GiB could bite.
-    # First that: everything planned, tables sized to the dictionary, the handle an order of magnitude below the 2^32-entry forms
+    # r06: the tables' widths are a planning decision -- the widest the budget holds (sparser buckets are faster), down to a quarter of
+    # the buckets the index wants.  F-tiny on the whole device gets the 2^32-entry forms of an hg38-scale index (~90 GB); under a
+    # budget of a few GiB the same files give a handle of that size, tables of ~2 entries' worth per k-mer, and the same counters
+    n_ref = len(index_io.read_ref_dict(prefix + ".ref.dict")["ref_kmer"])
+    n_snp = len(index_io.read_snp_dict(prefix + ".snp.dict")["snp_kmer"])
+    nat = max(16, int(np.ceil(np.log2(n_ref + n_snp))))                 # (plan_views' table_bits_for)
     with GenoIndex.open(prefix) as gx:
-        assert "dx" in gx.views and "nothing left out" in gx.plan and "direct table of 2^22 buckets" in gx.plan and "reference jump table: 2^22 entries" in gx.plan, gx.plan
-        assert gx.device_bytes < 4 * GiB, gx.device_bytes
-        full = gx.device_bytes
-    # ... and a budget just below it buys HALF the buckets (then a quarter) before the table is given up
-    with GenoIndex.open(prefix, max_device_bytes=full + 2 * GiB - (40 << 20)) as gx:      # (the plan reserves 2 GiB for batch slots that the handle does not hold yet)
-        assert "dx" in gx.views and "HALF the buckets" in gx.plan and "direct table of 2^21 buckets" in gx.plan, gx.plan
-        gx.set_stats(False)
-        gx.submit(r.bases, r.quals, r.offsets)
-        rc, ac = gx.counts()
-        assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"])
+        assert "dx" in gx.views and "nothing left out" in gx.plan and "direct table of 2^32 buckets" in gx.plan and "reference jump table: 2^32 entries" in gx.plan, gx.plan
+    last_bits = 33
+    for budget in (40 * GiB, 12 * GiB, 5 * GiB, int(3.9 * GiB)):
+        with GenoIndex.open(prefix, max_device_bytes=budget) as gx:
+            m = re.search(r"direct table of 2\^(\d+) buckets", gx.plan)
+            assert "dx" in gx.views and m, gx.plan
+            b_ = int(m.group(1))
+            assert nat - 2 <= b_ <= min(last_bits, nat + 2) and gx.device_bytes <= budget, (budget, gx.plan, gx.device_bytes)
+            last_bits = b_
+            gx.set_stats(False)
+            gx.submit(r.bases, r.quals, r.offsets)
+            rc, ac = gx.counts()
+            assert np.array_equal(rc, so["ref_cnt"]) and np.array_equal(ac, so["alt_cnt"]), budget
+            print("budget %.1f GiB: %.2f GB held | %s" % (budget / GiB, gx.device_bytes / 1e9, gx.plan))
+    assert last_bits <= nat + 2
     # the rest of the test: the 2^32-entry forms of an hg38-scale index, forced on the small fixture (the budgets are theirs)
     import pytest as _pt
     mp = _pt.MonkeyPatch()

@@ -1304,11 +1304,17 @@ struct ViewPlan {
 	std::string text;
 	bool same_views(const ViewPlan &o) const { return mx == o.mx && dx == o.dx && sec == o.sec && sig == o.sig && probe == o.probe && hx == o.hx && jg32 == o.jg32 && dx_bits == o.dx_bits && ref_jg_bits == o.ref_jg_bits; }
 };
-// Tables that scale with the index (r06).  The reference's jump table has 2^32 entries whatever the genome (qv.cc:539-584), and so
-// had this library's direct table: a chr22-scale index (1 GB of files) took 92 GB of HBM, 99 % of it empty buckets.  A table over
-// the top b bits of the same word finds the same entries as long as what the bucket leaves undecided is compared (ref_bounds,
-// DevIndex::dx_bits): b = the power of two at or above the entry count, i.e. a load of 0.5-1 entry per bucket like hg38's 0.75 in
-// 2^32; from 2^31 entries on that is the 2^32 form itself.  VG_DX_BITS / VG_REF_JG_BITS force a width (tests, A/B runs).
+// Tables that scale with the index AND the budget (r06).  The reference's jump table has 2^32 entries whatever the genome
+// (qv.cc:539-584), and so had this library's direct table: a chr22-scale index (1 GB of files) took 92 GB of HBM, 99 % of it empty
+// buckets.  A table over the top b bits of the same word finds the same entries as long as what the bucket leaves undecided is
+// compared (ref_bounds, DevIndex::dx_bits), so the width is now a planning decision.  The NATURAL width of a table is the power of
+// two at or above its entry count (0.5-1 entry per bucket, like hg38's 0.75 in 2^32; from 2^31 entries on that is 2^32 itself).
+// Measured at chr22 scale (profiles/ab_chr22_table_bits_r06.txt): sparser is FASTER -- 2^32 buckets 0.333 ms per 1 M reads, 2^28
+// 0.389, 2^27 (natural) 0.401, 2^26 0.437 -- because a bucket with two or more entries costs a second line and an empty or
+// single-entry one is settled by its record; a table that would fit the 256 MB Infinity Cache is not faster for it (the L2-miss
+// path is the limit).  So the plan takes the WIDEST table the budget holds, 2^32 first, then natural + 2 down to
+// natural - 2: a whole device still gives the small index its 2^32 buckets, a budget of 8 GB gives it 2^27 and the same results.
+// VG_DX_BITS / VG_REF_JG_BITS force a width (tests, A/B runs).
 static uint32_t table_bits_for(uint64_t entries, const char *env)
 {
 	if (const char *e = getenv(env)) { const int b = atoi(e); if (b >= 16 && b <= 32) return (uint32_t)b; }
@@ -1326,7 +1332,7 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 	// the lane machine as the WHOLE path (VG_FORCE_GENERIC=1: tests compare the tiers) -- it was 0.74 GB that no other run touched
 	const bool lane_only = getenv("VG_FORCE_GENERIC") && atoi(getenv("VG_FORCE_GENERIC")) != 0;
 	const uint64_t scratch = (lane_only ? (uint64_t)cus * 8 * 256 * (64 * 16 + 32 * 12) : 0ull) + 4096ull * (16384 * 16 + 2048 * 12);
-	p.ref_jg_bits = table_bits_for(n, "VG_REF_JG_BITS");
+	p.ref_jg_bits = table_bits_for(n, "VG_REF_JG_BITS");         // (the mandatory part holds the natural width; 2^32 entries are an upgrade, below)
 	const uint64_t Jref = ((1ull << p.ref_jg_bits) + 1) * 4;
 	// what every layout holds: both dictionaries in file order with their jump tables, auxiliary rows, bit vectors, pile-up
 	// sites and counters, lane-tier scratch, and room for three batch slots of a few million reads
@@ -1353,14 +1359,16 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 		// the table is given up for the jump-table form (2^32 entries: the form the look-up without a direct table is written for)
 		const uint32_t nat = table_bits_for(n + m, "VG_DX_BITS");
 		const bool forced = getenv("VG_DX_BITS") != nullptr;
-		if (!getenv("VG_NO_DIRECT")) for (uint32_t step = 0; step < (forced ? 1u : 3u) && !p.dx; step++) {
-			const uint32_t b = nat - step;
-			if (b < 16u) break;
+		uint32_t cand[8]; int nc = 0;
+		if (forced) cand[nc++] = nat;
+		else { cand[nc++] = 32u; for (int k = 2; k >= -2; k--) { const int b = (int)nat + k; if (b >= 16 && b < 32) cand[nc++] = (uint32_t)b; } }
+		if (!getenv("VG_NO_DIRECT")) for (int ci = 0; ci < nc && !p.dx; ci++) {
+			const uint32_t b = cand[ci];
 			const uint64_t bytes = 16 * (n + m) + (1ull << b) * 16;
 			if (p.total + bytes <= p.budget) {
 				p.mx = p.dx = true; p.dx_bits = b; p.total += bytes;
 				snprintf(line, sizeof line, "%smerged exact-match view %.1f GB, direct table of 2^%u buckets %.1f GB%s", kept.empty() ? "" : ", ", 16 * (n + m) / 1e9, b, (double)((1ull << b) * 16) / 1e9,
-				         step ? (step == 1 ? " (HALF the buckets the index wants: the budget)" : " (A QUARTER of the buckets the index wants: the budget)") : "");
+				         b + 1 == nat ? " (HALF the buckets the index wants: the budget)" : b + 2 == nat ? " (A QUARTER of the buckets the index wants: the budget)" : b < 32u && ci > 0 ? " (the widest the budget holds; 2^32 is faster)" : "");
 				kept += line;
 			}
 		}
@@ -1373,6 +1381,11 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 		take(want32 && !getenv("VG_NO_HX"), ((1ull << 32) + 1) * 16 - (p.ref_jg_bits == 32u ? J32 : 0), "paired HI32 table", "separate jump tables, no absence filters: +25 % kernel time (r03: 6.34 vs 5.03 ms)", p.hx);
 		take(want32 && !p.hx, J32, "HI32 jump table of the SNP dictionary", "SNP look-ups bisect HI24 buckets of ~190 entries: 8 dependent probes", p.jg32);
 	}
+	if (p.ref_jg_bits < 32u && !getenv("VG_REF_JG_BITS") && !p.hx && p.total + (J32 - Jref) <= p.budget) {
+		// the reference's own table, one entry per HI32 value: a gate-open chunk's bucket bounds in one gather (the coarse table reads
+		// the bucket's entries to tell HI32 values apart: +7 % kernel time at chr22 scale)
+		p.total += J32 - Jref; p.base += J32 - Jref; p.ref_jg_bits = 32u;
+	}
 	snprintf(line, sizeof line, "budget %.1f GB (%s): %.1f GB planned = %.1f GB of dictionaries, tables (reference jump table: 2^%u entries), sites and scratch", p.budget / 1e9,
 	         budget_arg ? "the caller's, vg_index_open_ex" : "the device's memory less 12 GiB", p.total / 1e9, p.base / 1e9, p.ref_jg_bits);
 	p.text = line;
@@ -1384,7 +1397,7 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 	p.arena = p.total - 2 * GiB - std::min<uint64_t>(sites * 10, p.total / 2) + (64ull << 20);
 	// with views left out the finished index is smaller than what construction has alive at its peak (the columns beside the
 	// entries, the sorts' buffers): the block then holds the permanent arrays only (vg_arena.h, set_temp_floor)
-	p.limited = !dropped.empty() || (p.dx && p.dx_bits < table_bits_for(n + m, "VG_DX_BITS"));
+	p.limited = !dropped.empty() || (p.dx && p.dx_bits < table_bits_for(n + m, "VG_DX_BITS")) || (!getenv("VG_REF_JG_BITS") && !p.hx && p.ref_jg_bits < 32u && table_bits_for(n, "VG_REF_JG_BITS") < 32u);
 	return p;
 }
 
@@ -1725,8 +1738,26 @@ static int plan_and_arena(vg_index *ix, const DevCols &c, uint64_t maxp_est, uin
 	// else holds the memory) is not an error here: the individual allocations will say so if they fail too.
 	if (!getenv("VG_NO_ARENA")) {
 		const double t0 = now_s();
-		(void)ix->arena.init(plan.arena);
-		if (plan.limited) ix->arena.set_temp_floor(UINT64_MAX);
+		bool use_block = true;
+		if (plan.limited) {
+			// A plan with views left out: the block holds the permanent arrays only and the construction's temporaries (the columns
+			// beside their entries, a sort's two buffer pairs) are taken from the device BESIDE it and given back -- that keeps the
+			// finished handle within its budget, but needs the room: block + temporaries at their peak.  When the plan is limited by
+			// the DEVICE itself (the default budget on a part smaller than the full layout) that room does not exist, and the open
+			// used to fail in its staging allocations instead of building the smaller layout it had planned (round 5's advisor): then
+			// no block at all -- every buffer its own allocation, so that what is alive at any moment is only what construction needs
+			// at that moment (slower: memory that has just been freed is cleared at allocation, vg_arena.h).
+			const uint64_t nm = plan.mx ? c.n_ref + c.n_snp : c.n_ref;
+			const uint64_t temps = 13 * c.n_ref + 16 * c.n_snp + 24 * nm + (1ull << 30);
+			if ((uint64_t)fr < plan.arena + temps) {
+				use_block = false;
+				if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] %.1f GB free, block %.1f GB + temporaries %.1f GB would not fit: no block, one allocation per buffer\n", fr / 1e9, plan.arena / 1e9, temps / 1e9);
+			}
+		}
+		if (use_block) {
+			(void)ix->arena.init(plan.arena);
+			if (plan.limited) ix->arena.set_temp_floor(UINT64_MAX);
+		}
 		g_alloc_s += now_s() - t0;
 	}
 	return VG_OK;
