@@ -85,6 +85,7 @@ def parse_args():
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
     ap.add_argument("--no-pretouch", action="store_true", help="do not have a child process take the device's free memory once before the genome is generated (see pretouch_start)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the secondary end-to-end number (FASTQ text in pinned host memory -> counters)")
+    ap.add_argument("--device-budget", type=int, default=None, help="device-memory budget of the index in bytes (vg_index_open_ex): the plan takes the widest tables and the views it holds")
     ap.add_argument("--detail-out", default=None, help="where the run's full record goes (every leg's phases, plans, notes: what used to be on the line before it outgrew the driver's parser); "
                     "default: bench_detail.json beside the index files, and gpurun_out/bench_detail_<workload>.json when that directory exists.  The LAST stdout line stays a compact object (< 8000 bytes)")
     args = ap.parse_args()
@@ -602,6 +603,9 @@ BUDGET_S = float(os.environ.get("VG_BENCH_BUDGET_S", "1500"))
 # (estimated wall seconds, bench.py arguments) of the secondary legs that run as child processes, in this order
 # (measured on the pool's boxes: 15 s, 145 s, 315 s)
 CHILD_LEGS = [("chr22", 60, ["--workload", "chr22", "--steps", "40", "--warmup", "5"]),
+              # the same index under a 10 GB budget (vg_index_open_ex through $VG_MAX_DEVICE_BYTES): tables of the index's own size -- ~7.6 GB of HBM
+              # instead of 91 -- at the price profiles/ab_chr22_table_bits_r06.txt measures (sparser buckets are faster)
+              ("chr22_compact", 60, ["--workload", "chr22", "--steps", "40", "--warmup", "5", "--device-budget", "10000000000"]),
               ("repeats30", 240, ["--workload", "hg38", "--repeats", "0.3"]),
               ("hg38f", 450, ["--workload", "hg38f", "--steps", "20", "--warmup", "3"]),
               ("softmask50", 240, ["--workload", "hg38", "--softmask", "0.5"])]
@@ -868,7 +872,7 @@ def main():
 
     default_workload = args.workload == "hg38" and args.repeats == 0.0 and args.lowq == 0.08 and args.read_len == 150 and args.softmask == 0.0 and args.genome == PRESETS["hg38"]["genome"] and args.snps == PRESETS["hg38"]["snps"] and args.reads == PRESETS["hg38"]["reads"]
     if args.secondary == "auto":
-        legs = ["lowq50", "len101", "len250", "chr22", "repeats30", "hg38f", "softmask50"] if (default_workload and world == 1 and args.cpu_sample > 0) else []
+        legs = ["lowq50", "len101", "len250", "chr22", "chr22_compact", "repeats30", "hg38f", "softmask50"] if (default_workload and world == 1 and args.cpu_sample > 0) else []
     else:
         legs = [x for x in args.secondary.split(",") if x and x != "none"]
 
@@ -957,6 +961,8 @@ def main():
         b = torch.tensor([int(_l().vg_share_budget(dev_index, int(sharers)))], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(b, op=dist.ReduceOp.MIN)
         budget = int(b.item()) or None
+    if args.device_budget:
+        budget = min(budget, args.device_budget) if budget else args.device_budget
     gx = GenoIndex.open(prefix, device=dev_index, max_device_bytes=budget)
     t_open = time.time() - t0
     cpu_open = time.process_time() - cpu0                  # host CPU seconds of this process (all its threads) inside vg_index_open

@@ -650,7 +650,7 @@ def test_a_device_memory_budget_decides_the_views_and_nothing_else_does(ftiny_di
             m = re.search(r"direct table of 2\^(\d+) buckets", gx.plan)
             assert "dx" in gx.views and m, gx.plan
             b_ = int(m.group(1))
-            assert nat - 2 <= b_ <= min(last_bits, nat + 2) and gx.device_bytes <= budget, (budget, gx.plan, gx.device_bytes)
+            assert nat - 4 <= b_ <= min(last_bits, nat + 2) and gx.device_bytes <= budget, (budget, gx.plan, gx.device_bytes)
             last_bits = b_
             gx.set_stats(False)
             gx.submit(r.bases, r.quals, r.offsets)

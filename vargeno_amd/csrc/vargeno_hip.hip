@@ -1313,7 +1313,7 @@ struct ViewPlan {
 // 0.389, 2^27 (natural) 0.401, 2^26 0.437 -- because a bucket with two or more entries costs a second line and an empty or
 // single-entry one is settled by its record; a table that would fit the 256 MB Infinity Cache is not faster for it (the L2-miss
 // path is the limit).  So the plan takes the WIDEST table the budget holds, 2^32 first, then natural + 2 down to
-// natural - 2: a whole device still gives the small index its 2^32 buckets, a budget of 8 GB gives it 2^27 and the same results.
+// natural - 4: a whole device still gives the small index its 2^32 buckets, a budget of 8 GB gives it 2^27 and the same results.
 // VG_DX_BITS / VG_REF_JG_BITS force a width (tests, A/B runs).
 static uint32_t table_bits_for(uint64_t entries, const char *env)
 {
@@ -1361,14 +1361,14 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 		const bool forced = getenv("VG_DX_BITS") != nullptr;
 		uint32_t cand[8]; int nc = 0;
 		if (forced) cand[nc++] = nat;
-		else { cand[nc++] = 32u; for (int k = 2; k >= -2; k--) { const int b = (int)nat + k; if (b >= 16 && b < 32) cand[nc++] = (uint32_t)b; } }
+		else { cand[nc++] = 32u; for (int k = 2; k >= -4; k--) { const int b = (int)nat + k; if (b >= 16 && b < 32) cand[nc++] = (uint32_t)b; } }
 		if (!getenv("VG_NO_DIRECT")) for (int ci = 0; ci < nc && !p.dx; ci++) {
 			const uint32_t b = cand[ci];
 			const uint64_t bytes = 16 * (n + m) + (1ull << b) * 16;
 			if (p.total + bytes <= p.budget) {
 				p.mx = p.dx = true; p.dx_bits = b; p.total += bytes;
 				snprintf(line, sizeof line, "%smerged exact-match view %.1f GB, direct table of 2^%u buckets %.1f GB%s", kept.empty() ? "" : ", ", 16 * (n + m) / 1e9, b, (double)((1ull << b) * 16) / 1e9,
-				         b + 1 == nat ? " (HALF the buckets the index wants: the budget)" : b + 2 == nat ? " (A QUARTER of the buckets the index wants: the budget)" : b < 32u && ci > 0 ? " (the widest the budget holds; 2^32 is faster)" : "");
+				         b + 1 == nat ? " (HALF the buckets the index wants: the budget)" : b + 2 == nat ? " (A QUARTER of the buckets the index wants: the budget)" : b + 2 < nat ? " (AN EIGHTH OR LESS of the buckets the index wants: the budget)" : b < 32u && ci > 0 ? " (the widest the budget holds; 2^32 is faster)" : "");
 				kept += line;
 			}
 		}
@@ -1719,6 +1719,19 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 	if ((rc = dev_alloc(ix, &ix->d_fq, 1, true, true))) return rc;
 	if ((rc = dev_alloc(ix, &ix->d_stats, S_COUNT, true, true))) return rc;
 	HIP_TRY(hipStreamSynchronize(st));
+#ifdef VG_VIEW_COUNTERS
+	{
+		VcRange r[24]; int nr = 0;
+		auto add = [&](const void *p, uint64_t bytes, int id) { if (p && nr < 24) { r[nr].lo = (unsigned long long)p; r[nr].hi = r[nr].lo + bytes; r[nr].id = id; r[nr].pad = 0; nr++; } };
+		add(d.dx, (1ull << d.dx_bits) * 16, VC_DX); add(d.mx, nm * 16, VC_MX); add(d.ref_jg, ((1ull << d.ref_jg_bits) + 1) * 4, VC_REF_JG); add(d.ref, c.n_ref * 16, VC_REF);
+		add(d.snp_jg, ((1ull << 24) + 1) * 4, VC_SNP_JG); add(d.snp, c.n_snp * 16, VC_SNP); add(d.sec_jg, ((1ull << d.sec_bits) + 1) * 4, VC_SEC_JG); add(d.sec3, c.n_ref * 12 + 16, VC_SEC3);
+		add(d.snp_sig, (c.n_snp + 16) * 2, VC_SIG); add(d.ref_bf, 1ull << 29, VC_REF_BF); add(d.snp_bf, (d.snp_bf_bits + 7) / 8, VC_SNP_BF);
+		add(d.ref_aux, c.n_ref_aux * 40, VC_AUX_ANY); add(d.snp_aux_pos, c.n_snp_aux * 40, VC_AUX_ANY); add(d.snp_aux_info, c.n_snp_aux * 10, VC_AUX_ANY);
+		add(d.pile, d.pile_len, VC_PILE_ANY); add(d.srank, (d.pile_len / 64 + 1) * 16, VC_SRANK); add(d.cnt4, (4 * ix->n_sites + 4) * 4, VC_CNT4);
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(vg_vc_ranges), r, sizeof r));
+		HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(vg_vc_nranges), &nr, sizeof nr));
+	}
+#endif
 	return VG_OK;
 }
 
@@ -2867,6 +2880,23 @@ extern "C" int vg_timing_get(vg_index *ix, vg_timing *out)
 	if (!ix || !out) return fail(VG_EINVAL, "null argument");
 	memset(out, 0, sizeof *out);
 	int rc = finish_pending(ix);
+#ifdef VG_VIEW_COUNTERS
+	{
+		// the census since the last vg_timing_get (all launches of all tiers): loads and 128-byte lines asked for, per view
+		static const char *names[VC_N] = {"other", "reads (k-mers, offsets, flag words)", "dx (direct table)", "mx (merged view)", "ref_jg", "ref entries", "snp_jg", "snp entries", "sec_jg", "sec3 (LO32-ordered view)",
+		                                  "snp_sig", "ref_bf", "snp_bf", "aux rows, stage A", "aux rows, stage B (= any - A)", "-", "-", "srank (walk)", "cnt4 (atomics)", "aux rows, any stage", "pile (site bytes, stage B)"};
+		unsigned long long ln[VC_N], ld[VC_N], zero[VC_N] = {0};
+		if (hipMemcpyFromSymbol(ln, HIP_SYMBOL(vg_vc_lines), sizeof ln) == hipSuccess && hipMemcpyFromSymbol(ld, HIP_SYMBOL(vg_vc_loads), sizeof ld) == hipSuccess) {
+			ln[VC_AUX_B] = ln[VC_AUX_ANY] - ln[VC_AUX_A]; ld[VC_AUX_B] = ld[VC_AUX_ANY] - ld[VC_AUX_A];
+			unsigned long long tot = 0;
+			for (int i = 0; i < VC_N; i++) if (i != VC_AUX_ANY) tot += ln[i];
+			fprintf(stderr, "[view census] %llu batches; lines asked for (all lanes, before L1 / L2 merge anything): %llu\n", (unsigned long long)ix->t_batches, tot);
+			for (int i = 0; i < VC_N; i++) if (ld[i] && i != VC_AUX_ANY) fprintf(stderr, "[view census]   %-38s loads %12llu  lines %12llu  (%.1f %%)\n", names[i], ld[i], ln[i], 100.0 * (double)ln[i] / (double)(tot ? tot : 1));
+		}
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(vg_vc_lines), zero, sizeof zero);
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(vg_vc_loads), zero, sizeof zero);
+	}
+#endif
 #ifdef VG_STAGE_CLOCKS
 	{
 		unsigned long long h[8];

@@ -258,6 +258,38 @@ __device__ inline int classify_bad_wide(const uint8_t *p, uint32_t n)
 #ifndef VG_NT_WALK
 #define VG_NT_WALK 0
 #endif
+
+// -DVG_VIEW_COUNTERS: development aid, never in the shipped build -- a census of the 128-byte lines the read loop ASKS for, per view of
+// the index (profiles/view_traffic_r06.txt: which view do the extra lines of a repeat-rich genome belong to?).  Every load that goes
+// through gather<> / gather_bf / gather_walk / load_row10 / load_row4 is classified by its ADDRESS against the handle's arrays (a table
+// of ranges the loader fills in: vg_vc_ranges); the few plain dereferences and the row / site-byte loads whose stage matters are counted
+// at their sites under an explicit id.  "Lines" = the 128-byte lines one load's bytes span, summed over lanes: what is requested of the
+// memory system before L1 / L2 merge anything -- to be read beside TCC_MISS of the same launch.
+#ifdef VG_VIEW_COUNTERS
+enum VcId { VC_OTHER, VC_READS, VC_DX, VC_MX, VC_REF_JG, VC_REF, VC_SNP_JG, VC_SNP, VC_SEC_JG, VC_SEC3, VC_SIG, VC_REF_BF, VC_SNP_BF, VC_AUX_A, VC_AUX_B, VC_PILE_B, VC_PILE_C, VC_SRANK, VC_CNT4, VC_AUX_ANY, VC_PILE_ANY, VC_N };
+struct VcRange { unsigned long long lo, hi; int id; int pad; };
+__device__ VcRange vg_vc_ranges[24];
+__device__ int vg_vc_nranges;
+__device__ unsigned long long vg_vc_lines[VC_N], vg_vc_loads[VC_N];
+__device__ inline void vc_count_as(int id, const void *p, uint32_t bytes)
+{
+	const unsigned long long a = (unsigned long long)p;
+	atomicAdd(&vg_vc_loads[id], 1ull);
+	atomicAdd(&vg_vc_lines[id], (a + bytes - 1) / 128 - a / 128 + 1);
+}
+__device__ inline void vc_count(const void *p, uint32_t bytes)
+{
+	const unsigned long long a = (unsigned long long)p;
+	int id = VC_OTHER;
+	for (int i = 0; i < vg_vc_nranges; i++) if (a >= vg_vc_ranges[i].lo && a < vg_vc_ranges[i].hi) { id = vg_vc_ranges[i].id; break; }
+	vc_count_as(id, p, bytes);
+}
+#define VG_VC(p, bytes) vc_count((p), (bytes))
+#define VG_VC_AS(id, p, bytes) vc_count_as((id), (p), (bytes))
+#else
+#define VG_VC(p, bytes) do { } while (0)
+#define VG_VC_AS(id, p, bytes) do { } while (0)
+#endif
 typedef uint32_t nt_v4a16 __attribute__((ext_vector_type(4), aligned(16)));
 typedef uint32_t nt_v4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t nt_v2a8 __attribute__((ext_vector_type(2), aligned(8)));
@@ -278,9 +310,9 @@ __device__ __forceinline__ T load_policy(const void *p)
 	else { const uint32_t v = __builtin_nontemporal_load((const uint32_t *)p); __builtin_memcpy(&r, &v, 4); }
 	return r;
 }
-template <typename T, int ALIGN = alignof(T)> __device__ __forceinline__ T gather(const void *p) { return load_policy<VG_NT_TAB != 0, T, ALIGN>(p); }        // dictionaries, views, jump tables
-template <typename T> __device__ __forceinline__ T gather_bf(const T *p) { return load_policy<VG_NT_BF != 0, T, alignof(T)>(p); }                           // bit vectors
-template <typename T> __device__ __forceinline__ T gather_walk(const T *p) { return load_policy<VG_NT_WALK != 0, T, alignof(T)>(p); }                       // rank blocks
+template <typename T, int ALIGN = alignof(T)> __device__ __forceinline__ T gather(const void *p) { VG_VC(p, sizeof(T)); return load_policy<VG_NT_TAB != 0, T, ALIGN>(p); }        // dictionaries, views, jump tables
+template <typename T> __device__ __forceinline__ T gather_bf(const T *p) { VG_VC(p, sizeof(T)); return load_policy<VG_NT_BF != 0, T, alignof(T)>(p); }                           // bit vectors
+template <typename T> __device__ __forceinline__ T gather_walk(const T *p) { VG_VC(p, sizeof(T)); return load_policy<VG_NT_WALK != 0, T, alignof(T)>(p); }                       // rank blocks
 
 // filters of the paired HI32 table (DevIndex::hx), over the low 32 bits of a k-mer
 __device__ __host__ inline uint32_t hx_fp16(uint32_t lo) { return (lo ^ (lo >> 16)) & 0xFFFFu; }
@@ -336,6 +368,7 @@ __device__ inline void ref_bounds(const DevIndex &d, uint64_t h, uint32_t &lo, u
 __device__ inline void load_row4(const uint32_t *row, int j0, uint32_t (&v)[4])
 {
 	uint2 a, b = make_uint2(0u, 0u);
+	VG_VC(row + j0, j0 + 2 < AUX_COLS ? 16 : 8);
 	__builtin_memcpy(&a, row + j0, 8);
 	if (j0 + 2 < AUX_COLS) __builtin_memcpy(&b, row + j0 + 2, 8);
 	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
@@ -344,8 +377,9 @@ __device__ inline void load_row4(const uint32_t *row, int j0, uint32_t (&v)[4])
 // a whole row (AUX_COLS = 10 positions, 8-byte aligned) as three independent gathers: one wait
 __device__ inline void load_row10(const uint32_t *row, uint32_t (&v)[AUX_COLS])
 {
-	const uint4 a = gather<uint4, 8>(row), b = gather<uint4, 8>(row + 4);
-	const uint2 c = gather<uint2, 8>(row + 8);
+	VG_VC(row, 40);
+	const uint4 a = load_policy<VG_NT_TAB != 0, uint4, 8>(row), b = load_policy<VG_NT_TAB != 0, uint4, 8>(row + 4);
+	const uint2 c = load_policy<VG_NT_TAB != 0, uint2, 8>(row + 8);
 	v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = c.x; v[9] = c.y;
 }
 
@@ -501,6 +535,7 @@ template <class ST>
 __device__ inline bool site_loose(const DevIndex &d, ST &st, uint32_t p)     // !(ref == 0 && alt == 0), qv.cc:990-991
 {
 	st.add(S_SITE_TEST, 1);
+	if (p < d.pile_len) VG_VC(d.pile + p, 1);
 	return p < d.pile_len && (d.pile[p] & 15u) != 0;
 }
 

@@ -229,6 +229,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	tot.clear(); cur.clear();
 
 	auto chunk_kmer = [&](uint32_t c) -> uint64_t {
+		VG_VC_AS(VC_READS, pk_kmer + ((uint64_t)slot0 + (pass ? n - 1 - c : c)), 8);
 		const uint64_t kf = pk_kmer[(uint64_t)slot0 + (pass ? n - 1 - c : c)];
 		return pass ? revcomp64(kf) : kf;
 	};
@@ -236,6 +237,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	// chunks c and c + 1 of the current strand sit side by side in pk_kmer whichever the strand: one 16-byte gather
 	auto chunk_kmer2 = [&](uint32_t c, uint64_t &k0, uint64_t &k1) {
 		ulonglong2 v;
+		VG_VC_AS(VC_READS, pk_kmer + ((uint64_t)slot0 + (pass ? n - 2 - c : c)), 16);
 		__builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + (pass ? n - 2 - c : c)), 16);
 		k0 = pass ? revcomp64(v.y) : v.x;
 		k1 = pass ? revcomp64(v.x) : v.y;
@@ -297,6 +299,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(freem >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)freem, 0u));   // free lanes below this one
 				if (rank < take) {
 					rid = read_ids ? read_ids[cursor + rank] : (uint32_t)(cursor + rank);
+					VG_VC_AS(VC_READS, offsets + rid, 16); VG_VC_AS(VC_READS, pk_meta + rid, 8);
 					const uint64_t off = offsets[rid];
 					n = (uint32_t)((offsets[rid + 1] - off) >> 5);
 					slot0 = (uint32_t)(off >> 5);
@@ -410,6 +413,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				return;                                                 // timing experiment only (wrong results): what do the rows cost?
 #endif
 				uint32_t rw[AUX_COLS];
+				VG_VC_AS(VC_AUX_A, row, 40);
 				load_row10(row, rw);
 				uint32_t todo = 0, newk = 0;                            // columns left to the careful path / columns whose keys are new
 				if (!ovf) {
@@ -722,6 +726,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 				if (has) {
 					const uint32_t row = N_kpos[rr_mine][ocol], mt = N_meta[rr_mine][ocol];
 					cc = mt & 31u;
+					VG_VC_AS(VC_AUX_A, ((mt >> 5) & 1u ? d.snp_aux_pos : d.ref_aux) + (uint64_t)row * AUX_COLS, 40);
 					load_row10(((mt >> 5) & 1u ? d.snp_aux_pos : d.ref_aux) + (uint64_t)row * AUX_COLS, rw);
 				}
 				uint32_t nlive = 0;
@@ -818,6 +823,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					const uint32_t o_n = __shfl(n, own), o_pass = __shfl(pass, own);
 					const uint64_t o_slot0 = __shfl(slot0, own);
 					if (mine) {
+						VG_VC_AS(VC_READS, pk_kmer + (o_slot0 + (o_pass ? o_n - 1 - c : c)), 8);
 						const uint64_t kf = pk_kmer[o_slot0 + (o_pass ? o_n - 1 - c : c)];
 						const uint64_t k = o_pass ? revcomp64(kf) : kf;
 						const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
@@ -853,6 +859,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								// the usual bucket: its (at most SEC_W) 12-byte records in one go, no search.  With a verified bit vector the
 								// records also answer "is the bit of this LO32 set" (qv.cc:955): it is iff one of them carries it.
 								uint3 rec[SEC_W];
+								VG_VC(d.sec3 + 3ull * b0, 12u * (b1 - b0));
 								#pragma unroll
 								for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = b0 + z < b1 ? b0 + z : b1 - 1; rec[z] = gather12(d.sec3 + 3ull * e); }
 								#pragma unroll
@@ -962,6 +969,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							const uint32_t khi = P_khi[p][wv];
 							const uint32_t j = (uint32_t)__ffs((int)hitmask) - 1u;
 							hitmask &= hitmask - 1u;
+							VG_VC(d.sec3 + 3ull * ((uint64_t)xrec + (uint64_t)j * xNI), 12);
 							const uint3 rec = gather12(d.sec3 + 3ull * ((uint64_t)xrec + (uint64_t)j * xNI));
 							const int dd = onebase((uint64_t)(rec.x ^ khi));      // (a neighbour: the first pass has seen it)
 							ri = rec.y; rdirect = 1u | ((rec.z >> 31) << 1); mod = 16u + (uint32_t)dd; nbase = (rec.x >> (2 * dd)) & 3u;
@@ -1056,7 +1064,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 									const uint64_t rb = P_hidx[0][p][wv];
 									uint3 rec[LW];
 									#pragma unroll
-									for (uint32_t j = 0; j < LW; j++) { const uint32_t r_ = h + j * NI; rec[j] = make_uint3(0u, 0u, ~klo); if (r_ < S) rec[j] = gather12(d.sec3 + 3ull * (rb + r_)); }
+									for (uint32_t j = 0; j < LW; j++) { const uint32_t r_ = h + j * NI; rec[j] = make_uint3(0u, 0u, ~klo); if (r_ < S) { VG_VC(d.sec3 + 3ull * (rb + r_), 12); rec[j] = gather12(d.sec3 + 3ull * (rb + r_)); } }
 									#pragma unroll
 									for (uint32_t j = LW; j-- > 0u;) if (((rec[j].z ^ klo) & 0x7FFFFFFFu) == 0u && (bf_from_sec || (fl & 1u))) {      // (downwards: the lowest hit is the one kept for this pass)
 										const int dd = onebase((uint64_t)(rec[j].x ^ khi));
@@ -1149,7 +1157,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								}
 								kmm &= (1u << lv) - 1u;
 								#pragma unroll
-								for (int j = 0; j < AUX_COLS; j++) { const uint64_t a = (uint64_t)v[j] + mod; sb[j] = 0; if (((kmm >> j) & 1u) && a < d.pile_len) sb[j] = d.pile[a]; }
+								for (int j = 0; j < AUX_COLS; j++) { const uint64_t a = (uint64_t)v[j] + mod; sb[j] = 0; if (((kmm >> j) & 1u) && a < d.pile_len) { VG_VC(d.pile + a, 1); sb[j] = d.pile[a]; } }
 								#pragma unroll
 								for (int j = 0; j < AUX_COLS; j++) if (((kmm >> j) & 1u) && !(sb[j] & 15u)) keepm |= 1u << j;
 							} else {
@@ -1184,6 +1192,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							for (int j0 = 0; j0 < AUX_COLS; j0 += 4) {
 								uint32_t v[4], inf[4];
 								load_row4(prow, j0, v);
+								VG_VC(irow + j0, 4);
 								#pragma unroll
 								for (int j = 0; j < 4; j++) inf[j] = irow[j0 + j < AUX_COLS ? j0 + j : 0];
 								bool live = true;
@@ -1235,6 +1244,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 									if (!r_aux) { N_kpos[at][col0 + own] = rpos; N_meta[at][col0 + own] = mt; at++; }
 									else {                                       // kept contexts out of a row are rare: re-read those columns
 										const uint32_t *row = d.ref_aux + (uint64_t)rpos * AUX_COLS;
+										VG_VC(row, 40);
 										for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << j)) { N_kpos[at][col0 + own] = row[j]; N_meta[at][col0 + own] = mt; at++; }
 									}
 								}
@@ -1242,6 +1252,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 									if (!s_aux) { N_kpos[at][col0 + own] = spos; N_meta[at][col0 + own] = mt; at++; }
 									else {
 										const uint32_t *prow = d.snp_aux_pos + (uint64_t)spos * AUX_COLS;
+										VG_VC(prow, 40);
 										for (int j = 0; j < AUX_COLS; j++) if (keepm & (1u << (10 + j))) { N_kpos[at][col0 + own] = prow[j]; N_meta[at][col0 + own] = mt; at++; }
 									}
 								}
@@ -1304,6 +1315,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							const uint32_t blk0 = target >> 6, blk_last = (target + 32u * n - 1u) >> 6;
 							// named scalars, not arrays: an array the compiler cannot keep in registers ends up in scratch memory
 							const ulonglong2 zz = make_ulonglong2(0ull, 0ull);
+							VG_VC_AS(VC_READS, pk_kmer + (uint64_t)slot0, 8u * n);
 							const ulonglong2 r0 = gather_walk<ulonglong2>(d.srank + blk0);
 							const ulonglong2 r1 = blk0 + 1u <= blk_last ? gather_walk<ulonglong2>(d.srank + (blk0 + 1u)) : zz;
 							const ulonglong2 r2 = blk0 + 2u <= blk_last ? gather_walk<ulonglong2>(d.srank + (blk0 + 2u)) : zz;
@@ -1346,6 +1358,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 									const uint32_t ob = o + b, zb = ob >> 6;
 									const uint64_t mx_ = zb == 0 ? r0.x : zb == 1 ? r1.x : r2.x, my_ = zb == 0 ? r0.y : zb == 1 ? r1.y : r2.y;
 									const uint32_t sid = (uint32_t)my_ + (uint32_t)__popcll(mx_ & ((1ull << (ob & 63u)) - 1ull));
+									VG_VC(&d.cnt4[4ull * sid + ((uint32_t)(kk >> (2 * b)) & 3u)], 4);
 									atomicAdd(&d.cnt4[4ull * sid + ((uint32_t)(kk >> (2 * b)) & 3u)], 1u);
 								}
 							}
