@@ -823,11 +823,45 @@ def write_detail(out, args, d):
     return wrote
 
 
+def cgroup_room():
+    """Bytes the container may still take (cgroup v2 memory.max - memory.current; tmpfs and the page cache count), or None without a limit.
+    A box of the pool is lost when its container reaches the limit: every leg that needs tens of GB asks first and is watched while it runs."""
+    def rd(path):
+        try:
+            v = open(path).read().split()[0]
+            return None if v == "max" else int(v)
+        except Exception:
+            return None
+    mx, cur = rd("/sys/fs/cgroup/memory.max"), rd("/sys/fs/cgroup/memory.current")
+    return None if mx is None or cur is None else mx - cur
+
+
+def drop_file_cache(directory):
+    """The page cache of the files under `directory` given up (it is charged to the container)."""
+    for root, _, files in os.walk(directory):
+        for fn in files:
+            try:
+                fd = os.open(os.path.join(root, fn), os.O_RDONLY)
+                try:
+                    os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+                finally:
+                    os.close(fd)
+            except OSError:
+                pass
+
+
+# host memory a child leg needs at its peak, GB: index files on tmpfs or in the page cache + `vargeno index`'s arrays + the oracle's copy
+CHILD_LEG_ROOM_GB = {"chr22": 12, "chr22_compact": 12, "repeats30": 140, "hg38f": 250, "softmask50": 140}
+
+
 def run_child_leg(name, est, extra, args, ref):
     """One secondary configuration as a child process of this one (which holds no index any more): its own bench.py line."""
     left = BUDGET_S - (time.time() - T_START)
     if left < est:
         return {"skipped": "time budget: %.0f s of $VG_BENCH_BUDGET_S = %.0f s left, this leg is estimated at %d s" % (left, BUDGET_S, est)}
+    room = cgroup_room()
+    if room is not None and room < CHILD_LEG_ROOM_GB.get(name, 100) * 1e9:
+        return {"skipped": "container memory: %.0f GB left (cgroup memory.max), this leg needs %d GB" % (room / 1e9, CHILD_LEG_ROOM_GB.get(name, 100))}
     ref.wait_quiet("secondary leg %s" % name)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--secondary", "none", "--no-gather-probe", "--no-ingest", "--cpu-reference", "no", "--sustain-seconds", "0",
            "--cleanup", "--cpu-sample", "200000", "--job-reads", "0", "--no-pretouch"] + extra
@@ -840,22 +874,57 @@ def run_child_leg(name, est, extra, args, ref):
     log("[bench] secondary leg %s: %s" % (name, " ".join(cmd[2:])))
     try:
         ref.heavy_begin()
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=max(60.0, min(left - 20.0, 2.5 * est)))
+        limit = max(60.0, min(left - 20.0, 2.5 * est))
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        # (watched while it runs: should the container come within 12 GB of its memory limit the leg is ended -- a skipped leg, not a lost box)
+        import threading
+
+        verdict = {}
+
+        def watch():
+            while p.poll() is None:
+                r_ = cgroup_room()
+                if r_ is not None and r_ < 12e9:
+                    verdict["why"] = "container memory: %.0f GB left while the leg ran" % (r_ / 1e9)
+                elif time.time() - t0 > limit:
+                    verdict["why"] = "child run exceeded its share of the time budget"
+                if verdict:
+                    try:
+                        os.killpg(p.pid, 9)
+                    except OSError:
+                        pass
+                    import shutil
+                    shutil.rmtree("/dev/shm/vg_bench", ignore_errors=True)
+                    return
+                time.sleep(0.5)
+        th = threading.Thread(target=watch, daemon=True)
+        th.start()
+        out_s, err_s = p.communicate()
+        th.join(2.0)
         ref.heavy_end()
-        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-        if p.returncode != 0 or not lines:
-            return {"skipped": "child run failed (rc %d): %s" % (p.returncode, (p.stderr or "").strip().splitlines()[-1:] or ["no output"]), "wall_s": time.time() - t0}
+        if verdict or p.returncode != 0:
+            # (a leg that did not end by itself has not cleaned up: its index files -- up to 48 GB on a 79 GB root -- go now)
+            import shutil
+            for sub in os.listdir(args.workdir):
+                full = os.path.join(args.workdir, sub)
+                if os.path.isdir(full) and os.path.abspath(full) != os.path.abspath(args.main_dir):
+                    shutil.rmtree(full, ignore_errors=True)
+        if verdict:
+            return {"skipped": verdict["why"], "wall_s": time.time() - t0}
+        if p.returncode != 0 or not os.path.exists(detail):
+            return {"skipped": "child run failed (rc %d): %s" % (p.returncode, (err_s or "").strip().splitlines()[-1:] or ["no output"]), "wall_s": time.time() - t0}
         j = json.load(open(detail))                        # the child's full record (its stdout line is the compact one)
         rf = j["roofline"]
         return {"workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "input_form": j["input_form"],
                 "other_input_form": j.get("other_input_form") and {k: j["other_input_form"][k] for k in ("input", "value", "ms_per_step")},
                 "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "algorithmic_bytes_per_read", "traffic", "traffic_source")},
                 "parity": j.get("parity"), "device_ms_per_step": j.get("device_ms_per_step"), "reads_per_step_redone_by_deep_list_tier": j.get("reads_per_step_redone_by_deep_list_tier"),
-                "index_bytes_hbm": j["config"].get("index_bytes_hbm"), "index_open_s": j["config"].get("index_open_s"), "index_open_phases": j["config"].get("index_open_phases"), "index_views": j["config"].get("index_views"), "cpu_port_reads_per_s": (j.get("cpu_baseline") or {}).get("value"), "wall_s": time.time() - t0}
-    except subprocess.TimeoutExpired:
-        ref.heavy_end()
-        return {"skipped": "child run exceeded its share of the time budget", "wall_s": time.time() - t0}
+                "index_bytes_hbm": j["config"].get("index_bytes_hbm"), "index_open_s": j["config"].get("index_open_s"), "index_open_phases": j["config"].get("index_open_phases"), "index_views": j["config"].get("index_views"), "index_plan": j["config"].get("index_plan"), "cpu_port_reads_per_s": (j.get("cpu_baseline") or {}).get("value"), "wall_s": time.time() - t0}
     except Exception as e:
+        try:
+            ref.heavy_end()
+        except Exception:
+            pass
         return {"skipped": "child run failed: %r" % (e,), "wall_s": time.time() - t0}
 
 
@@ -894,6 +963,7 @@ def main():
         if not os.path.exists(os.path.join(args.workdir, tag, "idx.done")) and free("/tmp") < need and free("/dev/shm") >= need:
             args.workdir = "/dev/shm/vg_bench"
     d = os.path.join(args.workdir, tag)
+    args.main_dir = d
     prefix = os.path.join(d, "idx")
     t0 = time.time()
     # (the chip's gather ceiling first: a child process whose 16 GiB table is freed -- and scrubbed by the driver -- long before
@@ -1370,6 +1440,8 @@ def main():
         shutil.rmtree(job_dir, ignore_errors=True)
 
     # ---- secondary legs with an index of their own: child processes, one after the other, now that this one holds no index ------
+    if rank == 0 and legs:
+        drop_file_cache(d)                                     # (48 GB of index files nobody reads any more: the page cache counts against the container's memory)
     if rank == 0:
         for name, est, extra in CHILD_LEGS:
             if name in legs:

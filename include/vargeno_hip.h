@@ -142,6 +142,7 @@ uint64_t vg_index_device_bytes(const vg_index *ix);
 #define VG_VIEW_SEC_IS_BF 128u  /* the reference bit vector was verified to be the LO32 set of the dictionary: the LO32-ordered
                                    view answers its probes too (false e.g. for an index built from a soft-masked FASTA)   */
 #define VG_VIEW_HX        32u   /* paired HI32 table of both dictionaries (indexes too large for the merged view)          */
+#define VG_VIEW_SSEC     256u   /* LO32-ordered view of the SNP dictionary (high-half SNP neighbours, qv.cc:1303-1352; r06) */
 uint32_t vg_index_views(const vg_index *ix);
 
 /* Replaces the FASTQ loop body, qv.cc:760-1558, for a batch of reads: flat ASCII bases and quality

@@ -116,6 +116,11 @@ static uint64_t replay(const char *name, uint64_t n, uint64_t m, uint64_t aux_r,
 	T("s_pos", 4 * sites); T("s_ref", sites); T("s_alt", sites); T("s_rf", sites); T("s_af", sites); P("site_ba", sites); P("cnt4", 16 * sites);
 	g("winner"); g("blk"); g("scan_tmp"); g("s_pos"); g("s_ref"); g("s_alt"); g("s_rf"); g("s_af"); g("snp_rf"); g("snp_af");
 	P("snp_jg", ((1ull << 24) + 1) * 4); P("snp", 16 * m); g("snp_pos"); g("snp_info"); g("snp_amb"); P("snp_sig", 2 * (m + 16));
+	{	// r06: LO32-ordered view of the SNP dictionary (sorted while the SNP k-mers are still there)
+		T("ska", 8 * m); T("sva", 4 * m); T("skb", 8 * m); T("svb", 4 * m); T("sort_tmp", 64ull << 20); g("sort_tmp"); g("skb"); g("svb");
+		uint64_t sb = 14; while (sb < 30 && (1ull << sb) < m) sb++;
+		P("ssec_jg", ((1ull << sb) + 1) * 4); P("ssec3", 12 * m + 16); g("ska"); g("sva");
+	}
 	if (!mx) g("snp_kmer");
 	if (mx) P("ref_jg", Jref);
 	P("ref", 16 * n); g("ref_pos"); g("ref_amb");

@@ -76,6 +76,117 @@ def pytest_sessionfinish(session, exitstatus):
             p.kill()
 
 
+# ---- the container's memory -------------------------------------------------------------------------------------------------
+# A GPU box of the pool is LOST when its container fills its memory limit (cgroup memory.max, 300 GiB there: tmpfs and the page
+# cache count) -- round 5 lost one to bench.py, round 6 one to this suite (hg38 + full-dbSNP index files in /dev/shm, the index
+# builder's arrays, the page cache of the hg38 index files and a 60 GB reference process at the same time).  /proc/meminfo shows
+# the HOST's memory, not the container's: the tests that need tens of GB ask cgroup_room() and skip, and a watchdog thread ends the
+# session (exit status 86, a line on stderr) before the limit is reached -- a failed suite instead of a lost box.
+def _cg(path):
+    try:
+        v = open(path).read().split()[0]
+        return None if v == "max" else int(v)
+    except Exception:
+        return None
+
+
+def cgroup_room():
+    """Bytes the container may still take (memory.max - memory.current), or None when there is no limit to read."""
+    mx, cur = _cg("/sys/fs/cgroup/memory.max"), _cg("/sys/fs/cgroup/memory.current")
+    if mx is None or cur is None:
+        return None
+    return mx - cur
+
+
+def drop_file_cache(directory):
+    """The page cache of the (written-back) files under `directory` given up: it is charged to the container like everything else."""
+    for root, _, files in os.walk(directory):
+        for fn in files:
+            try:
+                fd = os.open(os.path.join(root, fn), os.O_RDONLY)
+                try:
+                    os.fsync(fd)
+                    os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+                finally:
+                    os.close(fd)
+            except OSError:
+                pass
+
+
+def finish_background(timeout=900):
+    """Wait for jobs a test left running beside the suite (the reference binary at hg38 scale: 60 GB) before a test that needs the memory."""
+    import time
+
+    t0 = time.time()
+    for job in BACKGROUND.values():
+        p = job.get("ref")
+        while p is not None and p.poll() is None and time.time() - t0 < timeout:
+            time.sleep(1.0)
+
+
+@pytest.fixture(autouse=True)
+def _big_files_do_not_pile_up(request):
+    """Every index `vargeno index` writes carries 1.3 GB of bit-vector files whatever the genome; pytest keeps a session's tmp_path
+    directories until the session ends, and some thirty tests build an index -- on a 79 GB root next to the 48 GB of hg38 index
+    files.  What a test leaves in its tmp_path beyond 32 MB per file goes when the test is over."""
+    yield
+    if "tmp_path" in request.fixturenames:
+        try:
+            d = str(request.getfixturevalue("tmp_path"))
+        except Exception:
+            return
+        for root, _, files in os.walk(d):
+            for fn in files:
+                fp = os.path.join(root, fn)
+                try:
+                    if not os.path.islink(fp) and os.path.getsize(fp) > (32 << 20):
+                        os.remove(fp)
+                except OSError:
+                    pass
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _memory_watchdog():
+    import threading
+    import time
+
+    mx = _cg("/sys/fs/cgroup/memory.max")
+    stop = threading.Event()
+    if mx is None or mx > (2 << 40):
+        yield
+        return
+
+    def watch():
+        warned = False
+        while not stop.wait(0.5):
+            cur = _cg("/sys/fs/cgroup/memory.current")
+            if cur is None:
+                continue
+            if cur > 0.85 * mx and not warned:
+                warned = True
+                sys.stderr.write("\n[memory watchdog] %.0f of %.0f GB in use: dropping the page cache of /tmp/vg_bench\n" % (cur / 1e9, mx / 1e9))
+                drop_file_cache("/tmp/vg_bench")
+            try:                                                     # (the root file system: 79 GB on the pool's boxes, and a full one costs the box too)
+                st = os.statvfs("/tmp")
+                disk_left = st.f_bavail * st.f_frsize
+            except OSError:
+                disk_left = None
+            if cur > 0.95 * mx or (disk_left is not None and disk_left < 3e9):
+                sys.stderr.write("\n[memory watchdog] %.0f of %.0f GB of memory in use, %s GB of /tmp left: ending the session before the container is killed\n" % (cur / 1e9, mx / 1e9, "%.1f" % (disk_left / 1e9) if disk_left is not None else "?"))
+                sys.stderr.flush()
+                for job in BACKGROUND.values():
+                    p = job.get("ref")
+                    if p is not None and p.poll() is None:
+                        p.kill()
+                import shutil
+                shutil.rmtree("/dev/shm/vg_bench", ignore_errors=True)
+                os._exit(86)
+    t = threading.Thread(target=watch, daemon=True)
+    t.start()
+    yield
+    stop.set()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

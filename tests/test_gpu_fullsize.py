@@ -144,24 +144,39 @@ def test_hg38_sample_against_oracle_and_linearity_at_full_batch(hg38):
 
 @pytest.fixture(scope="module")
 def hg38f():
-    """~104 GB of index files (about three minutes of host work), shared with `bench.py --workload hg38f` through the work
-    directory; ~245 GB of HBM once open."""
-    d = bench_dir(need_gb=130) + "/g3100000000_s100000000_c24"
+    """An index of MORE THAN 2^32 k-mers in the two dictionaries together at hg38's genome size -- the layout of BASELINE.json
+    configs[4] (no merged view, the paired HI32 table, vg_wave_kernel_big) -- with 50 M SNPs: 2.9 G reference + 1.6 G SNP k-mers,
+    ~66 GB of index files (two minutes of host work).  (Through round 5 this fixture used configs[4]'s own 100 M SNPs: 104 GB of
+    files on tmpfs beside ~100 GB of index-builder arrays and, later, ~100 GB of oracle tables -- within 60 GB of the pool's 300 GiB
+    container limit, and in round 6 the suite lost a box there.  `bench.py --workload hg38f`, a process of its own that sizes
+    itself by the container's room, measures the 100 M-SNP index and checks its parity on 8 M reads.)"""
+    d = bench_dir(need_gb=90) + "/g3100000000_s50000000_c24"
     if not os.path.exists(d + "/idx.done"):
-        # 104 GB of index files + ~110 GB of host memory for the oracle's copy: a box without them cannot run this test
+        # 66 GB of index files + ~70 GB of host memory for the oracle's copy: a box without them cannot run this test
         probe = os.path.dirname(d)
         while not os.path.isdir(probe):
             probe = os.path.dirname(probe)
         st = os.statvfs(probe)
-        if st.f_bavail * st.f_frsize < 120e9:
-            pytest.skip("no file system with 120 GB free for the hg38 + full-dbSNP index (set VG_BENCH_DIR)")
+        if st.f_bavail * st.f_frsize < 80e9:
+            pytest.skip("no file system with 80 GB free for the index (set VG_BENCH_DIR)")
     try:
         avail = [int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0] * 1024
     except Exception:
         avail = 0
-    if avail and avail < 260e9:
-        pytest.skip("less than 260 GB of host memory available (index files in the page cache / on tmpfs + the oracle's tables)")
-    g, s, _ = synth.genome_and_snps(genome_len=3_100_000_000, n_snps=100_000_000, n_chroms=24, genotypes="hwe")
+    if avail and avail < 180e9:
+        pytest.skip("less than 180 GB of host memory available (index files in the page cache / on tmpfs + the oracle's tables)")
+    # ... and the CONTAINER's memory (cgroup limit; /proc/meminfo is the host's): this test holds 66 GB of index files on tmpfs
+    # while `vargeno index` builds them (~70 GB of arrays) and, later, next to the oracle's copy of the index (~70 GB).  A box of
+    # the pool is lost when its container reaches its limit (round 6 lost one here): nothing else heavy may run beside it -- the
+    # reference binary a test before this one left running (60 GB) is waited for, the page cache of the hg38 index files is given
+    # up -- and without 170 GB of room the test is skipped
+    import conftest
+    conftest.finish_background()
+    conftest.drop_file_cache("/tmp/vg_bench")
+    room = conftest.cgroup_room()
+    if room is not None and room < 170e9:
+        pytest.skip("the container has %.0f GB of memory left, this test needs 170 (cgroup memory.max)" % (room / 1e9))
+    g, s, _ = synth.genome_and_snps(genome_len=3_100_000_000, n_snps=50_000_000, n_chroms=24, genotypes="hwe")
     if not os.path.exists(d + "/idx.done"):
         os.makedirs(d, exist_ok=True)
         synth.write_fasta(d + "/ref.fa", g)
@@ -176,14 +191,14 @@ def hg38f():
     del src
     torch.cuda.empty_cache()
     yield d, big
-    if d.startswith("/dev/shm/"):                                   # memory-backed: give the 104 GB back
+    if d.startswith("/dev/shm/"):                                   # memory-backed: give the 66 GB back
         import shutil
 
         shutil.rmtree(d, ignore_errors=True)
 
 
 def test_hg38f_sample_against_oracle_and_linearity(hg38f):
-    """configs[4]'s layout at its own size: vg_wave_kernel_big (no merged view / direct table), ~190-entry HI24 buckets in the
+    """the layout of configs[4] (more than 2^32 k-mers) at hg38's genome size: vg_wave_kernel_big (no merged view / direct table), ~95-entry HI24 buckets in the
     SNP dictionary (iterate_snp_dict, qv.cc:413-464, whose `int i` overflows on this dictionary in the reference itself, :447 --
     so parity here is against the oracle).  60 000 reads against the oracle: all site counters for both builds of the kernel,
     all event counters; then 2 M reads in uneven shards against the whole."""
@@ -196,10 +211,10 @@ def test_hg38f_sample_against_oracle_and_linearity(hg38f):
     ox.process(sample.bases, sample.quals, sample.offsets, nthreads=min(32, os.cpu_count() or 1))
     so, want = ox.sites(), ox.stats.as_dict()
     ox.close()
-    assert want["scan_snp"] > 100 * want["gate_open"]                # the dense-bucket regime: > 100 SNP-bucket entries per gate-open chunk
+    assert want["scan_snp"] > 50 * want["gate_open"]                 # the dense-bucket regime: ~95 SNP-bucket entries per gate-open chunk
     with GenoIndex.open(prefix) as gx:
         assert "mx" not in gx.views and "dx" not in gx.views and "hx" in gx.views     # 2^32 or more k-mers: the layout of vg_wave_kernel_big
-        assert gx.num_sites > 90_000_000
+        assert gx.num_sites > 45_000_000
         b0, b1 = int(to[lo_s].item()), int(to[hi_s].item())
         so_dev = (to[lo_s:hi_s + 1] - to[lo_s]).contiguous()
         for stats in (True, False):                                  # counting build, then the timed build

@@ -81,6 +81,7 @@ def test_stats_off_build_gives_same_counts(ftiny_dir, ftiny_reads):
                                   # r06: tables that scale with the index.  A small fixture gets small tables by itself (2^22 buckets here); these force the
                                   # 2^32-entry forms an hg38-scale index gets (the headline kernel instantiation), a direct table of 2^16 buckets (~35 entries
                                   # each: the in-bucket bisection) and a 2^16-entry reference jump table (long coarse buckets: ref_bounds' bisection)
+                                  "VG_NO_SSEC",      # r06: without the SNP dictionary's LO32-ordered view (the high-half SNP queries one by one, as through r05)
                                   "VG_DX_BITS=32+VG_REF_JG_BITS=32", "VG_DX_BITS=16", "VG_REF_JG_BITS=16", "VG_DX_BITS=19+VG_NO_SEC", "VG_REF_JG_BITS=16+VG_NO_MX+VG_NO_HX"])
 def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, knob):
     """The timed kernel reads re-laid-out views of the dictionaries (direct table, merged view, LO32-ordered view, strided-probe
@@ -98,6 +99,7 @@ def test_fallback_layouts_give_same_counts(ftiny_dir, ftiny_reads, monkeypatch, 
             assert "reference jump table: 2^%s entries" % knob.split("VG_REF_JG_BITS=")[1][:2] in gx.plan, gx.plan
         # (F-tiny's FASTA is upper case: its reference bit vector is the LO32 set of its dictionary, which the loader verifies)
         assert ("sec_is_bf" in gx.views) == ("VG_NO_BF_FROM_SEC" not in knob and "VG_NO_SEC" not in knob), gx.views
+        assert ("ssec" in gx.views) == ("VG_NO_SSEC" not in knob), gx.views
         gx.set_stats(False)
         step = r.n // 5 + 1
         for lo in range(0, r.n, step):

@@ -203,7 +203,7 @@ class GenoIndex:
     def device_bytes(self):
         return int(lib().vg_index_device_bytes(self._h))
 
-    VIEW_NAMES = {1: "sec", 2: "mx", 4: "dx", 8: "snp_probe", 16: "snp_jg32", 32: "hx", 64: "snp_sig", 128: "sec_is_bf"}
+    VIEW_NAMES = {1: "sec", 2: "mx", 4: "dx", 8: "snp_probe", 16: "snp_jg32", 32: "hx", 64: "snp_sig", 128: "sec_is_bf", 256: "ssec"}
 
     @property
     def views(self):

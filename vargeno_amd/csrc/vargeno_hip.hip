@@ -205,6 +205,18 @@ __global__ void vg_make_sec3(const uint64_t *__restrict__ skey, const uint32_t *
 		out[3 * i + 2] = ((uint32_t)(k >> 32) & 0x7FFFFFFFu) | (e.amb ? 0x80000000u : 0u);
 	}
 }
+// ... and of the SNP dictionary's (DevIndex::ssec3): the low word keeps 26 bits of LO32 and carries SNP_INFO_POS (where in the k-mer the SNP
+// sits: a neighbour whose mutated base is the SNP base itself is not a hit, qv.cc:1308-1352) and the ambiguity flag
+__global__ void vg_make_ssec3(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ sidx, const SnpEnt *__restrict__ snp, uint64_t n, uint32_t *__restrict__ out)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t k = skey[i];
+		const SnpEnt e = snp[sidx[i]];
+		out[3 * i] = (uint32_t)k;
+		out[3 * i + 1] = e.pos;
+		out[3 * i + 2] = ((uint32_t)(k >> 32) & 0x03FFFFFFu) | ((uint32_t)((e.key >> 43) & 0x1Fu) << 26) | (((e.key >> 48) & 0xFFu) ? 0x80000000u : 0u);
+	}
+}
 // Is the reference bit vector exactly the set of LO32 values of the dictionary (qv.cc:955 tests bit hash32(LO32), and hash32 is a
 // bijection)?  out[0]: dictionary LO32 values whose bit is NOT set; out[1]: distinct LO32 values; out[2]: bits set in the vector.
 __global__ void vg_sec_bf_check(const uint64_t *__restrict__ skey, uint64_t n, const uint64_t *__restrict__ bf, unsigned long long *__restrict__ out)
@@ -1296,13 +1308,13 @@ static int init_handle(vg_index *ix, int device)
 // the device got the slower layout without being told).  Views are taken in a fixed order while the planned total stays within
 // the budget; vg_index_plan() says what was kept, what was left out and what that costs.
 struct ViewPlan {
-	bool mx = false, dx = false, sec = false, sig = false, probe = false, hx = false, jg32 = false;
+	bool mx = false, dx = false, sec = false, sig = false, probe = false, hx = false, jg32 = false, ssec = false;
 	uint64_t base = 0, total = 0, budget = 0;
 	uint64_t arena = 0;                    // bytes of the handle's one block (vg_arena.h): the finished index less what lives outside it
 	bool limited = false;                  // views were left out for the budget
 	uint32_t dx_bits = 32, ref_jg_bits = 32;   // buckets of the direct table / of the reference dictionary's jump table (DevIndex)
 	std::string text;
-	bool same_views(const ViewPlan &o) const { return mx == o.mx && dx == o.dx && sec == o.sec && sig == o.sig && probe == o.probe && hx == o.hx && jg32 == o.jg32 && dx_bits == o.dx_bits && ref_jg_bits == o.ref_jg_bits; }
+	bool same_views(const ViewPlan &o) const { return mx == o.mx && dx == o.dx && sec == o.sec && sig == o.sig && probe == o.probe && hx == o.hx && jg32 == o.jg32 && ssec == o.ssec && dx_bits == o.dx_bits && ref_jg_bits == o.ref_jg_bits; }
 };
 // Tables that scale with the index AND the budget (r06).  The reference's jump table has 2^32 entries whatever the genome
 // (qv.cc:539-584), and so had this library's direct table: a chr22-scale index (1 GB of files) took 92 GB of HBM, 99 % of it empty
@@ -1380,6 +1392,11 @@ static ViewPlan plan_views(const DevCols &c, uint64_t maxp, uint64_t ref_bf_bits
 		const bool want32 = !getenv("VG_NO_SNP_JG32");
 		take(want32 && !getenv("VG_NO_HX"), ((1ull << 32) + 1) * 16 - (p.ref_jg_bits == 32u ? J32 : 0), "paired HI32 table", "separate jump tables, no absence filters: +25 % kernel time (r03: 6.34 vs 5.03 ms)", p.hx);
 		take(want32 && !p.hx, J32, "HI32 jump table of the SNP dictionary", "SNP look-ups bisect HI24 buckets of ~190 entries: 8 dependent probes", p.jg32);
+	}
+	{
+		uint32_t sb = 14;
+		while (sb < 30 && (1ull << sb) < m) sb++;
+		take(!getenv("VG_NO_SSEC") && m > 0, 12 * m + 16 + ((1ull << sb) + 1) * 4, "LO32-ordered view of the SNP dictionary", "the high-half SNP neighbour queries of a chunk whose SNP bit-vector probe is positive are made one by one: up to 36 bisections of a HI24 bucket, in stage B1's rounds", p.ssec);
 	}
 	if (p.ref_jg_bits < 32u && !getenv("VG_REF_JG_BITS") && !p.hx && p.total + (J32 - Jref) <= p.budget) {
 		// the reference's own table, one entry per HI32 value: a gate-open chunk's bucket bounds in one gather (the coarse table reads
@@ -1570,9 +1587,28 @@ static int build_on_device(vg_index *ix, DevCols &c, const ViewPlan &plan, uint6
 			HIP_TRY(hipGetLastError());
 			d.snp_jg32 = j32;
 		}
+		// LO32-ordered view of the SNP dictionary: device radix sort of the swapped k-mers + a jump table over LO32's top bits
+		if (plan.ssec && c.n_snp) {
+			uint32_t sb = 14;
+			while (sb < 30 && (1ull << sb) < c.n_snp) sb++;
+			TempDev<uint64_t> ka, kb; TempDev<uint32_t> va, vb;
+			if ((rc = ka.alloc(c.n_snp)) || (rc = va.alloc(c.n_snp))) return rc;
+			vg_make_sec_keys<<<2048, 256, 0, st>>>(c.snp_kmer.p, c.n_snp, ka.p, va.p);
+			HIP_TRY(hipGetLastError());
+			if ((rc = kb.alloc(c.n_snp)) || (rc = vb.alloc(c.n_snp))) return rc;
+			if ((rc = sort_into_a(ka, kb, va, vb, c.n_snp))) return rc;
+			uint32_t *sjg = nullptr, *s3 = nullptr;
+			if ((rc = dev_alloc(ix, &sjg, (1ull << sb) + 1))) return rc;
+			if ((rc = dev_alloc(ix, &s3, 3 * c.n_snp + 4))) return rc;
+			vg_build_jumpgate<<<(unsigned)((1ull << sb) / JG_SPAN), 256, 0, st>>>(ka.p, c.n_snp, sjg, 1ull << sb, (int)(64 - sb));
+			vg_make_ssec3<<<2048, 256, 0, st>>>(ka.p, va.p, ent, c.n_snp, s3);
+			HIP_TRY(hipGetLastError());
+			HIP_TRY(hipStreamSynchronize(st));
+			d.ssec3 = s3; d.ssec_jg = sjg; d.ssec_bits = sb;
+		}
 		if (!want_mx) c.snp_kmer.release();
 	}
-	pc.lap("SNP dictionary, scan view");
+	pc.lap("SNP dictionary, scan view, LO32-ordered view");
 	// ---- reference dictionary: 16-byte entries, and -- unless the paired HI32 table will stand in for it -- the jump table over HI32
 	{
 		uint32_t *jg = nullptr; RefEnt *ent = nullptr;
@@ -2062,7 +2098,7 @@ extern "C" uint32_t vg_index_views(const vg_index *ix)
 {
 	if (!ix) return 0;
 	const DevIndex &d = ix->d;
-	return (d.sec3 ? VG_VIEW_SEC : 0u) | (d.sec_is_bf ? VG_VIEW_SEC_IS_BF : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.dx ? VG_VIEW_DX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u) | (d.hx ? VG_VIEW_HX : 0u) | (d.snp_sig ? VG_VIEW_SNP_SIG : 0u);
+	return (d.sec3 ? VG_VIEW_SEC : 0u) | (d.sec_is_bf ? VG_VIEW_SEC_IS_BF : 0u) | (d.mx ? VG_VIEW_MX : 0u) | (d.dx ? VG_VIEW_DX : 0u) | (d.snp_probe ? VG_VIEW_SNP_PROBE : 0u) | (d.snp_jg32 ? VG_VIEW_SNP_JG32 : 0u) | (d.hx ? VG_VIEW_HX : 0u) | (d.snp_sig ? VG_VIEW_SNP_SIG : 0u) | (d.ssec3 ? VG_VIEW_SSEC : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -89,6 +89,16 @@ struct DevIndex {
 	// where the probe view holds 8: the ~190-entry buckets of hg38 + full dbSNP are 3 lines instead of 12, and one 16-byte load
 	// covers eight entries of the scan.
 	const uint16_t *snp_sig;       // [n_snp + 16]
+	// LO32-ordered view of the SNP dictionary (r06), the counterpart of sec3 above: every SNP k-mer that shares a chunk's first 16 bases
+	// is adjacent, so the high-half SNP neighbour queries of a gate-open chunk (qv.cc:1303-1352: up to 36 of them when the SNP bit
+	// vector's probe is positive, each a jump-table gather + a ~5-deep bisection of a HI24 bucket, nearly all of them misses) are one
+	// short bucket read in stage B0.  One 12-byte record per k-mer: {HI32, pos (or auxiliary row), LO32 & 0x03FFFFFF |
+	// SNP_INFO_POS << 26 | ambig_flag << 31}; ssec_jg over the top ssec_bits (>= 14) bits of LO32, which with the record's 26 low bits
+	// pin all 32.  profiles/view_census_*_r06.txt: those queries asked for 1.4 of a default read's 19.8 lines and 3.7 of a
+	// repeat-rich read's 25.2, in dependent chains.
+	const uint32_t *ssec3;         // [n_snp][3]
+	const uint32_t *ssec_jg;       // [2^ssec_bits + 1]
+	uint32_t ssec_bits;
 	// jump table of the SNP dictionary over HI32 (2^32 + 1 words, like ref_jg): built only for an index too large for the merged view
 	// (2^32 or more k-mers in the two dictionaries together: hg38 + full dbSNP), where a HI24 bucket holds ~190 entries and the
 	// reference's bsearch would be 8 dependent probes; a HI32 bucket holds one or two.  Same entries found: the dictionary is
@@ -355,8 +365,12 @@ __device__ inline void ref_bounds(const DevIndex &d, uint64_t h, uint32_t &lo, u
 			while (x < y) { const uint32_t m = x + ((y - x) >> 1); if (gather<uint32_t>(&d.ref[m].pad) <= hh) x = m + 1; else y = m; }
 			hi = x;
 		} else {
-			uint32_t below = 0, same = 0;
-			for (uint32_t i = a; i < e; i++) { const uint32_t p = gather<uint32_t>(&d.ref[i].pad); below += p < hh ? 1u : 0u; same += p == hh ? 1u : 0u; }
+			// (all of the bucket's entries asked for before any is looked at: one wait, not one per entry)
+			uint32_t pv[8], below = 0, same = 0;
+			#pragma unroll
+			for (uint32_t i = 0; i < 8u; i++) { pv[i] = 0u; if (a + i < e) pv[i] = gather<uint32_t>(&d.ref[a + i].pad); }
+			#pragma unroll
+			for (uint32_t i = 0; i < 8u; i++) if (a + i < e) { below += pv[i] < hh ? 1u : 0u; same += pv[i] == hh ? 1u : 0u; }
 			lo = a + below; hi = lo + same;
 		}
 	}

@@ -171,6 +171,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	// build keeps the 48 individual queries because the event counters price each of them.
 	const bool use_sec = !STATS && d.sec3 != nullptr;
 	const bool bf_from_sec = use_sec && d.sec_is_bf != 0u;          // the reference bit vector is the LO32 set of the dictionary (verified by the loader)
+	const bool use_ssec = !STATS && d.ssec3 != nullptr;              // ... and the SNP dictionary's counterpart answers the (up to 36 + 12) high-half SNP queries
 	const bool use_mx = !STATS && !NOMX && d.mx != nullptr;
 	const bool use_sig = !STATS && d.snp_sig != nullptr;
 	const bool use_probe = !STATS && !use_sig && d.snp_probe != nullptr;
@@ -878,6 +879,46 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								if (bf_from_sec) { if ((gather_bf<uint64_t>(d.ref_bf + (rp >> 6)) >> (rp & 63)) & 1u) fl |= 1u; }   // (and its bit is read after all)
 							}
 						}
+						// high-half SNP hits from the SNP dictionary's LO32-ordered view (r06): the live SNP slots [s_lo, s_hi) -- 36 of them when the SNP
+						// bit vector's probe is positive, 12 more under a large block -- used to be one stage-B1 item each, a jump-table gather and a
+						// ~5-deep bisection of a HI24 bucket apiece, nearly all of them misses (the probe is a one-hash filter over the wrong k-mers:
+						// SURVEY.md B2).  Every SNP k-mer with this chunk's first 16 bases lies in one short bucket of the view: a record whose last
+						// 16 bases differ from the chunk's in exactly one base, at a live slot, whose SNP does not sit on the mutated base
+						// (qv.cc:1308-1352; ambiguous entries check that per column of their row, later), IS the hit -- it joins the pair's hit
+						// list (the reference hits first), and the pair has no SNP slots left to query.  Rare (1.5 % of the gate-open chunks):
+						// its two dependent waits are only paid by waves that hold such a pair.
+						bool ssec_ok = false;
+						uint32_t hsnp = 0;                                         // bit z: hit z comes from the SNP dictionary
+						if (use_ssec && s_hi > s_lo && !longsec) {
+							uint32_t c0, c1;
+							jg_pair(d.ssec_jg, klo >> (32 - d.ssec_bits), c0, c1);
+							if (c1 - c0 <= (uint32_t)SEC_W) {
+								ssec_ok = true;
+								const uint32_t nh_ref = nh, hu_ref = hu, hamb_ref = hamb;
+								if (c1 > c0) {
+									uint3 rec[SEC_W];
+									VG_VC(d.ssec3 + 3ull * c0, 12u * (c1 - c0));
+									#pragma unroll
+									for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) { const uint32_t e = c0 + z < c1 ? c0 + z : c1 - 1; rec[z] = gather12(d.ssec3 + 3ull * e); }
+									#pragma unroll
+									for (uint32_t z = 0; z < (uint32_t)SEC_W; z++) if (c0 + z < c1 && ((rec[z].z ^ klo) & 0x03FFFFFFu) == 0u && ssec_ok) {
+										const int dd = onebase((uint64_t)(rec[z].x ^ khi));
+										if (dd < 0) continue;
+										const uint32_t nbb = (rec[z].x >> (2 * dd)) & 3u, base = (khi >> (2 * dd)) & 3u;
+										const uint32_t u = (uint32_t)dd * 3u + nbb - (nbb > base ? 1u : 0u), amb = rec[z].z >> 31;
+										if (u < s_lo || u >= s_hi) continue;                   // not a slot the reference queries for this chunk
+										if (!amb && ((rec[z].z >> 26) & 31u) == 16u + (uint32_t)dd) continue;      // the mutated base is the SNP base itself
+										if (nh == (uint32_t)HCAP) { ssec_ok = false; continue; }
+										P_hidx[nh][p][wv] = rec[z].y;
+										hamb |= amb << nh; hsnp |= 1u << nh;
+										hu |= u << (8 * nh);
+										nh++;
+									}
+								}
+								if (!ssec_ok) { nh = nh_ref; hu = hu_ref; hamb = hamb_ref; hsnp = 0; }       // more hits than the list holds: the slots are queried after all
+							}
+						}
+						const bool snp_settled = s_hi == s_lo || ssec_ok;
 						uint32_t mode = 0, u_lo = 0, nhigh = 0;                  // mode 0: slots [u_lo, u_lo + nhigh); mode 1: the nh hits
 						if (!longsec) {
 							// the (at most four) hits in SLOT order, each byte = slot << 2 | hit number (0xFF: none): sorted here, once per pair, so that
@@ -889,9 +930,10 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							hu = b0_ | (b1_ << 8) | (b2_ << 16) | (b3_ << 24);
 						}
 						if (longsec) { u_lo = s_lo; nhigh = (((b1 - b0) + LW - 1u) >> LW_LOG) + (s_hi - s_lo); hu = b1 - b0; }      // the bucket's records (LW per item), then the live SNP slots
+						else if (snp_settled && (!(fl & 1u) || sec_ok)) { mode = 1; nhigh = nh; }      // both dictionaries' high-half neighbours are in the hit list
 						else if (!(fl & 1u)) { u_lo = s_lo; nhigh = s_hi - s_lo; }
-						else if (sec_ok && s_hi == s_lo) { mode = 1; nhigh = nh; }
 						else { u_lo = 0; nhigh = 48; }
+						// (mode 0 never sees an SNP hit in the list: it is only consulted under sec_ok, and sec_ok without mode 1 means the SNP view did not settle its side)
 						// items of the strided scans: one per reference-bucket entry; SNP-bucket entries eight per item (their signatures lie
 						// side by side in the signature view): the SNP scan is most of stage B's items at hg38 scale, and every round of 64
 						// items pays the full chain of dependent waits of the few items in it that do have something to look up
@@ -902,7 +944,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						P_cnt[p][wv] = L + nhigh;
 						if (longsec) P_hidx[0][p][wv] = sec_b0;
 						P_hu[p][wv] = hu;
-						P_hamb[p][wv] = (uint8_t)hamb;
+						P_hamb[p][wv] = (uint8_t)(hamb | (hsnp << 4));          // bits 0-3: hit z is ambiguous, bits 4-7: hit z is an SNP-dictionary hit
 					}
 				}
 				if constexpr (STATS) {
@@ -955,6 +997,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 					uint32_t own = 64, c = 0, mod = 0, nbase = 0, o_ecnt = 0;
 					uint32_t ri = NOHIT, si = NOHIT;                          // entry indices (dictionaries hold < 2^32 - 1 entries) or NOHIT
 					uint32_t rdirect = 0;                                     // bit 0: ri holds the entry's POSITION field instead (bit 1: its ambig_flag)
+					uint32_t sdirect = 0;                                     // the same for si (a hit of the SNP dictionary's LO32-ordered view)
 					LaneStats<STATS> hs;
 					hs.clear();
 					if (extra) {
@@ -1077,10 +1120,12 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							if (slot_item) {
 							if (mode == 1) {                                     // the h-th hit in slot order
 								const uint32_t hb = (P_hu[p][wv] >> (8u * (h & 3u))) & 0xFFu, zsel = hb & 3u;      // (sorted by slot in stage B0)
+								const uint32_t ha = (uint32_t)P_hamb[p][wv];
 								u = hb >> 2;
-								ri = P_hidx[zsel][p][wv];                        // (a hit of the LO32-ordered view comes with its position: no entry to fetch)
-								rdirect = 1u | (((uint32_t)P_hamb[p][wv] >> zsel) & 1u) << 1;
-								have_ri = true;
+								// (a hit of either LO32-ordered view comes with its position: no entry to fetch)
+								if ((ha >> (4u + zsel)) & 1u) { si = P_hidx[zsel][p][wv]; sdirect = 1u | ((ha >> zsel) & 1u) << 1; }
+								else { ri = P_hidx[zsel][p][wv]; rdirect = 1u | ((ha >> zsel) & 1u) << 1; }
+								have_ri = true;                                  // (both dictionaries' sides of this pair are settled by the list)
 							} else u = u_lo + h;
 							const uint32_t pair = 16u + u / 3, sel = u % 3, base = (uint32_t)(k >> (2 * pair)) & 3u;
 							nbase = sel + (sel >= base ? 1u : 0u);
@@ -1090,7 +1135,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								if (sec_ok) { const uint32_t hu = P_hu[p][wv]; for (uint32_t z = 0; z < nh; z++) { const uint32_t hb = (hu >> (8 * z)) & 0xFFu, zz = hb & 3u; if ((hb >> 2) == u) { ri = P_hidx[zz][p][wv]; rdirect = 1u | (((uint32_t)P_hamb[p][wv] >> zz) & 1u) << 1; } } }
 								else q_r = true;
 							}
-							q_s = (large || 2 * pair >= 40u) && 2 * pair < ssb;
+							q_s = mode == 0u && (large || 2 * pair >= 40u) && 2 * pair < ssb;
 							}
 						}
 #ifdef VG_STAGE_CLOCKS
@@ -1121,7 +1166,8 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						re.pos = POS_AMBIGUOUS; re.amb = 0; se.pos = POS_AMBIGUOUS; se.key = 0;
 						if (rdirect) { re.pos = ri; re.amb = rdirect >> 1; }         // ri IS the position (or the row index) here
 						else if (ri != NOHIT) re = gather<RefEnt>(d.ref + ri);
-						if (si != NOHIT) se = gather<SnpEnt>(d.snp + si);
+						if (sdirect) { se.pos = si; se.key = (uint64_t)(sdirect >> 1) << 48; }   // likewise (stage B0 has compared SNP_INFO_POS with the mutated base already: 0 here, never a high-half base)
+						else if (si != NOHIT) se = gather<SnpEnt>(d.snp + si);
 						const bool r_ok = re.pos != POS_AMBIGUOUS, s_ok = se.pos != POS_AMBIGUOUS;
 						r_aux = r_ok && re.amb != 0; s_aux = s_ok && ((se.key >> 48) & 0xFFu) != 0;
 						rpos = re.pos; spos = se.pos;
