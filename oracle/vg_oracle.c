@@ -19,6 +19,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -543,20 +546,49 @@ static int read_bf(const char *path, uint64_t *bits, uint64_t **words, uint64_t 
 	return 0;
 }
 
+/* A dictionary file as bytes: mapped (no copy: at hg38 + full-dbSNP scale the two files are ~100 GB, on tmpfs they are memory
+ * already, and a GPU box's container has 300 GiB for everything), read whole only where mapping fails.  One file at a time. */
+typedef struct { void *p; uint64_t len; int mapped; } filebytes;
+static int file_open(const char *path, filebytes *fb)
+{
+	fb->p = NULL; fb->len = 0; fb->mapped = 0;
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0) return -1;
+	struct stat sb;
+	if (fstat(fd, &sb) == 0 && sb.st_size > 0) {
+		void *m = mmap(NULL, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+		if (m != MAP_FAILED) { fb->p = m; fb->len = (uint64_t)sb.st_size; fb->mapped = 1; (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL); }
+	}
+	close(fd);
+	if (fb->p) return 0;
+	return read_all(path, &fb->p, &fb->len);
+}
+static void file_close(const char *path, filebytes *fb)
+{
+	if (!fb->p) return;
+	if (fb->mapped) {
+		munmap(fb->p, (size_t)fb->len);
+		const int fd = open(path, O_RDONLY);             /* a file on disk: its page cache is not needed again */
+		if (fd >= 0) { (void)posix_fadvise(fd, 0, 0, POSIX_FADV_DONTNEED); close(fd); }
+	} else free(fb->p);
+	fb->p = NULL;
+}
+
 vgo_index *vgo_index_load(const char *prefix)
 {
-	char path[4200];
-	void *rd = NULL, *sd = NULL; uint64_t rlen = 0, slen = 0;
-	snprintf(path, sizeof path, "%s.ref.dict", prefix); if (read_all(path, &rd, &rlen)) return NULL;
-	snprintf(path, sizeof path, "%s.snp.dict", prefix); if (read_all(path, &sd, &slen)) { free(rd); return NULL; }
-	const uint8_t *p = rd;
+	char path[4200], spath[4200];
+	filebytes rf, sf;
+	snprintf(path, sizeof path, "%s.ref.dict", prefix); if (file_open(path, &rf)) return NULL;
+	const uint8_t *p = rf.p;
 	uint64_t n_ref, n_ref_aux; memcpy(&n_ref, p, 8); memcpy(&n_ref_aux, p + 8, 8); p += 16;
 	uint64_t *rk = xmalloc(n_ref * 8); uint32_t *rp = xmalloc(n_ref * 4); uint8_t *ra = xmalloc(n_ref);
 	#pragma omp parallel for schedule(static)
 	for (int64_t i = 0; i < (int64_t)n_ref; i++) { const uint8_t *q = p + 13 * i; memcpy(&rk[i], q, 8); memcpy(&rp[i], q + 8, 4); ra[i] = q[12]; }   /* dictgen.c:63-154 */
 	p += 13 * n_ref;
 	uint32_t *raux = xmalloc(n_ref_aux * 40 + 8); memcpy(raux, p, n_ref_aux * 40);
-	p = sd;
+	file_close(path, &rf);
+	snprintf(spath, sizeof spath, "%s.snp.dict", prefix); if (file_open(spath, &sf)) return NULL;
+	p = sf.p;
 	uint64_t n_snp, n_snp_aux; memcpy(&n_snp, p, 8); memcpy(&n_snp_aux, p + 8, 8); p += 16;
 	uint64_t *sk = xmalloc(n_snp * 8); uint32_t *sp = xmalloc(n_snp * 4);
 	uint8_t *si = xmalloc(n_snp), *sa = xmalloc(n_snp), *srf = xmalloc(n_snp), *saf = xmalloc(n_snp);
@@ -571,7 +603,7 @@ vgo_index *vgo_index_load(const char *prefix)
 	uint64_t rbits = 0, sbits = 0; uint64_t *rw = NULL, *sw = NULL;
 	snprintf(path, sizeof path, "%s.ref.bf", prefix); if (read_bf(path, &rbits, &rw, 1ull << 32)) return NULL;
 	snprintf(path, sizeof path, "%s.snp.bf", prefix); if (read_bf(path, &sbits, &sw, ~0ull)) return NULL;
-	free(rd); free(sd);
+	file_close(spath, &sf);
 	/* the unpacked columns become the index's own arrays (no second copy of 37 GB at hg38 scale) */
 	vgo_index *ix = index_from_owned(n_ref, rk, rp, ra, n_ref_aux, raux, n_snp, sk, sp, si, sa, srf, saf,
 	                                 n_snp_aux, sap, sai, rbits, rw, sbits, sw);
