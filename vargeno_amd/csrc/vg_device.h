@@ -351,7 +351,11 @@ __device__ inline void ref_bounds(const DevIndex &d, uint64_t h, uint32_t &lo, u
 		const uint32_t c = r.z & 0xFFFFu;
 		lo = r.x;
 		hi = c == 0xFFFFu ? gather<uint32_t>(&d.hx[h + 1].x) : lo + c;
-	} else if (d.ref_jg_bits >= 32u) jg_pair(d.ref_jg, h, lo, hi);
+	}
+#if defined(VG_AB_NO_COARSE)                                       // (A/B builds only: the reference jump table's coarse form compiled out)
+	else jg_pair(d.ref_jg, h, lo, hi);
+#else
+	else if (d.ref_jg_bits >= 32u) jg_pair(d.ref_jg, h, lo, hi);
 	else {
 		// coarse table: the bucket of h's top bits, then the run of entries whose k-mer has exactly this HI32 (RefEnt::pad) inside it --
 		// the entries are sorted by the whole k-mer, so by HI32 first.  Mostly zero to two entries: walked; a long bucket: bisected.
@@ -374,6 +378,7 @@ __device__ inline void ref_bounds(const DevIndex &d, uint64_t h, uint32_t &lo, u
 			lo = a + below; hi = lo + same;
 		}
 	}
+#endif
 }
 
 // columns [j0, j0 + 4) of an auxiliary-table row (AUX_COLS = 10 positions, rows 8-byte aligned) as two independent 8-byte

@@ -102,6 +102,8 @@ struct FuseIn {
 #define VG_FUSE_PACK 0
 #endif
 
+template <bool WIDE> struct XKey { typedef uint32_t type; };
+template <> struct XKey<true> { typedef uint64_t type; };
 template <bool NARROW> struct KMask { typedef uint32_t type; };
 template <> struct KMask<true> { typedef uint16_t type; };
 
@@ -171,7 +173,11 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 	// build keeps the 48 individual queries because the event counters price each of them.
 	const bool use_sec = !STATS && d.sec3 != nullptr;
 	const bool bf_from_sec = use_sec && d.sec_is_bf != 0u;          // the reference bit vector is the LO32 set of the dictionary (verified by the loader)
-	const bool use_ssec = !STATS && d.ssec3 != nullptr;              // ... and the SNP dictionary's counterpart answers the (up to 36 + 12) high-half SNP queries
+#if defined(VG_AB_NO_SSEC_CODE)                                     // (A/B builds only: the SNP view's code compiled out)
+	constexpr bool use_ssec = false;
+#else
+	const bool use_ssec = !STATS && d.ssec3 != nullptr;
+#endif              // ... and the SNP dictionary's counterpart answers the (up to 36 + 12) high-half SNP queries
 	const bool use_mx = !STATS && !NOMX && d.mx != nullptr;
 	const bool use_sig = !STATS && d.snp_sig != nullptr;
 	const bool use_probe = !STATS && !use_sig && d.snp_probe != nullptr;
@@ -544,23 +550,27 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 						VG_CLKW(9);
 						// what an entry is compared with: lo32 of the key -- and, under SDX, field F above it (the high word's bits below the
 						// bucket, left-aligned; see DevIndex::dx_bits).  ekey() of a record / entry is the same 32 or 64 bits of ITS key.
+						// (the 2^32-bucket instantiation compares 32-bit words, as through round 5: 64-bit keys there cost it four registers and
+						// 3-12 % of its time -- profiles/ab_hg38_r06_bisect.txt)
+						using xkey_t = typename XKey<SDX>::type;
 						const uint32_t dxb = SDX ? d.dx_bits : 32u;
-						auto ekey = [](const uint4 &e) -> uint64_t { return SDX ? ((uint64_t)(e.z & 0xFFFF0000u) << 32) | e.x : (uint64_t)e.x; };
+						auto ekey = [](const uint4 &e) -> xkey_t { if constexpr (SDX) return ((uint64_t)(e.z & 0xFFFF0000u) << 32) | e.x; else return e.x; };
 						auto ecnt = [](const uint4 &b) -> uint32_t { return SDX ? (b.z >> 8) & 0xFFu : b.z >> 8; };
 						uint4 bq[4];
+						xkey_t kx[4];
 						#pragma unroll
 						for (uint32_t z = 0; z < 4; z++) {
 							bq[z] = make_uint4(0, 0, 0, 0);
 							if (z < m) bq[z] = gather<uint4>(d.dx + (SDX ? kq[z] >> (64u - dxb) : kq[z] >> 32));
-							if constexpr (SDX) kq[z] = ((uint64_t)(((uint32_t)(kq[z] >> 32) << dxb) & 0xFFFF0000u) << 32) | (uint32_t)kq[z];      // (F, lo32): what is left to compare
-							else kq[z] = (uint32_t)kq[z];
+							if constexpr (SDX) kx[z] = ((uint64_t)(((uint32_t)(kq[z] >> 32) << dxb) & 0xFFFF0000u) << 32) | (uint32_t)kq[z];      // (F, lo32): what is left to compare
+							else kx[z] = (uint32_t)kq[z];
 						}
 						VG_CLKW(10);
 						// `more`: the bucket has further entries that may hold the key (entries are sorted by lo: nothing below the first; a
 						// match on the first entry is final unless the table says its successor has the same k-mer -- flag TIE)
 						bool more[4];
 						#pragma unroll
-						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && ecnt(bq[z]) > 1u && (ekey(bq[z]) < kq[z] || (ekey(bq[z]) == kq[z] && (bq[z].z & 16u)));
+						for (uint32_t z = 0; z < 4; z++) more[z] = z < m && (bq[z].z & 1u) && ecnt(bq[z]) > 1u && (ekey(bq[z]) < kx[z] || (ekey(bq[z]) == kx[z] && (bq[z].z & 16u)));
 						// Two chunks at a time: the rest of a small bucket -- up to VG_SCAN_W more entries -- arrives together (one wait;
 						// anything deeper is rare and goes one by one); then each chunk's exact contexts are appended (qv.cc:850-937),
 						// reference hit first, then SNP hit.  An ambiguous k-mer with exactly two positions carries both in its entry
@@ -591,7 +601,7 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 								if (z >= m) continue;
 								cur.add(S_CHUNKS, 1);
 								const uint4 b = bq[z];
-								const uint64_t key = kq[z];                             // (lo32, or (F, lo32) under SDX)
+								const xkey_t key = kx[z];                               // (lo32, or (F, lo32) under SDX)
 								// hit state: position (or row index), second position of a PAIR, flags 1 hit, 2 ambiguous, 4 PAIR -- for this pass's
 								// strand, and (x...) for the other strand
 								uint32_t rp = 0, rp2 = 0, rf = 0, sp = 0, sp2 = 0, sf = 0;
