@@ -630,7 +630,7 @@ def traffic_for(args, build_id):
             tj = json.load(open(path))
             w = dict(tj["workload"])
             if {k: w.get(k) for k in want} != want or float(w.get("lowq", 0.08)) != args.lowq or float(w.get("repeats", 0.0)) != args.repeats or bool(w.get("gate_words", True)) != bool(args.gate_words) \
-                    or int(w.get("read_len", 150)) != args.read_len or float(w.get("softmask", 0.0)) != args.softmask:
+                    or int(w.get("read_len", 150)) != args.read_len or float(w.get("softmask", 0.0)) != args.softmask or (w.get("device_budget") or None) != (args.device_budget or None):
                 continue
             if tj.get("build_id") != build_id:
                 note = "%s was measured on build %s, this is build %s: not quoted" % (os.path.basename(path), tj.get("build_id"), build_id)
@@ -735,7 +735,7 @@ def compact_line(out, detail_path):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     line = {k: _r(out[k], 7) if k in ("value", "ms_per_step") else out[k] for k in keep}
     line["config"] = {"workload": _short(c["workload"], 140), "reads_per_step_per_gpu": c["reads_per_step_per_gpu"], "resident_batches": c["resident_batches"], "genome_bp": c["genome_bp"],
-                      "snps_requested": c["snps_requested"], "read_len": c["read_len"], "lowq": c["lowq"], "repeats": c["repeats"], "softmask": c["softmask"], "gate_words": c["gate_words"],
+                      "snps_requested": c["snps_requested"], "read_len": c["read_len"], "lowq": c["lowq"], "repeats": c["repeats"], "softmask": c["softmask"], "gate_words": c["gate_words"], "device_budget": c.get("device_budget"),
                       "index_bytes_hbm": c["index_bytes_hbm"], "index_views": _short(",".join(c.get("index_views") or []) if isinstance(c.get("index_views"), (list, tuple)) else c.get("index_views"), 80), "index_open_s": _r(c["index_open_s"], 4), "lib_build_id": c["lib_build_id"],
                       "parallelism": _short(c["parallelism"], 120)}
     gcl = rf.get("gather_ceiling") or {}
@@ -1482,7 +1482,7 @@ def main():
                                        "hg38-scale (BASELINE.json configs[2])" if args.genome >= 10 ** 9 else "chr22-scale (BASELINE.json configs[1])",
                                        args.genome, args.chroms, args.snps, args.reads, args.read_len, args.batches, 100 * args.lowq,
                                        "" if not args.repeats else "; REPEAT-RICH genome: %g%% of it in planted families of near-identical copies (2-10 and 11-200 copies), 50 microsatellites per Mbp" % (100 * args.repeats)),
-                       "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps, "lowq": args.lowq, "repeats": args.repeats, "read_len": args.read_len, "softmask": args.softmask, "gate_words": bool(args.gate_words),
+                       "reads_per_step_per_gpu": args.reads, "resident_batches": args.batches, "genome_bp": args.genome, "snps_requested": args.snps, "lowq": args.lowq, "repeats": args.repeats, "read_len": args.read_len, "softmask": args.softmask, "gate_words": bool(args.gate_words), "device_budget": args.device_budget,
                        "index_bytes_hbm": dev_bytes, "index_views": views, "index_plan": plan_text, "index_open_s": t_open, "index_open_cpu_s": cpu_open, "index_open_phases": open_report, "device_memory_pretouch": pretouched, "index_files_read_before_open": files_warm, "lib_build_id": build_id,
                        "parallelism": "reads sharded over %d GPU(s), index replicated, one RCCL all-reduce of the site counters after the K steps" % world},
             "roofline": roof,

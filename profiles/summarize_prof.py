@@ -13,7 +13,9 @@ ksel = sys.argv[3] if len(sys.argv) > 3 else "vg_wave_kernel<false, "
 
 
 def is_main(name):
-    return ksel in name and ", 4>" in name
+    # the main tier's instantiation: four waves per workgroup ("..., 4>" through round 5; "..., 4, false>" / "..., 4, true>" since the SDX template argument of round 6)
+    import re
+    return ksel in name and re.search(r", 4(, (false|true))?>", name) is not None
 
 
 out = []
@@ -64,7 +66,7 @@ if "WRITE_SIZE" in means and ("TCC_EA0_RDREQ_DRAM_32B" in means or "TCC_MISS_sum
     try:
         cfg = json.loads(open(os.path.join(src, "kt.json")).read().strip().splitlines()[-1])["config"]
         wl = {"genome": cfg["genome_bp"], "snps": cfg["snps_requested"], "reads": cfg["reads_per_step_per_gpu"], "lowq": cfg.get("lowq", 0.08), "repeats": cfg.get("repeats", 0.0), "gate_words": cfg.get("gate_words", True),
-              "read_len": cfg.get("read_len", 150), "softmask": cfg.get("softmask", 0.0)}
+              "read_len": cfg.get("read_len", 150), "softmask": cfg.get("softmask", 0.0), "device_budget": cfg.get("device_budget")}
         build_id = cfg.get("lib_build_id")
     except Exception:
         pass
@@ -81,7 +83,7 @@ if "WRITE_SIZE" in means and ("TCC_EA0_RDREQ_DRAM_32B" in means or "TCC_MISS_sum
           "TCC_EA0_RDREQ_128B": means.get("TCC_EA0_RDREQ_128B"), "TCC_EA0_RDREQ_64B": means.get("TCC_EA0_RDREQ_64B"), "TCC_EA0_RDREQ_DRAM_32B": means.get("TCC_EA0_RDREQ_DRAM_32B"),
           "TCC_MISS_sum": means.get("TCC_MISS_sum"), "TCC_HIT_sum": means.get("TCC_HIT_sum"), "TCP_TCC_READ_REQ_sum": means.get("TCP_TCC_READ_REQ_sum"),
           "kernel_trace_avg_ns": kt_avg,
-          "source": "profiles/run_prof_r05.sh %s -> profiles/rocprof_summary_%s.txt; what one L2 miss moves: profiles/line_probe_r03.*" % (tag, tag)}
+          "source": "profiles/run_prof_r06.sh %s -> profiles/rocprof_summary_%s.txt; what one L2 miss moves: profiles/line_probe_r03.*" % (tag, tag)}
     open(os.path.join(src, "traffic_%s.json" % tag), "w").write(json.dumps(tj, indent=1) + "\n")
     out.append("== traffic_%s.json" % tag)
     out.append(json.dumps(tj))
