@@ -81,6 +81,8 @@ def parse_args():
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the `sustained` leg: blocks of K steps back to back for at least this long (0 = skip)")
     ap.add_argument("--job-reads", type=int, default=None, help="the `job` leg: one whole `vargeno geno` run (index open + FASTQ ingest + caller + VCF) on a FASTQ file of this many distinct reads written by this bench "
                     "(default: 200 000 000 for the default workload at N = 1 -- scaled down to what the work directory's file system holds --, else 0 = skip)")
+    ap.add_argument("--stream-reads", type=int, default=None, help="the `job_stream` leg: one whole `vargeno geno` run on this many reads streamed through a FIFO (default: 620 000 000 = 30x, BASELINE.json's metric, "
+                    "for the default workload at N = 1 when the `job` leg runs; 0 = skip)")
     ap.add_argument("--cleanup", action="store_true", help="remove this run's index files when done (the secondary legs' child runs do)")
     ap.add_argument("--no-gather-probe", action="store_true", help="do not measure the chip's random-gather ceiling (tools/gather_probe, ~5 s)")
     ap.add_argument("--no-pretouch", action="store_true", help="do not have a child process take the device's free memory once before the genome is generated (see pretouch_start)")
@@ -597,6 +599,159 @@ def job_run(d, job_dir, job, log):
     return out
 
 
+def job_stream(src, d, job_dir, prefix, dev_index, n_reads, batch_reads, lowq, read_len, log, deadline_s=90.0):
+    """The metric's own job size through the command line: BASELINE.json quotes "hg38 + dbSNP 30x" = 620 M reads, 195 GB of FASTQ -- more
+    than the container may keep in a file beside everything else, so the reads are never a file: this process generates them batch
+    by batch on the device (the seeds of the `job` leg, continued), puts the FASTQ text together there, and writes it into a FIFO that
+    `vargeno geno idx <fifo> snps.vcf out.vcf` reads -- the once-only route of the command line (one descriptor, host packer,
+    read store while the index opens, then straight into the read loop: host/main.cpp, PipeIngest).  The reference reads such a
+    stream the same way (fopen + fgets, qv.cc:2182, 760-763).  Wall time from the child's start to its exit; what bounds it is on the
+    line (the generator's and the pipe's rates beside the command line's own numbers).  Afterwards this process opens the index
+    again and runs the SAME batches through the resident-batch path: the command line's counters must be identical.
+    `deadline_s` ends the stream early (a complete record, EOF) when the feed is slower than planned: the line says how many reads went through."""
+    import re
+    import threading
+
+    import torch
+
+    from vargeno_amd.api import GenoIndex, pinned_buffer
+
+    fifo = os.path.join(job_dir, "job.fifo")
+    dump = os.path.join(job_dir, "job_stream.counts")
+    out_vcf = os.path.join(job_dir, "job_stream.vcf")
+    for pth in (fifo, dump, out_vcf):
+        if os.path.exists(pth):
+            os.remove(pth)
+    os.mkfifo(fifo)
+    env = dict(os.environ, VARGENO_VERBOSE="1", VARGENO_DUMP_COUNTS=dump, VARGENO_PREPACK_GB="16")
+    time.sleep(IDLE_BEFORE_CHILD_S)                                   # (the device idle for a while: see job_run)
+    t0 = time.time()
+    p = subprocess.Popen([BIN, "geno", "idx", fifo, "snps.vcf", out_vcf], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    import errno
+    import fcntl
+
+    fd = None
+    while fd is None:                                                 # (a FIFO opens for writing once somebody reads it: the child does so first thing)
+        try:
+            fd = os.open(fifo, os.O_WRONLY | os.O_NONBLOCK)
+        except OSError as e:
+            if e.errno != errno.ENXIO or p.poll() is not None or time.time() - t0 > 60:
+                p.kill()
+                return {"skipped": "the command line did not open the FIFO: %r / %s" % (e, (p.communicate()[1] or "")[-300:])}
+            time.sleep(0.01)
+    fcntl.fcntl(fd, fcntl.F_SETFL, fcntl.fcntl(fd, fcntl.F_GETFL) & ~os.O_NONBLOCK)
+    try:
+        fcntl.fcntl(fd, 1031, 1 << 20)                                # F_SETPIPE_SZ: the largest pipe an unprivileged process may ask for
+    except Exception:
+        pass
+    pins = [None, None]
+    done, gen_s, write_s, nb = 0, 0.0, 0.0, 0
+    t_feed = time.time()
+    wr = {"th": None, "err": None}
+
+    def write_all(view):
+        try:
+            at, n = 0, len(view)
+            while at < n:
+                at += os.write(fd, view[at:at + (64 << 20)])
+        except Exception as e:                                        # (EPIPE: the child has gone)
+            wr["err"] = e
+    try:
+        while done < n_reads and wr["err"] is None and p.poll() is None:
+            if time.time() - t_feed > deadline_s:
+                break
+            tg = time.time()
+            n = min(batch_reads, n_reads - done)
+            tb, tq, to = src.batch(500_000 + nb, n, length=read_len, lowq=lowq)[:3]
+            L = int(to[1].item())
+            rec = 13 + L + 3 + L + 1                                  # "@r%010d\n" bases "\n+\n" quals "\n"
+            m = torch.empty((n, rec), dtype=torch.uint8, device=tb.device)
+            ids = torch.arange(done, done + n, device=tb.device, dtype=torch.int64)
+            m[:, 0] = 64
+            m[:, 1] = 114
+            for k in range(10):
+                m[:, 2 + k] = (48 + (ids // 10 ** (9 - k)) % 10).to(torch.uint8)
+            m[:, 12] = 10
+            m[:, 13:13 + L] = tb.view(n, L)
+            m[:, 13 + L] = 10
+            m[:, 14 + L] = 43
+            m[:, 15 + L] = 10
+            m[:, 16 + L:16 + 2 * L] = tq.view(n, L)
+            m[:, 16 + 2 * L] = 10
+            nbytes = n * rec
+            k2 = nb & 1
+            if wr["th"] is not None and pins[k2] is not None:
+                pass                                                  # (the buffer of two batches ago: its writer has been joined below)
+            if pins[k2] is None or len(pins[k2][0]) < nbytes:
+                pins[k2] = pinned_buffer(nbytes)
+            torch.as_tensor(pins[k2][0][:nbytes]).copy_(m.view(-1))   # device -> page-locked host
+            del m, ids, tb, tq, to
+            gen_s += time.time() - tg
+            tw = time.time()
+            if wr["th"] is not None:
+                wr["th"].join()                                       # one batch is written while the next is generated
+            write_s += time.time() - tw
+            wr["th"] = threading.Thread(target=write_all, args=(memoryview(pins[k2][0][:nbytes]),))
+            wr["th"].start()
+            done += n
+            nb += 1
+        if wr["th"] is not None:
+            tw = time.time()
+            wr["th"].join()
+            write_s += time.time() - tw
+    finally:
+        os.close(fd)
+    feed_s = time.time() - t_feed
+    try:
+        so, se = p.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        so, se = p.communicate()
+    wall = time.time() - t0
+    out = {"reads": done, "reads_wanted": n_reads, "fastq_GB": done * (2 * read_len + 17) / 1e9, "wall_s": wall, "whole_job_reads_per_s": done / wall, "rc": p.returncode,
+           "feed_s": feed_s, "generator_s": gen_s, "generator_waiting_for_the_pipe_s": write_s, "feed_GB_per_s": done * (2 * read_len + 17) / 1e9 / max(feed_s, 1e-9),
+           "input": "a FIFO this process writes (reads generated on the device, FASTQ text put together there, one batch in flight): the command line's once-only route",
+           "bound_by": "the feed (generator + pipe): the command line waits for text" if feed_s > 0.8 * wall else "the command line"}
+    if p.returncode != 0 or wr["err"] is not None:
+        out["failed"] = ((se or "")[-500:] + " | writer: %r" % (wr["err"],))
+        return out
+    mt = re.search(r"wall: ([\d.]+) s = index load ([\d.]+) \+ FASTQ->counters ([\d.]+) \(([\d.]+) M reads/s\) \+ call/VCF ([\d.]+)", se)
+    if mt:
+        out.update({"cli_wall_s": float(mt.group(1)), "index_open_s": float(mt.group(2)), "ingest_after_open_s": float(mt.group(3)), "call_vcf_s": float(mt.group(5)), "wall_minus_open_s": wall - float(mt.group(2))})
+    for ln in se.splitlines():
+        if ln.startswith("ingest, replica 0:"):
+            out["ingest_route"] = ln[len("ingest, replica 0:"):].strip()[:400]
+    text = open(out_vcf, "rb").read()
+    calls = re.findall(rb"\t([01]/[01]):(\d+)\n", text)
+    gq = np.array([int(q) for _, q in calls], dtype=np.int64) if calls else np.zeros(0, np.int64)
+    hist, edges = np.histogram(gq, bins=[0, 10, 20, 30, 50, 100, 200, 400, 10 ** 6]) if len(gq) else ([], [])
+    out.update({"called": len(calls), "gq_histogram": {"%d-%d" % (edges[i], edges[i + 1] - 1): int(hist[i]) for i in range(len(hist))}, "gq_median": float(np.median(gq)) if len(gq) else None})
+    del text, calls
+    # the same batches through the resident-batch path of a handle of this process: identical counters
+    time.sleep(5.0)
+    tv = time.time()
+    with GenoIndex.open(prefix, device=dev_index) as gx2:
+        gx2.set_stats(False)
+        at = 0
+        for b in range(nb):
+            n = min(batch_reads, done - at)
+            tb, tq, to = src.batch(500_000 + b, n, length=read_len, lowq=lowq)[:3]
+            gx2.process_device(tb, tq, to, n)
+            gx2.sync()
+            del tb, tq, to
+            at += n
+        rc, ac = gx2.counts()
+    cnt = np.fromfile(dump, dtype=np.uint8)
+    ns = len(rc)
+    out["counters_equal_resident_batch_path"] = bool(len(cnt) == 2 * ns and np.array_equal(cnt[:ns], rc) and np.array_equal(cnt[ns:], ac))
+    out["verification_s"] = time.time() - tv
+    out["mean_coverage_per_site"] = float((rc.astype(np.int64).sum() + ac.astype(np.int64).sum()) / max(ns, 1))
+    assert out["counters_equal_resident_batch_path"], "the streamed job's counters differ from the resident-batch path's on the same reads"
+    log("[bench] job_stream: %d reads through a FIFO, wall %.1f s (open %.2f, feed %.1f s = %.2f GB/s: generator %.1f s, waiting for the pipe %.1f s), %.4g reads/s whole job, %d called, counters equal the resident path's (checked in %.0f s)" % (
+        done, wall, out.get("index_open_s", 0), feed_s, out["feed_GB_per_s"], gen_s, write_s, out["whole_job_reads_per_s"], out["called"], out["verification_s"]))
+    return out
+
+
 IDLE_BEFORE_CHILD_S = 20.0        # seconds between this process's release of the device and a child's start (see job_run)
 T_START = time.time()
 BUDGET_S = float(os.environ.get("VG_BENCH_BUDGET_S", "1500"))
@@ -774,6 +929,12 @@ def compact_line(out, detail_path):
             {k: _r(jb.get(k), 4) for k in ("reads", "wall_s", "index_open_s", "ingest_after_open_s", "call_vcf_s", "wall_minus_open_s", "whole_job_reads_per_s", "fastq_source_reads_per_s", "called", "gq_median", "counters_equal_resident_batch_path") if k in jb}
         if "first_reads_against_oracle" in jb and jb["first_reads_against_oracle"]:
             line["job"]["first_reads_against_oracle"] = {k: jb["first_reads_against_oracle"].get(k) for k in ("equal", "reads") if k in jb["first_reads_against_oracle"]}
+    js = out.get("job_stream")
+    if js:
+        line["job_stream"] = {"skipped": _short(js["skipped"], 100)} if "skipped" in js else \
+            {k: _r(js.get(k), 4) for k in ("reads", "wall_s", "index_open_s", "wall_minus_open_s", "whole_job_reads_per_s", "feed_GB_per_s", "called", "gq_median", "counters_equal_resident_batch_path") if k in js}
+        if "bound_by" in js:
+            line["job_stream"]["bound_by"] = _short(js["bound_by"], 60)
     if out.get("multi_gpu_verification"):
         line["multi_gpu_verification"] = out["multi_gpu_verification"]
     pr = out.get("multi_gpu_per_rank")
@@ -794,7 +955,7 @@ def compact_line(out, detail_path):
     line["bench_wall_s"] = _r(out.get("bench_wall_s"), 4)
     text = json.dumps(line)
     if len(text) >= LINE_LIMIT:                                  # never again an unparseable line: shed the optional summaries, largest first
-        for k in ("multi_gpu_per_rank", "ingest_end_to_end", "sustained", "other_input_form", "job", "secondary"):
+        for k in ("multi_gpu_per_rank", "ingest_end_to_end", "sustained", "other_input_form", "job_stream", "job", "secondary"):
             line.pop(k, None)
             text = json.dumps(line)
             if len(text) < LINE_LIMIT:
@@ -1059,6 +1220,8 @@ def main():
     want_job = args.job_reads if args.job_reads is not None else (200_000_000 if (default_workload and world == 1 and rank == 0 and args.cpu_sample > 0) else 0)
     if world > 1 or rank != 0:
         want_job = 0
+    if args.stream_reads is None:
+        args.stream_reads = 620_000_000 if (want_job and default_workload) else 0
     if not want_job:
         src.release()
         del src
@@ -1418,9 +1581,6 @@ def main():
             except Exception as e:
                 job_out = {"skipped": "writing the job's FASTQ failed: %r" % (e,)}
                 log("[bench] job leg: %r" % (e,))
-    if src is not None:
-        src.release()
-        del src
     gx.close()
     del batches
     torch.cuda.empty_cache()
@@ -1434,6 +1594,29 @@ def main():
             raise
         except Exception as e:
             job_out = {"skipped": "failed: %r" % (e,)}
+    # ---- ... and the metric's own job size, 30x = 620 M reads, streamed through a FIFO (never a file): job_stream
+    stream_out = None
+    if rank == 0 and src is not None and args.stream_reads:
+        left = BUDGET_S - (time.time() - T_START)
+        if job_out is not None and "skipped" in job_out and job_dir is None:
+            job_dir = "/tmp/vg_bench_job"
+        if left < 900:                                                # (the child legs behind this one need ~800 s)
+            stream_out = {"skipped": "time budget: %.0f s left" % left}
+        else:
+            try:
+                os.makedirs(job_dir, exist_ok=True)
+                if os.path.exists(os.path.join(job_dir, "job.fq")):
+                    os.remove(os.path.join(job_dir, "job.fq"))        # (63 GB of tmpfs back before anything else)
+                stream_out = job_stream(src, d, job_dir, prefix, dev_index, args.stream_reads, args.reads, args.lowq, args.read_len, log)
+            except AssertionError:
+                raise
+            except Exception as e:
+                stream_out = {"skipped": "failed: %r" % (e,)}
+                log("[bench] job_stream: %r" % (e,))
+    if src is not None:
+        src.release()
+        del src
+    torch.cuda.empty_cache()
     if job_dir is not None:
         import shutil
 
@@ -1499,6 +1682,7 @@ def main():
             "sustained": sustained,
             "ingest_end_to_end": ingest,
             "job": job_out,
+            "job_stream": stream_out,
             "multi_gpu_verification": verification,
             "multi_gpu_per_rank": per_rank,
             "secondary": secondary if legs else None,
