@@ -1012,7 +1012,7 @@ def drop_file_cache(directory):
 
 
 # host memory a child leg needs at its peak, GB: index files on tmpfs or in the page cache + `vargeno index`'s arrays + the oracle's copy
-CHILD_LEG_ROOM_GB = {"chr22": 12, "chr22_compact": 12, "repeats30": 140, "hg38f": 250, "softmask50": 140}
+CHILD_LEG_ROOM_GB = {"chr22": 12, "chr22_compact": 12, "repeats30": 140, "hg38f": 235, "softmask50": 140}
 
 
 def run_child_leg(name, est, extra, args, ref):
