@@ -60,6 +60,14 @@ def test_cli_matches_the_reference_binary_at_scale(tmp_path):
     ref = open(os.path.join(d, "ref.vcf"), "rb").read()
     assert ours.count(b"\n") > 100_000
     assert ours == ref
+    # r06: the same job under a 10 GB device budget (tables of the index's own size: ~7.6 GB instead of 91) -- the same bytes; and with a
+    # direct table forced down to 2^16 buckets, whose buckets then hold ~1 100 entries where the record's count field has 8 bits: the loader
+    # must notice, give the merged view up (the look-up falls back to the dictionaries' own tables) and say so -- the same bytes again
+    for extra, must_say in (({"VARGENO_MAX_DEVICE_GB": "10"}, "direct table of 2^2"), ({"VG_DX_BITS": "16"}, "not kept: a bucket of more than 255 entries")):
+        p = subprocess.run([BIN, "geno", "idx", "reads.fq", "snps.vcf", "ours2.vcf"], cwd=d, env=dict(env, VARGENO_VERBOSE="1", **extra), capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        assert must_say in p.stderr, p.stderr
+        assert open(os.path.join(d, "ours2.vcf"), "rb").read() == ref, extra
 
 
 def _hg38_cli_job(tmp_dir):
