@@ -4,6 +4,8 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/r06_suite
 mkdir -p $OUT
+# (the pool hands the same box to consecutive leases: what earlier ones left behind goes first -- a 79 GB root fills up)
+rm -rf /tmp/vg_bench /tmp/vg_bench_job /dev/shm/vg_bench* /tmp/pytest-of-* 2>/dev/null
 cd $R
 ( while true; do echo "$(date +%s) mem $(cat /sys/fs/cgroup/memory.current 2>/dev/null) max $(cat /sys/fs/cgroup/memory.max 2>/dev/null) root $(df --output=used -B1 / | tail -1) shm $(df --output=used -B1 /dev/shm | tail -1)"; sleep 5; done ) > $OUT/watch.txt 2>&1 &
 W=$!
