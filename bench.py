@@ -994,7 +994,16 @@ def cgroup_room():
         except Exception:
             return None
     mx, cur = rd("/sys/fs/cgroup/memory.max"), rd("/sys/fs/cgroup/memory.current")
-    return None if mx is None or cur is None else mx - cur
+    if mx is None or cur is None:
+        return None
+    # (page cache of files on disk is charged too, but given up under pressure: memory.stat's `file` less `shmem` does not count against the room)
+    cache = 0
+    try:
+        stat = dict(ln.split()[:2] for ln in open("/sys/fs/cgroup/memory.stat"))
+        cache = max(0, int(stat.get("file", 0)) - int(stat.get("shmem", 0)))
+    except Exception:
+        pass
+    return mx - max(0, cur - cache)
 
 
 def drop_file_cache(directory):

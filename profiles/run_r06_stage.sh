@@ -5,6 +5,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
 OUT=$R/gpurun_out/r06_stage_$TAG
 mkdir -p $OUT
+# (the pool hands the same box to consecutive leases: what earlier ones left behind goes first -- a 79 GB root fills up)
+rm -rf /tmp/vg_bench /tmp/vg_bench_job /dev/shm/vg_bench* /tmp/pytest-of-* 2>/dev/null
+cat /sys/fs/cgroup/memory.stat 2>/dev/null | grep -E "^(anon|file|shmem|kernel|slab) " | tr '\n' ' '; echo
 cd $R
 ( while true; do echo "$(date +%s) mem $(cat /sys/fs/cgroup/memory.current) root $(df --output=used -B1 / | tail -1) shm $(df --output=used -B1 /dev/shm | tail -1)"; sleep 5; done ) > $OUT/watch.txt 2>&1 &
 W=$!

@@ -95,7 +95,14 @@ def cgroup_room():
     mx, cur = _cg("/sys/fs/cgroup/memory.max"), _cg("/sys/fs/cgroup/memory.current")
     if mx is None or cur is None:
         return None
-    return mx - cur
+    # (page cache of files on disk is charged too, but given up under pressure: memory.stat's `file` less `shmem` does not count against the room)
+    cache = 0
+    try:
+        stat = dict(ln.split()[:2] for ln in open("/sys/fs/cgroup/memory.stat"))
+        cache = max(0, int(stat.get("file", 0)) - int(stat.get("shmem", 0)))
+    except Exception:
+        pass
+    return mx - max(0, cur - cache)
 
 
 def drop_file_cache(directory):
@@ -159,9 +166,10 @@ def _memory_watchdog():
     def watch():
         warned = False
         while not stop.wait(0.5):
-            cur = _cg("/sys/fs/cgroup/memory.current")
-            if cur is None:
+            room = cgroup_room()
+            if room is None:
                 continue
+            cur = mx - room                                          # (what cannot be reclaimed: anonymous memory + tmpfs)
             if cur > 0.85 * mx and not warned:
                 warned = True
                 sys.stderr.write("\n[memory watchdog] %.0f of %.0f GB in use: dropping the page cache of /tmp/vg_bench\n" % (cur / 1e9, mx / 1e9))
