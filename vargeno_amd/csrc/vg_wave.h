@@ -1420,8 +1420,61 @@ __device__ __forceinline__ void vg_wave_body(const DevIndex &d, const uint64_t *
 							}
 							VG_CLK(7);
 							VG_CLKW(8);
+						} else if (!STATS && n <= 8u && (uint64_t)target + 32u * n <= d.pile_len) {
+							// Reads of five to eight chunks (250 bp: seven) the same way (r06): their supporting contexts lie in [target, target + 256),
+							// which five rank blocks cover -- one or two lines for the whole read, where the byte-per-position walk below costs a pile
+							// line and a rank line PER CONTEXT (5.6 contexts per 250 bp read: 11 of its ~25 lines; profiles/traffic_r05_len250.json had
+							// the kernel at 1.38 x its algorithmic bytes for that).  A block of its own, so that the four-chunk walk keeps its registers.
+							const uint32_t blk0 = target >> 6, blk_last = (target + 32u * n - 1u) >> 6;
+							const ulonglong2 zz = make_ulonglong2(0ull, 0ull);
+							VG_VC_AS(VC_READS, pk_kmer + (uint64_t)slot0, 8u * n);
+							const ulonglong2 r0 = gather_walk<ulonglong2>(d.srank + blk0);
+							const ulonglong2 r1 = blk0 + 1u <= blk_last ? gather_walk<ulonglong2>(d.srank + (blk0 + 1u)) : zz;
+							const ulonglong2 r2 = blk0 + 2u <= blk_last ? gather_walk<ulonglong2>(d.srank + (blk0 + 2u)) : zz;
+							const ulonglong2 r3 = blk0 + 3u <= blk_last ? gather_walk<ulonglong2>(d.srank + (blk0 + 3u)) : zz;
+							const ulonglong2 r4 = blk0 + 4u <= blk_last ? gather_walk<ulonglong2>(d.srank + (blk0 + 4u)) : zz;
+							uint64_t f0, f1, f2, f3, f4, f5 = 0, f6 = 0, f7 = 0;   // the read's k-mers in file order (n >= 5)
+							{
+								ulonglong2 v;
+								__builtin_memcpy(&v, pk_kmer + (uint64_t)slot0, 16); f0 = v.x; f1 = v.y;
+								__builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + 2), 16); f2 = v.x; f3 = v.y;
+								if (n >= 6u) { __builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + 4), 16); f4 = v.x; f5 = v.y; } else f4 = pk_kmer[(uint64_t)slot0 + 4];
+								if (n == 8u) { __builtin_memcpy(&v, pk_kmer + ((uint64_t)slot0 + 6), 16); f6 = v.x; f7 = v.y; } else if (n == 7u) f6 = pk_kmer[(uint64_t)slot0 + 6];
+							}
+							uint32_t em = bmask, ni = 0;
+							for (;;) {
+								uint32_t c, mod = NOMOD;
+								if (em) { c = (uint32_t)__ffs((int)em) - 1u; em &= em - 1u; }
+								else {
+									if (ni >= ncnt) break;
+									const uint32_t mt = N_meta[ni][col], p = N_kpos[ni][col];
+									ni++;
+									c = mt & 31u; mod = (mt >> 5) & 31u;
+									if (p - 32u * c != target) continue;
+								}
+								const uint32_t fi = pass ? n - 1u - c : c;
+								uint64_t kk = fi == 0 ? f0 : fi == 1 ? f1 : fi == 2 ? f2 : fi == 3 ? f3 : fi == 4 ? f4 : fi == 5 ? f5 : fi == 6 ? f6 : f7;
+								if (pass) kk = revcomp64(kk);
+								const uint32_t o = (target & 63u) + 32u * c;         // bit offset of the window in the blocks (< 288: blocks 0 .. 4)
+								const uint32_t z = o >> 6, sh = o & 63u;
+								const uint64_t w0 = z == 0 ? r0.x : z == 1 ? r1.x : z == 2 ? r2.x : z == 3 ? r3.x : r4.x;
+								const uint64_t w1 = z == 0 ? r1.x : z == 1 ? r2.x : z == 2 ? r3.x : r4.x;       // only read when the window crosses into it (then z <= 3)
+								uint32_t sites = (uint32_t)(w0 >> sh);
+								if (sh > 32u) sites |= (uint32_t)(w1 << (64u - sh));
+								if (mod < 32u) sites &= ~(1u << mod);
+								while (sites) {
+									const uint32_t b = (uint32_t)__ffs((int)sites) - 1;
+									sites &= sites - 1;
+									const uint32_t ob = o + b, zb = ob >> 6;
+									const uint64_t mx_ = zb == 0 ? r0.x : zb == 1 ? r1.x : zb == 2 ? r2.x : zb == 3 ? r3.x : r4.x;
+									const uint64_t my_ = zb == 0 ? r0.y : zb == 1 ? r1.y : zb == 2 ? r2.y : zb == 3 ? r3.y : r4.y;
+									const uint32_t sid = (uint32_t)my_ + (uint32_t)__popcll(mx_ & ((1ull << (ob & 63u)) - 1ull));
+									VG_VC(&d.cnt4[4ull * sid + ((uint32_t)(kk >> (2 * b)) & 3u)], 4);
+									atomicAdd(&d.cnt4[4ull * sid + ((uint32_t)(kk >> (2 * b)) & 3u)], 1u);
+								}
+							}
 						} else {
-						// Reads of more than four chunks, and the counting build: the byte-per-position walk of qv.cc:1386-1436 -- per
+						// Reads of more than eight chunks, and the counting build: the byte-per-position walk of qv.cc:1386-1436 -- per
 					// supporting context its k-mer and its 32-byte pile window, then one rank-block gather + atomic per counted base
 					// (the base a neighbour context was found with lies at the one position the walk leaves out, :1397)
 					auto count = [&](uint32_t p, uint32_t which) { cur.add(S_INCR, 1); bump_site(d, p, which); };
