@@ -846,12 +846,46 @@ __global__ __launch_bounds__(256) void vg_fq_gather(const uint8_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // host side of the handle
 // ------------------------------------------------------------------------------------------------
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// hipMalloc that waits for memory on its way back.  Device memory that a handle -- or a process that has just ended -- gave up is
+// not there for the next allocation at once: the driver clears it first, about 88 GB in 2.4 s on this part, and until then the
+// runtime's book (hipMemGetInfo) already counts it free while hipMalloc still says no (profiles/vram_release_lag_r06.txt: four
+// small jobs one after the other, each with the whole device's widest tables, had 300 GB "in use" between them).  So a refusal is
+// final only when the book agrees: while it says the bytes are free -- or the free figure is still growing -- the call is repeated,
+// for at most $VG_ALLOC_WAIT_S seconds (default 20; 0 = one attempt).
+static hipError_t vg_malloc_patient(void **p, size_t bytes)
+{
+	hipError_t e = hipMalloc(p, bytes);
+	if (e == hipSuccess) return e;
+	(void)hipGetLastError();
+	const char *w = getenv("VG_ALLOC_WAIT_S");
+	const double limit = w && *w ? atof(w) : 20.0;
+	const double t0 = now_s();
+	double grew = t0;
+	size_t best = 0;
+	while (now_s() - t0 < limit) {
+		size_t fr = 0, tot = 0;
+		if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); break; }
+		if (fr > best + (256u << 20)) { best = fr; grew = now_s(); }
+		if (fr < bytes && now_s() - grew > 4.0) break;           // somebody holds it: that is the answer
+		usleep(100000);
+		e = hipMalloc(p, bytes);
+		if (e == hipSuccess) {
+			if (getenv("VG_VERBOSE")) fprintf(stderr, "[vargeno_hip] hipMalloc(%.1f GB) waited %.1f s for memory the driver was still clearing\n", bytes / 1e9, now_s() - t0);
+			return e;
+		}
+		(void)hipGetLastError();
+	}
+	return e;
+}
+
 // the driver calls behind vg_arena.h: one hipMalloc per handle
 struct HipBlock {
 	static void *alloc(uint64_t bytes)
 	{
 		void *p = nullptr;
-		if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+		if (vg_malloc_patient(&p, bytes) != hipSuccess) return nullptr;
 		return p;
 	}
 	static void free(void *p) { (void)hipFree(p); }
@@ -947,7 +981,6 @@ struct vg_index {
 // on one thread each): where TempDev finds the arena and the stream.
 static thread_local vg_index *g_building = nullptr;
 static thread_local double g_alloc_s = 0;                  // seconds spent inside allocation calls since the last lap (VG_VERBOSE)
-static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // a permanent array of the index: out of the arena's bottom half; hipMalloc when the arena is not there (or `plain`: buffers that
 // other libraries get to see -- RCCL reduces the counters in place)
@@ -959,8 +992,8 @@ static int dev_alloc(vg_index *ix, T **p, uint64_t count, bool zero = false, boo
 	const double t0 = now_s();
 	if (!plain) { q = ix->arena.take(bytes, false); if (!q && ix->arena.ready()) { ix->arena_misses++; ix->arena_miss_bytes += bytes; } }
 	if (!q) {
-		hipError_t e = hipMalloc(&q, bytes);
-		if (e != hipSuccess) { (void)hipGetLastError(); return fail(VG_ENOMEM, "hipMalloc(%s bytes): %s", std::to_string(bytes).c_str(), hipGetErrorString(e)); }
+		hipError_t e = vg_malloc_patient(&q, bytes);
+		if (e != hipSuccess) { return fail(VG_ENOMEM, "hipMalloc(%s bytes): %s", std::to_string(bytes).c_str(), hipGetErrorString(e)); }
 		ix->owned.push_back(q);
 		ix->owned_bytes[q] = bytes;
 		ix->dev_bytes += bytes;
@@ -1004,8 +1037,8 @@ struct TempDev {
 		const double t0 = now_s();
 		if (g_building) { p = (T *)g_building->arena.take(bytes, true); if (p) ix = g_building; else if (g_building->arena.ready()) { g_building->arena_misses++; g_building->arena_miss_bytes += bytes; } }
 		if (!p) {
-			hipError_t e = hipMalloc((void **)&p, bytes);
-			if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; return fail(VG_ENOMEM, "hipMalloc(staging): %s", hipGetErrorString(e)); }
+			hipError_t e = vg_malloc_patient((void **)&p, bytes);
+			if (e != hipSuccess) { p = nullptr; return fail(VG_ENOMEM, "hipMalloc(staging): %s", hipGetErrorString(e)); }
 		}
 		g_alloc_s += now_s() - t0;
 		return VG_OK;
@@ -2462,7 +2495,7 @@ extern "C" int vg_read_store_create(int device, uint64_t max_bytes, vg_read_stor
 		std::unique_ptr<vg_read_store> rs(new vg_read_store);
 		rs->device = device;
 		max_bytes = (max_bytes + 4095) & ~4095ull;
-		hipError_t e = hipMalloc((void **)&rs->block, max_bytes);
+		hipError_t e = vg_malloc_patient((void **)&rs->block, max_bytes);
 		if (e != hipSuccess) { char t[64]; snprintf(t, sizeof t, "%.1f GB", max_bytes / 1e9); return fail(VG_ENOMEM, "hipMalloc(read store, %s): %s", t, hipGetErrorString(e)); }
 		rs->bytes = max_bytes;
 		if (hipStreamCreateWithFlags(&rs->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(rs->block); return fail(VG_ENODEV, "hipStreamCreate(read store) failed"); }
