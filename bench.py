@@ -772,6 +772,23 @@ def main_kernel_name(views):
     return "vg_wave_kernel_big" if "mx" not in views else "vg_wave_kernel"
 
 
+def same_device_code(a, b):
+    """Two builds of the library whose kernels are the same machine code (profiles/device_code_sha.sh prints build id and the sha256
+    of the gfx950 code object's .text; profiles/device_code_r*.txt keeps the lines): a counter profile of one holds for the other.
+    Returns the file and hash that say so, or None."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "device_code_r*.txt"))):
+        sha = {}
+        for line in open(path):
+            f = line.split()
+            if len(f) >= 8 and f[0] == "build" and "sha256" in f:
+                sha[f[1]] = f[f.index("sha256") + 1]
+        if a in sha and b in sha and sha[a] == sha[b]:
+            return "%s, .text sha256 %s" % (os.path.basename(path), sha[a][:16])
+    return None
+
+
 def traffic_for(args, build_id):
     """HBM traffic and L2 misses of the dominant kernel cannot be counted inside a timed run: they come from the separate
     rocprofv3 --pmc passes of this same command, committed under profiles/ -- and only of THIS build of the library: a traffic
@@ -787,11 +804,14 @@ def traffic_for(args, build_id):
             if {k: w.get(k) for k in want} != want or float(w.get("lowq", 0.08)) != args.lowq or float(w.get("repeats", 0.0)) != args.repeats or bool(w.get("gate_words", True)) != bool(args.gate_words) \
                     or int(w.get("read_len", 150)) != args.read_len or float(w.get("softmask", 0.0)) != args.softmask or (w.get("device_budget") or None) != (args.device_budget or None):
                 continue
-            if tj.get("build_id") != build_id:
+            same = same_device_code(tj.get("build_id"), build_id)
+            if tj.get("build_id") != build_id and not same:
                 note = "%s was measured on build %s, this is build %s: not quoted" % (os.path.basename(path), tj.get("build_id"), build_id)
                 continue
             traffic, misses = tj["traffic_bytes_per_launch"], tj.get("TCC_MISS_sum")
-            note = "%s (separate rocprofv3 --pmc passes of this command on this build; %s)" % (os.path.basename(path), tj.get("traffic_formula", "FETCH_SIZE + WRITE_SIZE"))
+            note = "%s (separate rocprofv3 --pmc passes of this command on %s; %s)" % (
+                os.path.basename(path), "this build" if tj.get("build_id") == build_id else "build %s, whose kernels are byte-identical to this build's: %s" % (tj.get("build_id"), same),
+                tj.get("traffic_formula", "FETCH_SIZE + WRITE_SIZE"))
             break
         except Exception:
             pass
