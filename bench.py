@@ -599,6 +599,112 @@ def job_run(d, job_dir, job, log):
     return out
 
 
+class FifoFeed:
+    """The writing end of the `job_stream` leg's FIFO.  A pipe is two copies (write(): user -> pipe pages, read(): pipe pages -> user)
+    and a page allocation per 4 KiB; `vmsplice` lends the pipe the writer's own pages instead, so that only the reader's copy is left
+    (1.6 x the rate in the build container: 2.5 -> 4.0 GB/s).  Lent pages must not change before they are read: the last
+    2 x pipe-size bytes of every buffer go through write() -- when that returns every slot of the pipe's ring holds a copied page, so no
+    page of the buffer is in the pipe any more and the caller may refill it.  Memory the kernel cannot lend (device-driver mappings such
+    as hipHostMalloc's) or a kernel that refuses the call: plain write() from the first refusal on."""
+
+    def __init__(self, fd, lend=True):
+        import ctypes
+        import fcntl
+
+        self.fd = fd
+        self.lent_bytes = 0
+        self.copied_bytes = 0
+        self.refusal = None
+        try:
+            fcntl.fcntl(fd, 1031, 1 << 20)                            # F_SETPIPE_SZ: the largest pipe an unprivileged process may ask for
+        except Exception:
+            pass
+        try:
+            self.pipe_bytes = int(fcntl.fcntl(fd, 1032))              # F_GETPIPE_SZ
+        except Exception:
+            self.pipe_bytes = 1 << 16
+        self.libc = None
+        if lend:
+            try:
+                self.libc = ctypes.CDLL(None, use_errno=True)
+                self.libc.vmsplice.restype = ctypes.c_ssize_t
+                self.libc.vmsplice.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_ulong, ctypes.c_uint]
+            except Exception as e:
+                self.libc, self.refusal = None, repr(e)
+
+    def write_all(self, view):
+        """All of `view` (a writable contiguous buffer: memoryview / numpy uint8 array) into the pipe; returns when none of its pages is
+        in the pipe any more."""
+        import ctypes
+
+        mv = memoryview(view).cast("B")
+        n = len(mv)
+        tail = min(n, 2 * self.pipe_bytes + 8192)
+        at = 0
+        if self.libc is not None and n > tail:
+            base = ctypes.addressof(ctypes.c_char.from_buffer(mv))
+
+            class IoVec(ctypes.Structure):
+                _fields_ = [("base", ctypes.c_void_p), ("len", ctypes.c_size_t)]
+            iov = IoVec()
+            while at < n - tail:
+                iov.base, iov.len = base + at, min(n - tail - at, 16 << 20)
+                w = self.libc.vmsplice(self.fd, ctypes.byref(iov), 1, 0)
+                if w < 0:
+                    err = ctypes.get_errno()
+                    if err == 4:                                       # EINTR
+                        continue
+                    if err == 32:                                      # EPIPE: the reader has gone
+                        raise BrokenPipeError(err, os.strerror(err))
+                    self.libc, self.refusal = None, "vmsplice: %s" % os.strerror(err)
+                    break
+                at += w
+            self.lent_bytes += at
+        while at < n:
+            w = os.write(self.fd, mv[at:at + (64 << 20)])
+            at += w
+            self.copied_bytes += w
+
+
+def lendable_pinned_buffer(nbytes):
+    """(numpy uint8 view, owner, kind): anonymous memory -- which a pipe can borrow, FifoFeed -- page-locked for the device's copy engine
+    through hipHostRegister; when that is not to be had, the library's page-locked allocation (hipHostMalloc: a driver mapping, copies
+    at the same rate, but a pipe cannot borrow it)."""
+    import ctypes
+    import mmap
+
+    try:
+        import torch
+
+        m = mmap.mmap(-1, int(nbytes))                                # page-aligned, zero-filled on first touch
+        try:
+            m.madvise(mmap.MADV_HUGEPAGE)
+        except Exception:
+            pass
+        arr = np.frombuffer(m, dtype=np.uint8)
+        arr[::4096] = 0                                               # every page exists before it is locked
+        addr = ctypes.addressof(ctypes.c_char.from_buffer(m))
+        rc = torch.cuda.cudart().cudaHostRegister(addr, int(nbytes), 0)
+        if int(rc) != 0:
+            raise RuntimeError("hipHostRegister: %r" % (rc,))
+
+        class _Owner:
+            def __init__(self):
+                self.m, self.addr = m, addr
+
+            def __del__(self):
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(self.addr)
+                except Exception:
+                    pass
+        return arr, _Owner(), "anonymous memory, hipHostRegister"
+    except Exception as e:
+        from vargeno_amd.api import pinned_buffer
+
+        a, own = pinned_buffer(nbytes)
+        return a, own, "hipHostMalloc (%r)" % (e,)
+
+
 def job_stream(src, d, job_dir, prefix, dev_index, n_reads, batch_reads, lowq, read_len, log, deadline_s=90.0):
     """The metric's own job size through the command line: BASELINE.json quotes "hg38 + dbSNP 30x" = 620 M reads, 195 GB of FASTQ -- more
     than the container may keep in a file beside everything else, so the reads are never a file: this process generates them batch
@@ -640,20 +746,16 @@ def job_stream(src, d, job_dir, prefix, dev_index, n_reads, batch_reads, lowq, r
                 return {"skipped": "the command line did not open the FIFO: %r / %s" % (e, (p.communicate()[1] or "")[-300:])}
             time.sleep(0.01)
     fcntl.fcntl(fd, fcntl.F_SETFL, fcntl.fcntl(fd, fcntl.F_GETFL) & ~os.O_NONBLOCK)
-    try:
-        fcntl.fcntl(fd, 1031, 1 << 20)                                # F_SETPIPE_SZ: the largest pipe an unprivileged process may ask for
-    except Exception:
-        pass
+    feed = FifoFeed(fd, lend=os.environ.get("VG_BENCH_FIFO_LEND", "1") != "0")
     pins = [None, None]
+    pin_kind = None
     done, gen_s, write_s, nb = 0, 0.0, 0.0, 0
     t_feed = time.time()
     wr = {"th": None, "err": None}
 
     def write_all(view):
         try:
-            at, n = 0, len(view)
-            while at < n:
-                at += os.write(fd, view[at:at + (64 << 20)])
+            feed.write_all(view)
         except Exception as e:                                        # (EPIPE: the child has gone)
             wr["err"] = e
     try:
@@ -683,8 +785,13 @@ def job_stream(src, d, job_dir, prefix, dev_index, n_reads, batch_reads, lowq, r
             if wr["th"] is not None and pins[k2] is not None:
                 pass                                                  # (the buffer of two batches ago: its writer has been joined below)
             if pins[k2] is None or len(pins[k2][0]) < nbytes:
-                pins[k2] = pinned_buffer(nbytes)
+                pins[k2] = None
+                pins[k2] = lendable_pinned_buffer(nbytes) if feed.libc is not None else pinned_buffer(nbytes) + ("hipHostMalloc",)
+                pin_kind = pins[k2][2]
             torch.as_tensor(pins[k2][0][:nbytes]).copy_(m.view(-1))   # device -> page-locked host
+            if nb == 0 and os.environ.get("VG_BENCH_KEEP_FASTQ"):      # (profiles/pipe_ab.py feeds this text again and again)
+                with open(os.environ["VG_BENCH_KEEP_FASTQ"], "wb") as f:
+                    f.write(memoryview(pins[k2][0][:nbytes]))
             del m, ids, tb, tq, to
             gen_s += time.time() - tg
             tw = time.time()
@@ -711,6 +818,7 @@ def job_stream(src, d, job_dir, prefix, dev_index, n_reads, batch_reads, lowq, r
     out = {"reads": done, "reads_wanted": n_reads, "fastq_GB": done * (2 * read_len + 17) / 1e9, "wall_s": wall, "whole_job_reads_per_s": done / wall, "rc": p.returncode,
            "feed_s": feed_s, "generator_s": gen_s, "generator_waiting_for_the_pipe_s": write_s, "feed_GB_per_s": done * (2 * read_len + 17) / 1e9 / max(feed_s, 1e-9),
            "input": "a FIFO this process writes (reads generated on the device, FASTQ text put together there, one batch in flight): the command line's once-only route",
+           "feed_pages": {"lent_to_the_pipe_GB": feed.lent_bytes / 1e9, "copied_GB": feed.copied_bytes / 1e9, "pipe_bytes": feed.pipe_bytes, "buffers": pin_kind, "refusal": feed.refusal},
            "bound_by": "the feed (generator + pipe): the command line waits for text" if feed_s > 0.8 * wall else "the command line"}
     if p.returncode != 0 or wr["err"] is not None:
         out["failed"] = ((se or "")[-500:] + " | writer: %r" % (wr["err"],))

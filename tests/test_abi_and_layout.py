@@ -238,3 +238,63 @@ def test_bench_line_stays_small_enough_for_the_driver_to_parse():
     small = json.loads(bench.compact_line(full, "x"))
     assert set(small["secondary"]) == set(full["secondary"]) and small["secondary"]["chr22"]["parity"] is True
     assert abs(small["value"] / full["value"] - 1) < 1e-5 and abs(small["roofline"]["frac"] / full["roofline"]["frac"] - 1) < 1e-3
+
+
+@pytest.mark.parametrize("lend", [True, False])
+def test_bench_fifo_feed_never_changes_bytes_the_reader_has_not_seen(lend):
+    """bench.FifoFeed (the `job_stream` leg's writer) lends the pipe its own pages (vmsplice) and refills a buffer as soon as
+    write_all has returned: a slow reader must still see every byte as it was written.  ONE buffer refilled at once (the bench
+    rotates two: this is the stronger claim), odd sizes, a reader that sleeps; also the copying route (lend=False: what a refused vmsplice falls back to)."""
+    import importlib.util
+    import mmap
+    import sys
+    import threading
+    import time
+
+    import numpy as np
+
+    spec = importlib.util.spec_from_file_location("vg_bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    r, w = os.pipe()
+    feed = bench.FifoFeed(w, lend=lend)
+    n = 5 * (1 << 20) + 12345
+    buf = np.frombuffer(mmap.mmap(-1, n), dtype=np.uint8)
+    rounds = 7
+    got = []
+
+    def reader():
+        k = 0
+        while True:
+            b = os.read(r, 200_000 + 4096 * (k % 5))
+            if not b:
+                return
+            got.append(b)
+            k += 1
+            if k % 4 == 0:
+                time.sleep(0.03)                                  # (slow enough that a megabyte of lent pages is still in the pipe when the writer refills:
+                                                                  #  without the copied tail this test fails)
+    th = threading.Thread(target=reader)
+    th.start()
+    want = []
+    base = np.arange(n, dtype=np.uint32)
+    pats = [((base * (2 * k + 3) + k) >> 3).astype(np.uint8) for k in range(rounds)]
+    for k in range(rounds):
+        buf[:] = pats[k]
+        feed.write_all(buf[: n - 17 * k])                        # (ends that are not page ends)
+        want.append(pats[k][: n - 17 * k])
+    os.close(w)
+    th.join()
+    os.close(r)
+    assert b"".join(got) == b"".join(x.tobytes() for x in want)
+    total = sum(len(x) for x in want)
+    assert feed.lent_bytes + feed.copied_bytes == total
+    if lend and feed.refusal is None:
+        assert feed.lent_bytes > total // 2                       # (the pages were lent, the tails copied)
+    else:
+        assert feed.lent_bytes == 0

@@ -823,7 +823,10 @@ int main(int argc, const char *argv[])
 			if (fd < 0) throw vgh::Error{std::string("cannot open ") + argv[2]};
 			const uint64_t chunk = argc > 3 ? (uint64_t)atoll(argv[3]) : (1ull << 20);
 			std::vector<std::string> lines;
+			const bool quiet = env_int("VARGENO_FQPIPE_QUIET", 0) != 0;          // (a rate probe of the route: count, print nothing)
+			uint64_t counted = 0;
 			auto one = [&](uint64_t nch, const uint64_t *km, uint64_t meta) {
+				if (quiet) { counted += 1 + (nch & 0); return; }
 				if (meta >> 63) { lines.push_back("X"); return; }
 				if ((meta >> 62) & 1u) { lines.push_back("N"); return; }
 				std::string l = std::to_string(nch) + " ";
@@ -840,6 +843,7 @@ int main(int argc, const char *argv[])
 			pin.finish();
 			if (!pin.error.empty()) throw vgh::Error{pin.error};
 			fprintf(stderr, "fqpipe: %lu records framed by the packer, %lu bytes consumed of %lu read, refused %d\n", (unsigned long)pin.records, (unsigned long)pin.consumed, (unsigned long)pin.bytes_read, pin.refused ? 1 : 0);
+			if (quiet) fprintf(stderr, "fqpipe: %lu reads through the sink, %.3f s, %.3f GB/s of text\n", (unsigned long)counted, pin.seconds, pin.seconds > 0 ? (double)pin.bytes_read / pin.seconds / 1e9 : 0.0);
 			vgh::FastqReader rd(fd, pin.span_base, pin.spans);
 			vgh::ReadBatch rb;
 			if (pin.records) { rd.seek(pin.last); rb.clear(); (void)rd.next(rb, 1); }
