@@ -508,3 +508,57 @@ def test_fastq_that_can_be_read_only_once(tmp_path):
     f = tmp_path / "plain.fq"
     got = subprocess.run(["bash", "-c", "%s fqpipe <(cat %s) 65536 2" % (str(BIN), f)], capture_output=True, check=True).stdout.decode().split("\n")[:-1]
     assert got == _reduce_fqcheck(subprocess.run([BIN, "fqcheck", str(f)], capture_output=True, check=True).stdout)
+
+
+def test_once_only_fastq_route_is_clean_under_thread_sanitizer(tmp_path):
+    """The once-only FASTQ route is three kinds of threads around a ring of chunks (PipeIngest's reader and worker, host/main.cpp;
+    the packer's pool, vg_hostpack.cpp: atomics, a brief spin, a condition variable).  The command line is built here with
+    -fsanitize=thread, with an INSTRUMENTED packer linked in (tests/packer_shim_tsan.cpp: the library's own copy is built by hipcc
+    without the sanitizer, which then cannot see the pool's hand-over), and `fqpipe` is run over FIFOs fed in uneven pieces -- plain,
+    a truncated final record, a refusal in the middle (the host reader takes over what the reader thread had read ahead), an empty
+    stream -- with chunks of 64 KiB to 1 MiB and 1 / 3 / 6 packer threads: no report, and the same records as the ordinary binary."""
+    import random
+    import threading
+
+    CSRC = os.path.join(ROOT, "vargeno_amd", "csrc")
+    flags = ["-std=c++17", "-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-march=x86-64-v2", "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
+    objs = []
+    for src, extra in (("vg_hostpack.cpp", []), ("vg_hostpack_avx2.cpp", ["-mavx2", "-mbmi2"])):
+        o = str(tmp_path / (src + ".o"))
+        subprocess.check_call(["g++"] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", o])
+        objs.append(o)
+    exe = str(tmp_path / "vargeno_tsan")
+    host = [os.path.join(CSRC, "host", f) for f in ("main.cpp", "index_build.cpp", "fastq.cpp", "caller_vcf.cpp")]
+    subprocess.check_call(["g++"] + flags + ["-fopenmp", '-DVG_HOST_BUILD_ID="tsan"', "-o", exe] + host + [os.path.join(ROOT, "tests", "packer_shim_tsan.cpp")] + objs
+                          + ["-L" + CSRC, "-lvargeno_hip", "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib", "-ldl", "-lpthread"])
+    rng = random.Random(11)
+
+    def rec(i, n, q=None):
+        s = "".join(rng.choice("ACGT") for _ in range(n))
+        qq = (q * n)[:n] if q is not None else "".join(rng.choice("#'5:I") for _ in range(n))
+        return ("@r%d\n%s\n+\n%s\n" % (i, s, qq)).encode()
+
+    body = b"".join(rec(i, rng.choice([150, 150, 150, 101, 250, 64, 31, 33])) for i in range(6000))
+    cases = {"plain": body, "empty": b"", "truncated_tail": body + b"@rX\n" + b"ACGT" * 40 + b"\n+",
+             "long_line_in_the_middle": body[:700000] + rec(7, 1500, q="I") + body[700000:]}
+    for name, data in cases.items():
+        f = tmp_path / (name + ".fq")
+        f.write_bytes(data)
+        want = subprocess.run([BIN, "fqpipe", str(f), str(1 << 16), "2"], capture_output=True, check=True).stdout
+        for chunk, threads in ((1 << 16, 1), (300000, 3), (1 << 20, 6)):
+            fifo = str(tmp_path / ("%s_%d.fifo" % (name, chunk)))
+            os.mkfifo(fifo)
+
+            def feed():
+                with open(fifo, "wb", buffering=0) as w:
+                    at = 0
+                    while at < len(data):
+                        n = rng.choice([7, 4096, 65536, 100000, 1 << 20])
+                        w.write(data[at:at + n])
+                        at += n
+            t = threading.Thread(target=feed)
+            t.start()
+            p = subprocess.run([exe, "fqpipe", fifo, str(chunk), str(threads)], capture_output=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
+            t.join()
+            assert b"ThreadSanitizer" not in p.stderr and p.returncode == 0, (name, chunk, threads, p.stderr[-3000:].decode(errors="replace"))
+            assert p.stdout == want, (name, chunk, threads)
