@@ -296,5 +296,5 @@ def test_bench_fifo_feed_never_changes_bytes_the_reader_has_not_seen(lend):
     assert feed.lent_bytes + feed.copied_bytes == total
     if lend and feed.refusal is None:
         assert feed.lent_bytes > total // 2                       # (the pages were lent, the tails copied)
-    else:
+    elif not lend:
         assert feed.lent_bytes == 0
