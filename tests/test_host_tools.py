@@ -502,6 +502,13 @@ def test_fastq_that_can_be_read_only_once(tmp_path):
         got = subprocess.run([BIN, "fqpipe", fifo, str(1 << 16), "2"], capture_output=True, check=True).stdout.decode().split("\n")[:-1]
         t.join()
         assert got == want, (name, "fifo")
+        # ... and with the reader thread reading the descriptor itself / dealing it to one and to seven copier threads (the default is four)
+        for copiers in ("0", "1", "7"):
+            t = threading.Thread(target=feed)
+            t.start()
+            got = subprocess.run([BIN, "fqpipe", fifo, str(1 << 18), "2"], capture_output=True, check=True, env=dict(os.environ, VARGENO_PIPE_COPIERS=copiers)).stdout.decode().split("\n")[:-1]
+            t.join()
+            assert got == want, (name, "fifo", copiers)
         # (c) /dev/stdin and bash's process substitution
         got = subprocess.run([BIN, "fqpipe", "/dev/stdin", str(1 << 16), "2"], input=data, capture_output=True, check=True).stdout.decode().split("\n")[:-1]
         assert got == want, (name, "stdin")
@@ -516,7 +523,8 @@ def test_once_only_fastq_route_is_clean_under_thread_sanitizer(tmp_path):
     -fsanitize=thread, with an INSTRUMENTED packer linked in (tests/packer_shim_tsan.cpp: the library's own copy is built by hipcc
     without the sanitizer, which then cannot see the pool's hand-over), and `fqpipe` is run over FIFOs fed in uneven pieces -- plain,
     a truncated final record, a refusal in the middle (the host reader takes over what the reader thread had read ahead), an empty
-    stream -- with chunks of 64 KiB to 1 MiB and 1 / 3 / 6 packer threads: no report, and the same records as the ordinary binary."""
+    stream -- with chunks of 64 KiB to 1 MiB, 1 / 3 / 6 packer threads and as many copier threads (the reader deals the stream to them
+    through private pipes, splice): no report, and the same records as the ordinary binary."""
     import random
     import threading
 
@@ -558,7 +566,7 @@ def test_once_only_fastq_route_is_clean_under_thread_sanitizer(tmp_path):
                         at += n
             t = threading.Thread(target=feed)
             t.start()
-            p = subprocess.run([exe, "fqpipe", fifo, str(chunk), str(threads)], capture_output=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
+            p = subprocess.run([exe, "fqpipe", fifo, str(chunk), str(threads)], capture_output=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", VARGENO_PIPE_COPIERS=str(threads)))
             t.join()
             assert b"ThreadSanitizer" not in p.stderr and p.returncode == 0, (name, chunk, threads, p.stderr[-3000:].decode(errors="replace"))
             assert p.stdout == want, (name, chunk, threads)

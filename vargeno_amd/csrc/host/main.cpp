@@ -336,6 +336,7 @@ public:
 	bool refused = false;
 	uint64_t to_store = 0, direct = 0;                       // reads that went through a read store / straight into the read loop
 	double seconds = 0.0;                                    // from construction to the end of the stream
+	int copiers = 0;                                         // copier threads the reader dealt the stream to (0: it read() the descriptor itself)
 	std::string error;
 	// bytes [span_base, span_base + the spans) of the stream are still in memory (every chunk from the one that holds `last` on);
 	// the descriptor continues behind them
@@ -344,27 +345,88 @@ public:
 private:
 	struct Buf { std::vector<uint8_t> data; uint64_t len = 0, off = 0; bool last = false; };
 	static constexpr int NB = 4;                             // the chunk before the packer's (its tail may hold the last framed record), the packer's, two read ahead
+	// A pipe is one copy stream per reader: read() copies page by page under the pipe's lock (~5 GB/s against a producer that
+	// write()s, ~9 GB/s against one that lends its pages, profiles/pipe_ab_r06.jsonl).  splice() between two pipes MOVES page
+	// references instead: the reader thread deals the stream in segments to a few private pipes, and a copier thread per private
+	// pipe read()s its segments into their places in the chunk -- the copies run side by side ($VARGENO_PIPE_COPIERS, default 4;
+	// 0: the plain read() loop).  Everything taken from the descriptor has reached the ring when a chunk is handed on, so the
+	// host reader still continues at the descriptor.  A descriptor that cannot be spliced from (EINVAL on the first call): read().
+	struct Copier {
+		int r = -1, w = -1;
+		std::thread th;
+		std::mutex mu; std::condition_variable cv;
+		std::vector<std::pair<uint8_t *, size_t>> q; size_t head = 0;      // segments of the current chunk, in order
+		bool stop = false, failed = false;
+		void run()
+		{
+			for (;;) {
+				std::pair<uint8_t *, size_t> job;
+				{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return head < q.size() || stop; }); if (head >= q.size()) return; job = q[head]; }
+				size_t at = 0;
+				bool bad = false;
+				while (at < job.second) {
+					const ssize_t got = read(r, job.first + at, job.second - at);
+					if (got < 0 && errno == EINTR) continue;
+					if (got <= 0) { bad = true; break; }
+					at += (size_t)got;
+				}
+				{ std::lock_guard<std::mutex> g(mu); head++; if (bad) failed = true; }
+				cv.notify_all();
+			}
+		}
+		void push(uint8_t *dest, size_t n) { { std::lock_guard<std::mutex> g(mu); q.emplace_back(dest, n); } cv.notify_all(); }
+		bool drain() { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return head >= q.size(); }); q.clear(); head = 0; return !failed; }
+	};
 	void read_loop()
 	{
+		const int want = std::min(16, std::max(0, env_int("VARGENO_PIPE_COPIERS", 4)));
+		std::vector<std::unique_ptr<Copier>> cop;
+		for (int k = 0; k < want; k++) {
+			int p[2];
+			if (pipe(p) != 0) break;
+			(void)fcntl(p[1], F_SETPIPE_SZ, 1 << 20);               // (fails harmlessly when the user's pipe pages are used up: 64 KiB then)
+			cop.emplace_back(new Copier());
+			cop.back()->r = p[0]; cop.back()->w = p[1];
+			Copier *c = cop.back().get();
+			c->th = std::thread([c] { c->run(); });
+		}
+		bool fan = !cop.empty();
+		uint64_t seg = 0, spliced = 0;
 		for (uint64_t i = 0;; i++) {
 			{ std::unique_lock<std::mutex> g(mu_); cv_.wait(g, [&] { return i + 2 <= done_ + (uint64_t)NB || stop_reading_; }); if (stop_reading_) break; }
 			Buf &b = ring_[i % NB];
 			uint64_t got = 0;
-			bool eof = false;
+			bool eof = false, bad = false;
 			while (got < chunk_) {
-				const ssize_t g = read(fd_, b.data.data() + got, (size_t)(chunk_ - got));
-				if (g < 0 && errno == EINTR) continue;
-				if (g < 0) { std::lock_guard<std::mutex> l(mu_); io_error_ = true; eof = true; break; }
+				ssize_t g;
+				if (fan) {
+					Copier &c = *cop[(size_t)(seg % cop.size())];
+					g = splice(fd_, nullptr, c.w, nullptr, (size_t)std::min<uint64_t>(chunk_ - got, 1u << 20), SPLICE_F_MOVE);
+					if (g < 0 && errno == EINTR) continue;
+					if (g < 0 && spliced == 0 && (errno == EINVAL || errno == ENOSYS || errno == EBADF)) { fan = false; continue; }
+					if (g > 0) { c.push(b.data.data() + got, (size_t)g); seg++; spliced += (uint64_t)g; }
+				} else {
+					g = read(fd_, b.data.data() + got, (size_t)(chunk_ - got));
+					if (g < 0 && errno == EINTR) continue;
+				}
+				if (g < 0) { bad = true; eof = true; break; }
 				if (g == 0) { eof = true; break; }
 				got += (uint64_t)g;
 				// (a refusal: the packer will read no further -- hand over what has arrived, the host reader reads on from the descriptor)
 				{ std::lock_guard<std::mutex> l(mu_); if (stop_reading_) break; }
 			}
-			{ std::lock_guard<std::mutex> l(mu_); b.len = got; b.off = total_read_; b.last = eof; total_read_ += got; filled_ = i + 1; if (eof) eof_ = true; }
+			for (auto &c : cop) if (!c->drain()) { bad = true; eof = true; }      // (every byte taken from the descriptor is in the chunk now)
+			{ std::lock_guard<std::mutex> l(mu_); if (bad) io_error_ = true; b.len = got; b.off = total_read_; b.last = eof; total_read_ += got; filled_ = i + 1; if (eof) eof_ = true; }
 			cv_.notify_all();
 			if (eof) break;
 		}
-		{ std::lock_guard<std::mutex> l(mu_); reader_done_ = true; }
+		for (auto &c : cop) {
+			{ std::lock_guard<std::mutex> g(c->mu); c->stop = true; }
+			c->cv.notify_all();
+			c->th.join();
+			close(c->r); close(c->w);
+		}
+		{ std::lock_guard<std::mutex> l(mu_); reader_done_ = true; copiers_ = fan ? (int)cop.size() : 0; }
 		cv_.notify_all();
 	}
 	void work_loop()
@@ -430,6 +492,7 @@ private:
 			std::lock_guard<std::mutex> g(mu_);
 			if (io_error_) bail("error reading the FASTQ stream");
 			bytes_read = total_read_;
+			copiers = copiers_;
 			// chunks [first, filled_) are intact in the ring: first = the chunk before the last one the packer saw (or 0)
 			const uint64_t seen = i;                                             // chunks the packer has been given
 			const uint64_t first = seen >= 2 ? seen - 2 : 0;
@@ -448,6 +511,7 @@ private:
 	std::mutex mu_; std::condition_variable cv_;
 	uint64_t filled_ = 0, done_ = 0, total_read_ = 0;
 	bool eof_ = false, reader_done_ = false, stop_reading_ = false, io_error_ = false, attached_ = false;
+	int copiers_ = 0;
 	std::thread reader_, worker_;
 	struct timespec born_;
 };
@@ -627,8 +691,8 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		for (int g = 0; g < ngpu; g++) if (store[(size_t)g] && vg_read_store_reads(store[(size_t)g])) VG_CHECK(vg_reads_submit_store(ix[(size_t)g], store[(size_t)g]));
 		if (!pipe_in->error.empty()) { fprintf(stderr, "vargeno: %s\n", pipe_in->error.c_str()); exit(EXIT_FAILURE); }
 		total += pipe_in->records;
-		if (verbose) fprintf(stderr, "ingest, replica 0: the FASTQ is not a regular file: one descriptor read once, %lu reads framed + packed by %d host threads (%lu into the read stores while the index opened, %lu straight into the read loop), "
-		                             "%.2f GB of text in %.2f s (%.2f GB/s)%s\n", (unsigned long)pipe_in->records, std::max(1, pack_threads * ngpu), (unsigned long)pipe_in->to_store, (unsigned long)pipe_in->direct,
+		if (verbose) fprintf(stderr, "ingest, replica 0: the FASTQ is not a regular file: one descriptor read once (%d copier threads), %lu reads framed + packed by %d host threads (%lu into the read stores while the index opened, %lu straight into the read loop), "
+		                             "%.2f GB of text in %.2f s (%.2f GB/s)%s\n", pipe_in->copiers, (unsigned long)pipe_in->records, std::max(1, pack_threads * ngpu), (unsigned long)pipe_in->to_store, (unsigned long)pipe_in->direct,
 		                     (double)pipe_in->bytes_read / 1e9, pipe_in->seconds, pipe_in->seconds > 0 ? (double)pipe_in->bytes_read / 1e9 / pipe_in->seconds : 0.0, pipe_in->refused ? "; the stream framing refused a chunk: the host reader takes the rest" : "");
 	} else if (!host_framing) {
 		if (!cuts_ok) {
@@ -843,7 +907,7 @@ int main(int argc, const char *argv[])
 			pin.finish();
 			if (!pin.error.empty()) throw vgh::Error{pin.error};
 			fprintf(stderr, "fqpipe: %lu records framed by the packer, %lu bytes consumed of %lu read, refused %d\n", (unsigned long)pin.records, (unsigned long)pin.consumed, (unsigned long)pin.bytes_read, pin.refused ? 1 : 0);
-			if (quiet) fprintf(stderr, "fqpipe: %lu reads through the sink, %.3f s, %.3f GB/s of text\n", (unsigned long)counted, pin.seconds, pin.seconds > 0 ? (double)pin.bytes_read / pin.seconds / 1e9 : 0.0);
+			if (quiet) fprintf(stderr, "fqpipe: %lu reads through the sink, %d copier threads, %.3f s, %.3f GB/s of text\n", (unsigned long)counted, pin.copiers, pin.seconds, pin.seconds > 0 ? (double)pin.bytes_read / pin.seconds / 1e9 : 0.0);
 			vgh::FastqReader rd(fd, pin.span_base, pin.spans);
 			vgh::ReadBatch rb;
 			if (pin.records) { rd.seek(pin.last); rb.clear(); (void)rd.next(rb, 1); }
