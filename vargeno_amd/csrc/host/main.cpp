@@ -691,9 +691,9 @@ static int run_geno(const std::string &prefix, const std::string &fastq, const s
 		for (int g = 0; g < ngpu; g++) if (store[(size_t)g] && vg_read_store_reads(store[(size_t)g])) VG_CHECK(vg_reads_submit_store(ix[(size_t)g], store[(size_t)g]));
 		if (!pipe_in->error.empty()) { fprintf(stderr, "vargeno: %s\n", pipe_in->error.c_str()); exit(EXIT_FAILURE); }
 		total += pipe_in->records;
-		if (verbose) fprintf(stderr, "ingest, replica 0: the FASTQ is not a regular file: one descriptor read once (%d copier threads), %lu reads framed + packed by %d host threads (%lu into the read stores while the index opened, %lu straight into the read loop), "
-		                             "%.2f GB of text in %.2f s (%.2f GB/s)%s\n", pipe_in->copiers, (unsigned long)pipe_in->records, std::max(1, pack_threads * ngpu), (unsigned long)pipe_in->to_store, (unsigned long)pipe_in->direct,
-		                     (double)pipe_in->bytes_read / 1e9, pipe_in->seconds, pipe_in->seconds > 0 ? (double)pipe_in->bytes_read / 1e9 / pipe_in->seconds : 0.0, pipe_in->refused ? "; the stream framing refused a chunk: the host reader takes the rest" : "");
+		if (verbose) fprintf(stderr, "ingest, replica 0: the FASTQ is not a regular file: one descriptor read once, %lu reads framed + packed by %d host threads (%lu into the read stores while the index opened, %lu straight into the read loop), "
+		                             "%.2f GB of text in %.2f s (%.2f GB/s), dealt to %d copier threads%s\n", (unsigned long)pipe_in->records, std::max(1, pack_threads * ngpu), (unsigned long)pipe_in->to_store, (unsigned long)pipe_in->direct,
+		                     (double)pipe_in->bytes_read / 1e9, pipe_in->seconds, pipe_in->seconds > 0 ? (double)pipe_in->bytes_read / 1e9 / pipe_in->seconds : 0.0, pipe_in->copiers, pipe_in->refused ? "; the stream framing refused a chunk: the host reader takes the rest" : "");
 	} else if (!host_framing) {
 		if (!cuts_ok) {
 			host_from = 0;                                              // no record start found where one should be: the host reader takes the file
