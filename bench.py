@@ -604,8 +604,12 @@ class FifoFeed:
     and a page allocation per 4 KiB; `vmsplice` lends the pipe the writer's own pages instead, so that only the reader's copy is left
     (1.6 x the rate in the build container: 2.5 -> 4.0 GB/s).  Lent pages must not change before they are read: the last
     2 x pipe-size bytes of every buffer go through write() -- when that returns every slot of the pipe's ring holds a copied page, so no
-    page of the buffer is in the pipe any more and the caller may refill it.  Memory the kernel cannot lend (device-driver mappings such
-    as hipHostMalloc's) or a kernel that refuses the call: plain write() from the first refusal on."""
+    page of the buffer is in the pipe any more and the caller may refill it.  (That holds for a reader that copies out of this pipe.  The
+    command line MOVES the pipe's pages on to private pipes -- splice, host/main.cpp PipeIngest -- where up to a few MiB of them wait
+    for their copier thread: `job_stream` therefore rotates two buffers of a whole batch, 2.5 GB, and refills one only after the
+    other has gone through completely -- every lent page of the first is then gigabytes behind the reader's copiers.)  Memory the
+    kernel cannot lend (device-driver mappings such as hipHostMalloc's) or a kernel that refuses the call: plain write() from the
+    first refusal on."""
 
     def __init__(self, fd, lend=True):
         import ctypes
