@@ -606,8 +606,8 @@ class FifoFeed:
     2 x pipe-size bytes of every buffer go through write() -- when that returns every slot of the pipe's ring holds a copied page, so no
     page of the buffer is in the pipe any more and the caller may refill it.  (That holds for a reader that copies out of this pipe.  The
     command line MOVES the pipe's pages on to private pipes -- splice, host/main.cpp PipeIngest -- where up to a few MiB of them wait
-    for their copier thread: `job_stream` therefore rotates two buffers of a whole batch, 2.5 GB, and refills one only after the
-    other has gone through completely -- every lent page of the first is then gigabytes behind the reader's copiers.)  Memory the
+    for their copier thread: `job_stream` therefore rotates THREE buffers of a whole batch, 2.5 GB, and refills one only after a whole
+    later batch has gone through the pipe completely -- every lent page of the first is then gigabytes behind the reader's copiers.)  Memory the
     kernel cannot lend (device-driver mappings such as hipHostMalloc's) or a kernel that refuses the call: plain write() from the
     first refusal on."""
 
@@ -751,7 +751,7 @@ def job_stream(src, d, job_dir, prefix, dev_index, n_reads, batch_reads, lowq, r
             time.sleep(0.01)
     fcntl.fcntl(fd, fcntl.F_SETFL, fcntl.fcntl(fd, fcntl.F_GETFL) & ~os.O_NONBLOCK)
     feed = FifoFeed(fd, lend=os.environ.get("VG_BENCH_FIFO_LEND", "1") != "0")
-    pins = [None, None]
+    pins = [None, None, None]                                         # (three: see below)
     pin_kind = None
     done, gen_s, write_s, nb = 0, 0.0, 0.0, 0
     t_feed = time.time()
@@ -785,9 +785,10 @@ def job_stream(src, d, job_dir, prefix, dev_index, n_reads, batch_reads, lowq, r
             m[:, 16 + L:16 + 2 * L] = tq.view(n, L)
             m[:, 16 + 2 * L] = 10
             nbytes = n * rec
-            k2 = nb & 1
-            if wr["th"] is not None and pins[k2] is not None:
-                pass                                                  # (the buffer of two batches ago: its writer has been joined below)
+            # the buffer of THREE batches ago: batch nb - 2 has gone through the pipe completely since its last lent page (its writer was
+            # joined in the previous iteration), so none of its pages can still be anywhere between this process and the reader's copiers --
+            # whatever the scheduler does (with two buffers only the start of batch nb - 1 lay between, a margin of time, not of bytes)
+            k2 = nb % 3
             if pins[k2] is None or len(pins[k2][0]) < nbytes:
                 pins[k2] = None
                 pins[k2] = lendable_pinned_buffer(nbytes) if feed.libc is not None else pinned_buffer(nbytes) + ("hipHostMalloc",)
