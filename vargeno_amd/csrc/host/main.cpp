@@ -308,8 +308,8 @@ private:
 // <(zcat reads.fq.gz) all work there by construction.  Here the file routes above pread / mmap ranges of the file from many
 // threads, cut it at record starts per replica, and re-open it for the host reader -- none of which a pipe allows: a FIFO
 // loses its only reader between two open()s, a /dev/fd/N substitution has size 0.  So a path that is not a regular file takes THIS
-// route: the one descriptor is read by one thread (read() of whole chunks into a small ring, from the moment the command line
-// starts -- beside the index open), the chunks are framed + packed by the host packer (vg_packer_*: bytes cut anywhere), and the
+// route: the one descriptor is drained by one thread (whole chunks into a small ring, from the moment the command line
+// starts -- beside the index open; the pipe's pages are moved on to a few copier threads, see read_loop), the chunks are framed + packed by the host packer (vg_packer_*: bytes cut anywhere), and the
 // packed batches go to the replicas round robin -- into their read stores while the index is still opening, straight into the
 // read loop (vg_reads_submit_packed) afterwards.  No ranges, no seek.  What the packer refuses (a line beyond fgets' 1023
 // characters ...) and the possibly truncated tail go through the host reader like on the file routes: it is given the bytes
