@@ -1919,32 +1919,24 @@ extern "C" int vg_index_create(const vg_index_arrays *a, int device, vg_index **
 // dictionary is a single memcpy stream, and a copy from pageable memory is staged a second time by the runtime).
 // the page-locked staging of the file reads: made once per vg_index_open (eight 64 MiB buffers take 0.12 s to pin and 0.08 s to
 // release, tools/alloc_probe), shared by both dictionary files
-// (r06: pieces and ring size are run-time numbers -- $VG_FILE_PIECE_MB x $VG_FILE_RING -- so that one lease can measure them: with
-// eight slots only eight of the sixteen readers work at a time and the 49 GB of hg38-scale files cross the link at 26-31 GB/s of its 52)
 struct FileRing {
-	uint64_t PIECE = 64ull << 20;
-	int NBUF = 8;
-	std::vector<uint8_t *> buf;
-	std::vector<hipEvent_t> copied;
-	uint8_t *block = nullptr;
+	static constexpr uint64_t PIECE = 64ull << 20;
+	static constexpr int NBUF = 8;
+	uint8_t *buf[NBUF] = {};
+	hipEvent_t copied[NBUF] = {};
 	hipStream_t cs = nullptr;
 	int init()
 	{
-		if (const char *e = getenv("VG_FILE_PIECE_MB")) if (atoi(e) >= 1 && atoi(e) <= 1024) PIECE = (uint64_t)atoi(e) << 20;
-		if (const char *e = getenv("VG_FILE_RING")) if (atoi(e) >= 2 && atoi(e) <= 256) NBUF = atoi(e);
-		if (hipHostMalloc((void **)&block, PIECE * (uint64_t)NBUF, hipHostMallocDefault) != hipSuccess) { block = nullptr; return fail(VG_ENOMEM, "hipHostMalloc(staging) failed"); }
-		buf.assign((size_t)NBUF, nullptr);
-		copied.assign((size_t)NBUF, nullptr);
 		for (int i = 0; i < NBUF; i++) {
-			buf[(size_t)i] = block + (uint64_t)i * PIECE;
-			if (hipEventCreateWithFlags(&copied[(size_t)i], hipEventDisableTiming) != hipSuccess) return fail(VG_ENODEV, "hipEventCreate failed");
+			if (hipHostMalloc((void **)&buf[i], PIECE, hipHostMallocDefault) != hipSuccess) return fail(VG_ENOMEM, "hipHostMalloc(staging) failed");
+			if (hipEventCreateWithFlags(&copied[i], hipEventDisableTiming) != hipSuccess) return fail(VG_ENODEV, "hipEventCreate failed");
 		}
 		if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return fail(VG_ENODEV, "hipStreamCreate failed");
 		return VG_OK;
 	}
 	~FileRing()
 	{
-		if (block) (void)hipHostFree(block);
+		for (auto p : buf) if (p) (void)hipHostFree(p);
 		for (auto e : copied) if (e) (void)hipEventDestroy(e);
 		if (cs) (void)hipStreamDestroy(cs);
 	}
@@ -1952,8 +1944,8 @@ struct FileRing {
 static int file_to_device(FileRing &R, int fd, uint64_t off, uint64_t bytes, uint8_t *dst, const std::string &path)
 {
 	if (bytes == 0) return VG_OK;
-	const uint64_t PIECE = R.PIECE;
-	const int NBUF = R.NBUF;
+	constexpr uint64_t PIECE = FileRing::PIECE;
+	constexpr int NBUF = FileRing::NBUF;
 	const uint64_t n_pieces = (bytes + PIECE - 1) / PIECE;
 	int rc = VG_OK;
 	std::mutex mu; std::condition_variable cv;
