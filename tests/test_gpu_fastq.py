@@ -396,3 +396,56 @@ def test_cli_reads_a_fastq_that_is_not_a_regular_file(ftiny_dir, tmp_path, repli
     p = subprocess.run(["bash", "-c", "%s geno %s <(cat %s) %s %s" % (str(BIN), idx, fq, snps, out)], env=base_env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr
     assert out.read_bytes() == golden["whole"]
+
+
+@pytest.mark.parametrize("copiers", ["4", "0"])
+def test_cli_reads_a_fifo_whose_writer_lends_its_pages(ftiny_dir, tmp_path, copiers):
+    """A producer may hand a pipe its own pages instead of copying into it (vmsplice: what bench.py's `job_stream` feed does), and the
+    command line's reader moves a pipe's pages on to its copier threads (splice) instead of read()ing them: F-tiny's FASTQ lent to a
+    FIFO in one piece, small chunks, with the copier threads and with the plain read() loop -- the golden VCF, byte for byte, and every
+    record framed by the packer."""
+    import errno
+    import importlib.util
+    import mmap
+    import re
+    import sys
+    import time
+
+    spec = importlib.util.spec_from_file_location("vg_bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    idx, snps = os.path.join(ftiny_dir, "idx"), os.path.join(ftiny_dir, "snps.vcf")
+    whole = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read()
+    n_whole = whole.count(b"\n") // 4
+    golden = gzip.open(os.path.join(GOLDEN, "ftiny.out.vcf.gz"), "rb").read()
+    m = mmap.mmap(-1, len(whole))
+    m[:] = whole
+    fifo, out = str(tmp_path / "lent.fifo"), tmp_path / "lent.vcf"
+    os.mkfifo(fifo)
+    env = dict(os.environ, VARGENO_CHUNK_MB="1", VARGENO_PACK_THREADS="2", VARGENO_VERBOSE="1", VARGENO_PIPE_COPIERS=copiers)
+    p = subprocess.Popen([BIN, "geno", idx, fifo, snps, str(out)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    fd, t0 = None, time.time()
+    while fd is None:                                                   # (a FIFO opens for writing once its reader is there)
+        try:
+            fd = os.open(fifo, os.O_WRONLY | os.O_NONBLOCK)
+        except OSError as e:
+            assert e.errno == errno.ENXIO and p.poll() is None and time.time() - t0 < 120, (e, p.poll())
+            time.sleep(0.01)
+    import fcntl
+
+    fcntl.fcntl(fd, fcntl.F_SETFL, fcntl.fcntl(fd, fcntl.F_GETFL) & ~os.O_NONBLOCK)
+    feed = bench.FifoFeed(fd, lend=True)
+    feed.pipe_bytes = 1 << 16            # (the copied tail is 2 x this: F-tiny's FASTQ is one megabyte, and this buffer is never refilled)
+    feed.write_all(memoryview(m))
+    os.close(fd)
+    so, se = p.communicate(timeout=300)
+    assert p.returncode == 0, se
+    assert out.read_bytes() == golden, se
+    mt = re.search(r"not a regular file: one descriptor read once, (\d+) reads framed .* dealt to (\d+) copier threads", se)
+    assert mt and int(mt.group(1)) == n_whole and int(mt.group(2)) == int(copiers), se
+    if feed.refusal is None:
+        assert feed.lent_bytes > len(whole) // 2, (feed.lent_bytes, feed.copied_bytes)
