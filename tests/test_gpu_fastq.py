@@ -449,3 +449,41 @@ def test_cli_reads_a_fifo_whose_writer_lends_its_pages(ftiny_dir, tmp_path, copi
     assert mt and int(mt.group(1)) == n_whole and int(mt.group(2)) == int(copiers), se
     if feed.refusal is None:
         assert feed.lent_bytes > len(whole) // 2, (feed.lent_bytes, feed.copied_bytes)
+
+
+@pytest.mark.parametrize("replicas", ["1", "2"])
+def test_cli_long_line_in_the_middle_of_a_fifo_goes_on_through_the_host_reader(ftiny_dir, tmp_path, replicas):
+    """The once-only route's hand-over on the device path: a record with lines beyond fgets' 1023 characters (see the file test above)
+    in the middle of a stream that arrives through a FIFO.  The packer refuses from that chunk on; the host reader gets what the
+    reader thread (and its copier threads) had already taken from the pipe, then the descriptor.  The VCF must equal the one from
+    framing the same bytes, as a file, on the host -- with the copier threads and with the plain read() loop."""
+    import threading
+
+    lines = open(os.path.join(ftiny_dir, "reads.fq"), "rb").read().split(b"\n")[:-1]
+    odd = [b"@" + b"ACGT" * 300, b"ACGT" * 20, b"+", b"ACGT" * 800]
+    k = 4 * 1500
+    data = b"\n".join(lines[:k] + odd + lines[k:]) + b"\n"
+    fq = tmp_path / "reads_long.fq"
+    fq.write_bytes(data)
+    idx, snps = os.path.join(ftiny_dir, "idx"), os.path.join(ftiny_dir, "snps.vcf")
+    base_env = dict(os.environ, VARGENO_CHUNK_MB="1", VARGENO_BATCH="900", VARGENO_VERBOSE="1", VARGENO_GPUS=replicas, VARGENO_SHARE_DEVICES="1", VARGENO_PACK_THREADS="2")
+    want_out = tmp_path / "want.vcf"
+    p = subprocess.run([BIN, "geno", idx, str(fq), snps, str(want_out)], env=dict(base_env, VARGENO_HOST_FASTQ="1", VARGENO_GPUS="1"), capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    want = want_out.read_bytes()
+    assert want.count(b"\n") > 2000
+    for copiers in ("4", "0"):
+        fifo, out = str(tmp_path / ("long_%s.fifo" % copiers)), tmp_path / ("long_%s.vcf" % copiers)
+        os.mkfifo(fifo)
+
+        def feed():
+            with open(fifo, "wb", buffering=0) as w:
+                for a in range(0, len(data), 70_000):
+                    w.write(data[a:a + 70_000])
+        t = threading.Thread(target=feed)
+        t.start()
+        p = subprocess.run([BIN, "geno", idx, fifo, snps, str(out)], env=dict(base_env, VARGENO_PIPE_COPIERS=copiers), capture_output=True, text=True, timeout=300)
+        t.join()
+        assert p.returncode == 0, p.stderr
+        assert "the stream framing refused a chunk" in p.stderr and "reads: %d " % (len(lines) // 4 + 2) in p.stderr, p.stderr
+        assert out.read_bytes() == want, (copiers, p.stderr)
